@@ -1,0 +1,4 @@
+"""CPU oracle (test infrastructure only).  See oracle/smg_oracle.h.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this package.
+"""
