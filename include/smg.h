@@ -1,0 +1,186 @@
+/*
+ * smg.h -- C ABI of libsmg: the MI355X-native surface-multigrid solve path.
+ *
+ * Drop-in boundary for the `mg_VCycle` / `min_quad_with_fixed_mg_*` path of
+ * HTDerekLiu/surface_multigrid_code.  The reference has no FFI layer: its boundary is the set of C++
+ * free functions in src/min_quad_with_fixed_mg.h:32-113, src/mg_VCycle.h:22-76 and
+ * src/mg_precompute.h:15-32 taking Eigen objects by reference.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference checkout).  The C++ mirror with the
+ * reference's own function names/argument order lives in surface_multigrid_code_amd/csrc/mg_api.hpp;
+ * INTEGRATION.md shows the Eigen-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; fp64 values, int32 indices (Eigen's default StorageIndex);
+ *   - sparse matrices are passed as CSR (rowptr, col, val).  For the symmetric system matrix these are the
+ *     very arrays Eigen's column-major SparseMatrix holds (outerIndexPtr, innerIndexPtr, valuePtr); for the
+ *     prolongation P a `_csc` twin takes Eigen's compressed-column arrays directly;
+ *   - dense blocks are column-major n x k with a leading dimension, exactly Eigen::MatrixXd / VectorXd;
+ *   - every function returns an int status: 0 = ok, < 0 = error (enum below); nothing throws across the ABI;
+ *     `smg_last_error()` gives a thread-local message;
+ *   - a handle owns its device memory and one HIP stream; a handle is not thread-safe, distinct handles are;
+ *   - compute entry points REQUIRE a HIP device: without one they fail with SMG_ERR_NO_DEVICE -- there is no
+ *     CPU fallback inside this library (the CPU oracle lives in oracle/ and is test infrastructure only).
+ */
+#ifndef SMG_H
+#define SMG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMG_VERSION 100
+
+enum {
+    SMG_OK = 0,
+    SMG_ERR_INVALID = -1,     /* bad argument / call order */
+    SMG_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    SMG_ERR_HIP = -3,         /* a HIP runtime call failed */
+    SMG_ERR_NONFINITE = -4,   /* residual became NaN/Inf */
+    SMG_ERR_ALLOC = -5,
+    SMG_ERR_IO = -6
+};
+
+enum { SMG_HOST = 0, SMG_DEVICE = 1 };         /* where the dense blocks handed to smg_solve live */
+
+/* decimation types of mg_precompute (src/mg_precompute.h:9: 0 qslim, 1 midpoint, 2 vertex removal) */
+enum { SMG_DEC_QSLIM = 0, SMG_DEC_MIDPOINT = 1, SMG_DEC_VERTEX_REMOVAL = 2 };
+
+typedef struct smg_hierarchy smg_hierarchy;
+
+/* Parameters the reference hard-codes or passes through default-argument overloads:
+ *   tol = 1e-3 (min_quad_with_fixed_mg.cpp:63,270), max_iter = 20 (:77,:285), pre = post = 2 (:102-103,:324-325) */
+typedef struct {
+    double tol;
+    int max_iter;
+    int pre, post;
+    int verbosity;     /* 0 silent; 1 prints "MG iteration: i, residual: r" lines like the reference (:111) */
+    int check_every;   /* host polls the device-side convergence flag every this many iterations (>=1) */
+    int use_graph;     /* 1: replay one captured hipGraph per outer iteration; 0: eager launches */
+} smg_solve_opts;
+void smg_solve_opts_default(smg_solve_opts *o);
+
+int smg_version(void);
+const char *smg_last_error(void);
+int smg_device_count(void);
+
+/* ---- std::vector<mg_data> (src/mg_data.h:11-27) ---------------------------------------------------------------- */
+/* mg.reserve(nLvs) */
+smg_hierarchy *smg_hierarchy_create(int n_levels);
+void smg_hierarchy_destroy(smg_hierarchy *h);
+int smg_hierarchy_levels(const smg_hierarchy *h);
+/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) instead of the handle's own. */
+int smg_hierarchy_set_stream(smg_hierarchy *h, void *hip_stream);
+/* mg[lv].P_full = mg[lv].P = P; mg[lv].PT = P^T  (what mg_precompute stores per level, src/mg_precompute.cpp:71-77).
+ * P is #V_{lv-1} x #V_lv for lv = 1 .. n_levels-1 (the operator lives on the COARSER level, mg_VCycle.cpp:80,:91). */
+int smg_level_set_prolong(smg_hierarchy *h, int lv, int n_fine, int n_coarse, const int *rowptr, const int *col,
+                          const double *val);
+int smg_level_set_prolong_csc(smg_hierarchy *h, int lv, int n_fine, int n_coarse, const int *colptr,
+                              const int *rowidx, const double *val);
+/* mg[lv].V / mg[lv].F (optional; not used by the solve) */
+int smg_level_set_mesh(smg_hierarchy *h, int lv, const double *V, int nV, const int *F, int nF);
+
+/* ---- mg_precompute (src/mg_precompute.h:26-32, src/mg_precompute.cpp:15-87) ------------------------------------ */
+/* Builds the hierarchy from a triangle mesh: level count by the reference's float rule (:27-38), per level
+ * tarF = round(#F * ratio) (:59), edge-collapse decimation + prolongation.  V: nV x 3 row-major, F: nF x 3.
+ * NOTE: the decimator/prolongation here is libsmg's own host implementation (shortest-edge mid-point collapse
+ * with successive closest-point re-parameterisation), NOT the reference's joint-LSCM self-parameterisation
+ * (SURVEY.md section 8 row f-1); same API, same P structure (3 stored entries per row, rows sum to 1). */
+int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
+                      smg_hierarchy **out);
+/* Hierarchy of a mid-point-subdivided mesh: the n_sub finest transfer operators are the subdivision operators
+ * (09_random_subdiv_remesh/main.cpp:46-140), levels below the base mesh come from smg_mg_precompute's decimator
+ * (ratio, nVCoarsest applied to the base mesh; pass n_extra_levels = -1 for the float rule).  Outputs the fine
+ * mesh through V_out/F_out (caller-allocated: nV_fine x 3, nF * 4^n_sub x 3) when non-null. */
+int smg_mg_precompute_subdiv(const double *V, int nV, const int *F, int nF, int n_sub, float ratio, int nVCoarsest,
+                             int n_extra_levels, smg_hierarchy **out, double *V_out, int *F_out);
+
+/* ---- min_quad_with_fixed_mg_precompute (src/min_quad_with_fixed_mg.h:32-36 and :72-77) ------------------------- */
+/* A: n x n symmetric, CSR == CSC.  known == NULL / n_known == 0 selects the no-constraint overload
+ * (.cpp:3-51); otherwise the `known` overload (.cpp:137-257): unknown = setdiff, LHS/Auk slices, P re-organised
+ * to unknowns with the all-(<=1e-15) column drop cascade, Galerkin A_l = PT_l A_{l-1} P_l, +1e-12 on the coarsest
+ * diagonal, A_diag, coarsest factorisation (here: dense inverse computed on the device).  May be called again on
+ * the same handle (new matrix every time step, 05_example_mean_curvature_flow/main.cpp:74); always restarts
+ * from P_full. */
+int smg_precompute(smg_hierarchy *h, int n, const int *rowptr, const int *col, const double *val, const int *known,
+                   int n_known);
+
+/* ---- min_quad_with_fixed_mg_solve (src/min_quad_with_fixed_mg.h:38-69 and :79-113) ------------------------------ */
+/* RHS, z0, z: n x k column-major (n = full size incl. known rows); known_val: n_known x k (ignored without
+ * constraints).  r_his must hold opts->max_iter doubles; *n_his <= max_iter entries are written, one per loop
+ * entry incl. the one that triggers the break (.cpp:108-116).  *converged = !(last measured residual > tol)
+ * (.cpp:131-134).  memspace: SMG_HOST or SMG_DEVICE for RHS/known_val/z0/z (r_his is always host). */
+int smg_solve(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *known_val, int ld_kv, const double *z0,
+              int ld_z0, int k, int memspace, const smg_solve_opts *opts, double *z, int ld_z, double *r_his,
+              int *n_his, int *converged);
+
+/* Split-phase form of the same loop for column-sharded multi-GPU runs: the caller owns
+ * the all-reduce of the residual sum of squares between the two halves of an iteration.
+ *   begin:     gathers RHS/z0 (device, column-major) into the handle, resets the control block;
+ *   residual:  *d_sumsq (device double) = sum over the local columns of |RHS_u - A_0 z_u|^2   (.cpp:110/:332);
+ *   cycle:     r = sqrt(*d_sumsq) -> r_his, break test, then one V-cycle (skipped on the device once done);
+ *   end:       scatters z, copies r_his back, reports convergence. */
+int smg_solve_begin(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *known_val, int ld_kv,
+                    const double *z0, int ld_z0, int k, int memspace, const smg_solve_opts *opts);
+int smg_solve_iter_residual(smg_hierarchy *h, double *d_sumsq);
+int smg_solve_iter_cycle(smg_hierarchy *h, const double *d_sumsq);
+int smg_solve_poll(smg_hierarchy *h, int *done, int *n_his);      /* synchronising read of the control block */
+int smg_solve_end(smg_hierarchy *h, double *z, int ld_z, int memspace, double *r_his, int *n_his, int *converged);
+
+/* ---- mg_VCycle.h pieces, host column-major blocks in the level's own (caller) numbering ------------------------ */
+/* Level lv has smg_level_rows(h, lv) unknowns (after constraint elimination). */
+int smg_level_rows(const smg_hierarchy *h, int lv);
+int smg_vcycle(smg_hierarchy *h, const double *B, int pre, int post, int lv, double *u, int k);   /* mg_VCycle.h:22-30 */
+int smg_apply_A(smg_hierarchy *h, int lv, const double *u, int k, double *Au);                    /* A()       :32-37 */
+int smg_restrict(smg_hierarchy *h, int lv, const double *x, int k, double *Rx);                   /* restrict  :39-44 */
+int smg_prolong(smg_hierarchy *h, int lv, const double *x, int k, double *Px);                    /* prolong   :46-51 */
+int smg_relax(smg_hierarchy *h, int lv, const double *B, int k, int iters, double *u);            /* relax     :62-68 */
+int smg_coarse_solve(smg_hierarchy *h, const double *B, int k, double *u);                        /* coarseSolve :70-76 */
+int smg_residual_norm(smg_hierarchy *h, int lv, const double *B, const double *u, int k, double *norm);
+
+/* ---- device-resident raw interface (internal numbering / internal row-major n x k layout) ---------------------- */
+/* For benchmarks and callers that keep everything in HBM.  x, y, b: device pointers, rows in the level's
+ * internal order (smg_level_get_perm), k columns interleaved.  mode: 0 y=Ax, 1 y=b-Ax, 3 y+=Ax. */
+int smg_raw_spmv(smg_hierarchy *h, int lv, int mode, const double *x, const double *b, double *y, int k);
+int smg_raw_relax(smg_hierarchy *h, int lv, const double *b, double *u, int k, int iters);
+int smg_raw_outer_iteration(smg_hierarchy *h, int n_iter);   /* residual + decide + V-cycle, n_iter times, on the
+                                                                state loaded by smg_solve_begin; no host sync */
+int smg_synchronize(smg_hierarchy *h);
+
+/* ---- introspection (tests, tools) ------------------------------------------------------------------------------ */
+/* which: 0 = A, 1 = P (lv >= 1), 2 = PT (lv >= 1), 3 = P_full (lv >= 1), 4 = Auk (lv == 0).
+ * internal = 0: caller numbering; 1: the device numbering.  Query sizes with NULL arrays first. */
+int smg_level_get_matrix(const smg_hierarchy *h, int lv, int which, int internal, int *n_rows, int *n_cols, int *nnz,
+                         int *rowptr, int *col, double *val);
+int smg_level_get_perm(const smg_hierarchy *h, int lv, int *perm);              /* internal -> caller, n entries */
+int smg_level_get_colors(const smg_hierarchy *h, int lv, int *n_colors, int *color_ptr /* n_colors+1 or NULL */);
+int smg_level_get_Adiag(const smg_hierarchy *h, int lv, double *diag);          /* mg[lv].A_diag, caller numbering */
+int smg_get_unknown(const smg_hierarchy *h, int *n_unknown, int *unknown /* or NULL */);
+int smg_level_sell_stats(const smg_hierarchy *h, int lv, int which, long *stored, long *padded, int *n_slices);
+/* algorithmic bytes of one y = A_lv x with k columns: 12 nnz + 4 (n+1) + 16 n k   */
+long smg_level_spmv_bytes(const smg_hierarchy *h, int lv, int k);
+/* algorithmic bytes of one V(pre,post) cycle incl. the outer residual evaluation, k columns */
+long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);
+
+/* ---- profc.h mirror: named scopes accumulated with hipEvents (src/profc.h:9-13; mg_VCycle.cpp:121) ------------- */
+int smg_prof_enable(smg_hierarchy *h, int on);     /* forces eager launches while on */
+int smg_prof_reset(smg_hierarchy *h);
+int smg_prof_count(smg_hierarchy *h);
+int smg_prof_get(smg_hierarchy *h, int idx, char *name, int name_cap, long *count, double *total_ms);
+
+/* ---- caller-side mesh numerics (host C++; libigl stand-ins used by the demos around the solve) ----------------- */
+int smg_mesh_read(const char *path, double **V, int *nV, int **F, int *nF);   /* free with smg_free */
+void smg_free(void *p);
+int smg_mesh_normalize_unit_area(double *V, int nV, const int *F, int nF);        /* src/normalize_unit_area.cpp */
+/* cotmatrix (negative semi-definite, igl convention).  Query nnz with NULL arrays, then fill. */
+int smg_mesh_cotmatrix(const double *V, int nV, const int *F, int nF, int *nnz, int *rowptr, int *col, double *val);
+int smg_mesh_massmatrix(const double *V, int nV, const int *F, int nF, int voronoi, double *diag);
+int smg_mesh_boundary_loop(const int *F, int nF, int nV, int *loop, int *n_loop); /* longest loop; loop holds <= nV */
+/* one mid-point upsampling step: S is (nV+nE) x nV in CSR (nV + 2 nE entries), NF is 4 nF x 3 */
+int smg_mesh_midpoint_upsample(int nV, const int *F, int nF, int *nE, int *S_rowptr, int *S_col, double *S_val,
+                               int *NF);
+int smg_mesh_torus(int nu, int nv, double R, double r, double *V, int *F);    /* V: nu*nv x 3, F: 2*nu*nv x 3 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

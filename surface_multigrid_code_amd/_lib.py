@@ -1,0 +1,94 @@
+"""ctypes loader for lib/libsmg.so.  Fails loudly when the library is missing (no fallback path)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsmg.so")
+
+SMG_HOST, SMG_DEVICE = 0, 1
+
+
+class SolveOptsC(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("pre", C.c_int), ("post", C.c_int),
+                ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libsmg.so not built: run `python -m surface_multigrid_code_amd.build` "
+                          "(expected at %s); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    ip, dp, vp, lp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_long)
+    i, d, f = C.c_int, C.c_double, C.c_float
+    sig = {
+        "smg_version": (i, []),
+        "smg_last_error": (C.c_char_p, []),
+        "smg_device_count": (i, []),
+        "smg_solve_opts_default": (None, [C.POINTER(SolveOptsC)]),
+        "smg_hierarchy_create": (vp, [i]),
+        "smg_hierarchy_destroy": (None, [vp]),
+        "smg_hierarchy_levels": (i, [vp]),
+        "smg_hierarchy_set_stream": (i, [vp, vp]),
+        "smg_level_set_prolong": (i, [vp, i, i, i, ip, ip, dp]),
+        "smg_level_set_prolong_csc": (i, [vp, i, i, i, ip, ip, dp]),
+        "smg_level_set_mesh": (i, [vp, i, dp, i, ip, i]),
+        "smg_mg_precompute": (i, [dp, i, ip, i, f, i, i, C.POINTER(vp)]),
+        "smg_mg_precompute_subdiv": (i, [dp, i, ip, i, i, f, i, i, C.POINTER(vp), dp, ip]),
+        "smg_precompute": (i, [vp, i, ip, ip, dp, ip, i]),
+        "smg_solve": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC), vp, i, dp, ip, ip]),
+        "smg_solve_begin": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC)]),
+        "smg_solve_iter_residual": (i, [vp, vp]),
+        "smg_solve_iter_cycle": (i, [vp, vp]),
+        "smg_solve_poll": (i, [vp, ip, ip]),
+        "smg_solve_end": (i, [vp, vp, i, i, dp, ip, ip]),
+        "smg_level_rows": (i, [vp, i]),
+        "smg_vcycle": (i, [vp, dp, i, i, i, dp, i]),
+        "smg_apply_A": (i, [vp, i, dp, i, dp]),
+        "smg_restrict": (i, [vp, i, dp, i, dp]),
+        "smg_prolong": (i, [vp, i, dp, i, dp]),
+        "smg_relax": (i, [vp, i, dp, i, i, dp]),
+        "smg_coarse_solve": (i, [vp, dp, i, dp]),
+        "smg_residual_norm": (i, [vp, i, dp, dp, i, dp]),
+        "smg_raw_spmv": (i, [vp, i, i, vp, vp, vp, i]),
+        "smg_raw_relax": (i, [vp, i, vp, vp, i, i]),
+        "smg_raw_outer_iteration": (i, [vp, i]),
+        "smg_synchronize": (i, [vp]),
+        "smg_level_get_matrix": (i, [vp, i, i, i, ip, ip, ip, ip, ip, dp]),
+        "smg_level_get_perm": (i, [vp, i, ip]),
+        "smg_level_get_colors": (i, [vp, i, ip, ip]),
+        "smg_level_get_Adiag": (i, [vp, i, dp]),
+        "smg_get_unknown": (i, [vp, ip, ip]),
+        "smg_level_sell_stats": (i, [vp, i, i, lp, lp, ip]),
+        "smg_level_spmv_bytes": (C.c_long, [vp, i, i]),
+        "smg_vcycle_bytes": (C.c_long, [vp, i, i, i]),
+        "smg_prof_enable": (i, [vp, i]),
+        "smg_prof_reset": (i, [vp]),
+        "smg_prof_count": (i, [vp]),
+        "smg_prof_get": (i, [vp, i, C.c_char_p, i, lp, dp]),
+        "smg_mesh_read": (i, [C.c_char_p, C.POINTER(dp), ip, C.POINTER(ip), ip]),
+        "smg_free": (None, [vp]),
+        "smg_mesh_normalize_unit_area": (i, [dp, i, ip, i]),
+        "smg_mesh_cotmatrix": (i, [dp, i, ip, i, ip, ip, ip, dp]),
+        "smg_mesh_massmatrix": (i, [dp, i, ip, i, i, dp]),
+        "smg_mesh_boundary_loop": (i, [ip, i, i, ip, ip]),
+        "smg_mesh_midpoint_upsample": (i, [i, ip, i, ip, ip, ip, dp, ip]),
+        "smg_mesh_torus": (i, [i, i, d, d, dp, ip]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = the library does not export what smg.h declares
+        fn.restype = res
+        fn.argtypes = args
+    L._smg_signatures = sig
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Every entry point include/smg.h declares (used by the CPU-side ABI test)."""
+    return sorted(load()._smg_signatures.keys())

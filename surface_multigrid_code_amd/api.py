@@ -1,0 +1,341 @@
+"""Python host mirror of the reference's operator API for the solve path, over the C ABI (include/smg.h).
+
+Reference (HTDerekLiu/surface_multigrid_code) usage pattern, README.md:47-48 / 03_mg_solver/main.cpp:38-75:
+
+    vector<mg_data> mg;   mg_precompute(V, F, ratio, nVCoarsest, dec_type, mg);
+    min_quad_with_fixed_mg_precompute(A, known, data, mg, solver);
+    min_quad_with_fixed_mg_solve(data, RHS, known_val, z0, solver, tol, maxIter, mg, z, rHis);
+
+Here `mg` is a `Hierarchy` (owning the device-resident std::vector<mg_data>, the min_quad_with_fixed_mg_data and
+the coarse solver); output arguments become return values.  Nothing in this module computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import SMG_DEVICE, SMG_HOST, SolveOptsC
+
+
+class SmgError(RuntimeError):
+    def __init__(self, code, where):
+        msg = _lib.load().smg_last_error()
+        super().__init__("%s failed (%d): %s" % (where, code, msg.decode() if msg else ""))
+        self.code = code
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise SmgError(rc, where)
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _csr(M):
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    return (np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+            np.ascontiguousarray(M.data, dtype=np.float64))
+
+
+def _colmajor(X):
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    return np.asfortranarray(X)
+
+
+class SolveOpts:
+    """tol / maxIter / pre / post with the reference's defaults (src/min_quad_with_fixed_mg.cpp:63,77,102-103)."""
+
+    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1):
+        self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph)
+
+
+class Hierarchy:
+    """std::vector<mg_data> mg (+ solver data) living in HBM.  Wraps smg_hierarchy*."""
+
+    def __init__(self, n_levels=None, handle=None):
+        self.L = _lib.load()
+        if handle is None:
+            handle = self.L.smg_hierarchy_create(int(n_levels))
+            if not handle:
+                raise SmgError(-1, "smg_hierarchy_create")
+        self.h = C.c_void_p(handle)
+        self.n = None
+        self.known = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.smg_hierarchy_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- container
+    @property
+    def n_levels(self):
+        return self.L.smg_hierarchy_levels(self.h)
+
+    def set_prolong(self, lv, P):
+        """mg[lv].P_full = mg[lv].P = P, mg[lv].PT = P^T (src/mg_precompute.cpp:71-77)."""
+        ptr, col, val = _csr(P)
+        _chk(self.L.smg_level_set_prolong(self.h, lv, P.shape[0], P.shape[1], _ip(ptr), _ip(col), _dp(val)),
+             "smg_level_set_prolong")
+
+    def set_stream(self, stream_ptr):
+        _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr)), "smg_hierarchy_set_stream")
+
+    @classmethod
+    def from_prolongs(cls, Ps):
+        H = cls(len(Ps) + 1)
+        for l, P in enumerate(Ps, start=1):
+            H.set_prolong(l, P)
+        return H
+
+    # ---- min_quad_with_fixed_mg_precompute
+    def precompute(self, A, known=None):
+        ptr, col, val = _csr(A)
+        n = A.shape[0]
+        if known is None or len(known) == 0:
+            rc = self.L.smg_precompute(self.h, n, _ip(ptr), _ip(col), _dp(val), None, 0)
+            self.known = None
+        else:
+            kn = np.ascontiguousarray(known, dtype=np.int32)
+            rc = self.L.smg_precompute(self.h, n, _ip(ptr), _ip(col), _dp(val), _ip(kn), len(kn))
+            self.known = kn
+        _chk(rc, "smg_precompute")
+        self.n = n
+
+    # ---- min_quad_with_fixed_mg_solve (host blocks)
+    def solve(self, RHS, z0, known_val=None, opts=None):
+        opts = opts or SolveOpts()
+        RHS, z0 = _colmajor(RHS), _colmajor(z0)
+        n, k = RHS.shape
+        z = np.zeros((n, k), order="F")
+        r_his = np.zeros(max(opts.c.max_iter, 1))
+        n_his, conv = C.c_int(0), C.c_int(0)
+        kv_p, ld_kv = None, 0
+        if self.known is not None:
+            kv = _colmajor(known_val if known_val is not None else np.zeros((len(self.known), k)))
+            kv_p, ld_kv = kv.ctypes.data, kv.shape[0]
+        rc = self.L.smg_solve(self.h, RHS.ctypes.data, n, kv_p, ld_kv, z0.ctypes.data, n, k, SMG_HOST,
+                              C.byref(opts.c), z.ctypes.data, n, _dp(r_his), C.byref(n_his), C.byref(conv))
+        _chk(rc, "smg_solve")
+        return bool(conv.value), z, r_his[: n_his.value].copy()
+
+    # ---- mg_VCycle.h pieces (host blocks in the level's caller numbering)
+    def rows(self, lv):
+        return self.L.smg_level_rows(self.h, lv)
+
+    def _piece(self, fn, name, lv, x, nout):
+        x = _colmajor(x)
+        y = np.zeros((nout, x.shape[1]), order="F")
+        _chk(fn(self.h, lv, _dp(x), x.shape[1], _dp(y)), name)
+        return y
+
+    def A(self, lv, u):
+        return self._piece(self.L.smg_apply_A, "smg_apply_A", lv, u, self.rows(lv))
+
+    def restrict(self, lv, x):
+        return self._piece(self.L.smg_restrict, "smg_restrict", lv, x, self.rows(lv + 1))
+
+    def prolong(self, lv, x):
+        return self._piece(self.L.smg_prolong, "smg_prolong", lv, x, self.rows(lv))
+
+    def relax(self, lv, B, u, iters):
+        B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        _chk(self.L.smg_relax(self.h, lv, _dp(B), B.shape[1], iters, _dp(u)), "smg_relax")
+        return u
+
+    def coarse_solve(self, B, u):
+        B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        _chk(self.L.smg_coarse_solve(self.h, _dp(B), B.shape[1], _dp(u)), "smg_coarse_solve")
+        return u
+
+    def vcycle(self, B, u, lv=0, pre=2, post=2):
+        B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        _chk(self.L.smg_vcycle(self.h, _dp(B), pre, post, lv, _dp(u), B.shape[1]), "smg_vcycle")
+        return u
+
+    def residual_norm(self, lv, B, u):
+        B, u = _colmajor(B), _colmajor(u)
+        out = C.c_double(0)
+        _chk(self.L.smg_residual_norm(self.h, lv, _dp(B), _dp(u), B.shape[1], C.byref(out)), "smg_residual_norm")
+        return out.value
+
+    # ---- introspection
+    def matrix(self, lv, which="A", internal=False):
+        w = {"A": 0, "P": 1, "PT": 2, "P_full": 3, "Auk": 4}[which]
+        nr, nc, nnz = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.L.smg_level_get_matrix(self.h, lv, w, int(internal), C.byref(nr), C.byref(nc), C.byref(nnz),
+                                         None, None, None), "smg_level_get_matrix")
+        ptr = np.zeros(nr.value + 1, np.int32)
+        col = np.zeros(max(nnz.value, 1), np.int32)
+        val = np.zeros(max(nnz.value, 1))
+        _chk(self.L.smg_level_get_matrix(self.h, lv, w, int(internal), None, None, None, _ip(ptr), _ip(col), _dp(val)),
+             "smg_level_get_matrix")
+        return sp.csr_matrix((val[: nnz.value], col[: nnz.value], ptr), shape=(nr.value, nc.value))
+
+    def perm(self, lv):
+        p = np.zeros(self.rows(lv), np.int32)
+        _chk(self.L.smg_level_get_perm(self.h, lv, _ip(p)), "smg_level_get_perm")
+        return p
+
+    def colors(self, lv):
+        nc = C.c_int()
+        _chk(self.L.smg_level_get_colors(self.h, lv, C.byref(nc), None), "smg_level_get_colors")
+        cp = np.zeros(nc.value + 1, np.int32)
+        _chk(self.L.smg_level_get_colors(self.h, lv, None, _ip(cp)), "smg_level_get_colors")
+        return cp
+
+    def Adiag(self, lv):
+        d = np.zeros(self.rows(lv))
+        _chk(self.L.smg_level_get_Adiag(self.h, lv, _dp(d)), "smg_level_get_Adiag")
+        return d
+
+    def unknown(self):
+        n = C.c_int()
+        _chk(self.L.smg_get_unknown(self.h, C.byref(n), None), "smg_get_unknown")
+        u = np.zeros(n.value, np.int32)
+        _chk(self.L.smg_get_unknown(self.h, None, _ip(u)), "smg_get_unknown")
+        return u
+
+    def sell_stats(self, lv, which="A"):
+        st, pd, ns = C.c_long(), C.c_long(), C.c_int()
+        _chk(self.L.smg_level_sell_stats(self.h, lv, {"A": 0, "P": 1, "PT": 2}[which], C.byref(st), C.byref(pd),
+                                         C.byref(ns)), "smg_level_sell_stats")
+        return {"stored": st.value, "padded": pd.value, "n_slices": ns.value}
+
+    def spmv_bytes(self, lv=0, k=1):
+        return self.L.smg_level_spmv_bytes(self.h, lv, k)
+
+    def vcycle_bytes(self, k=1, pre=2, post=2):
+        return self.L.smg_vcycle_bytes(self.h, k, pre, post)
+
+    # ---- profc mirror
+    def prof_enable(self, on=True):
+        _chk(self.L.smg_prof_enable(self.h, int(on)), "smg_prof_enable")
+
+    def prof_reset(self):
+        _chk(self.L.smg_prof_reset(self.h), "smg_prof_reset")
+
+    def prof_table(self):
+        out = {}
+        for i in range(self.L.smg_prof_count(self.h)):
+            name = C.create_string_buffer(128)
+            cnt, ms = C.c_long(), C.c_double()
+            _chk(self.L.smg_prof_get(self.h, i, name, 128, C.byref(cnt), C.byref(ms)), "smg_prof_get")
+            out[name.value.decode()] = (cnt.value, ms.value)
+        return out
+
+    # ---- device-resident interface (torch tensors / raw device pointers)
+    def solve_begin(self, rhs_ptr, ld_rhs, z0_ptr, ld_z0, k, known_val_ptr=None, ld_kv=0, opts=None,
+                    memspace=SMG_DEVICE):
+        opts = opts or SolveOpts()
+        self._opts = opts
+        _chk(self.L.smg_solve_begin(self.h, rhs_ptr, ld_rhs, known_val_ptr, ld_kv, z0_ptr, ld_z0, k, memspace,
+                                    C.byref(opts.c)), "smg_solve_begin")
+
+    def iter_residual(self, d_sumsq_ptr):
+        _chk(self.L.smg_solve_iter_residual(self.h, d_sumsq_ptr), "smg_solve_iter_residual")
+
+    def iter_cycle(self, d_sumsq_ptr):
+        _chk(self.L.smg_solve_iter_cycle(self.h, d_sumsq_ptr), "smg_solve_iter_cycle")
+
+    def outer_iterations(self, n):
+        _chk(self.L.smg_raw_outer_iteration(self.h, n), "smg_raw_outer_iteration")
+
+    def poll(self):
+        done, nh = C.c_int(), C.c_int()
+        _chk(self.L.smg_solve_poll(self.h, C.byref(done), C.byref(nh)), "smg_solve_poll")
+        return bool(done.value), nh.value
+
+    def solve_end(self, z_ptr, ld_z, memspace=SMG_DEVICE, max_iter=None):
+        cap = max(max_iter or self._opts.c.max_iter, 1)
+        r_his = np.zeros(max(cap, 1024))
+        n_his, conv = C.c_int(0), C.c_int(0)
+        _chk(self.L.smg_solve_end(self.h, z_ptr, ld_z, memspace, _dp(r_his), C.byref(n_his), C.byref(conv)),
+             "smg_solve_end")
+        return bool(conv.value), r_his[: n_his.value].copy()
+
+    def raw_spmv(self, lv, mode, x_ptr, b_ptr, y_ptr, k=1):
+        _chk(self.L.smg_raw_spmv(self.h, lv, mode, x_ptr, b_ptr, y_ptr, k), "smg_raw_spmv")
+
+    def raw_relax(self, lv, b_ptr, u_ptr, k=1, iters=1):
+        _chk(self.L.smg_raw_relax(self.h, lv, b_ptr, u_ptr, k, iters), "smg_raw_relax")
+
+    def synchronize(self):
+        _chk(self.L.smg_synchronize(self.h), "smg_synchronize")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's free functions
+
+def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1):
+    """mg_precompute(V, F, ratio, nVCoarsest, dec_type, mg)  (src/mg_precompute.cpp:15-87) -> Hierarchy."""
+    L = _lib.load()
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    F = np.ascontiguousarray(F, dtype=np.int32)
+    out = C.c_void_p()
+    _chk(L.smg_mg_precompute(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, C.byref(out)),
+         "smg_mg_precompute")
+    return Hierarchy(handle=out.value)
+
+
+def mg_precompute_subdiv(V, F, n_sub, ratio=0.25, nVCoarsest=500, n_extra_levels=-1):
+    """Hierarchy of a mid-point-subdivided mesh (benchmark configs C3/C5).  Returns (mg, V_fine, F_fine)."""
+    L = _lib.load()
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    F = np.ascontiguousarray(F, dtype=np.int32)
+    nV, nF = V.shape[0], F.shape[0]
+    # closed-form sizes: every step adds one vertex per edge and quadruples the faces
+    nv, nf = nV, nF
+    he = set()
+    if n_sub > 0:
+        E0 = np.sort(np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]]), axis=1)
+        ne = np.unique(E0, axis=0).shape[0]
+        for _ in range(n_sub):
+            nv, ne, nf = nv + ne, 2 * ne + 3 * nf, 4 * nf
+    Vo = np.zeros((nv, 3))
+    Fo = np.zeros((nf, 3), dtype=np.int32)
+    out = C.c_void_p()
+    _chk(L.smg_mg_precompute_subdiv(_dp(V), nV, _ip(F), nF, n_sub, ratio, nVCoarsest, n_extra_levels, C.byref(out),
+                                    _dp(Vo), _ip(Fo)), "smg_mg_precompute_subdiv")
+    return Hierarchy(handle=out.value), Vo, Fo
+
+
+class min_quad_with_fixed_mg_data:
+    """min_quad_with_fixed_mg_data (src/min_quad_with_fixed_mg.h:22-29); LHS/Auk live in the Hierarchy."""
+
+    def __init__(self, mg):
+        self.n = mg.n
+        self.known = mg.known if mg.known is not None else np.zeros(0, np.int32)
+        self.unknown = mg.unknown()
+
+
+def min_quad_with_fixed_mg_precompute(A, known, mg):
+    """min_quad_with_fixed_mg_precompute(A, [known,] data, mg, solver)  (src/min_quad_with_fixed_mg.cpp:3-51, :137-257).
+    Returns `data`; the coarse `solver` is owned by `mg`."""
+    mg.precompute(A, known)
+    return min_quad_with_fixed_mg_data(mg)
+
+
+def min_quad_with_fixed_mg_solve(data, RHS, known_val, z0, mg, tol=1e-3, maxIter=20, opts=None):
+    """bool min_quad_with_fixed_mg_solve(data, RHS, [known_val,] z0, solver, [tol, [maxIter,]] mg, z, r_his)
+    (src/min_quad_with_fixed_mg.cpp:80-135, :288-361).  Returns (converged, z, r_his)."""
+    o = opts or SolveOpts(tol=tol, max_iter=maxIter)
+    return mg.solve(RHS, z0, known_val, o)
+
+
+def mg_VCycle(mg, B, preRelaxIter, postRelaxIter, lv, u):
+    """mg_VCycle(solver, B, pre, post, lv, u, mg)  (src/mg_VCycle.cpp:3-59).  Returns the updated u."""
+    return mg.vcycle(B, u, lv, preRelaxIter, postRelaxIter)

@@ -1,0 +1,1147 @@
+// smg_capi.cpp -- implementation of the C ABI declared in include/smg.h.
+//
+// Host orchestration of the reference's solve path on one MI355X:
+//   min_quad_with_fixed_mg_precompute  (reference src/min_quad_with_fixed_mg.cpp:3-51, :137-257)  -> smg_precompute
+//   min_quad_with_fixed_mg_solve       (reference src/min_quad_with_fixed_mg.cpp:80-135, :288-361) -> smg_solve*
+//   mg_VCycle and its pieces           (reference src/mg_VCycle.cpp:3-201)                          -> enqueue_vcycle
+// The V-cycle never leaves the GPU: every kernel is enqueued on the handle's stream, the outer loop's
+// break test runs on the device (Ctrl, smg_device.hpp) and one outer iteration is replayed as a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/smg.h"
+#include "smg_hier.hpp"
+#include "smg_mesh.hpp"
+
+using namespace smg;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) return fail(SMG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" const char* smg_last_error(void) { return g_err.c_str(); }
+extern "C" int smg_version(void) { return SMG_VERSION; }
+extern "C" int smg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" void smg_solve_opts_default(smg_solve_opts* o)
+{
+    if (!o) return;
+    o->tol = 1e-3;       // reference src/min_quad_with_fixed_mg.cpp:63, :270
+    o->max_iter = 20;    // :77, :285
+    o->pre = 2;          // :102, :324
+    o->post = 2;         // :103, :325
+    o->verbosity = 0;
+    o->check_every = 1;
+    o->use_graph = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ device plumbing
+static int ensure_device(smg_hierarchy* h)
+{
+    if (h->device >= 0) return SMG_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SMG_ERR_NO_DEVICE, "no HIP device: libsmg has no CPU fallback (the CPU oracle lives in oracle/)");
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    h->device = dev;
+    if (!h->stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    HIPCHK(h->d_ctrl.alloc(1));
+    HIPCHK(hipMemset(h->d_ctrl.p, 0, sizeof(Ctrl)));
+    return SMG_OK;
+}
+
+static void drop_graphs(smg_hierarchy* h)
+{
+    if (h->g_iter) (void)hipGraphExecDestroy(h->g_iter);
+    if (h->g_resid) (void)hipGraphExecDestroy(h->g_resid);
+    if (h->g_cycle) (void)hipGraphExecDestroy(h->g_cycle);
+    h->g_iter = h->g_resid = h->g_cycle = nullptr;
+    h->g_k = 0;
+}
+
+hipError_t SellBuf::upload(const Sell& S)
+{
+    hipError_t e;
+    if ((e = slice_row.upload(S.slice_row)) != hipSuccess) return e;
+    if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
+    if ((e = col.upload(S.col)) != hipSuccess) return e;
+    if ((e = val.upload(S.val)) != hipSuccess) return e;
+    view.n_rows = S.n_rows; view.n_cols = S.n_cols; view.n_slices = S.n_slices;
+    view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.col = col.p; view.val = val.p;
+    color_slice_ptr = S.color_slice_ptr;
+    stored = S.nnz; padded = S.padded();
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------ profc mirror
+static int prof_scope_id(smg_hierarchy* h, const char* name)
+{
+    for (size_t i = 0; i < h->scopes.size(); i++) if (h->scopes[i].name == name) return (int)i;
+    ProfScope s; s.name = name;
+    h->scopes.push_back(s);
+    return (int)h->scopes.size() - 1;
+}
+static hipEvent_t prof_event(smg_hierarchy* h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfGuard {  // PROFC_NODE(name) (reference src/profc.h:9-13), timed on the GPU timeline
+    smg_hierarchy* h; int idx = -1;
+    ProfGuard(smg_hierarchy* hh, const char* name) : h(hh)
+    {
+        if (!h->prof_on) return;
+        ProfRec r; r.scope = prof_scope_id(h, name); r.e0 = prof_event(h); r.e1 = prof_event(h);
+        (void)hipEventRecord(r.e0, h->stream);
+        h->recs.push_back(r);
+        idx = (int)h->recs.size() - 1;
+    }
+    ~ProfGuard() { if (idx >= 0) (void)hipEventRecord(h->recs[idx].e1, h->stream); }
+};
+static void prof_collect(smg_hierarchy* h)
+{
+    if (h->recs.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { h->scopes[r.scope].ms += ms; h->scopes[r.scope].count++; }
+        h->ev_pool.push_back(r.e0); h->ev_pool.push_back(r.e1);
+    }
+    h->recs.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ container
+extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
+{
+    if (n_levels < 1) { fail(SMG_ERR_INVALID, "n_levels must be >= 1"); return nullptr; }
+    smg_hierarchy* h = new (std::nothrow) smg_hierarchy();
+    if (!h) { fail(SMG_ERR_ALLOC, "out of memory"); return nullptr; }
+    h->n_levels = n_levels;
+    h->lv.resize(n_levels);
+    return h;
+}
+
+extern "C" void smg_hierarchy_destroy(smg_hierarchy* h)
+{
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int smg_hierarchy_levels(const smg_hierarchy* h) { return h ? h->n_levels : SMG_ERR_INVALID; }
+
+extern "C" int smg_hierarchy_set_stream(smg_hierarchy* h, void* hip_stream)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    if (!hip_stream && h->device >= 0) {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return SMG_OK;
+}
+
+static int set_prolong(smg_hierarchy* h, int lv, Csr&& P)
+{
+    Level& L = h->lv[lv];
+    L.P_full = std::move(P);          // reference src/mg_precompute.cpp:76
+    L.P = L.P_full;                   // :74
+    L.PT = transpose(L.P);            // :75
+    h->precomputed = false;
+    return SMG_OK;
+}
+
+extern "C" int smg_level_set_prolong(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* rowptr,
+                                     const int* col, const double* val)
+{
+    if (!h || lv < 1 || lv >= h->n_levels || !rowptr || n_fine < 0 || n_coarse < 0)
+        return fail(SMG_ERR_INVALID, "smg_level_set_prolong: bad arguments (lv=%d)", lv);
+    return set_prolong(h, lv, csr_from_arrays(n_fine, n_coarse, rowptr, col, val));
+}
+
+extern "C" int smg_level_set_prolong_csc(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* colptr,
+                                         const int* rowidx, const double* val)
+{
+    if (!h || lv < 1 || lv >= h->n_levels || !colptr || n_fine < 0 || n_coarse < 0)
+        return fail(SMG_ERR_INVALID, "smg_level_set_prolong_csc: bad arguments (lv=%d)", lv);
+    return set_prolong(h, lv, csr_from_csc_arrays(n_fine, n_coarse, colptr, rowidx, val));
+}
+
+extern "C" int smg_level_set_mesh(smg_hierarchy* h, int lv, const double* V, int nV, const int* F, int nF)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_set_mesh: bad level");
+    h->lv[lv].V.assign(V, V + (size_t)nV * 3);
+    h->lv[lv].F.assign(F, F + (size_t)nF * 3);
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ precompute
+// Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
+static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known)
+{
+    const int n = A.nr;
+    const int L = h->n_levels;
+    h->n_full = n;
+    h->has_known = (known != nullptr && n_known > 0);
+    h->known.clear(); h->unknown.clear();
+    for (int lv = 1; lv < L; lv++) {
+        if (h->lv[lv].P_full.empty()) return fail(SMG_ERR_INVALID, "level %d has no prolongation (smg_level_set_prolong)", lv);
+        h->lv[lv].P = h->lv[lv].P_full;  // always restart from P_full (see smg.h)
+    }
+    if (L > 1 && h->lv[1].P_full.nr != n)
+        return fail(SMG_ERR_INVALID, "A is %d x %d but P_1 has %d rows", n, n, h->lv[1].P_full.nr);
+    if (!h->has_known) {
+        // reference src/min_quad_with_fixed_mg.cpp:17-22
+        h->lv[0].A = std::move(A);
+        h->Auk = Csr();
+        for (int lv = 1; lv < L; lv++) h->lv[lv].PT = transpose(h->lv[lv].P);
+    } else {
+        // unknown = setdiff(0..n-1, known), ascending (:155-158); known keeps the caller's order (:178)
+        std::vector<char> isk(n, 0);
+        for (int i = 0; i < n_known; i++) {
+            if (known[i] < 0 || known[i] >= n) return fail(SMG_ERR_INVALID, "known[%d] = %d out of range", i, known[i]);
+            isk[known[i]] = 1;
+        }
+        h->known.assign(known, known + n_known);
+        for (int i = 0; i < n; i++) if (!isk[i]) h->unknown.push_back(i);
+        h->lv[0].A = slice(A, &h->unknown, &h->unknown);  // LHS = A(unknown, unknown)   (:166-167, :175)
+        h->Auk = slice(A, &h->unknown, &h->known);        // Auk = A(unknown, known)     (:169-170, :176)
+        if (L > 1) {
+            h->lv[1].P = slice(h->lv[1].P_full, &h->unknown, nullptr);  // :185
+            for (int lv = 1; lv < L; lv++) {
+                Csr& P = h->lv[lv].P;
+                // keep the columns holding at least one entry > 1e-15 (:190-203)
+                std::vector<char> keepflag(P.nc, 0);
+                for (long p = 0; p < P.nnz(); p++) if (P.val[p] > 1e-15) keepflag[P.col[p]] = 1;
+                std::vector<int> keep;
+                for (int c = 0; c < P.nc; c++) if (keepflag[c]) keep.push_back(c);
+                if ((int)keep.size() < P.nc) {                                   // :206
+                    P = slice(P, nullptr, &keep);                                // :210-211
+                    if (lv < L - 1) h->lv[lv + 1].P = slice(h->lv[lv + 1].P_full, &keep, nullptr);  // :213-214
+                } else break;                                                    // :216-219
+            }
+        }
+        for (int lv = 1; lv < L; lv++) h->lv[lv].PT = transpose(h->lv[lv].P);  // :226
+    }
+    // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
+    for (int lv = 1; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        if (Lv.P.nr != h->lv[lv - 1].A.nr)
+            return fail(SMG_ERR_INVALID, "P_%d has %d rows but level %d has %d unknowns", lv, Lv.P.nr, lv - 1, h->lv[lv - 1].A.nr);
+        Csr tmp = spgemm(Lv.PT, h->lv[lv - 1].A);
+        Lv.A = spgemm(tmp, Lv.P);
+    }
+    // small diagonal shift on the coarsest level only (:32-36, :236-241)
+    {
+        Csr& Ac = h->lv[L - 1].A;
+        for (int i = 0; i < Ac.nr; i++) {
+            bool found = false;
+            for (int p = Ac.ptr[i]; p < Ac.ptr[i + 1]; p++) if (Ac.col[p] == i) { Ac.val[p] += 1e-12; found = true; break; }
+            if (!found) return fail(SMG_ERR_INVALID, "coarsest matrix has no stored diagonal at row %d", i);
+        }
+    }
+    for (int lv = 0; lv < L; lv++) {                       // A_diag (:39-41, :244-246)
+        h->lv[lv].A_diag = diagonal(h->lv[lv].A);
+        h->lv[lv].n = h->lv[lv].A.nr;
+    }
+    return SMG_OK;
+}
+
+// Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
+static int precompute_device(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        // smoothed levels get the colour-major numbering; the coarsest is only ever hit by the dense solve
+        Lv.ord = (lv < L - 1) ? make_ordering(Lv.A) : identity_ordering(Lv.n);
+        Lv.b.release(); Lv.u.release(); Lv.r.release();
+    }
+    h->kcap = 0;
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        if (lv < L - 1) {
+            Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm);
+            Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr);
+            HIPCHK(Lv.dA.upload(S));
+        } else {
+            Lv.A_int = Lv.A;
+        }
+        if (lv >= 1) {
+            const Ordering& of = h->lv[lv - 1].ord;
+            Lv.P_int = permute(Lv.P, of.perm, Lv.ord.perm);
+            Lv.PT_int = permute(Lv.PT, Lv.ord.perm, of.perm);
+            Sell SP = build_sell(Lv.P_int, nullptr);
+            Sell SPT = build_sell(Lv.PT_int, nullptr);
+            HIPCHK(Lv.dP.upload(SP));
+            HIPCHK(Lv.dPT.upload(SPT));
+        }
+    }
+    // level-0 index maps
+    {
+        const Level& L0 = h->lv[0];
+        std::vector<int> map0(L0.n);
+        for (int i = 0; i < L0.n; i++) map0[i] = h->has_known ? h->unknown[L0.ord.perm[i]] : L0.ord.perm[i];
+        HIPCHK(h->d_map0.upload(map0));
+        HIPCHK(h->d_perm0.upload(L0.ord.perm));
+        if (h->has_known) {
+            HIPCHK(h->d_unknown.upload(h->unknown));
+            HIPCHK(h->d_known.upload(h->known));
+            HIPCHK(h->d_auk_ptr.upload(h->Auk.ptr));
+            HIPCHK(h->d_auk_col.upload(h->Auk.col));
+            HIPCHK(h->d_auk_val.upload(h->Auk.val));
+        }
+    }
+    // coarsest level: dense inverse on the device (stands in for solver.compute(Ac), :47-48 / :253-254)
+    {
+        const Level& Lc = h->lv[L - 1];
+        const int nc = Lc.n;
+        const int np = ((nc + 63) / 64) * 64;
+        h->nc = nc; h->nc_pad = np;
+        std::vector<double> dense((size_t)np * np, 0.0);
+        for (int i = nc; i < np; i++) dense[(size_t)i * np + i] = 1.0;
+        for (int i = 0; i < nc; i++)
+            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) dense[(size_t)i * np + Lc.A.col[p]] = Lc.A.val[p];
+        HIPCHK(h->d_Ainv.upload(dense));
+        DevBuf<double> work;
+        HIPCHK(work.alloc((size_t)2 * np * 32 + 32 * 32));
+        HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
+                              const int* known, int n_known)
+{
+    if (!h || n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_precompute: bad arguments");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute called between smg_solve_begin and smg_solve_end");
+    h->precomputed = false;
+    int rc = precompute_host(h, csr_from_arrays(n, n, rowptr, col, val), known, n_known);
+    if (rc != SMG_OK) return rc;
+    rc = ensure_device(h);
+    if (rc != SMG_OK) return rc;
+    rc = precompute_device(h);
+    if (rc != SMG_OK) return rc;
+    h->precomputed = true;
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ V-cycle
+static int ensure_work(smg_hierarchy* h, int k)
+{
+    if (k <= h->kcap) return SMG_OK;
+    drop_graphs(h);
+    const int L = h->n_levels;
+    size_t maxblocks = 0;
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        size_t rows = (lv == L - 1) ? (size_t)h->nc_pad : (size_t)Lv.n;
+        HIPCHK(Lv.b.alloc(rows * k));
+        HIPCHK(Lv.u.alloc(rows * k));
+        HIPCHK(hipMemsetAsync(Lv.b.p, 0, rows * k * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
+        if (lv < L - 1) HIPCHK(Lv.r.alloc(rows * k));
+        if (lv < L - 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4));
+    }
+    HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
+    h->kcap = k;
+    return SMG_OK;
+}
+
+// `iters` forward Gauss-Seidel sweeps: one launch per colour (reference relax(), src/mg_VCycle.cpp:113-178)
+static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl)
+{
+    Level& Lv = h->lv[lv];
+    ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
+    const std::vector<int>& cs = Lv.dA.color_slice_ptr;
+    for (int it = 0; it < iters; it++)
+        for (size_t c = 0; c + 1 < cs.size(); c++)
+            HIPCHK(launch_sell(SELL_GS, Lv.dA.view, cs[c], cs[c + 1], u, b, u, k, ctrl, nullptr, nullptr, h->stream));
+    return SMG_OK;
+}
+
+// reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
+static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+{
+    const int L = h->n_levels;
+    Level& Lv = h->lv[lv];
+    if (lv == L - 1) {  // coarseSolve: u = u + solver.solve(B)  (:28-33, :199-200)
+        ProfGuard pg(h, "MG: coarse solve");
+        HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, ctrl, h->stream));
+        return SMG_OK;
+    }
+    Level& Lc = h->lv[lv + 1];
+    int rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, pre, ctrl);  // :36
+    if (rc) return rc;
+    {   // r = B - A u  (:40-42)
+        ProfGuard pg(h, "MG: residual");
+        HIPCHK(launch_sell(SELL_RESID, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, Lv.r.p, k, ctrl, nullptr, nullptr, h->stream));
+    }
+    {   // rc = PT r  (:43-44, :80)
+        ProfGuard pg(h, "MG: restrict");
+        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream));
+    }
+    // uc = 0  (:46-47).  Skipped iterations leave garbage-free state: a memset is harmless after `done`.
+    HIPCHK(hipMemsetAsync(Lc.u.p, 0, (size_t)Lc.n * k * sizeof(double), h->stream));
+    rc = enqueue_vcycle(h, lv + 1, k, pre, post, ctrl);  // :48
+    if (rc) return rc;
+    {   // u = u + P uc  (:51-53, :91)
+        ProfGuard pg(h, "MG: prolong");
+        HIPCHK(launch_sell(SELL_ADD, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.u.p, k, ctrl, nullptr, nullptr, h->stream));
+    }
+    return enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, post, ctrl);  // :57
+}
+
+// sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
+static int enqueue_residual_ss(smg_hierarchy* h, int k)
+{
+    Level& L0 = h->lv[0];
+    ProfGuard pg(h, "MG: outer residual");
+    int nb = 0;
+    if (h->n_levels == 1) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, mg_precompute.cpp:39)");
+    HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
+    HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+    return SMG_OK;
+}
+
+static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
+{
+    HIPCHK(launch_decide(h->d_ctrl.p, d_sumsq, h->stream));
+    {
+        ProfGuard pg(h, "MG: total VCycle");  // PROFC_NODE at src/min_quad_with_fixed_mg.cpp:123
+        int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p);
+        if (rc) return rc;
+    }
+    HIPCHK(launch_count_cycle(h->d_ctrl.p, h->stream));
+    return SMG_OK;
+}
+
+template <typename Fn>
+static int capture_graph(smg_hierarchy* h, hipGraphExec_t* out, Fn&& body)
+{
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = body();
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(SMG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(SMG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    return SMG_OK;
+}
+
+static int ensure_graphs(smg_hierarchy* h)
+{
+    if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post) return SMG_OK;
+    drop_graphs(h);
+    const int k = h->k;
+    int rc = capture_graph(h, &h->g_iter, [&]() {
+        int r = enqueue_residual_ss(h, k);
+        if (r) return r;
+        return enqueue_cycle_part(h, k, &h->d_ctrl.p->sumsq);
+    });
+    if (rc) return rc;
+    rc = capture_graph(h, &h->g_resid, [&]() { return enqueue_residual_ss(h, k); });
+    if (rc) return rc;
+    h->g_k = k; h->g_pre = h->pre; h->g_post = h->post;
+    return SMG_OK;
+}
+
+static bool graphs_usable(const smg_hierarchy* h) { return h->use_graph && !h->prof_on; }
+
+// one full outer iteration, single-GPU form
+static int enqueue_outer_iteration(smg_hierarchy* h)
+{
+    if (graphs_usable(h)) {
+        int rc = ensure_graphs(h);
+        if (rc) return rc;
+        HIPCHK(hipGraphLaunch(h->g_iter, h->stream));
+    } else {
+        int rc = enqueue_residual_ss(h, h->k);
+        if (rc) return rc;
+        rc = enqueue_cycle_part(h, h->k, &h->d_ctrl.p->sumsq);
+        if (rc) return rc;
+    }
+    h->iters_enqueued++;
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ solve
+static int check_ready(const smg_hierarchy* h, const char* who)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "%s: null handle", who);
+    if (!h->precomputed) return fail(SMG_ERR_INVALID, "%s: call smg_precompute first", who);
+    if (h->device < 0) return fail(SMG_ERR_NO_DEVICE, "%s: no HIP device", who);
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
+                               const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts)
+{
+    int rc = check_ready(h, "smg_solve_begin");
+    if (rc) return rc;
+    smg_solve_opts o;
+    smg_solve_opts_default(&o);
+    if (opts) o = *opts;
+    const int n = h->n_full;
+    if (!RHS || !z0 || k < 1 || ld_rhs < n || ld_z0 < n) return fail(SMG_ERR_INVALID, "smg_solve: bad RHS/z0/k/ld");
+    if (o.max_iter < 0 || o.max_iter > SMG_MAX_HIS) return fail(SMG_ERR_INVALID, "max_iter must be in [0, %d]", SMG_MAX_HIS);
+    if (h->has_known && (!known_val || ld_kv < (int)h->known.size())) return fail(SMG_ERR_INVALID, "known_val missing or ld_kv too small");
+    h->tol = o.tol; h->max_iter = o.max_iter; h->pre = o.pre; h->post = o.post; h->verbosity = o.verbosity;
+    h->check_every = std::max(1, o.check_every); h->use_graph = o.use_graph;
+    rc = ensure_work(h, k);
+    if (rc) return rc;
+    h->k = k;
+    const int nk = (int)h->known.size();
+    // stage host inputs
+    const double *dR = RHS, *dZ = z0, *dK = known_val;
+    int ldR = ld_rhs, ldZ = ld_z0, ldK = ld_kv;
+    if (memspace == SMG_HOST) {
+        HIPCHK(h->d_stage_rhs.ensure((size_t)n * k));
+        HIPCHK(h->d_stage_z.ensure((size_t)n * k));
+        HIPCHK(hipMemcpy2DAsync(h->d_stage_rhs.p, (size_t)n * 8, RHS, (size_t)ld_rhs * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpy2DAsync(h->d_stage_z.p, (size_t)n * 8, z0, (size_t)ld_z0 * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
+        dR = h->d_stage_rhs.p; dZ = h->d_stage_z.p; ldR = n; ldZ = n;
+        if (h->has_known) {
+            HIPCHK(h->d_stage_kv.ensure((size_t)nk * k));
+            HIPCHK(hipMemcpy2DAsync(h->d_stage_kv.p, (size_t)nk * 8, known_val, (size_t)ld_kv * 8, (size_t)nk * 8, k, hipMemcpyHostToDevice, h->stream));
+            dK = h->d_stage_kv.p; ldK = nk;
+        }
+    } else if (h->has_known) {
+        // keep a private copy: the caller may reuse its buffer before smg_solve_end scatters z(known)
+        HIPCHK(h->d_stage_kv.ensure((size_t)nk * k));
+        HIPCHK(hipMemcpy2DAsync(h->d_stage_kv.p, (size_t)nk * 8, known_val, (size_t)ld_kv * 8, (size_t)nk * 8, k, hipMemcpyDeviceToDevice, h->stream));
+        dK = h->d_stage_kv.p; ldK = nk;
+    }
+    h->cur_kv = dK; h->cur_ld_kv = ldK;
+    Level& L0 = h->lv[0];
+    // z_u = z0(unknown)  (:310-311)  /  z = z0 (:97)
+    HIPCHK(launch_gather_in(L0.u.p, dZ, h->d_map0.p, L0.n, k, ldZ, h->stream));
+    if (h->has_known) {
+        // RHS_u = RHS(unknown) - Auk * known_val  (:316-318)
+        const int nu = L0.n;
+        HIPCHK(h->d_tmp_cm.ensure((size_t)nu * k));
+        HIPCHK(launch_gather_cm(h->d_tmp_cm.p, dR, h->d_unknown.p, nu, k, ldR, nu, h->stream));
+        HIPCHK(launch_csr_sub(nu, h->d_auk_ptr.p, h->d_auk_col.p, h->d_auk_val.p, dK, ldK, h->d_tmp_cm.p, nu, k, h->stream));
+        HIPCHK(launch_gather_in(L0.b.p, h->d_tmp_cm.p, h->d_perm0.p, nu, k, nu, h->stream));
+    } else {
+        HIPCHK(launch_gather_in(L0.b.p, dR, h->d_map0.p, L0.n, k, ldR, h->stream));
+    }
+    Ctrl zero;
+    std::memset(&zero, 0, sizeof(zero));
+    zero.tol = h->tol;
+    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, offsetof(Ctrl, r_his), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // `zero` lives on this stack frame
+    h->iters_enqueued = 0;
+    h->in_solve = true;
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_residual: no solve in progress");
+    if (graphs_usable(h)) {
+        int rc = ensure_graphs(h);
+        if (rc) return rc;
+        HIPCHK(hipGraphLaunch(h->g_resid, h->stream));
+    } else {
+        int rc = enqueue_residual_ss(h, h->k);
+        if (rc) return rc;
+    }
+    if (d_sumsq) HIPCHK(hipMemcpyAsync(d_sumsq, &h->d_ctrl.p->sumsq, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_iter_cycle(smg_hierarchy* h, const double* d_sumsq)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle: no solve in progress");
+    const double* src = d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq;
+    // (eager: the external sumsq pointer changes the decide kernel's argument, so no cached graph here)
+    int rc = enqueue_cycle_part(h, h->k, src);
+    if (rc) return rc;
+    h->iters_enqueued++;
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_poll(smg_hierarchy* h, int* done, int* n_his)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_poll: no solve in progress");
+    int hdr[4];
+    HIPCHK(hipMemcpyAsync(hdr, h->d_ctrl.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (done) *done = hdr[0];
+    if (n_his) *n_his = hdr[1];
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace, double* r_his, int* n_his, int* converged)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_end: no solve in progress");
+    const int n = h->n_full, k = h->k;
+    if (!z || ld_z < n) return fail(SMG_ERR_INVALID, "smg_solve_end: bad z / ld_z");
+    Level& L0 = h->lv[0];
+    double* dz = z;
+    int ldz = ld_z;
+    if (memspace == SMG_HOST) {
+        HIPCHK(h->d_stage_z.ensure((size_t)n * k));
+        dz = h->d_stage_z.p; ldz = n;
+    }
+    // z(unknown) = z_u ; z(known) = known_val  (:353-355)
+    HIPCHK(launch_scatter_out(dz, L0.u.p, h->d_map0.p, L0.n, k, ldz, h->stream));
+    if (h->has_known)
+        HIPCHK(launch_scatter_cm(dz, h->cur_kv, h->d_known.p, (int)h->known.size(), k, h->cur_ld_kv, ldz, h->stream));
+    if (memspace == SMG_HOST)
+        HIPCHK(hipMemcpy2DAsync(z, (size_t)ld_z * 8, dz, (size_t)n * 8, (size_t)n * 8, k, hipMemcpyDeviceToHost, h->stream));
+    static thread_local Ctrl hc;
+    HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->in_solve = false;
+    prof_collect(h);
+    const int cnt = std::min(hc.n_his, SMG_MAX_HIS);
+    if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = hc.r_his[i];
+    if (n_his) *n_his = cnt;
+    const double last = cnt > 0 ? hc.r_his[cnt - 1] : HUGE_VAL;
+    if (converged) *converged = (last > h->tol) ? 0 : 1;  // :131-134 / :357-360
+    if (h->verbosity > 0) {
+        for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, hc.r_his[i]);  // :111
+        if (cnt) std::printf("residual norm: %g\n", hc.r_his[cnt - 1]);                                    // :127
+    }
+    if (hc.status != 0) return fail(SMG_ERR_NONFINITE, "non-finite residual at iteration %d", cnt - 1);
+    return SMG_OK;
+}
+
+extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
+                         const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts, double* z, int ld_z,
+                         double* r_his, int* n_his, int* converged)
+{
+    int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
+    if (rc) return rc;
+    // for (iter < maxIter) { residual; push; if (residual < tol) break; V-cycle }   (:108-125 / :330-347)
+    // Enqueued `check_every` iterations at a time; the break happens on the device, the host only stops feeding.
+    int it = 0;
+    while (it < h->max_iter) {
+        const int chunk = std::min(h->check_every, h->max_iter - it);
+        for (int c = 0; c < chunk; c++) {
+            rc = enqueue_outer_iteration(h);
+            if (rc) { h->in_solve = false; return rc; }
+        }
+        it += chunk;
+        if (it < h->max_iter) {
+            int done = 0;
+            rc = smg_solve_poll(h, &done, nullptr);
+            if (rc) { h->in_solve = false; return rc; }
+            if (done) break;
+        }
+    }
+    return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
+}
+
+extern "C" int smg_raw_outer_iteration(smg_hierarchy* h, int n_iter)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_raw_outer_iteration: call smg_solve_begin first");
+    for (int i = 0; i < n_iter; i++) {
+        int rc = enqueue_outer_iteration(h);
+        if (rc) return rc;
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_synchronize(smg_hierarchy* h)
+{
+    if (!h || h->device < 0) return fail(SMG_ERR_INVALID, "smg_synchronize: no device");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ V-cycle pieces (host blocks)
+extern "C" int smg_level_rows(const smg_hierarchy* h, int lv)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return SMG_ERR_INVALID;
+    return h->lv[lv].n;
+}
+
+// host column-major (caller numbering of level lv) -> device internal layout
+static int put_block(smg_hierarchy* h, int lv, const double* src, int k, double* dst)
+{
+    const Level& Lv = h->lv[lv];
+    std::vector<double> tmp((size_t)Lv.n * k);
+    for (int i = 0; i < Lv.n; i++)
+        for (int c = 0; c < k; c++) tmp[(size_t)i * k + c] = src[(size_t)Lv.ord.perm[i] + (size_t)c * Lv.n];
+    HIPCHK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMG_OK;
+}
+static int get_block(smg_hierarchy* h, int lv, const double* src, int k, double* dst)
+{
+    const Level& Lv = h->lv[lv];
+    std::vector<double> tmp((size_t)Lv.n * k);
+    HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < Lv.n; i++)
+        for (int c = 0; c < k; c++) dst[(size_t)Lv.ord.perm[i] + (size_t)c * Lv.n] = tmp[(size_t)i * k + c];
+    return SMG_OK;
+}
+
+static int piece_prolog(smg_hierarchy* h, int lv, int k, const char* who, bool need_coarser)
+{
+    int rc = check_ready(h, who);
+    if (rc) return rc;
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "%s: a split-phase solve is in progress", who);
+    if (lv < 0 || lv >= h->n_levels || (need_coarser && lv >= h->n_levels - 1) || k < 1)
+        return fail(SMG_ERR_INVALID, "%s: bad level %d or k %d", who, lv, k);
+    return ensure_work(h, k);
+}
+
+extern "C" int smg_apply_A(smg_hierarchy* h, int lv, const double* u, int k, double* Au)
+{
+    int rc = piece_prolog(h, lv, k, "smg_apply_A", true);
+    if (rc) return rc;
+    Level& Lv = h->lv[lv];
+    if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
+    HIPCHK(launch_sell(SELL_AX, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
+    return get_block(h, lv, Lv.r.p, k, Au);
+}
+
+extern "C" int smg_restrict(smg_hierarchy* h, int lv, const double* x, int k, double* Rx)
+{
+    int rc = piece_prolog(h, lv, k, "smg_restrict", true);
+    if (rc) return rc;
+    Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
+    if ((rc = put_block(h, lv, x, k, Lv.r.p))) return rc;
+    HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, nullptr, nullptr, nullptr, h->stream));
+    return get_block(h, lv + 1, Lc.b.p, k, Rx);
+}
+
+extern "C" int smg_prolong(smg_hierarchy* h, int lv, const double* x, int k, double* Px)
+{
+    int rc = piece_prolog(h, lv, k, "smg_prolong", true);
+    if (rc) return rc;
+    Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
+    if ((rc = put_block(h, lv + 1, x, k, Lc.u.p))) return rc;
+    HIPCHK(launch_sell(SELL_AX, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
+    return get_block(h, lv, Lv.r.p, k, Px);
+}
+
+extern "C" int smg_relax(smg_hierarchy* h, int lv, const double* B, int k, int iters, double* u)
+{
+    int rc = piece_prolog(h, lv, k, "smg_relax", true);
+    if (rc) return rc;
+    Level& Lv = h->lv[lv];
+    if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
+    if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
+    if ((rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, iters, nullptr))) return rc;
+    return get_block(h, lv, Lv.u.p, k, u);
+}
+
+extern "C" int smg_coarse_solve(smg_hierarchy* h, const double* B, int k, double* u)
+{
+    const int lv = h ? h->n_levels - 1 : 0;
+    int rc = piece_prolog(h, lv, k, "smg_coarse_solve", false);
+    if (rc) return rc;
+    Level& Lv = h->lv[lv];
+    if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
+    if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
+    HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, nullptr, h->stream));
+    return get_block(h, lv, Lv.u.p, k, u);
+}
+
+extern "C" int smg_vcycle(smg_hierarchy* h, const double* B, int pre, int post, int lv, double* u, int k)
+{
+    int rc = piece_prolog(h, lv, k, "smg_vcycle", false);
+    if (rc) return rc;
+    Level& Lv = h->lv[lv];
+    if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
+    if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
+    if ((rc = enqueue_vcycle(h, lv, k, pre, post, nullptr))) return rc;
+    return get_block(h, lv, Lv.u.p, k, u);
+}
+
+extern "C" int smg_residual_norm(smg_hierarchy* h, int lv, const double* B, const double* u, int k, double* norm)
+{
+    int rc = piece_prolog(h, lv, k, "smg_residual_norm", true);
+    if (rc) return rc;
+    Level& Lv = h->lv[lv];
+    if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
+    if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
+    int nb = 0;
+    Ctrl zero;
+    std::memset(&zero, 0, sizeof(zero));
+    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, offsetof(Ctrl, r_his), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(launch_sell(SELL_RESID_SS, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, nullptr, k, nullptr, h->d_partials.p, &nb, h->stream));
+    HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+    double ss = 0.0;
+    HIPCHK(hipMemcpyAsync(&ss, &h->d_ctrl.p->sumsq, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *norm = std::sqrt(ss);
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ raw device interface
+extern "C" int smg_raw_spmv(smg_hierarchy* h, int lv, int mode, const double* x, const double* b, double* y, int k)
+{
+    int rc = check_ready(h, "smg_raw_spmv");
+    if (rc) return rc;
+    if (lv < 0 || lv >= h->n_levels - 1 || k < 1 || (mode != SELL_AX && mode != SELL_RESID && mode != SELL_ADD))
+        return fail(SMG_ERR_INVALID, "smg_raw_spmv: bad level/mode");
+    Level& Lv = h->lv[lv];
+    HIPCHK(launch_sell((SellMode)mode, Lv.dA.view, 0, Lv.dA.view.n_slices, x, b, y, k, nullptr, nullptr, nullptr, h->stream));
+    return SMG_OK;
+}
+
+extern "C" int smg_raw_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters)
+{
+    int rc = check_ready(h, "smg_raw_relax");
+    if (rc) return rc;
+    if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_relax: bad level");
+    return enqueue_relax(h, lv, b, u, k, iters, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ introspection
+static const Csr* pick_matrix(const smg_hierarchy* h, int lv, int which, int internal)
+{
+    const Level& Lv = h->lv[lv];
+    switch (which) {
+        case 0: return internal ? &Lv.A_int : &Lv.A;
+        case 1: return lv >= 1 ? (internal ? &Lv.P_int : &Lv.P) : nullptr;
+        case 2: return lv >= 1 ? (internal ? &Lv.PT_int : &Lv.PT) : nullptr;
+        case 3: return (lv >= 1 && !internal) ? &Lv.P_full : nullptr;
+        case 4: return (lv == 0 && !internal) ? &h->Auk : nullptr;
+    }
+    return nullptr;
+}
+
+extern "C" int smg_level_get_matrix(const smg_hierarchy* h, int lv, int which, int internal, int* n_rows, int* n_cols,
+                                    int* nnz, int* rowptr, int* col, double* val)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: bad level");
+    const Csr* M = pick_matrix(h, lv, which, internal);
+    if (!M) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: no such matrix");
+    if (n_rows) *n_rows = M->nr;
+    if (n_cols) *n_cols = M->nc;
+    if (nnz) *nnz = (int)M->nnz();
+    if (rowptr) { if (M->ptr.empty()) rowptr[0] = 0; else std::copy(M->ptr.begin(), M->ptr.end(), rowptr); }
+    if (col) std::copy(M->col.begin(), M->col.end(), col);
+    if (val) std::copy(M->val.begin(), M->val.end(), val);
+    return SMG_OK;
+}
+
+extern "C" int smg_level_get_perm(const smg_hierarchy* h, int lv, int* perm)
+{
+    if (!h || lv < 0 || lv >= h->n_levels || !perm) return fail(SMG_ERR_INVALID, "smg_level_get_perm: bad arguments");
+    std::copy(h->lv[lv].ord.perm.begin(), h->lv[lv].ord.perm.end(), perm);
+    return SMG_OK;
+}
+
+extern "C" int smg_level_get_colors(const smg_hierarchy* h, int lv, int* n_colors, int* color_ptr)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_colors: bad level");
+    const Ordering& o = h->lv[lv].ord;
+    if (n_colors) *n_colors = o.n_colors();
+    if (color_ptr) std::copy(o.color_ptr.begin(), o.color_ptr.end(), color_ptr);
+    return SMG_OK;
+}
+
+extern "C" int smg_level_get_Adiag(const smg_hierarchy* h, int lv, double* diag)
+{
+    if (!h || lv < 0 || lv >= h->n_levels || !diag) return fail(SMG_ERR_INVALID, "smg_level_get_Adiag: bad arguments");
+    std::copy(h->lv[lv].A_diag.begin(), h->lv[lv].A_diag.end(), diag);
+    return SMG_OK;
+}
+
+extern "C" int smg_get_unknown(const smg_hierarchy* h, int* n_unknown, int* unknown)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    if (n_unknown) *n_unknown = h->has_known ? (int)h->unknown.size() : h->n_full;
+    if (unknown) {
+        if (h->has_known) std::copy(h->unknown.begin(), h->unknown.end(), unknown);
+        else for (int i = 0; i < h->n_full; i++) unknown[i] = i;
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_level_sell_stats(const smg_hierarchy* h, int lv, int which, long* stored, long* padded, int* n_slices)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_sell_stats: bad level");
+    const SellBuf* S = which == 0 ? &h->lv[lv].dA : which == 1 ? &h->lv[lv].dP : which == 2 ? &h->lv[lv].dPT : nullptr;
+    if (!S) return fail(SMG_ERR_INVALID, "smg_level_sell_stats: which must be 0,1,2");
+    if (stored) *stored = S->stored;
+    if (padded) *padded = S->padded;
+    if (n_slices) *n_slices = S->view.n_slices;
+    return SMG_OK;
+}
+
+extern "C" long smg_level_spmv_bytes(const smg_hierarchy* h, int lv, int k)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return -1;
+    const Csr& A = h->lv[lv].A;
+    return 12L * A.nnz() + 4L * (A.nr + 1) + 16L * A.nr * k;
+}
+
+// Algorithmic bytes of one outer iteration: per smoothed level
+//   (pre+post) GS sweeps: 12 nnz + 4(n+1) + 24 n k [b, u read, u write]   (the reference also reads A_diag: +8n; the
+//                          HIP kernel takes the diagonal from the row, so it is not counted)
+//   residual:             12 nnz + 4(n+1) + 24 n k
+//   restrict:             12 nnzPT + 4(nc+1) + 8 n k + 8 nc k
+//   prolong-add:          12 nnzP + 4(n+1) + 8 nc k + 16 n k
+//   + coarsest dense solve 8 nc^2 + 24 nc k, + outer residual 12 nnz0 + 4(n0+1) + 16 n0 k.
+extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int post)
+{
+    if (!h || !h->precomputed) return -1;
+    long tot = 0;
+    const int L = h->n_levels;
+    for (int lv = 0; lv < L - 1; lv++) {
+        const Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
+        const long n = Lv.n, nc = Lc.n, nnz = Lv.A.nnz(), nnzP = Lc.P.nnz();
+        const long sweep = 12 * nnz + 4 * (n + 1) + 24 * n * k;
+        tot += (long)(pre + post) * sweep;
+        tot += 12 * nnz + 4 * (n + 1) + 24 * n * k;
+        tot += 12 * nnzP + 4 * (nc + 1) + 8 * n * k + 8 * nc * k;
+        tot += 12 * nnzP + 4 * (n + 1) + 8 * nc * k + 16 * n * k;
+    }
+    const long nc = h->lv[L - 1].n;
+    tot += 8 * nc * nc + 24 * nc * k;
+    tot += 12 * h->lv[0].A.nnz() + 4L * (h->lv[0].n + 1) + 16L * h->lv[0].n * k;
+    return tot;
+}
+
+// ------------------------------------------------------------------------------------------------ profc mirror (API)
+extern "C" int smg_prof_enable(smg_hierarchy* h, int on)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    h->prof_on = on != 0;
+    return SMG_OK;
+}
+extern "C" int smg_prof_reset(smg_hierarchy* h)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    prof_collect(h);
+    for (auto& s : h->scopes) { s.count = 0; s.ms = 0.0; }
+    return SMG_OK;
+}
+extern "C" int smg_prof_count(smg_hierarchy* h)
+{
+    if (!h) return SMG_ERR_INVALID;
+    prof_collect(h);
+    return (int)h->scopes.size();
+}
+extern "C" int smg_prof_get(smg_hierarchy* h, int idx, char* name, int name_cap, long* count, double* total_ms)
+{
+    if (!h || idx < 0 || idx >= (int)h->scopes.size()) return fail(SMG_ERR_INVALID, "smg_prof_get: bad index");
+    prof_collect(h);
+    const ProfScope& s = h->scopes[idx];
+    if (name && name_cap > 0) { std::strncpy(name, s.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (count) *count = s.count;
+    if (total_ms) *total_ms = s.ms;
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mesh numerics (host)
+static Mesh wrap_mesh(const double* V, int nV, const int* F, int nF)
+{
+    Mesh m;
+    if (V) m.V.assign(V, V + (size_t)nV * 3);
+    if (F) m.F.assign(F, F + (size_t)nF * 3);
+    return m;
+}
+
+extern "C" int smg_mesh_read(const char* path, double** V, int* nV, int** F, int* nF)
+{
+    if (!path || !V || !nV || !F || !nF) return fail(SMG_ERR_INVALID, "smg_mesh_read: bad arguments");
+    Mesh m;
+    if (!read_mesh(path, m)) return fail(SMG_ERR_IO, "cannot read mesh '%s'", path);
+    *nV = m.nV(); *nF = m.nF();
+    *V = (double*)std::malloc(m.V.size() * sizeof(double) + 8);
+    *F = (int*)std::malloc(m.F.size() * sizeof(int) + 8);
+    if (!*V || !*F) return fail(SMG_ERR_ALLOC, "out of memory");
+    std::memcpy(*V, m.V.data(), m.V.size() * sizeof(double));
+    std::memcpy(*F, m.F.data(), m.F.size() * sizeof(int));
+    return SMG_OK;
+}
+extern "C" void smg_free(void* p) { std::free(p); }
+
+extern "C" int smg_mesh_normalize_unit_area(double* V, int nV, const int* F, int nF)
+{
+    if (!V || !F) return fail(SMG_ERR_INVALID, "smg_mesh_normalize_unit_area: bad arguments");
+    Mesh m = wrap_mesh(V, nV, F, nF);
+    normalize_unit_area(m);
+    std::copy(m.V.begin(), m.V.end(), V);
+    return SMG_OK;
+}
+
+extern "C" int smg_mesh_cotmatrix(const double* V, int nV, const int* F, int nF, int* nnz, int* rowptr, int* col, double* val)
+{
+    if (!V || !F) return fail(SMG_ERR_INVALID, "smg_mesh_cotmatrix: bad arguments");
+    static thread_local Csr cache;
+    static thread_local const double* cacheV = nullptr;
+    // two-call protocol (size query, then fill): keep the result of the query for the fill
+    if (!(rowptr && cacheV == V && cache.nr == nV)) { cache = cotmatrix(wrap_mesh(V, nV, F, nF)); cacheV = V; }
+    if (nnz) *nnz = (int)cache.nnz();
+    if (rowptr) {
+        std::copy(cache.ptr.begin(), cache.ptr.end(), rowptr);
+        if (col) std::copy(cache.col.begin(), cache.col.end(), col);
+        if (val) std::copy(cache.val.begin(), cache.val.end(), val);
+        cache = Csr(); cacheV = nullptr;
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_mesh_massmatrix(const double* V, int nV, const int* F, int nF, int voronoi, double* diag)
+{
+    if (!V || !F || !diag) return fail(SMG_ERR_INVALID, "smg_mesh_massmatrix: bad arguments");
+    std::vector<double> M = massmatrix_diag(wrap_mesh(V, nV, F, nF), voronoi ? MASS_VORONOI : MASS_BARYCENTRIC);
+    std::copy(M.begin(), M.end(), diag);
+    return SMG_OK;
+}
+
+extern "C" int smg_mesh_boundary_loop(const int* F, int nF, int nV, int* loop, int* n_loop)
+{
+    if (!F || !loop || !n_loop) return fail(SMG_ERR_INVALID, "smg_mesh_boundary_loop: bad arguments");
+    (void)nV;
+    std::vector<int> b = boundary_loop(wrap_mesh(nullptr, 0, F, nF));
+    *n_loop = (int)b.size();
+    std::copy(b.begin(), b.end(), loop);
+    return SMG_OK;
+}
+
+extern "C" int smg_mesh_midpoint_upsample(int nV, const int* F, int nF, int* nE, int* S_rowptr, int* S_col, double* S_val, int* NF)
+{
+    if (!F) return fail(SMG_ERR_INVALID, "smg_mesh_midpoint_upsample: bad arguments");
+    std::vector<int> Fv(F, F + (size_t)nF * 3), NFv;
+    Csr S;
+    midpoint_upsample(nV, Fv, S, NFv);
+    if (nE) *nE = S.nr - nV;
+    if (S_rowptr) std::copy(S.ptr.begin(), S.ptr.end(), S_rowptr);
+    if (S_col) std::copy(S.col.begin(), S.col.end(), S_col);
+    if (S_val) std::copy(S.val.begin(), S.val.end(), S_val);
+    if (NF) std::copy(NFv.begin(), NFv.end(), NF);
+    return SMG_OK;
+}
+
+extern "C" int smg_mesh_torus(int nu, int nv, double R, double r, double* V, int* F)
+{
+    if (nu < 3 || nv < 3 || !V || !F) return fail(SMG_ERR_INVALID, "smg_mesh_torus: bad arguments");
+    Mesh m = make_torus(nu, nv, R, r);
+    std::copy(m.V.begin(), m.V.end(), V);
+    std::copy(m.F.begin(), m.F.end(), F);
+    return SMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mg_precompute
+namespace smg {
+// smg_decimate.cpp: one coarsening step (reference get_prolong(), src/get_prolong.cpp:3-57)
+int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& P, std::string& err);
+}
+
+// number of levels by the reference's float rule (src/mg_precompute.cpp:27-38)
+static int level_count(int nV, float ratio, int nVCoarsest)
+{
+    int nLvs = 1;
+    float nv = (float)nV;
+    while (true) {
+        nv *= ratio;
+        if (nv > (float)nVCoarsest) nLvs += 1;
+        else break;
+    }
+    return nLvs;
+}
+
+static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& base, int n_new, float ratio, int dec_type)
+{
+    Mesh cur = base;
+    for (int s = 0; s < n_new; s++) {
+        const int lv = first_lv + s;
+        const int tarF = (int)std::round((float)cur.nF() * ratio);  // src/mg_precompute.cpp:59
+        Mesh coarse;
+        Csr P;
+        std::string err;
+        if (decimate_level(cur, tarF, dec_type, coarse, P, err) != 0) return fail(SMG_ERR_INVALID, "mg_precompute: %s", err.c_str());
+        h->lv[lv].V = coarse.V;
+        h->lv[lv].F = coarse.F;
+        set_prolong(h, lv, std::move(P));
+        cur = std::move(coarse);
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_mg_precompute(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                 smg_hierarchy** out)
+{
+    if (!V || !F || !out || nV <= 0 || nF <= 0 || !(ratio > 0.f && ratio < 1.f))
+        return fail(SMG_ERR_INVALID, "smg_mg_precompute: bad arguments");
+    const int nLvs = level_count(nV, ratio, nVCoarsest);
+    smg_hierarchy* h = smg_hierarchy_create(nLvs);
+    if (!h) return SMG_ERR_ALLOC;
+    Mesh m = wrap_mesh(V, nV, F, nF);
+    h->lv[0].V = m.V; h->lv[0].F = m.F;   // src/mg_precompute.cpp:46-47
+    int rc = build_decimated_levels(h, 1, m, nLvs - 1, ratio, dec_type);
+    if (rc) { smg_hierarchy_destroy(h); return rc; }
+    *out = h;
+    return SMG_OK;
+}
+
+extern "C" int smg_mg_precompute_subdiv(const double* V, int nV, const int* F, int nF, int n_sub, float ratio, int nVCoarsest,
+                                        int n_extra_levels, smg_hierarchy** out, double* V_out, int* F_out)
+{
+    if (!V || !F || !out || nV <= 0 || nF <= 0 || n_sub < 0) return fail(SMG_ERR_INVALID, "smg_mg_precompute_subdiv: bad arguments");
+    int extra = n_extra_levels >= 0 ? n_extra_levels : level_count(nV, ratio, nVCoarsest) - 1;
+    Mesh base = wrap_mesh(V, nV, F, nF);
+    Mesh fine = base;
+    std::vector<Csr> Ps;
+    subdivide(fine, n_sub, Ps);
+    smg_hierarchy* h = smg_hierarchy_create(1 + n_sub + extra);
+    if (!h) return SMG_ERR_ALLOC;
+    h->lv[0].V = fine.V; h->lv[0].F = fine.F;
+    for (int l = 1; l <= n_sub; l++) set_prolong(h, l, std::move(Ps[l - 1]));
+    h->lv[n_sub].V = base.V; h->lv[n_sub].F = base.F;
+    int rc = build_decimated_levels(h, n_sub + 1, base, extra, ratio, SMG_DEC_MIDPOINT);
+    if (rc) { smg_hierarchy_destroy(h); return rc; }
+    if (V_out) std::copy(fine.V.begin(), fine.V.end(), V_out);
+    if (F_out) std::copy(fine.F.begin(), fine.F.end(), F_out);
+    *out = h;
+    return SMG_OK;
+}

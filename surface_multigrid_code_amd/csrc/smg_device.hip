@@ -1,0 +1,434 @@
+// smg_device.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).  See smg_device.hpp.
+//
+// Everything here is HBM/L2-bandwidth bound irregular fp64 work (arithmetic intensity ~0.13 FLOP/B): no MFMA.
+// Design rules followed (cdna_hip_programming.md §2, §6 G2/G11/G13; MI355X_MICROARCH.md):
+//   * SELL-64-sigma: one wavefront = one slice, one lane = one row; val/col panels are column-major so a
+//     wave's load of panel column j is one contiguous 512 B (val) + 256 B (col) request;
+//   * the panel loop is unrolled 8-wide with all index/value loads issued before the dependent x-gathers
+//     so each wave keeps >= 8 x 768 B of matrix stream in flight;
+//   * blockIdx -> slice mapping is XCD-aware: the 8 XCDs each walk one contiguous eighth of the slices so an
+//     XCD's private 4 MiB L2 sees a compact window of x instead of the whole vector;
+//   * per-row sums are accumulated sequentially in ascending column order with separate multiply and add
+//     (build with -ffp-contract=off): bit-identical to the reference's Eigen CPU kernels.
+#include <hip/hip_runtime.h>
+
+#include "smg_device.hpp"
+
+namespace smg {
+
+// ---------------------------------------------------------------------------------------------- SELL kernels
+
+__device__ __forceinline__ int xcd_remap(int bid, int nb)
+{
+    // block b runs on XCD b % 8 (observed dispatch order; used for locality only, never for correctness):
+    // give every XCD one contiguous range of logical block ids.  Bijective for any nb.
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int MODE, int KB>
+__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, const double* x, const double* b,
+                                              double* y, int ld, const int* done, double* partials)
+{
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int s = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
+    double ss = 0.0;
+    if (s < s_end) {
+        const int row0 = A.slice_row[s];
+        const int nrow = A.slice_row[s + 1] - row0;
+        const int off0 = A.slice_off[s];
+        const int w = A.slice_off[s + 1] - off0;
+        const int* cp = A.col + (size_t)off0 * 64 + lane;
+        const double* vp = A.val + (size_t)off0 * 64 + lane;
+        const int row = row0 + lane;
+        double acc[KB];
+#pragma unroll
+        for (int q = 0; q < KB; q++) acc[q] = 0.0;
+        double diag = 1.0;
+        constexpr int U = 8;
+        for (int j0 = 0; j0 < w; j0 += U) {
+            int c[U];
+            double v[U];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const bool in = (j0 + t) < w;  // wave-uniform
+                c[t] = in ? cp[(size_t)(j0 + t) * 64] : -1;
+                v[t] = in ? vp[(size_t)(j0 + t) * 64] : 0.0;
+            }
+            double xv[U][KB];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                const bool use = (c[t] >= 0) && !(MODE == SELL_GS && c[t] == row);
+#pragma unroll
+                for (int q = 0; q < KB; q++) xv[t][q] = use ? x[(size_t)c[t] * ld + q] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                if (c[t] >= 0) {
+                    if (MODE == SELL_GS && c[t] == row) {
+                        diag = v[t];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
+                    }
+                }
+            }
+        }
+        if (lane < nrow) {
+            const size_t o = (size_t)row * ld;
+#pragma unroll
+            for (int q = 0; q < KB; q++) {
+                if (MODE == SELL_AX) y[o + q] = acc[q];
+                else if (MODE == SELL_RESID) y[o + q] = b[o + q] - acc[q];
+                else if (MODE == SELL_ADD) y[o + q] = y[o + q] + acc[q];
+                else if (MODE == SELL_GS) y[o + q] = (b[o + q] - acc[q]) / diag;
+                else { const double t = b[o + q] - acc[q]; ss += t * t; }
+            }
+        }
+    }
+    if (MODE == SELL_RESID_SS) {
+        __shared__ double red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+int sell_blocks(int n_slices) { return (n_slices + 3) / 4; }
+
+template <int MODE>
+static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, const double* x, const double* b, double* y,
+                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+{
+    const int ns = s_end - s_begin;
+    const int nb = sell_blocks(ns);
+    const int* done = ctrl ? &ctrl->done : nullptr;
+    int chunk = 0;
+    if (n_blocks) *n_blocks = 0;
+    if (ns <= 0) return hipSuccess;
+    for (int c0 = 0; c0 < k; c0 += 4, chunk++) {
+        const int kb = (k - c0) < 4 ? (k - c0) : 4;
+        const double* xx = x ? x + c0 : nullptr;
+        const double* bb = b ? b + c0 : nullptr;
+        double* yy = y ? y + c0 : nullptr;
+        double* pp = partials ? partials + (size_t)chunk * nb : nullptr;
+        switch (kb) {
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
+        }
+    }
+    if (n_blocks) *n_blocks = chunk * nb;
+    return hipGetLastError();
+}
+
+hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
+                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+{
+    switch (mode) {
+        case SELL_AX: return launch_sell_mode<SELL_AX>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_GS: return launch_sell_mode<SELL_GS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------- solve-loop control
+
+__global__ __launch_bounds__(256) void k_ss_finalize(const double* partials, int n, Ctrl* ctrl)
+{
+    if (ctrl->done) return;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ctrl->sumsq = red[0];
+}
+
+__global__ void k_decide(Ctrl* ctrl, const double* sumsq)
+{
+    if (ctrl->done) return;
+    const double tol = ctrl->tol;
+    const double r = sqrt(*sumsq);
+    const int i = ctrl->n_his;
+    if (i < SMG_MAX_HIS) ctrl->r_his[i] = r;
+    ctrl->n_his = i + 1;
+    if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
+    else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
+}
+
+__global__ void k_count_cycle(Ctrl* ctrl)
+{
+    if (ctrl->done) return;
+    ctrl->iters += 1;
+}
+
+hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl);
+    return hipGetLastError();
+}
+hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, st, ctrl, sumsq);
+    return hipGetLastError();
+}
+hipError_t launch_count_cycle(Ctrl* ctrl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_count_cycle, dim3(1), dim3(1), 0, st, ctrl);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- coarsest level
+
+// One wavefront per output row; 16 B per lane per load (1 KiB per wave-instruction); deterministic
+// shuffle-tree reduction.  n and lda are multiples of 64, b has lda rows (zero padded).
+template <int KB>
+__global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict__ Ainv, int n, int lda,
+                                                        const double* __restrict__ b, double* u, int ld, const int* done)
+{
+    if (done && *done) return;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double2* a2 = reinterpret_cast<const double2*>(Ainv + (size_t)row * lda);
+    double acc[KB];
+#pragma unroll
+    for (int q = 0; q < KB; q++) acc[q] = 0.0;
+    const int n2 = lda >> 1;
+#pragma unroll 4
+    for (int jj = lane; jj < n2; jj += 64) {
+        const double2 a = a2[jj];
+#pragma unroll
+        for (int q = 0; q < KB; q++) {
+            acc[q] += a.x * b[(size_t)(2 * jj) * ld + q];
+            acc[q] += a.y * b[(size_t)(2 * jj + 1) * ld + q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KB; q++) {
+        double s = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) u[(size_t)row * ld + q] = u[(size_t)row * ld + q] + s;
+    }
+}
+
+hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
+                                 const Ctrl* ctrl, hipStream_t st)
+{
+    const int* done = ctrl ? &ctrl->done : nullptr;
+    const int nb = (n + 3) / 4;
+    if (n <= 0) return hipSuccess;
+    for (int c0 = 0; c0 < k; c0 += 4) {
+        const int kb = (k - c0) < 4 ? (k - c0) : 4;
+        switch (kb) {
+            case 1: hipLaunchKernelGGL((k_dense_gemv_add<1>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 2: hipLaunchKernelGGL((k_dense_gemv_add<2>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 3: hipLaunchKernelGGL((k_dense_gemv_add<3>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemv_add<4>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+        }
+    }
+    return hipGetLastError();
+}
+
+// Blocked Gauss-Jordan inversion (no pivoting; the matrix is SPD), block size 32, 64x64 update tiles.
+constexpr int GJ_NB = 32;
+
+__global__ __launch_bounds__(1024) void k_gj_diag(const double* M, int n, int kb, double* dinv)
+{
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    const int i = threadIdx.x / GJ_NB, j = threadIdx.x % GJ_NB;
+    const int K = kb * GJ_NB;
+    a[i][j] = M[(size_t)(K + i) * n + K + j];
+    __syncthreads();
+    for (int p = 0; p < GJ_NB; p++) {
+        const double piv = a[p][p], f = a[i][p], r = a[p][j], cur = a[i][j];
+        __syncthreads();
+        const double d = 1.0 / piv;
+        double val;
+        if (i == p) val = (j == p) ? d : r * d;
+        else val = (j == p) ? -(f * d) : cur - f * (r * d);
+        a[i][j] = val;
+        __syncthreads();
+    }
+    dinv[i * GJ_NB + j] = a[i][j];
+}
+
+// block x handles columns [64x, 64x+64) of the scaled pivot row panel and rows [64x, 64x+64) of the column panel
+__global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int kb, const double* dinv, double* rowp,
+                                                   double* colp)
+{
+    __shared__ double d_s[GJ_NB][GJ_NB + 1];
+    __shared__ double m_s[GJ_NB][64 + 1];
+    const int K = kb * GJ_NB;
+    const int j0 = blockIdx.x * 64;
+    for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += 256) d_s[t / GJ_NB][t % GJ_NB] = dinv[t];
+    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) m_s[t / 64][t % 64] = M[(size_t)(K + t / 64) * n + j0 + t % 64];
+    // column panel copy: rows j0..j0+63, columns K..K+31
+    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) {
+        const int i = j0 + t / GJ_NB, c = t % GJ_NB;
+        colp[(size_t)i * GJ_NB + c] = M[(size_t)i * n + K + c];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) {
+        const int r = t / 64, c = t % 64, j = j0 + c;
+        double v;
+        if (j >= K && j < K + GJ_NB) v = d_s[r][j - K];
+        else {
+            v = 0.0;
+#pragma unroll 8
+            for (int s = 0; s < GJ_NB; s++) v += d_s[r][s] * m_s[s][c];
+        }
+        rowp[(size_t)r * n + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* rowp, const double* colp)
+{
+    __shared__ double c_s[64][GJ_NB + 1];
+    __shared__ double r_s[GJ_NB][64 + 1];
+    const int K = kb * GJ_NB;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) c_s[t / GJ_NB][t % GJ_NB] = colp[(size_t)(i0 + t / GJ_NB) * GJ_NB + t % GJ_NB];
+    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) r_s[t / 64][t % 64] = rowp[(size_t)(t / 64) * n + j0 + t % 64];
+    __syncthreads();
+    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[a][c] = 0.0;
+#pragma unroll 2
+    for (int t = 0; t < GJ_NB; t++) {
+        double cv[4], rv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cv[a] = c_s[ti + 16 * a][t];
+#pragma unroll
+        for (int c = 0; c < 4; c++) rv[c] = r_s[t][tj + 16 * c];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[a][c] += cv[a] * rv[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = i0 + ti + 16 * a;
+        const bool ipiv = (i >= K && i < K + GJ_NB);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = j0 + tj + 16 * c;
+            const bool jpiv = (j >= K && j < K + GJ_NB);
+            double* m = M + (size_t)i * n + j;
+            if (ipiv) *m = r_s[i - K][tj + 16 * c];
+            else *m = (jpiv ? 0.0 : *m) - acc[a][c];
+        }
+    }
+}
+
+hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (n % 64) return hipErrorInvalidValue;
+    double* rowp = work;
+    double* colp = work + (size_t)n * GJ_NB;
+    double* dinv = colp + (size_t)n * GJ_NB;
+    for (int kb = 0; kb < n / GJ_NB; kb++) {
+        hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(1024), 0, st, M, n, kb, dinv);
+        hipLaunchKernelGGL(k_gj_panels, dim3(n / 64), dim3(256), 0, st, M, n, kb, dinv, rowp, colp);
+        hipLaunchKernelGGL(k_gj_update, dim3(n / 64, n / 64), dim3(256), 0, st, M, n, kb, rowp, colp);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- layout helpers
+
+__global__ void k_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * k) return;
+    const int i = (int)(t / k), c = (int)(t % k);
+    dst[t] = src[(size_t)map[i] + (size_t)c * ld_src];
+}
+__global__ void k_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * k) return;
+    const int i = (int)(t / k), c = (int)(t % k);
+    dst[(size_t)map[i] + (size_t)c * ld_dst] = src[t];
+}
+__global__ void k_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * k) return;
+    const int c = (int)(t / n), i = (int)(t % n);
+    dst[(size_t)idx[i] + (size_t)c * ld_dst] = src[(size_t)i + (size_t)c * ld_src];
+}
+__global__ void k_gather_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * k) return;
+    const int c = (int)(t / n), i = (int)(t % n);
+    dst[(size_t)i + (size_t)c * ld_dst] = src[(size_t)idx[i] + (size_t)c * ld_src];
+}
+__global__ void k_csr_sub(int n_rows, const int* ptr, const int* col, const double* val, const double* x, int ldx,
+                          double* y, int ld, int k)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_rows * k) return;
+    const int c = (int)(t / n_rows), i = (int)(t % n_rows);
+    double s = 0.0;
+    for (int p = ptr[i]; p < ptr[i + 1]; p++) s += val[p] * x[(size_t)col[p] + (size_t)c * ldx];
+    y[(size_t)i + (size_t)c * ld] = y[(size_t)i + (size_t)c * ld] - s;
+}
+
+static inline unsigned grid1d(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src, hipStream_t st)
+{
+    if ((size_t)n * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_in, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, map, n, k, ld_src);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst, hipStream_t st)
+{
+    if ((size_t)n * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_out, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, map, n, k, ld_dst);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,
+                             hipStream_t st)
+{
+    if ((size_t)n * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_cm, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, idx, n, k, ld_src, ld_dst);
+    return hipGetLastError();
+}
+hipError_t launch_gather_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,
+                            hipStream_t st)
+{
+    if ((size_t)n * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_cm, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, idx, n, k, ld_src, ld_dst);
+    return hipGetLastError();
+}
+hipError_t launch_csr_sub(int n_rows, const int* ptr, const int* col, const double* val, const double* x, int ldx,
+                          double* y, int ld, int k, hipStream_t st)
+{
+    if ((size_t)n_rows * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_csr_sub, dim3(grid1d((size_t)n_rows * k, 256)), dim3(256), 0, st, n_rows, ptr, col, val, x, ldx, y, ld, k);
+    return hipGetLastError();
+}
+
+}  // namespace smg

@@ -1,0 +1,83 @@
+// smg_device.hpp -- launch interface of the hand-written gfx950 kernels (smg_device.hip).
+//
+// All dense blocks on the device use the INTERNAL layout: row-major n x k (the k right-hand-side columns
+// of one vertex are contiguous, so every neighbour gather is one k*8-byte segment), rows in the level's
+// colour-major internal numbering (smg_order.hpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace smg {
+
+constexpr int SMG_MAX_HIS = 1024;  // capacity of the device-side residual history (>= max_iter)
+
+// Solve-loop control block, resident in HBM.  The outer loop of min_quad_with_fixed_mg_solve
+// (reference src/min_quad_with_fixed_mg.cpp:108-125) is enqueued without host round trips: the decide
+// kernel appends to r_his and raises `done`; every later kernel of the stream starts with `if (done) return`.
+struct Ctrl {
+    int done;      // 1 once residual < tol (or non-finite) was observed
+    int n_his;     // entries of r_his written
+    int status;    // 0 ok, -1 non-finite residual
+    int iters;     // V-cycles actually executed
+    double sumsq;  // sum of squares of the last residual (all-reduced across ranks when column-sharded)
+    double tol;    // absolute tolerance of the break test (kept here so captured graphs do not bake it in)
+    double r_his[SMG_MAX_HIS];
+};
+
+struct SellDev {
+    int n_rows = 0, n_cols = 0, n_slices = 0;
+    const int* slice_row = nullptr;  // n_slices + 1
+    const int* slice_off = nullptr;  // n_slices + 1 (units of 64 entries)
+    const int* col = nullptr;
+    const double* val = nullptr;
+};
+
+enum SellMode {
+    SELL_AX = 0,        // y = A x                       (mg_VCycle.cpp:69 `A`, :91 `prolong`, :80 `restrict`)
+    SELL_RESID = 1,     // y = b - A x                   (mg_VCycle.cpp:41-42)
+    SELL_RESID_SS = 2,  // partial sums of |b - A x|^2   (min_quad_with_fixed_mg.cpp:110 / :332)
+    SELL_ADD = 3,       // y = y + A x                   (mg_VCycle.cpp:51-53  u = u + P uc)
+    SELL_GS = 4,        // y_i = (b_i - sum_{j != i} A_ij y_j) / A_ii on the given slice range (one colour)
+};
+
+// y/x/b: internal layout, ld = number of columns k.  Slices [s_begin, s_end).  `ctrl` may be null (no
+// early-exit test).  For SELL_RESID_SS, `partials` receives one double per launched block; the number of
+// blocks is returned through *n_blocks.
+hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
+                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st);
+int sell_blocks(int n_slices);
+
+// ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
+hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
+// r = sqrt(*sumsq); append to r_his; done = (r < ctrl->tol) or non-finite.  No-op when already done.
+hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st);
+// bookkeeping kernel at the end of a V-cycle (counts executed cycles)
+hipError_t launch_count_cycle(Ctrl* ctrl, hipStream_t st);
+
+// u[i,:] += sum_j Ainv[i,j] * b[j,:]   (mg_VCycle.cpp:199-200 with the factorisation pre-inverted)
+hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
+                                 const Ctrl* ctrl, hipStream_t st);
+// In-place inversion of an SPD matrix (n x n, row-major, leading dimension lda, n % 64 == 0, lda == n) by
+// blocked Gauss-Jordan elimination without pivoting.  work: 2*n*32 + 32*32 doubles.
+hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);
+
+// layout helpers ------------------------------------------------------------------------------------------
+// dst[i*k + c] = src[map[i] + c*ld_src]      (column-major caller block -> internal block)
+hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src,
+                            hipStream_t st);
+// dst[map[i] + c*ld_dst] = src[i*k + c]
+hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst,
+                              hipStream_t st);
+// dst[idx[i] + c*ld_dst] = src[i + c*ld_src]  (column-major -> column-major scatter, known values)
+hipError_t launch_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,
+                             hipStream_t st);
+// dst[i + c*ld_dst] = src[idx[i] + c*ld_src]  (column-major row gather, igl::slice(X, idx, 1, Y))
+hipError_t launch_gather_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,
+                            hipStream_t st);
+// y[i + c*ld] -= sum_p val[p] * x[col[p] + c*ldx]   (CSR, column-major blocks; RHS_u -= Auk * known_val,
+// min_quad_with_fixed_mg.cpp:318.  The product is summed first, then subtracted.)
+hipError_t launch_csr_sub(int n_rows, const int* ptr, const int* col, const double* val, const double* x, int ldx,
+                          double* y, int ld, int k, hipStream_t st);
+
+}  // namespace smg

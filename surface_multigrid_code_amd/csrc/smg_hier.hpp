@@ -1,0 +1,116 @@
+// smg_hier.hpp -- the hierarchy handle behind the C ABI (include/smg.h): host mirror of the reference's
+// std::vector<mg_data> + min_quad_with_fixed_mg_data + coarse solver, plus their device images.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "smg_device.hpp"
+#include "smg_order.hpp"
+#include "smg_sparse.hpp"
+
+namespace smg {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct SellBuf {  // device image of one SELL matrix
+    DevBuf<int> slice_row, slice_off, col;
+    DevBuf<double> val;
+    SellDev view;
+    std::vector<int> color_slice_ptr;
+    long stored = 0, padded = 0;
+    hipError_t upload(const Sell& S);
+};
+
+// one element of std::vector<mg_data> (reference src/mg_data.h:11-27)
+struct Level {
+    // ---- host, caller numbering: the mg_data fields ----
+    std::vector<double> V;  // mg_data::V (optional)
+    std::vector<int> F;     // mg_data::F (optional)
+    Csr P_full;             // mg_data::P_full
+    Csr A;                  // mg_data::A   (unknown-only system matrix of the level)
+    std::vector<double> A_diag;  // mg_data::A_diag
+    Csr P, PT;              // mg_data::P / PT (unknown-only, maps level lv -> lv-1 / back)
+    // ---- device numbering ----
+    Ordering ord;           // colour-major numbering of this level's unknowns
+    Csr A_int, P_int, PT_int;  // host copies in the internal numbering (introspection / tests)
+    SellBuf dA, dP, dPT;
+    // ---- work vectors, internal layout n x kcap ----
+    DevBuf<double> b, u, r;
+    int n = 0;
+};
+
+struct ProfScope { std::string name; long count = 0; double ms = 0.0; };
+struct ProfRec { int scope; hipEvent_t e0, e1; };
+
+}  // namespace smg
+
+struct smg_hierarchy {
+    int n_levels = 0;
+    std::vector<smg::Level> lv;
+    // ---- min_quad_with_fixed_mg_data (reference src/min_quad_with_fixed_mg.h:22-29) ----
+    int n_full = 0;
+    bool has_known = false, precomputed = false;
+    std::vector<int> known, unknown;
+    smg::Csr LHS_unused;  // data.LHS duplicates mg[0].A in the reference; not stored twice here
+    smg::Csr Auk;
+    smg::DevBuf<int> d_map0;      // internal row i of level 0 -> index in the caller's full-size vectors
+    smg::DevBuf<int> d_perm0;     // internal row i of level 0 -> unknown-numbering index
+    smg::DevBuf<int> d_unknown, d_known;
+    smg::DevBuf<int> d_auk_ptr, d_auk_col;
+    smg::DevBuf<double> d_auk_val;
+    // ---- coarse solver: stands in for Eigen::SimplicialLDLT (factorisation pre-inverted on the device) ----
+    int nc = 0, nc_pad = 0;
+    smg::DevBuf<double> d_Ainv;
+    // ---- execution ----
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    smg::DevBuf<smg::Ctrl> d_ctrl;
+    smg::DevBuf<double> d_partials;
+    int kcap = 0;
+    // ---- solve state ----
+    bool in_solve = false;
+    int k = 0;
+    double tol = 1e-3;
+    int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1;
+    int iters_enqueued = 0;
+    smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
+    const double* cur_kv = nullptr;  // device pointer to known_val (column-major) of the running solve
+    int cur_ld_kv = 0;
+    // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
+    hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
+    int g_k = 0, g_pre = 0, g_post = 0;
+    // ---- profc mirror ----
+    bool prof_on = false;
+    std::vector<smg::ProfScope> scopes;
+    std::vector<smg::ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+};

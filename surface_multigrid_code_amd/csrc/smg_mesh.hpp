@@ -1,0 +1,41 @@
+// smg_mesh.hpp -- caller-side mesh numerics (host C++): what the reference demos do around the solve
+// with libigl (03_mg_solver/main.cpp:29-61, 04_mg_solver_nobd/main.cpp:40-94,
+// 05_example_mean_curvature_flow/main.cpp:57-69) plus the mid-point upsampling operator of
+// 09_random_subdiv_remesh/main.cpp:46-140 used to generate the ~1M / ~4M-vertex benchmark meshes.
+// libigl is not part of the reference checkout (empty submodule): semantics follow SURVEY.md Appendix A.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "smg_sparse.hpp"
+
+namespace smg {
+
+struct Mesh {
+    std::vector<double> V;  // nV x 3, row-major
+    std::vector<int> F;     // nF x 3, row-major, 0-based
+    int nV() const { return (int)(V.size() / 3); }
+    int nF() const { return (int)(F.size() / 3); }
+};
+
+// igl::read_triangle_mesh for .obj (v / f records; "a", "a/b", "a//c", "a/b/c"; polygons fan-triangulated)
+// and the repo's binary .smgm fixtures.  Returns false on failure.
+bool read_mesh(const std::string& path, Mesh& m);
+bool write_smgm(const std::string& path, const Mesh& m);
+
+std::vector<double> doublearea(const Mesh& m);                 // igl::doublearea
+void normalize_unit_area(Mesh& m);                             // src/normalize_unit_area.cpp:3-25
+Csr cotmatrix(const Mesh& m);                                  // igl::cotmatrix (negative semi-definite)
+enum MassType { MASS_BARYCENTRIC = 0, MASS_VORONOI = 1 };
+std::vector<double> massmatrix_diag(const Mesh& m, MassType t); // igl::massmatrix (lumped, diagonal)
+std::vector<int> boundary_loop(const Mesh& m);                 // igl::boundary_loop(F, VectorXi): longest loop
+
+// Mid-point upsampling with Loop connectivity.  S is (#V + #E) x #V with NV = S * V; old vertices keep
+// their index; new vertex nV + e for the e-th edge of the lexicographically sorted unique (min,max) list.
+void midpoint_upsample(int nV, const std::vector<int>& F, Csr& S, std::vector<int>& NF);
+// Apply n_sub upsamplings in place; Ps[l-1] (l = 1..n_sub) maps level l -> level l-1, level 0 finest.
+void subdivide(Mesh& m, int n_sub, std::vector<Csr>& Ps);
+
+Mesh make_torus(int nu, int nv, double R, double r);           // BASELINE config C5 base mesh
+
+}  // namespace smg

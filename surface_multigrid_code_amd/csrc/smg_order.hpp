@@ -1,0 +1,49 @@
+// smg_order.hpp -- device-side numbering of one multigrid level and the SELL-64-sigma container.
+//
+// The reference smoother is a forward *lexicographic* Gauss-Seidel sweep (src/mg_VCycle.cpp:146-160),
+// inherently sequential.  libsmg renumbers the unknowns of every level colour-major (greedy colouring of
+// the pattern of A_l; reverse-Cuthill-McKee rank inside a colour for gather locality; rows bucketed by nnz
+// inside sigma-row windows to keep SELL padding small).  A lexicographic sweep in THAT numbering visits
+// colour 0, then colour 1, ... and rows of one colour never reference each other, so one kernel launch per
+// colour reproduces the reference sweep on the renumbered system exactly (bit for bit, given the same
+// ascending-column accumulation order per row).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "smg_sparse.hpp"
+
+namespace smg {
+
+struct Ordering {
+    std::vector<int> perm;       // internal (new) -> caller (old)
+    std::vector<int> iperm;      // caller (old) -> internal (new)
+    std::vector<int> color_ptr;  // n_colors + 1 row offsets in the internal numbering
+    int n_colors() const { return (int)color_ptr.size() - 1; }
+};
+
+std::vector<int> rcm_order(const Csr& A);                    // returns new -> old
+Ordering make_ordering(const Csr& A, int sigma = 512);       // A: square, structurally symmetric
+Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)
+
+constexpr int SELL_C = 64;  // slice height = one wavefront
+
+// SELL-C-sigma, C = 64: slice s covers rows [slice_row[s], slice_row[s+1]) (<= 64 of them; a slice never
+// straddles a colour boundary); its entries are stored column-major in a 64-wide panel starting at element
+// 64 * slice_off[s]; panel width = slice_off[s+1] - slice_off[s] = longest row of the slice.  Padding has
+// col = -1.  Inside a row the stored order is ascending column index of the *internal* numbering.
+struct Sell {
+    int n_rows = 0, n_cols = 0, n_slices = 0;
+    std::vector<int> slice_row;        // n_slices + 1
+    std::vector<int> slice_off;        // n_slices + 1, in units of 64 entries
+    std::vector<int> col;              // 64 * slice_off[n_slices]
+    std::vector<double> val;
+    std::vector<int> color_slice_ptr;  // n_colors + 1 slice offsets (single range when uncoloured)
+    long nnz = 0;                      // stored (unpadded) entries
+    long padded() const { return 64L * (slice_off.empty() ? 0 : slice_off.back()); }
+};
+
+// row_breaks: optional ascending row offsets (e.g. Ordering::color_ptr) at which a new slice must start.
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks);
+
+}  // namespace smg

@@ -1,0 +1,156 @@
+// smg_sparse.cpp -- host-side sparse kernels of libsmg (see smg_sparse.hpp).
+#include "smg_sparse.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <utility>
+
+namespace smg {
+
+Csr csr_from_arrays(int nr, int nc, const int* ptr, const int* col, const double* val)
+{
+    Csr A;
+    A.nr = nr; A.nc = nc;
+    A.ptr.assign(nr + 1, 0);
+    long nnz = ptr[nr];
+    A.col.reserve(nnz); A.val.reserve(nnz);
+    std::vector<std::pair<int, double>> row;
+    for (int i = 0; i < nr; i++) {
+        int b = ptr[i], e = ptr[i + 1];
+        bool sorted = true;
+        for (int p = b + 1; p < e; p++) if (col[p] <= col[p - 1]) { sorted = false; break; }
+        if (sorted) {
+            for (int p = b; p < e; p++) { A.col.push_back(col[p]); A.val.push_back(val[p]); }
+        } else {
+            row.clear();
+            for (int p = b; p < e; p++) row.emplace_back(col[p], val[p]);
+            std::stable_sort(row.begin(), row.end(),
+                             [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            for (size_t t = 0; t < row.size(); t++) {
+                if (t > 0 && row[t].first == A.col.back() && (long)A.col.size() > A.ptr[i]) A.val.back() += row[t].second;
+                else { A.col.push_back(row[t].first); A.val.push_back(row[t].second); }
+            }
+        }
+        A.ptr[i + 1] = (int)A.col.size();
+    }
+    return A;
+}
+
+Csr csr_from_csc_arrays(int nr, int nc, const int* colptr, const int* rowidx, const double* val)
+{
+    // the CSC arrays of an nr x nc matrix are the CSR arrays of its nc x nr transpose
+    Csr T = csr_from_arrays(nc, nr, colptr, rowidx, val);
+    return transpose(T);
+}
+
+Csr transpose(const Csr& A)
+{
+    Csr T;
+    T.nr = A.nc; T.nc = A.nr;
+    long nnz = A.nnz();
+    T.ptr.assign(T.nr + 1, 0);
+    T.col.resize(nnz); T.val.resize(nnz);
+    for (long p = 0; p < nnz; p++) T.ptr[A.col[p] + 1]++;
+    for (int i = 0; i < T.nr; i++) T.ptr[i + 1] += T.ptr[i];
+    std::vector<int> next(T.ptr.begin(), T.ptr.end() - 1);
+    for (int i = 0; i < A.nr; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++) {
+            int q = next[A.col[p]]++;
+            T.col[q] = i;
+            T.val[q] = A.val[p];
+        }
+    return T;
+}
+
+Csr spgemm(const Csr& A, const Csr& B)
+{
+    Csr C;
+    C.nr = A.nr; C.nc = B.nc;
+    C.ptr.assign(C.nr + 1, 0);
+    std::vector<int> mark(B.nc, -1);
+    std::vector<double> acc(B.nc, 0.0);
+    std::vector<int> idx;
+    idx.reserve(64);
+    // symbolic pass (row sizes)
+    for (int i = 0; i < A.nr; i++) {
+        int cnt = 0;
+        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+            int k = A.col[pa];
+            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                int j = B.col[pb];
+                if (mark[j] != i) { mark[j] = i; cnt++; }
+            }
+        }
+        C.ptr[i + 1] = C.ptr[i] + cnt;
+    }
+    C.col.resize(C.ptr[C.nr]); C.val.resize(C.ptr[C.nr]);
+    std::fill(mark.begin(), mark.end(), -1);
+    for (int i = 0; i < A.nr; i++) {
+        idx.clear();
+        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+            int k = A.col[pa];
+            double a = A.val[pa];
+            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                int j = B.col[pb];
+                if (mark[j] != i) { mark[j] = i; acc[j] = a * B.val[pb]; idx.push_back(j); }
+                else acc[j] += a * B.val[pb];
+            }
+        }
+        std::sort(idx.begin(), idx.end());
+        int base = C.ptr[i];
+        for (size_t t = 0; t < idx.size(); t++) { C.col[base + t] = idx[t]; C.val[base + t] = acc[idx[t]]; }
+    }
+    return C;
+}
+
+Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols)
+{
+    Csr Y;
+    Y.nr = rows ? (int)rows->size() : X.nr;
+    Y.nc = cols ? (int)cols->size() : X.nc;
+    Y.ptr.assign(Y.nr + 1, 0);
+    std::vector<int> cmap;
+    if (cols) {
+        cmap.assign(X.nc, -1);
+        for (int j = 0; j < Y.nc; j++) cmap[(*cols)[j]] = j;
+    }
+    std::vector<std::pair<int, double>> row;
+    for (int i = 0; i < Y.nr; i++) {
+        int r = rows ? (*rows)[i] : i;
+        row.clear();
+        for (int p = X.ptr[r]; p < X.ptr[r + 1]; p++) {
+            int j = cols ? cmap[X.col[p]] : X.col[p];
+            if (j >= 0) row.emplace_back(j, X.val[p]);
+        }
+        if (cols) std::sort(row.begin(), row.end(),
+                            [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+        for (auto& e : row) { Y.col.push_back(e.first); Y.val.push_back(e.second); }
+        Y.ptr[i + 1] = (int)Y.col.size();
+    }
+    return Y;
+}
+
+Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm)
+{
+    return slice(A, &rperm, &cperm);
+}
+
+std::vector<double> diagonal(const Csr& A)
+{
+    std::vector<double> d(A.nr, 0.0);
+    for (int i = 0; i < A.nr; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (A.col[p] == i) d[i] = A.val[p];
+    return d;
+}
+
+void spmv_host(const Csr& A, const double* x, double* y)
+{
+    for (int i = 0; i < A.nr; i++) {
+        double s = 0.0;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++) s += A.val[p] * x[A.col[p]];
+        y[i] = s;
+    }
+}
+
+}  // namespace smg

@@ -1,0 +1,46 @@
+// smg_sparse.hpp -- host-side sparse containers and kernels of the product library (libsmg).
+//
+// CSR, int32 indices, fp64 values: the row-major twin of the reference's Eigen::SparseMatrix<double>
+// (column-major, int32) that mg_data carries (reference src/mg_data.h:13-19).  For the symmetric system
+// matrices CSR == CSC; P and PT are both kept explicitly, as the reference does.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace smg {
+
+struct Csr {
+    int nr = 0, nc = 0;
+    std::vector<int> ptr;     // nr + 1
+    std::vector<int> col;     // nnz, ascending inside a row
+    std::vector<double> val;  // nnz
+    long nnz() const { return ptr.empty() ? 0 : (long)ptr.back(); }
+    bool empty() const { return nr == 0 && nc == 0; }
+};
+
+// Build from raw arrays; sorts every row by column and sums duplicate (row,col) pairs
+// (Eigen setFromTriplets semantics).  Explicit zeros are kept.
+Csr csr_from_arrays(int nr, int nc, const int* ptr, const int* col, const double* val);
+// Interpret (ptr,idx,val) as compressed *columns* of an nr x nc matrix and return its CSR.
+Csr csr_from_csc_arrays(int nr, int nc, const int* colptr, const int* rowidx, const double* val);
+
+Csr transpose(const Csr& A);
+
+// C = A * B.  Row i of C accumulates  A(i,k) * B(k,:)  over the stored k of row i in ascending order;
+// the first touch of an output entry assigns.  Entry-wise this is the same sequence of additions as
+// Eigen's column-major product (ascending k), so Galerkin operators are bit-identical to the
+// reference's  PT * A * P  (reference src/min_quad_with_fixed_mg.cpp:25, :227).  No pruning.
+Csr spgemm(const Csr& A, const Csr& B);
+
+// Y(i,j) = X(rows[i], cols[j])  (igl::slice).  A null pointer means "all, in order".  Indices unique.
+Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols);
+
+// B(i,j) = A(rperm[i], cperm[j])  with both lists permutations (new -> old).
+Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm);
+
+std::vector<double> diagonal(const Csr& A);
+
+// y = A x for dense column-major blocks (host; used only by precompute-time checks and tools)
+void spmv_host(const Csr& A, const double* x, double* y);
+
+}  // namespace smg
