@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycles/s + fine-level SpMV GB/s of libsmg on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one outer iteration of min_quad_with_fixed_mg_solve (reference src/min_quad_with_fixed_mg.cpp:108-125):
+the residual norm ||RHS - A_0 z||_2 followed by one V(2,2) cycle, on one right-hand-side column per GPU, with the
+hierarchy, RHS and z already resident in HBM.  Workload at N=1 = BASELINE config C3: bunny_15K_init.obj, unit
+area, 3x mid-point subdivision -> 1 011 330 vertices, 5 levels, system M_bary + 0.01 (-L) (SPD, no constraints).
+N > 1: every rank owns one independent RHS column of the same mesh (weak scaling); the only communication is the
+8-byte all-reduce of the residual sum of squares per iteration (RCCL), exactly SURVEY.md section 8e.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_workload(name, smg, mesh):
+    """Returns (mg, A (scipy csr), Vf, Ff, label)."""
+    t0 = time.time()
+    if name == "C3":
+        V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
+        V = mesh.normalize_unit_area(V, F)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 3, ratio=0.25, nVCoarsest=1000, n_extra_levels=1)
+        label = "C3: bunny_15K_init x3 midpoint subdivision, 1011330 verts, 5 levels, M_bary+0.01(-L), fp64"
+    elif name == "torus1m":
+        V, F = mesh.torus(64, 64)
+        V = mesh.normalize_unit_area(V, F)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 4, n_extra_levels=0)
+        label = "torus 64x64 x4 midpoint subdivision, 1048576 verts, 5 levels, M_bary+0.01(-L), fp64"
+    elif name == "C5":
+        V, F = mesh.torus(64, 64)
+        V = mesh.normalize_unit_area(V, F)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 5, n_extra_levels=0)
+        label = "C5: torus 64x64 x5 midpoint subdivision, 4194304 verts, 6 levels, M_bary+0.01(-L), fp64"
+    elif name == "small":
+        V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
+        V = mesh.normalize_unit_area(V, F)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 2, n_extra_levels=0)
+        label = "small: ogre_sim x2 midpoint subdivision, 40877 verts, 3 levels"
+    else:
+        raise SystemExit("unknown workload " + name)
+    L = mesh.cotmatrix(Vf, Ff)
+    Mb = mesh.massmatrix(Vf, Ff, "barycentric")
+    A = (Mb - 0.01 * L).tocsr()       # 05_example_mean_curvature_flow/main.cpp:68
+    A.sort_indices()
+    return mg, A, Mb, Vf, Ff, label, time.time() - t0
+
+
+def cpu_baseline(mg, A, rhs, budget_s=15.0):
+    """The oracle (CPU restatement of the reference algorithm, 1 thread) timed on this host on a bounded sample."""
+    from oracle.oracle import OracleMG
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    orc = OracleMG(Ps)
+    t0 = time.time()
+    orc.precompute(A)
+    t_pre = time.time() - t0
+    z0 = np.zeros_like(rhs)
+    # one cycle to size the sample
+    t0 = time.time()
+    orc.solve(rhs, z0, tol=0.0, max_iter=1)
+    t1 = time.time() - t0
+    m = int(max(2, min(200, budget_s / max(t1, 1e-6))))
+    orc.profile_reset()
+    t0 = time.time()
+    _, _, rh = orc.solve(rhs, z0, tol=0.0, max_iter=m)
+    dt = time.time() - t0
+    prof = orc.profile()
+    return {"value": m / dt, "unit": "V-cycles/s", "cores": 1, "kind": "port",
+            "sample": "%d outer iterations (residual + V(2,2) cycle) of the same workload, oracle/smg_oracle.c, gcc -O3, 1 thread; "
+                      "host has %d cores" % (m, os.cpu_count() or 0),
+            "ms_per_cycle": 1e3 * dt / m, "precompute_s": t_pre,
+            "relaxation_frac": prof["MG: relaxation"][1] / max(prof["MG: total VCycle"][1], 1e-12),
+            "r_his_head": [float(x) for x in rh[:4]]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--spmv-reps", type=int, default=500)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from surface_multigrid_code_amd import build as smg_build
+    if rank == 0:
+        smg_build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    import surface_multigrid_code_amd as smg
+    from surface_multigrid_code_amd import mesh
+
+    mg, A, Mb, Vf, Ff, label, t_host = build_workload(args.workload, smg, mesh)
+    n = A.shape[0]
+    t0 = time.time()
+    mg.precompute(A)
+    t_pre = time.time() - t0
+    stream = torch.cuda.Stream(device=dev)   # all libsmg work, the all-reduce and the timing events share it
+    torch.cuda.set_stream(stream)
+    mg.set_stream(stream.cuda_stream)
+
+    # one RHS column per rank: M * g, g uniform(-1,1), seed 100 + rank (synthetic)
+    rng = np.random.default_rng(100 + rank)
+    g = rng.uniform(-1.0, 1.0, n)
+    rhs_h = Mb @ g
+    rhs = torch.from_numpy(rhs_h).to(dev)
+    z0 = torch.zeros(n, dtype=torch.float64, device=dev)
+    z = torch.empty(n, dtype=torch.float64, device=dev)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    W, K = args.warmup, args.steps
+    opts = smg.SolveOpts(tol=0.0, max_iter=min(W + K, 1024), pre=2, post=2)
+
+    def run(n_it):
+        if world == 1:
+            mg.outer_iterations(n_it)
+        else:
+            for _ in range(n_it):
+                mg.iter_residual(sumsq.data_ptr())
+                dist.all_reduce(sumsq)            # RCCL, 8 bytes: the Frobenius norm couples the columns
+                mg.iter_cycle(sumsq.data_ptr())
+
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=opts)
+    run(W)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    conv, r_his = mg.solve_end(z.data_ptr(), n, max_iter=W + K)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms_step = 1e3 * dt / K
+        vcyc_bytes = mg.vcycle_bytes(1, 2, 2)
+        # ---- roofline of the fine-level SpMV kernel (k_sell<SELL_AX,1> on A_0), HIP events on the launch stream
+        x = torch.from_numpy(rng.uniform(-1.0, 1.0, n)).to(dev)
+        y = torch.empty_like(x)
+        for _ in range(20):
+            mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        R = args.spmv_reps
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(R):
+            mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        spmv_us = 1e3 * e0.elapsed_time(e1) / R
+        spmv_bytes = mg.spmv_bytes(0, 1)
+        spmv_gbs = spmv_bytes / (spmv_us * 1e-6) / 1e9
+        # ---- one full Gauss-Seidel sweep on level 0 (all colours), same byte model + b read
+        bvec = torch.from_numpy(rhs_h).to(dev)
+        u = torch.zeros_like(bvec)
+        for _ in range(5):
+            mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(100):
+            mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        gs_us = 1e3 * e0.elapsed_time(e1) / 100
+        nnz0 = A.nnz
+        gs_bytes = 12 * nnz0 + 4 * (n + 1) + 24 * n
+        # ---- per-scope timing of the V-cycle (profc mirror; eager launches with hipEvents)
+        mg.prof_enable(True)
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=8))
+        mg.outer_iterations(8)
+        mg.solve_end(z.data_ptr(), n, max_iter=8)
+        prof = mg.prof_table()
+        mg.prof_enable(False)
+        st = mg.sell_stats(0, "A")
+        out = {
+            "metric": "V-cycles/sec + fine-level SpMV GB/s (% HBM peak), 1M-vert mesh fp64",
+            "value": world * K / dt, "unit": "V-cycles/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
+                       "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
+                       "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],
+                       "rhs_columns_per_gpu": 1, "cycle": "V(2,2), multi-colour Gauss-Seidel, dense coarsest solve",
+                       "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU"},
+            "roofline": {"kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm",
+                         "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
+                         "sell_padding": st["padded"] / max(st["stored"], 1) - 1.0},
+            "roofline_gs_sweep": {"kernel": "k_sell<SELL_GS,1> x colours (one fine-level sweep)", "bound": "hbm",
+                                  "achieved": gs_bytes / (gs_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gs_bytes / (gs_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "us_per_sweep": gs_us,
+                                  "bytes_per_sweep": int(gs_bytes)},
+            "roofline_vcycle": {"bound": "hbm", "bytes_per_step": int(vcyc_bytes),
+                                "achieved": vcyc_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": vcyc_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "profc": {k: {"count": v[0], "ms_total": v[1]} for k, v in prof.items()},
+            "residual_history_head": [float(v) for v in r_his[:6]],
+            "setup_s": {"mesh_hierarchy_host": t_host, "precompute": t_pre},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(mg, A, rhs_h)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,7 +72,7 @@ static int ensure_device(smg_hierarchy* h)
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     h->device = dev;
-    if (!h->stream) {
+    if (!h->stream && !h->user_stream) {
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
@@ -173,12 +173,9 @@ extern "C" int smg_hierarchy_set_stream(smg_hierarchy* h, void* hip_stream)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graphs(h);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
-    h->stream = (hipStream_t)hip_stream;
+    h->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
     h->own_stream = false;
-    if (!hip_stream && h->device >= 0) {
-        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        h->own_stream = true;
-    }
+    h->user_stream = true;
     return SMG_OK;
 }
 
@@ -307,6 +304,18 @@ static int precompute_device(smg_hierarchy* h)
             Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm);
             Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr);
             HIPCHK(Lv.dA.upload(S));
+            // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
+            // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
+            // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
+            Csr AT = transpose(Lv.A_int);
+            Lv.gs_on_transpose = !(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col && AT.val == Lv.A_int.val);
+            Lv.dAT = SellBuf();
+            if (Lv.gs_on_transpose) {
+                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col))
+                    return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+                Sell ST = build_sell(AT, &Lv.ord.color_ptr);
+                HIPCHK(Lv.dAT.upload(ST));
+            }
         } else {
             Lv.A_int = Lv.A;
         }
@@ -397,10 +406,11 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
-    const std::vector<int>& cs = Lv.dA.color_slice_ptr;
+    const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
+    const std::vector<int>& cs = G.color_slice_ptr;
     for (int it = 0; it < iters; it++)
         for (size_t c = 0; c + 1 < cs.size(); c++)
-            HIPCHK(launch_sell(SELL_GS, Lv.dA.view, cs[c], cs[c + 1], u, b, u, k, ctrl, nullptr, nullptr, h->stream));
+            HIPCHK(launch_sell(SELL_GS, G.view, cs[c], cs[c + 1], u, b, u, k, ctrl, nullptr, nullptr, h->stream));
     return SMG_OK;
 }
 

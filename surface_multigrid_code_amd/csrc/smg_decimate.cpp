@@ -1,10 +1,323 @@
-// smg_decimate.cpp -- placeholder, replaced below in this round by the host decimator.
+// smg_decimate.cpp -- host hierarchy builder behind smg_mg_precompute: one coarsening step
+// (the role of the reference's get_prolong(), src/get_prolong.cpp:3-57:  decimate to tarF faces, push every
+// fine vertex through the collapse history to barycentric coordinates on the coarse mesh, assemble P with
+// exactly three stored entries per row).
+//
+// THIS IS NOT the reference's successive self-parameterisation (SSP_decimate + joint_lscm + query_fine_to_coarse,
+// ~4.5 kLoC on libigl internals).  It keeps the same contract -- greedy
+// shortest-edge collapse with mid-point placement (dec_type 1) or end-point placement (dec_type 2), link-condition
+// and fold-over rejection, every fine vertex carried along as (face, barycentric) -- but re-parameterises the
+// points of a collapsed 1-ring by closest-point projection onto the post-collapse 1-ring instead of a joint
+// conformal flattening.  Rows of P are non-negative, sum to 1 and reproduce linear functions on flat patches.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <queue>
 #include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "smg_mesh.hpp"
+
 namespace smg {
-int decimate_level(const Mesh&, int, int, Mesh&, Csr&, std::string& err)
+namespace {
+
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+
+// closest point of triangle (a,b,c) to p, as barycentric coordinates (Ericson, Real-Time Collision Detection 5.1.5)
+void closest_bary(V3 p, V3 a, V3 b, V3 c, double* w)
 {
-    err = "decimation-built levels are not available yet";
-    return -1;
+    V3 ab = b - a, ac = c - a, ap = p - a;
+    double d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { w[0] = 1; w[1] = 0; w[2] = 0; return; }
+    V3 bp = p - b;
+    double d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { w[0] = 0; w[1] = 1; w[2] = 0; return; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); w[0] = 1 - v; w[1] = v; w[2] = 0; return; }
+    V3 cp = p - c;
+    double d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { w[0] = 0; w[1] = 0; w[2] = 1; return; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double t = d2 / (d2 - d6); w[0] = 1 - t; w[1] = 0; w[2] = t; return; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        double t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        w[0] = 0; w[1] = 1 - t; w[2] = t;
+        return;
+    }
+    double den = 1.0 / (va + vb + vc);
+    double v = vb * den, t = vc * den;
+    w[0] = 1 - v - t; w[1] = v; w[2] = t;
 }
+
+struct QEntry {
+    double cost;
+    int a, b, va, vb;
+    bool operator<(const QEntry& o) const
+    {   // std::priority_queue is a max-heap: invert; ties broken deterministically
+        if (cost != o.cost) return cost > o.cost;
+        if (a != o.a) return a > o.a;
+        return b > o.b;
+    }
+};
+
+struct Decimator {
+    std::vector<V3> pos;
+    std::vector<char> valive;
+    std::vector<int> version;
+    std::vector<std::array<int, 3>> faces;
+    std::vector<char> falive;
+    std::vector<std::vector<int>> vfaces;   // incident faces (may hold dead ones; filtered on access)
+    std::vector<std::vector<int>> fpoints;  // fine points living on each face
+    std::vector<int> pface;
+    std::vector<std::array<double, 3>> pbary;
+    std::priority_queue<QEntry> pq;
+    int n_alive_faces = 0;
+    int dec_type = 1;
+
+    void clean(int v)
+    {
+        auto& l = vfaces[v];
+        l.erase(std::remove_if(l.begin(), l.end(), [&](int f) { return !falive[f]; }), l.end());
+    }
+    bool has(const std::array<int, 3>& f, int v) const { return f[0] == v || f[1] == v || f[2] == v; }
+
+    // faces containing both a and b
+    int edge_faces(int a, int b, int* out)
+    {
+        int n = 0;
+        for (int f : vfaces[a]) if (falive[f] && has(faces[f], b)) { if (n < 3) out[n] = f; n++; }
+        return n;
+    }
+    bool on_boundary(int v)
+    {
+        // v is a boundary vertex iff one of its edges has a single incident face
+        std::unordered_map<int, int> cnt;
+        for (int f : vfaces[v]) if (falive[f]) for (int c = 0; c < 3; c++) if (faces[f][c] != v) cnt[faces[f][c]]++;
+        for (auto& kv : cnt) if (kv.second == 1) return true;
+        return false;
+    }
+    void push_edge(int a, int b)
+    {
+        if (a > b) std::swap(a, b);
+        pq.push({norm(pos[a] - pos[b]), a, b, version[a], version[b]});
+    }
+    void push_star(int v)
+    {
+        std::vector<int> nb;
+        for (int f : vfaces[v]) if (falive[f]) for (int c = 0; c < 3; c++) if (faces[f][c] != v) nb.push_back(faces[f][c]);
+        std::sort(nb.begin(), nb.end());
+        nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+        for (int w : nb) push_edge(v, w);
+    }
+    V3 point_pos(int p) const
+    {
+        const auto& f = faces[pface[p]];
+        const auto& w = pbary[p];
+        return w[0] * pos[f[0]] + (w[1] * pos[f[1]] + w[2] * pos[f[2]]);
+    }
+
+    // try to collapse (a,b); returns true on success
+    bool collapse(int a, int b)
+    {
+        clean(a); clean(b);
+        int ef[3];
+        const int nef = edge_faces(a, b, ef);
+        if (nef < 1 || nef > 2) return false;
+        const bool edge_is_boundary = (nef == 1);
+        const bool ba = on_boundary(a), bb = on_boundary(b);
+        if (ba && bb && !edge_is_boundary) return false;  // interior chord between two boundary vertices
+        // link condition: common neighbours == vertices opposite to the edge
+        std::vector<int> na, nb;
+        for (int f : vfaces[a]) for (int c = 0; c < 3; c++) if (faces[f][c] != a) na.push_back(faces[f][c]);
+        for (int f : vfaces[b]) for (int c = 0; c < 3; c++) if (faces[f][c] != b) nb.push_back(faces[f][c]);
+        std::sort(na.begin(), na.end()); na.erase(std::unique(na.begin(), na.end()), na.end());
+        std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+        std::vector<int> common;
+        std::set_intersection(na.begin(), na.end(), nb.begin(), nb.end(), std::back_inserter(common));
+        if ((int)common.size() != nef) return false;
+        for (int i = 0; i < nef; i++) {
+            const auto& f = faces[ef[i]];
+            int opp = f[0] != a && f[0] != b ? f[0] : (f[1] != a && f[1] != b ? f[1] : f[2]);
+            if (!std::binary_search(common.begin(), common.end(), opp)) return false;
+        }
+        if ((int)na.size() + (int)nb.size() - 2 - nef < 3) return false;  // would leave a vertex of valence < 3
+        // placement
+        V3 m;
+        if (dec_type == 2) m = pos[a];                       // vertex removal: keep an end point
+        else if (ba && !bb) m = pos[a];                      // keep the boundary where it is
+        else if (bb && !ba) m = pos[b];
+        else m = 0.5 * (pos[a] + pos[b]);                    // mid-point (dec_type 1)
+        // fold-over / degeneracy test on the surviving faces
+        for (int pass = 0; pass < 2; pass++) {
+            const int v = pass == 0 ? a : b;
+            for (int f : vfaces[v]) {
+                const auto& fc = faces[f];
+                if (has(fc, a) && has(fc, b)) continue;
+                V3 p0 = pos[fc[0]], p1 = pos[fc[1]], p2 = pos[fc[2]];
+                V3 n0 = cross(p1 - p0, p2 - p0);
+                V3 q0 = (fc[0] == v) ? m : p0, q1 = (fc[1] == v) ? m : p1, q2 = (fc[2] == v) ? m : p2;
+                V3 n1 = cross(q1 - q0, q2 - q0);
+                const double l0 = norm(n0), l1 = norm(n1);
+                if (!(l1 > 1e-14 * (1.0 + l0))) return false;
+                if (dot(n0, n1) < 0.2 * l0 * l1) return false;
+                // reject slivers: height/longest-edge quality
+                const double e = std::max(norm(q1 - q0), std::max(norm(q2 - q1), norm(q0 - q2)));
+                if (l1 < 0.02 * e * e) return false;
+            }
+        }
+        // ---- gather the fine points of the pre-collapse 1-ring with their positions
+        std::vector<int> pts;
+        std::vector<V3> ppos;
+        auto take = [&](int f) {
+            for (int p : fpoints[f]) { pts.push_back(p); ppos.push_back(point_pos(p)); }
+            fpoints[f].clear();
+            fpoints[f].shrink_to_fit();
+        };
+        for (int f : vfaces[a]) take(f);
+        for (int f : vfaces[b]) if (!has(faces[f], a)) take(f);
+        // ---- connectivity surgery: b -> a, the edge faces die
+        for (int i = 0; i < nef; i++) { falive[ef[i]] = 0; n_alive_faces--; }
+        for (int f : vfaces[b]) {
+            if (!falive[f]) continue;
+            for (int c = 0; c < 3; c++) if (faces[f][c] == b) faces[f][c] = a;
+            vfaces[a].push_back(f);
+        }
+        vfaces[b].clear();
+        valive[b] = 0;
+        pos[a] = m;
+        version[a]++; version[b]++;
+        clean(a);
+        for (int w : common) clean(w);
+        // ---- re-home the points on the post-collapse star of a (closest-point re-parameterisation)
+        for (size_t i = 0; i < pts.size(); i++) {
+            double best = 1e300, bw[3] = {1, 0, 0};
+            int bf = -1;
+            for (int f : vfaces[a]) {
+                const auto& fc = faces[f];
+                double w[3];
+                closest_bary(ppos[i], pos[fc[0]], pos[fc[1]], pos[fc[2]], w);
+                V3 q = w[0] * pos[fc[0]] + (w[1] * pos[fc[1]] + w[2] * pos[fc[2]]);
+                V3 d = q - ppos[i];
+                const double d2 = dot(d, d);
+                if (d2 < best) { best = d2; bf = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
+            }
+            const int p = pts[i];
+            pface[p] = bf;
+            pbary[p] = {bw[0], bw[1], bw[2]};
+            fpoints[bf].push_back(p);
+        }
+        push_star(a);
+        return true;
+    }
+};
+
+}  // namespace
+
+int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& P, std::string& err)
+{
+    const int nV = fine.nV(), nF = fine.nF();
+    if (dec_type != 1 && dec_type != 2) { err = "dec_type must be 1 (mid-point) or 2 (vertex removal); qslim (0) is not implemented"; return -1; }
+    if (nV < 4 || nF < 4) { err = "mesh too small to decimate"; return -1; }
+    Decimator D;
+    D.dec_type = dec_type;
+    D.pos.resize(nV);
+    for (int i = 0; i < nV; i++) D.pos[i] = {fine.V[3 * i], fine.V[3 * i + 1], fine.V[3 * i + 2]};
+    D.valive.assign(nV, 1);
+    D.version.assign(nV, 0);
+    D.faces.resize(nF);
+    D.falive.assign(nF, 1);
+    D.vfaces.assign(nV, {});
+    D.fpoints.assign(nF, {});
+    D.n_alive_faces = nF;
+    for (int f = 0; f < nF; f++) {
+        for (int c = 0; c < 3; c++) {
+            int v = fine.F[3 * f + c];
+            if (v < 0 || v >= nV) { err = "face index out of range"; return -1; }
+            D.faces[f][c] = v;
+            D.vfaces[v].push_back(f);
+        }
+        if (D.faces[f][0] == D.faces[f][1] || D.faces[f][1] == D.faces[f][2] || D.faces[f][0] == D.faces[f][2]) { err = "degenerate face"; return -1; }
+    }
+    // manifoldness (the reference bails out on non-manifold input, src/SSP_decimate.cpp:20-23)
+    {
+        std::unordered_map<uint64_t, int> ecount;
+        ecount.reserve((size_t)nF * 3);
+        for (int f = 0; f < nF; f++)
+            for (int c = 0; c < 3; c++) {
+                int a = D.faces[f][c], b = D.faces[f][(c + 1) % 3];
+                uint64_t key = ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
+                if (++ecount[key] > 2) { err = "input mesh is not edge-manifold"; return -1; }
+            }
+        for (auto& kv : ecount) {
+            int a = (int)(kv.first >> 32), b = (int)(kv.first & 0xffffffffu);
+            D.push_edge(a, b);
+        }
+    }
+    // every fine vertex starts as a one-hot barycentric point on one of its faces (src/get_prolong.cpp:23-39)
+    D.pface.assign(nV, -1);
+    D.pbary.assign(nV, {0, 0, 0});
+    for (int f = 0; f < nF; f++)
+        for (int c = 0; c < 3; c++) {
+            int v = D.faces[f][c];
+            if (D.pface[v] < 0) { D.pface[v] = f; D.pbary[v] = {0, 0, 0}; D.pbary[v][c] = 1.0; D.fpoints[f].push_back(v); }
+        }
+    for (int v = 0; v < nV; v++) if (D.pface[v] < 0) { err = "unreferenced vertex in input mesh"; return -1; }
+    // greedy loop (src/SSP_midpoint.cpp:188-220): pop the cheapest valid edge until #faces <= tarF
+    // Rejected edges are parked and offered again once the queue runs dry after at least one success (their
+    // validity can change when a neighbouring collapse rewires the link).
+    std::vector<QEntry> parked;
+    bool progressed = false;
+    while (D.n_alive_faces > tarF) {
+        if (D.pq.empty()) {
+            if (!progressed || parked.empty()) break;
+            for (const QEntry& e : parked)
+                if (D.valive[e.a] && D.valive[e.b]) D.push_edge(e.a, e.b);
+            parked.clear();
+            progressed = false;
+            continue;
+        }
+        QEntry e = D.pq.top();
+        D.pq.pop();
+        if (!D.valive[e.a] || !D.valive[e.b] || D.version[e.a] != e.va || D.version[e.b] != e.vb) continue;
+        if (D.collapse(e.a, e.b)) progressed = true;
+        else parked.push_back(e);
+    }
+    // compact
+    std::vector<int> vmap(nV, -1);
+    int nVc = 0;
+    for (int v = 0; v < nV; v++) {
+        if (!D.valive[v]) continue;
+        D.clean(v);
+        if (D.vfaces[v].empty()) continue;
+        vmap[v] = nVc++;
+    }
+    coarse.V.resize((size_t)nVc * 3);
+    for (int v = 0; v < nV; v++) if (vmap[v] >= 0) { coarse.V[3 * vmap[v]] = D.pos[v].x; coarse.V[3 * vmap[v] + 1] = D.pos[v].y; coarse.V[3 * vmap[v] + 2] = D.pos[v].z; }
+    coarse.F.clear();
+    for (int f = 0; f < nF; f++) if (D.falive[f]) for (int c = 0; c < 3; c++) coarse.F.push_back(vmap[D.faces[f][c]]);
+    // P: three stored entries per row (explicit zeros kept), src/get_prolong.cpp:45-56
+    std::vector<int> ptr(nV + 1), col((size_t)nV * 3);
+    std::vector<double> val((size_t)nV * 3);
+    for (int p = 0; p < nV; p++) {
+        ptr[p] = 3 * p;
+        const auto& f = D.faces[D.pface[p]];
+        double s = 0;
+        double w[3];
+        for (int c = 0; c < 3; c++) { w[c] = std::max(D.pbary[p][c], 0.0); s += w[c]; }   // clamp + renormalise
+        for (int c = 0; c < 3; c++) { col[3 * p + c] = vmap[f[c]]; val[3 * p + c] = w[c] / s; }  // (src/query_fine_to_coarse.cpp:113-116)
+    }
+    ptr[nV] = 3 * nV;
+    P = csr_from_arrays(nV, nVc, ptr.data(), col.data(), val.data());
+    return 0;
+}
+
 }  // namespace smg

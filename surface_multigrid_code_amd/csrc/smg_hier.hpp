@@ -62,6 +62,8 @@ struct Level {
     Ordering ord;           // colour-major numbering of this level's unknowns
     Csr A_int, P_int, PT_int;  // host copies in the internal numbering (introspection / tests)
     SellBuf dA, dP, dPT;
+    SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
+    bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
     // ---- work vectors, internal layout n x kcap ----
     DevBuf<double> b, u, r;
     int n = 0;
@@ -92,7 +94,7 @@ struct smg_hierarchy {
     // ---- execution ----
     int device = -1;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
+    bool own_stream = false, user_stream = false;
     smg::DevBuf<smg::Ctrl> d_ctrl;
     smg::DevBuf<double> d_partials;
     int kcap = 0;

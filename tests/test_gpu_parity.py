@@ -1,0 +1,257 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI) with the CPU oracle.
+
+Parity contract:
+  K-level  SpMV / restrict / prolong / GS sweep: BIT-EXACT against the oracle run on the level's matrix in the
+           device numbering (same ascending-column accumulation, no FMA contraction), <= 1e-14 relative against the
+           oracle in the caller's numbering (summation order only);
+  norm / coarse solve: <= 1e-12 relative (tree reduction / explicit inverse instead of LDL^T);
+  solve-level: both reach the tolerance; relative solution difference <= 1e-8 at tol 1e-10, iteration counts within
+           +-2 of the lexicographic-GS reference run; golden r_his of the restatement reproduced by the oracle and
+           bracketed by the GPU run.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from problems import subdiv_problem
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def smg(smg_mod):
+    assert smg_mod._lib.load().smg_device_count() > 0, "GPU tests need a HIP device (no CPU fallback exists)"
+    return smg_mod
+
+
+def build(smg, oracle_mod, **kw):
+    p = subdiv_problem(**kw)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.precompute(p["A"], p["known"])
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], p["known"])
+    return p, mg, orc
+
+
+def oracle_on_device_numbering(oracle_mod, mg, lv):
+    """An oracle whose level 0 is level `lv` of the hierarchy IN THE DEVICE NUMBERING (so that the reference's
+    lexicographic sweep on it is the multi-colour sweep the GPU runs)."""
+    A = mg.matrix(lv, "A", internal=True)
+    P = mg.matrix(lv + 1, "P", internal=True)
+    o = oracle_mod.OracleMG([P])
+    o.precompute(A)
+    return o
+
+
+# ----------------------------------------------------------------------------------------------- K-level, bitwise
+@pytest.mark.parametrize("kind,k", [("mcf", 1), ("mcf", 3), ("poisson", 2), ("mcf", 6)])
+def test_kernels_bit_exact_in_device_numbering(smg, oracle_mod, kind, k):
+    p, mg, orc = build(smg, oracle_mod, kind=kind, k=k, n_sub=2)
+    rng = np.random.default_rng(3)
+    for lv in range(mg.n_levels - 1):
+        n, nc = mg.rows(lv), mg.rows(lv + 1)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        x, b, xc = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (nc, k))
+        # y = A x
+        assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), "SpMV not bit-exact on level %d" % lv
+        # Gauss-Seidel: 1 and 3 sweeps
+        for iters in (1, 3):
+            assert np.array_equal(mg.relax(lv, b, x, iters)[perm], oi.relax(0, b[perm], x[perm], iters)), \
+                "GS sweep not bit-exact on level %d" % lv
+        # restriction / prolongation with the explicitly stored PT / P
+        assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm]))
+        assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc]))
+        # same kernels against the oracle in the caller's numbering: summation order only
+        for got, ref in ((mg.A(lv, x), orc.A(lv, x)), (mg.restrict(lv, x), orc.restrict(lv, x)),
+                         (mg.prolong(lv, xc), orc.prolong(lv, xc))):
+            assert abs(got - ref).max() <= 1e-14 * max(abs(ref).max(), 1e-300) * 8
+        # residual norm (tree reduction)
+        rn = mg.residual_norm(lv, b, x)
+        ref = np.linalg.norm(b - orc.A(lv, x))
+        assert abs(rn - ref) <= 1e-13 * ref
+
+
+def test_colouring_is_valid_and_sell_matches_csr(smg, oracle_mod):
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=1, n_sub=2)
+    for lv in range(mg.n_levels - 1):
+        A = mg.matrix(lv, "A", internal=True).tocsr()
+        cp = mg.colors(lv)
+        assert cp[0] == 0 and cp[-1] == mg.rows(lv) and 3 <= len(cp) - 1 <= 12
+        Ac = A.tocoo()
+        color_of = np.searchsorted(cp, np.arange(mg.rows(lv)), side="right") - 1
+        off = Ac.row != Ac.col
+        assert (color_of[Ac.row[off]] != color_of[Ac.col[off]]).all(), "two coupled rows share a colour"
+        # internal matrix is the caller matrix under the permutation
+        perm = mg.perm(lv)
+        Ac2 = mg.matrix(lv, "A").tocsr()[perm][:, perm]
+        assert abs(Ac2 - A).max() == 0
+        st = mg.sell_stats(lv, "A")
+        assert st["stored"] == A.nnz and st["padded"] >= st["stored"]
+        if mg.rows(lv) > 20000:
+            assert st["padded"] / st["stored"] < 1.10, "SELL padding above 10%"
+
+
+def test_coarse_solve_matches_ldlt(smg, oracle_mod):
+    p, mg, orc = build(smg, oracle_mod, kind="poisson", k=2, n_sub=2)
+    rng = np.random.default_rng(5)
+    nc = mg.rows(mg.n_levels - 1)
+    B, u = rng.uniform(-1, 1, (nc, 2)), rng.uniform(-1, 1, (nc, 2))
+    got, ref = mg.coarse_solve(B, u), orc.coarse_solve(B, u)
+    assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
+
+
+# ----------------------------------------------------------------------------------------------- V-cycle
+@pytest.mark.parametrize("kind,k", [("mcf", 1), ("poisson", 1), ("mcf", 3)])
+def test_vcycle_matches_oracle_in_device_numbering(smg, oracle_mod, kind, k):
+    """One V(2,2) cycle on the 2-level hierarchy (level L-2 -> coarsest): the oracle runs the reference algorithm on
+    the renumbered system; everything but the coarse solve is bit-exact, the cycle agrees to 1e-11."""
+    p, mg, orc = build(smg, oracle_mod, kind=kind, k=k, n_sub=2)
+    lv = mg.n_levels - 2
+    oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+    rng = np.random.default_rng(9)
+    n = mg.rows(lv)
+    perm = mg.perm(lv)
+    B, u = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+    got = mg.vcycle(B, u, lv=lv)[perm]
+    ref = oi.vcycle(B[perm], u[perm], lv=0)
+    assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
+    # full-depth cycle against the oracle in the caller's numbering: same contraction to rounding of the smoother order
+    B0, u0 = rng.uniform(-1, 1, (mg.rows(0), k)), np.zeros((mg.rows(0), k))
+    r_gpu = np.linalg.norm(B0 - orc.A(0, mg.vcycle(B0, u0)))
+    r_ref = np.linalg.norm(B0 - orc.A(0, orc.vcycle(B0, u0)))
+    assert r_gpu < 2.0 * r_ref and r_gpu < 0.5 * np.linalg.norm(B0)
+
+
+# ----------------------------------------------------------------------------------------------- solve level
+@pytest.mark.parametrize("kind,k,tol", [("mcf", 3, 5e-7), ("poisson", 1, 1e-10), ("poisson", 2, 1e-3), ("mcf", 1, 1e-10)])
+def test_solve_matches_reference_algorithm(smg, oracle_mod, kind, k, tol):
+    p, mg, orc = build(smg, oracle_mod, kind=kind, k=k, n_sub=2)
+    opts = smg.SolveOpts(tol=tol, max_iter=40)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], opts)
+    conv2, z2, rh2 = orc.solve(p["RHS"], p["z0"], p["known_val"], tol=tol, max_iter=40)
+    assert conv and conv2
+    assert abs(len(rh) - len(rh2)) <= 2
+    assert abs(rh[0] - rh2[0]) <= 1e-12 * rh2[0]            # same initial residual
+    assert rh[-1] < tol and (np.diff(rh) < 0).all()
+    # A SPD: ||z_gpu - z_ref|| <= (r_gpu + r_ref) / lambda_min; stated bound: 1e-8 rel at tol 1e-10
+    rel = np.linalg.norm(z - z2) / np.linalg.norm(z2)
+    assert rel <= (1e-8 if tol <= 1e-9 else 1e-3)
+    if p["known"] is not None:
+        assert np.array_equal(z[p["known"]], p["known_val"])
+    # the residual the GPU reports is the true residual of what it returned
+    A = p["A"]
+    if p["known"] is None:
+        true = np.linalg.norm(p["RHS"] - A @ z)
+        assert true < tol * 1.5 + 1e-15
+
+
+def test_golden_residual_histories(smg, oracle_mod):
+    """The restatement-derived goldens: lexicographic GS history; the multi-colour GPU history starts from the same
+    residual, needs the same number of cycles (+-2) and lands on the same solution."""
+    g1 = np.load(os.path.join(G, "g1_mcf_k3.npz"))
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=3, n_sub=2)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=5e-7, max_iter=20))
+    assert conv and abs(len(rh) - len(g1["r_his"])) <= 2 and abs(rh[0] - g1["r_his"][0]) < 1e-12 * rh[0]
+    assert abs(np.linalg.norm(z) - g1["z_norm"]) < 1e-6 * g1["z_norm"]
+    g2 = np.load(os.path.join(G, "g2_poisson_bd.npz"))
+    p, mg, orc = build(smg, oracle_mod, kind="poisson", k=1, n_sub=2)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-10, max_iter=30))
+    assert conv and abs(len(rh) - len(g2["r_his"])) <= 2 and abs(rh[0] - g2["r_his"][0]) < 1e-12 * rh[0]
+    np.testing.assert_allclose(z[g2["idx"], 0], g2["z_samples"], rtol=0, atol=1e-8 * g2["z_norm"])
+
+
+def test_outer_loop_bookkeeping_matches_reference(smg, oracle_mod):
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=1, n_sub=1)
+    # exhausts max_iter: r_his has max_iter entries, converged False, last cycle's effect not measured
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-30, max_iter=3))
+    assert not conv and len(rh) == 3
+    # already converged: one entry, no cycle executed, z == z0 bitwise
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e30, max_iter=5))
+    assert conv and len(rh) == 1 and np.array_equal(z, p["z0"])
+    # the device-side break is independent of how often the host polls, and of graph replay vs eager launches
+    ref = None
+    for check_every, use_graph in ((1, 1), (4, 1), (50, 1), (1, 0), (7, 0)):
+        conv, z, rh = mg.solve(p["RHS"], p["z0"], None,
+                               smg.SolveOpts(tol=1e-9, max_iter=50, check_every=check_every, use_graph=use_graph))
+        assert conv
+        if ref is None:
+            ref = (z, rh)
+        else:
+            assert np.array_equal(z, ref[0]) and np.array_equal(rh, ref[1]), "result depends on polling/graph mode"
+
+
+def test_deterministic_and_reentrant(smg, oracle_mod):
+    p, mg, orc = build(smg, oracle_mod, kind="poisson", k=2, n_sub=2)
+    o = smg.SolveOpts(tol=1e-9, max_iter=30)
+    a = mg.solve(p["RHS"], p["z0"], p["known_val"], o)
+    b = mg.solve(p["RHS"], p["z0"], p["known_val"], o)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # re-precompute with another matrix on the same handle (time-stepping callers, 05_example.../main.cpp:74)
+    A2 = (p["A"] + 0.5 * sp.eye(p["A"].shape[0])).tocsr()
+    mg.precompute(A2, p["known"])
+    orc.precompute(A2, p["known"])
+    c = mg.solve(p["RHS"], p["z0"], p["known_val"], o)
+    d = orc.solve(p["RHS"], p["z0"], p["known_val"], tol=1e-9, max_iter=30)
+    assert c[0] and np.linalg.norm(c[1] - d[1]) <= 1e-7 * np.linalg.norm(d[1])
+    # and back without constraints on the same handle: restarts from P_full
+    pm = subdiv_problem(kind="mcf", k=2, n_sub=2)
+    mg.precompute(pm["A"], None)
+    e = mg.solve(pm["RHS"], pm["z0"], None, o)
+    assert e[0] and mg.rows(0) == pm["A"].shape[0]
+
+
+def test_profc_scopes(smg, oracle_mod):
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=1, n_sub=2)
+    mg.prof_enable(True)
+    mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=0.0, max_iter=3))
+    t = mg.prof_table()
+    mg.prof_enable(False)
+    # reference scope names (src/mg_VCycle.cpp:121, src/min_quad_with_fixed_mg.cpp:123)
+    assert t["MG: total VCycle"][0] == 3
+    assert t["MG: relaxation"][0] == 3 * 2 * (mg.n_levels - 1)
+    assert t["MG: relaxation"][1] > 0 and t["MG: total VCycle"][1] >= t["MG: relaxation"][1]
+
+
+def test_decimated_hierarchy_bunny_poisson(smg, oracle_mod):
+    """BASELINE config C1: bunny.obj Poisson with the boundary loop pinned (03_mg_solver), hierarchy from
+    smg_mg_precompute (libsmg's own decimator), tol 1e-3 / maxIter 20 defaults."""
+    from oracle import mesh_np as M
+    mesh = smg.mesh
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    A = (-M.cotmatrix(V, F)).tocsr()
+    b = M.boundary_loop(F)
+    n = V.shape[0]
+    B = M.massmatrix(V, F, "voronoi") @ np.ones(n)
+    B[b] = 0.0
+    data = smg.min_quad_with_fixed_mg_precompute(A, b, mg)
+    assert data.n == n and len(data.unknown) == n - 149
+    conv, z, rh = smg.min_quad_with_fixed_mg_solve(data, B, np.zeros(len(b)), np.zeros(n), mg)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A, b)
+    conv2, z2, rh2 = orc.solve(B, np.zeros(n), np.zeros(len(b)), tol=1e-3, max_iter=20)
+    assert conv and conv2 and abs(len(rh) - len(rh2)) <= 2
+    assert np.linalg.norm(z - z2) <= 1e-3 * np.linalg.norm(z2)
+    # tight solve: same solution to 1e-8
+    conv, z, rh = mg.solve(B, np.zeros(n), np.zeros(len(b)), smg.SolveOpts(tol=1e-10, max_iter=40))
+    conv2, z2, rh2 = orc.solve(B, np.zeros(n), np.zeros(len(b)), tol=1e-10, max_iter=40)
+    assert conv and conv2 and np.linalg.norm(z - z2) <= 1e-8 * np.linalg.norm(z2)
+
+
+def test_many_columns(smg, oracle_mod):
+    """BASELINE config C4 flavour at test size: k = 16 right-hand sides (5 column chunks), one Frobenius residual."""
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=16, n_sub=1)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=5e-7, max_iter=30))
+    conv2, z2, rh2 = orc.solve(p["RHS"], p["z0"], tol=5e-7, max_iter=30)
+    assert conv and conv2 and abs(len(rh) - len(rh2)) <= 2
+    assert np.linalg.norm(z - z2) <= 1e-5 * np.linalg.norm(z2)
+    # columns are independent: solving a subset alone gives the same per-column V-cycle iterates
+    u_all = mg.vcycle(p["RHS"], p["z0"])
+    u_one = mg.vcycle(p["RHS"][:, 5], p["z0"][:, 5])
+    assert np.array_equal(u_all[:, 5], u_one[:, 0])

