@@ -97,7 +97,9 @@ hipError_t SellBuf::upload(const Sell& S)
     if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
     if ((e = col.upload(S.col)) != hipSuccess) return e;
     if ((e = val.upload(S.val)) != hipSuccess) return e;
-    view.n_rows = S.n_rows; view.n_cols = S.n_cols; view.n_slices = S.n_slices;
+    if ((e = order.upload(S.region_order)) != hipSuccess) return e;
+    view.n_rows = S.n_rows; view.n_cols = S.n_cols; view.n_slices = S.n_slices; view.C = S.C;
+    view.order = S.region_order.empty() ? nullptr : order.p;
     view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.col = col.p; view.val = val.p;
     color_slice_ptr = S.color_slice_ptr;
     stored = S.nnz; padded = S.padded();
@@ -282,27 +284,48 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         h->lv[lv].A_diag = diagonal(h->lv[lv].A);
         h->lv[lv].n = h->lv[lv].A.nr;
     }
+    // ---- device numbering (still host work): colour-major ordering of every smoothed level and the operators
+    // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        Lv.ord = (lv < L - 1) ? make_ordering(Lv.A) : identity_ordering(Lv.n);
+    }
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        Lv.A_int = (lv < L - 1) ? permute(Lv.A, Lv.ord.perm, Lv.ord.perm) : Lv.A;
+        if (lv >= 1) {
+            const Ordering& of = h->lv[lv - 1].ord;
+            Lv.P_int = permute(Lv.P, of.perm, Lv.ord.perm);
+            Lv.PT_int = permute(Lv.PT, Lv.ord.perm, of.perm);
+        }
+    }
     return SMG_OK;
 }
 
 // Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
+static int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
 static int precompute_device(smg_hierarchy* h)
 {
     const int L = h->n_levels;
+    // tuning knobs (A/B experiments): slice height of the system matrices and region-major launch order
+    const int sellC = env_int("SMG_SELL_C", 64) == 128 ? 128 : 64;
+    const bool region = env_int("SMG_REGION_ORDER", 1) != 0;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
-        // smoothed levels get the colour-major numbering; the coarsest is only ever hit by the dense solve
-        Lv.ord = (lv < L - 1) ? make_ordering(Lv.A) : identity_ordering(Lv.n);
         Lv.b.release(); Lv.u.release(); Lv.r.release();
     }
     h->kcap = 0;
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
         if (lv < L - 1) {
-            Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm);
-            Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr);
+            Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, region);
             HIPCHK(Lv.dA.upload(S));
             // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
             // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
@@ -313,16 +336,11 @@ static int precompute_device(smg_hierarchy* h)
             if (Lv.gs_on_transpose) {
                 if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col))
                     return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
-                Sell ST = build_sell(AT, &Lv.ord.color_ptr);
+                Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
                 HIPCHK(Lv.dAT.upload(ST));
             }
-        } else {
-            Lv.A_int = Lv.A;
         }
         if (lv >= 1) {
-            const Ordering& of = h->lv[lv - 1].ord;
-            Lv.P_int = permute(Lv.P, of.perm, Lv.ord.perm);
-            Lv.PT_int = permute(Lv.PT, Lv.ord.perm, of.perm);
             Sell SP = build_sell(Lv.P_int, nullptr);
             Sell SPT = build_sell(Lv.PT_int, nullptr);
             HIPCHK(Lv.dP.upload(SP));

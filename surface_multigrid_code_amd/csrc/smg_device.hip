@@ -26,66 +26,96 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE, int KB>
-__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, const double* x, const double* b,
-                                              double* y, int ld, const int* done, double* partials)
+template <int RPL> struct PanelLoad;
+template <> struct PanelLoad<1> {
+    static __device__ __forceinline__ void ld(const int* cp, const double* vp, int* c, double* v) { c[0] = *cp; v[0] = *vp; }
+};
+template <> struct PanelLoad<2> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wave-instruction
+    static __device__ __forceinline__ void ld(const int* cp, const double* vp, int* c, double* v)
+    {
+        const int2 cc = *reinterpret_cast<const int2*>(cp);
+        const double2 vv = *reinterpret_cast<const double2*>(vp);
+        c[0] = cc.x; c[1] = cc.y; v[0] = vv.x; v[1] = vv.y;
+    }
+};
+
+// One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
+template <int MODE, int KB, int RPL>
+__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const double* x,
+                                              const double* b, double* y, int ld, const int* done, double* partials)
 {
     if (done && *done) return;
+    constexpr int C = 64 * RPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int s = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
+    const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
     double ss = 0.0;
-    if (s < s_end) {
+    if (ls < s_end) {
+        const int s = use_order ? A.order[ls] : ls;
         const int row0 = A.slice_row[s];
         const int nrow = A.slice_row[s + 1] - row0;
         const int off0 = A.slice_off[s];
         const int w = A.slice_off[s + 1] - off0;
-        const int* cp = A.col + (size_t)off0 * 64 + lane;
-        const double* vp = A.val + (size_t)off0 * 64 + lane;
-        const int row = row0 + lane;
-        double acc[KB];
+        const int* cp = A.col + (size_t)off0 * C + RPL * lane;
+        const double* vp = A.val + (size_t)off0 * C + RPL * lane;
+        const int rowb = row0 + RPL * lane;
+        double acc[RPL][KB];
+        double diag[RPL];
 #pragma unroll
-        for (int q = 0; q < KB; q++) acc[q] = 0.0;
-        double diag = 1.0;
+        for (int r = 0; r < RPL; r++) {
+            diag[r] = 1.0;
+#pragma unroll
+            for (int q = 0; q < KB; q++) acc[r][q] = 0.0;
+        }
         constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
-            int c[U];
-            double v[U];
+            int c[U][RPL];
+            double v[U][RPL];
 #pragma unroll
             for (int t = 0; t < U; t++) {
-                const bool in = (j0 + t) < w;  // wave-uniform
-                c[t] = in ? cp[(size_t)(j0 + t) * 64] : -1;
-                v[t] = in ? vp[(size_t)(j0 + t) * 64] : 0.0;
-            }
-            double xv[U][KB];
+                if ((j0 + t) < w) {  // wave-uniform
+                    PanelLoad<RPL>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
+                } else {
 #pragma unroll
-            for (int t = 0; t < U; t++) {
-                const bool use = (c[t] >= 0) && !(MODE == SELL_GS && c[t] == row);
-#pragma unroll
-                for (int q = 0; q < KB; q++) xv[t][q] = use ? x[(size_t)c[t] * ld + q] : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-                if (c[t] >= 0) {
-                    if (MODE == SELL_GS && c[t] == row) {
-                        diag = v[t];
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
-                    }
+                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = 0.0; }
                 }
             }
-        }
-        if (lane < nrow) {
-            const size_t o = (size_t)row * ld;
+            double xv[U][RPL][KB];
 #pragma unroll
-            for (int q = 0; q < KB; q++) {
-                if (MODE == SELL_AX) y[o + q] = acc[q];
-                else if (MODE == SELL_RESID) y[o + q] = b[o + q] - acc[q];
-                else if (MODE == SELL_ADD) y[o + q] = y[o + q] + acc[q];
-                else if (MODE == SELL_GS) y[o + q] = (b[o + q] - acc[q]) / diag;
-                else { const double t = b[o + q] - acc[q]; ss += t * t; }
+            for (int t = 0; t < U; t++)
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    const bool use = (c[t][r] >= 0) && !(MODE == SELL_GS && c[t][r] == rowb + r);
+#pragma unroll
+                    for (int q = 0; q < KB; q++) xv[t][r][q] = use ? x[(size_t)c[t][r] * ld + q] : 0.0;
+                }
+#pragma unroll
+            for (int t = 0; t < U; t++)
+#pragma unroll
+                for (int r = 0; r < RPL; r++) {
+                    if (c[t][r] >= 0) {
+                        if (MODE == SELL_GS && c[t][r] == rowb + r) {
+                            diag[r] = v[t][r];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < KB; q++) acc[r][q] += v[t][r] * xv[t][r][q];
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < RPL; r++) {
+            if (RPL * lane + r < nrow) {
+                const size_t o = (size_t)(rowb + r) * ld;
+#pragma unroll
+                for (int q = 0; q < KB; q++) {
+                    if (MODE == SELL_AX) y[o + q] = acc[r][q];
+                    else if (MODE == SELL_RESID) y[o + q] = b[o + q] - acc[r][q];
+                    else if (MODE == SELL_ADD) y[o + q] = y[o + q] + acc[r][q];
+                    else if (MODE == SELL_GS) y[o + q] = (b[o + q] - acc[r][q]) / diag[r];
+                    else { const double t = b[o + q] - acc[r][q]; ss += t * t; }
+                }
             }
         }
     }
@@ -101,13 +131,15 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
 
 int sell_blocks(int n_slices) { return (n_slices + 3) / 4; }
 
-template <int MODE>
+template <int MODE, int RPL>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, const double* x, const double* b, double* y,
                                    int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
 {
     const int ns = s_end - s_begin;
     const int nb = sell_blocks(ns);
     const int* done = ctrl ? &ctrl->done : nullptr;
+    // the region-major launch order only makes sense for whole-matrix launches
+    const int use_order = (A.order && s_begin == 0 && s_end == A.n_slices) ? 1 : 0;
     int chunk = 0;
     if (n_blocks) *n_blocks = 0;
     if (ns <= 0) return hipSuccess;
@@ -118,27 +150,35 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
         double* yy = y ? y + c0 : nullptr;
         double* pp = partials ? partials + (size_t)chunk * nb : nullptr;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, xx, bb, yy, k, done, pp); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
         }
     }
     if (n_blocks) *n_blocks = chunk * nb;
     return hipGetLastError();
 }
 
+template <int RPL>
+static hipError_t launch_sell_rpl(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
+                                  double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+{
+    switch (mode) {
+        case SELL_AX: return launch_sell_mode<SELL_AX, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_GS: return launch_sell_mode<SELL_GS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
 {
-    switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_ADD: return launch_sell_mode<SELL_ADD>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_GS: return launch_sell_mode<SELL_GS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-    }
-    return hipErrorInvalidValue;
+    if (A.C == 128) return launch_sell_rpl<2>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+    return launch_sell_rpl<1>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control

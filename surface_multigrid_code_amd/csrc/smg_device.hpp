@@ -27,8 +27,10 @@ struct Ctrl {
 
 struct SellDev {
     int n_rows = 0, n_cols = 0, n_slices = 0;
+    int C = 64;                      // slice height: 64 (one row per lane) or 128 (two adjacent rows per lane)
     const int* slice_row = nullptr;  // n_slices + 1
-    const int* slice_off = nullptr;  // n_slices + 1 (units of 64 entries)
+    const int* slice_off = nullptr;  // n_slices + 1 (units of C entries)
+    const int* order = nullptr;      // optional launch order of the slices (region-major), whole-matrix kernels only
     const int* col = nullptr;
     const double* val = nullptr;
 };
@@ -46,7 +48,7 @@ enum SellMode {
 // blocks is returned through *n_blocks.
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st);
-int sell_blocks(int n_slices);
+int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 
 // ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);

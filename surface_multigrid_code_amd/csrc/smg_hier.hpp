@@ -41,7 +41,7 @@ struct DevBuf {
 };
 
 struct SellBuf {  // device image of one SELL matrix
-    DevBuf<int> slice_row, slice_off, col;
+    DevBuf<int> slice_row, slice_off, col, order;
     DevBuf<double> val;
     SellDev view;
     std::vector<int> color_slice_ptr;

@@ -2,7 +2,10 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <numeric>
+#include <queue>
+#include <utility>
 
 namespace smg {
 
@@ -60,19 +63,30 @@ Ordering identity_ordering(int n)
     return o;
 }
 
-Ordering make_ordering(const Csr& A, int sigma)
+// ---- colouring -------------------------------------------------------------------------------------------
+// Every colour is one kernel launch per Gauss-Seidel sweep, on every level, and small levels are pure launch
+// latency: fewer colours = fewer launches.  Triangle-mesh graphs are 4-colourable in principle; plain first-fit
+// in BFS order gives 5-6 with one or two almost empty classes.  Pipeline: DSATUR, then try to dissolve the
+// smallest classes by local recolouring, then iterated greedy (Culberson) which can only lower the count.
+
+static int count_colors(const std::vector<int>& color)
 {
-    int n = A.nr;
-    Ordering o;
-    std::vector<int> rcm = rcm_order(A);  // new -> old
-    // greedy first-fit colouring, visiting vertices in RCM order
-    std::vector<int> color(n, -1);
-    std::vector<int> forbid;  // forbid[c] == v  <=> colour c used by a neighbour of v
+    int nc = 0;
+    for (int c : color) nc = std::max(nc, c + 1);
+    return nc;
+}
+
+// first-fit greedy over a given visiting order; returns the number of colours
+static int greedy_color(const Csr& A, const std::vector<int>& order, std::vector<int>& color)
+{
+    const int n = A.nr;
+    color.assign(n, -1);
+    std::vector<int> forbid;
     int ncol = 0;
     for (int t = 0; t < n; t++) {
-        int v = rcm[t];
+        const int v = order[t];
         for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) {
-            int w = A.col[p];
+            const int w = A.col[p];
             if (w != v && color[w] >= 0) {
                 if ((int)forbid.size() <= color[w]) forbid.resize(color[w] + 1, -1);
                 forbid[color[w]] = v;
@@ -84,6 +98,242 @@ Ordering make_ordering(const Csr& A, int sigma)
         color[v] = c;
         ncol = std::max(ncol, c + 1);
     }
+    return ncol;
+}
+
+// DSATUR (Brelaz): always colour the vertex that sees the most distinct colours; ties by degree, then index.
+static int dsatur_color(const Csr& A, std::vector<int>& color)
+{
+    const int n = A.nr;
+    color.assign(n, -1);
+    std::vector<uint64_t> seen(n, 0);  // bit c set <=> a neighbour has colour c (c < 64)
+    std::vector<int> sat(n, 0), deg(n);
+    for (int i = 0; i < n; i++) deg[i] = A.ptr[i + 1] - A.ptr[i];
+    struct E { int sat, deg, v; bool operator<(const E& o) const { return sat != o.sat ? sat < o.sat : (deg != o.deg ? deg < o.deg : v > o.v); } };
+    std::priority_queue<E> pq;
+    for (int i = 0; i < n; i++) pq.push({0, deg[i], i});
+    int ncol = 0;
+    while (!pq.empty()) {
+        const E e = pq.top();
+        pq.pop();
+        const int v = e.v;
+        if (color[v] >= 0 || e.sat != sat[v]) continue;
+        int c = 0;
+        while (c < 63 && ((seen[v] >> c) & 1)) c++;
+        color[v] = c;
+        ncol = std::max(ncol, c + 1);
+        for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) {
+            const int w = A.col[p];
+            if (w == v || color[w] >= 0) continue;
+            if (!((seen[w] >> c) & 1)) { seen[w] |= (1ull << c); sat[w]++; pq.push({sat[w], deg[w], w}); }
+        }
+    }
+    return ncol;
+}
+
+// Try to empty the highest class K.  Each of its vertices v is moved to a lower colour, by (1) a free colour,
+// (2) first moving the neighbours that hold some colour c to another free colour, (3) a Kempe-chain swap a<->b on
+// the (a,b)-components hanging off v's a-neighbours when those do not reach a b-neighbour of v (component size
+// capped, total work budgeted), (4) for the last stragglers an exhaustive re-colouring of a small ball around v.
+// Every step keeps the colouring valid; returns true when class K ended up empty.
+struct Recolor {
+    const Csr& A;
+    std::vector<int>& color;
+    int K;
+    std::vector<char> mark;
+    long budget;
+    Recolor(const Csr& A_, std::vector<int>& c, int K_) : A(A_), color(c), K(K_), mark(A_.nr, 0), budget(40L * A_.nr + 100000) {}
+
+    int free_color(int u, int avoid) const
+    {
+        uint64_t used = 0;
+        for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) { const int w = A.col[p]; if (w != u && color[w] >= 0) used |= 1ull << color[w]; }
+        for (int c = 0; c < K; c++) if (c != avoid && !((used >> c) & 1)) return c;
+        return -1;
+    }
+    bool exchange(int v)
+    {
+        for (int c = 0; c < K; c++) {
+            std::vector<std::pair<int, int>> undo;
+            bool ok = true;
+            for (int p = A.ptr[v]; p < A.ptr[v + 1] && ok; p++) {
+                const int u = A.col[p];
+                if (u == v || color[u] != c) continue;
+                const int d = free_color(u, c);
+                if (d < 0) ok = false;
+                else { undo.emplace_back(u, color[u]); color[u] = d; }
+            }
+            if (ok) { color[v] = c; return true; }
+            for (auto it = undo.rbegin(); it != undo.rend(); ++it) color[it->first] = it->second;
+        }
+        return false;
+    }
+    bool kempe(int v, int cap)
+    {
+        std::vector<int> comp, stack;
+        for (int a = 0; a < K; a++)
+            for (int b = 0; b < K; b++) {
+                if (a == b || budget <= 0) continue;
+                comp.clear(); stack.clear();
+                bool blocked = false;
+                auto push = [&](int u) { if (!mark[u]) { mark[u] = 1; comp.push_back(u); stack.push_back(u); } };
+                for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) { const int w = A.col[p]; if (w != v && color[w] == a) push(w); }
+                while (!stack.empty() && !blocked) {
+                    const int u = stack.back();
+                    stack.pop_back();
+                    for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) {
+                        const int w = A.col[p];
+                        if (w == u || w == v || (color[w] != a && color[w] != b)) continue;
+                        push(w);
+                    }
+                    if ((int)comp.size() > cap) blocked = true;
+                }
+                budget -= (long)comp.size() * 8;
+                if (!blocked)
+                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) { const int w = A.col[p]; if (w != v && color[w] == b && mark[w]) { blocked = true; break; } }
+                if (!blocked) for (int u : comp) color[u] = (color[u] == a) ? b : a;
+                for (int u : comp) mark[u] = 0;
+                if (!blocked) { color[v] = a; return true; }
+            }
+        return false;
+    }
+    // exhaustive K-colouring of the ball of given radius around v, colours outside the ball fixed
+    bool ball(int v, int radius, long node_limit)
+    {
+        std::vector<int> B{v}, dist{0};
+        mark[v] = 1;
+        for (size_t h = 0; h < B.size(); h++) {
+            if (dist[h] == radius) continue;
+            const int u = B[h];
+            for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) { const int w = A.col[p]; if (!mark[w]) { mark[w] = 1; B.push_back(w); dist.push_back(dist[h] + 1); } }
+        }
+        std::vector<int> saved(B.size());
+        for (size_t i = 0; i < B.size(); i++) { saved[i] = color[B[i]]; color[B[i]] = -1; }
+        long nodes = 0;
+        std::vector<int> stackv, stackc;  // iterative DFS: chosen vertex, next colour to try
+        auto avail = [&](int u) { uint64_t used = 0; for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) { const int w = A.col[p]; if (w != u && color[w] >= 0) used |= 1ull << color[w]; } return (~used) & ((1ull << K) - 1); };
+        auto pick = [&]() {  // most constrained uncoloured ball vertex
+            int best = -1, bc = 99;
+            for (int u : B) if (color[u] < 0) { const int c = __builtin_popcountll(avail(u)); if (c < bc) { bc = c; best = u; } }
+            return best;
+        };
+        bool ok = false;
+        int u = pick();
+        stackv.push_back(u); stackc.push_back(0);
+        while (!stackv.empty()) {
+            if (++nodes > node_limit) break;
+            const int cu = stackv.back();
+            int& next = stackc.back();
+            color[cu] = -1;
+            const uint64_t av = avail(cu);
+            int c = next;
+            while (c < K && !((av >> c) & 1)) c++;
+            if (c >= K) { stackv.pop_back(); stackc.pop_back(); continue; }
+            next = c + 1;
+            color[cu] = c;
+            const int nu = pick();
+            if (nu < 0) { ok = true; break; }
+            stackv.push_back(nu); stackc.push_back(0);
+        }
+        if (!ok) for (size_t i = 0; i < B.size(); i++) color[B[i]] = saved[i];
+        for (int w : B) mark[w] = 0;
+        return ok;
+    }
+    bool run()
+    {
+        std::vector<int> todo, left;
+        for (int v = 0; v < A.nr; v++) if (color[v] == K) todo.push_back(v);
+        for (int v : todo) {
+            const int d = free_color(v, -1);
+            if (d >= 0) { color[v] = d; continue; }
+            if (exchange(v)) continue;
+            left.push_back(v);
+        }
+        // Kempe passes with growing component caps: the expensive caps only ever see the few survivors
+        const int caps[] = {256, 2048, 16384};
+        for (int cap : caps) {
+            if (left.empty()) break;
+            todo.swap(left); left.clear();
+            budget = 40L * A.nr + 1000000;
+            for (int v : todo) {
+                if (color[v] != K) continue;
+                const int d = free_color(v, -1);   // earlier swaps may have freed a colour
+                if (d >= 0) { color[v] = d; continue; }
+                if (exchange(v)) continue;
+                if (budget > 0 && kempe(v, cap)) continue;
+                left.push_back(v);
+            }
+        }
+        if (left.size() <= 256)
+            for (int v : left) {
+                if (color[v] != K) continue;
+                if (ball(v, 2, 50000)) continue;
+                ball(v, 3, 400000);
+            }
+        for (int v = 0; v < A.nr; v++) if (color[v] == K) return false;
+        return true;
+    }
+};
+
+static bool dissolve_top_class(const Csr& A, std::vector<int>& color, int K)
+{
+    Recolor r(A, color, K);
+    return r.run();
+}
+
+static void compact_colors(std::vector<int>& color)
+{
+    // renumber classes by decreasing size (largest first: big launches first, stragglers last)
+    const int nc = count_colors(color);
+    std::vector<long> size(nc, 0);
+    for (int c : color) size[c]++;
+    std::vector<int> idx(nc);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return size[a] > size[b]; });
+    std::vector<int> remap(nc, -1);
+    int k = 0;
+    for (int c : idx) if (size[c] > 0) remap[c] = k++;
+    for (int& c : color) c = remap[c];
+}
+
+static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
+{
+    std::vector<int> best, cur;
+    int nbest = greedy_color(A, rcm, best);
+    if (A.nr == 0) return best;
+    if (dsatur_color(A, cur) <= nbest) best = cur;
+    compact_colors(best);
+    nbest = count_colors(best);
+    // two rounds of iterated greedy (Culberson): revisit class by class, can only lower the count
+    for (int it = 0; it < 2; it++) {
+        const int nc = count_colors(best);
+        std::vector<std::vector<int>> cls(nc);
+        for (int t = 0; t < A.nr; t++) cls[best[rcm[t]]].push_back(rcm[t]);
+        std::vector<int> order;
+        order.reserve(A.nr);
+        for (int c = nc - 1; c >= 0; c--) order.insert(order.end(), cls[c].begin(), cls[c].end());
+        if (greedy_color(A, order, cur) <= nc) { best = cur; compact_colors(best); }
+    }
+    nbest = count_colors(best);
+    // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle)
+    for (int guard = 0; guard < 6 && nbest > 3; guard++) {
+        cur = best;
+        const bool emptied = dissolve_top_class(A, cur, nbest - 1);
+        best = cur;  // partial progress is kept: the colouring stays valid
+        compact_colors(best);
+        nbest = count_colors(best);
+        if (!emptied) break;
+    }
+    return best;
+}
+
+Ordering make_ordering(const Csr& A, int sigma)
+{
+    int n = A.nr;
+    Ordering o;
+    std::vector<int> rcm = rcm_order(A);  // new -> old
+    std::vector<int> color = color_graph(A, rcm);
+    int ncol = count_colors(color);
     // colour-major, RCM rank inside a colour (counting sort keeps the RCM order stable)
     o.color_ptr.assign(ncol + 1, 0);
     for (int v = 0; v < n; v++) o.color_ptr[color[v] + 1]++;
@@ -109,9 +359,10 @@ Ordering make_ordering(const Csr& A, int sigma)
     return o;
 }
 
-Sell build_sell(const Csr& A, const std::vector<int>* row_breaks)
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order)
 {
     Sell S;
+    S.C = C;
     S.n_rows = A.nr; S.n_cols = A.nc; S.nnz = A.nnz();
     std::vector<int> breaks;
     if (row_breaks) breaks = *row_breaks;
@@ -120,8 +371,8 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks)
     S.slice_off.push_back(0);
     S.color_slice_ptr.push_back(0);
     for (size_t c = 0; c + 1 < breaks.size(); c++) {
-        for (int r0 = breaks[c]; r0 < breaks[c + 1]; r0 += SELL_C) {
-            int r1 = std::min(r0 + SELL_C, breaks[c + 1]);
+        for (int r0 = breaks[c]; r0 < breaks[c + 1]; r0 += C) {
+            int r1 = std::min(r0 + C, breaks[c + 1]);
             int w = 0;
             for (int r = r0; r < r1; r++) w = std::max(w, A.ptr[r + 1] - A.ptr[r]);
             S.slice_row.push_back(r1);
@@ -130,19 +381,31 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks)
         S.color_slice_ptr.push_back((int)S.slice_row.size() - 1);
     }
     S.n_slices = (int)S.slice_row.size() - 1;
-    size_t tot = (size_t)SELL_C * (size_t)S.slice_off.back();
+    size_t tot = (size_t)C * (size_t)S.slice_off.back();
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);
     for (int s = 0; s < S.n_slices; s++) {
-        size_t base = (size_t)SELL_C * (size_t)S.slice_off[s];
+        size_t base = (size_t)C * (size_t)S.slice_off[s];
         for (int r = S.slice_row[s]; r < S.slice_row[s + 1]; r++) {
             int lane = r - S.slice_row[s];
             int j = 0;
             for (int p = A.ptr[r]; p < A.ptr[r + 1]; p++, j++) {
-                S.col[base + (size_t)j * SELL_C + lane] = A.col[p];
-                S.val[base + (size_t)j * SELL_C + lane] = A.val[p];
+                S.col[base + (size_t)j * C + lane] = A.col[p];
+                S.val[base + (size_t)j * C + lane] = A.val[p];
             }
         }
+    }
+    if (region_order && S.color_slice_ptr.size() > 2) {
+        // key = position of the slice inside its colour block, in [0,1): rows of a colour are in RCM order, so equal
+        // keys across colours are the same region of the mesh
+        std::vector<std::pair<double, int>> key(S.n_slices);
+        for (size_t c = 0; c + 1 < S.color_slice_ptr.size(); c++) {
+            const int b = S.color_slice_ptr[c], e = S.color_slice_ptr[c + 1];
+            for (int s = b; s < e; s++) key[s] = {(s - b + 0.5) / (double)(e - b), s};
+        }
+        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
+        S.region_order.resize(S.n_slices);
+        for (int i = 0; i < S.n_slices; i++) S.region_order[i] = key[i].second;
     }
     return S;
 }

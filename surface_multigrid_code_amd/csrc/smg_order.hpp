@@ -26,24 +26,28 @@ std::vector<int> rcm_order(const Csr& A);                    // returns new -> o
 Ordering make_ordering(const Csr& A, int sigma = 512);       // A: square, structurally symmetric
 Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)
 
-constexpr int SELL_C = 64;  // slice height = one wavefront
+constexpr int SELL_C = 64;  // default slice height = one wavefront (one row per lane); 128 = two rows per lane
 
 // SELL-C-sigma, C = 64: slice s covers rows [slice_row[s], slice_row[s+1]) (<= 64 of them; a slice never
 // straddles a colour boundary); its entries are stored column-major in a 64-wide panel starting at element
 // 64 * slice_off[s]; panel width = slice_off[s+1] - slice_off[s] = longest row of the slice.  Padding has
 // col = -1.  Inside a row the stored order is ascending column index of the *internal* numbering.
 struct Sell {
+    int C = SELL_C;                    // slice height: 64 (one row per lane) or 128 (two adjacent rows per lane)
     int n_rows = 0, n_cols = 0, n_slices = 0;
     std::vector<int> slice_row;        // n_slices + 1
-    std::vector<int> slice_off;        // n_slices + 1, in units of 64 entries
+    std::vector<int> slice_off;        // n_slices + 1, in units of C entries (panel columns)
     std::vector<int> col;              // 64 * slice_off[n_slices]
     std::vector<double> val;
     std::vector<int> color_slice_ptr;  // n_colors + 1 slice offsets (single range when uncoloured)
     long nnz = 0;                      // stored (unpadded) entries
-    long padded() const { return 64L * (slice_off.empty() ? 0 : slice_off.back()); }
+    long padded() const { return (long)C * (slice_off.empty() ? 0 : slice_off.back()); }
+    // Launch order of the slices for whole-matrix kernels: sorted by relative position inside the colour block,
+    // so that consecutive logical blocks (= one XCD's share) cover ONE mesh region across all colours.
+    std::vector<int> region_order;     // n_slices, or empty (identity)
 };
 
 // row_breaks: optional ascending row offsets (e.g. Ordering::color_ptr) at which a new slice must start.
-Sell build_sell(const Csr& A, const std::vector<int>* row_breaks);
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C = SELL_C, bool region_order = false);
 
 }  // namespace smg
