@@ -288,7 +288,13 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
+        uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
+        auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
+        const int hdr[2] = {Lv.n, lv < L - 1 ? 1 : 0};
+        mix(hdr, 2); mix(Lv.A.ptr.data(), Lv.A.ptr.size()); mix(Lv.A.col.data(), Lv.A.col.size());
+        if (key == Lv.ord_key && (int)Lv.ord.perm.size() == Lv.n) continue;  // same pattern as last time
         Lv.ord = (lv < L - 1) ? make_ordering(Lv.A) : identity_ordering(Lv.n);
+        Lv.ord_key = key;
     }
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
@@ -451,10 +457,9 @@ static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, co
     }
     {   // rc = PT r  (:43-44, :80)
         ProfGuard pg(h, "MG: restrict");
-        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream));
+        // rc = PT r (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
+        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream, Lc.u.p));
     }
-    // uc = 0  (:46-47).  Skipped iterations leave garbage-free state: a memset is harmless after `done`.
-    HIPCHK(hipMemsetAsync(Lc.u.p, 0, (size_t)Lc.n * k * sizeof(double), h->stream));
     rc = enqueue_vcycle(h, lv + 1, k, pre, post, ctrl);  // :48
     if (rc) return rc;
     {   // u = u + P uc  (:51-53, :91)
@@ -465,26 +470,27 @@ static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, co
 }
 
 // sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
-static int enqueue_residual_ss(smg_hierarchy* h, int k)
+static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false)
 {
     Level& L0 = h->lv[0];
     ProfGuard pg(h, "MG: outer residual");
     int nb = 0;
     if (h->n_levels == 1) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, mg_precompute.cpp:39)");
     HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
-    HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+    if (fuse_decide) HIPCHK(launch_ss_finalize_decide(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+    else HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
     return SMG_OK;
 }
 
+// d_sumsq == nullptr: the break test already ran inside the residual launch (single-GPU path)
 static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
 {
-    HIPCHK(launch_decide(h->d_ctrl.p, d_sumsq, h->stream));
+    if (d_sumsq) HIPCHK(launch_decide(h->d_ctrl.p, d_sumsq, h->stream));
     {
         ProfGuard pg(h, "MG: total VCycle");  // PROFC_NODE at src/min_quad_with_fixed_mg.cpp:123
         int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p);
         if (rc) return rc;
     }
-    HIPCHK(launch_count_cycle(h->d_ctrl.p, h->stream));
     return SMG_OK;
 }
 
@@ -509,9 +515,9 @@ static int ensure_graphs(smg_hierarchy* h)
     drop_graphs(h);
     const int k = h->k;
     int rc = capture_graph(h, &h->g_iter, [&]() {
-        int r = enqueue_residual_ss(h, k);
+        int r = enqueue_residual_ss(h, k, true);
         if (r) return r;
-        return enqueue_cycle_part(h, k, &h->d_ctrl.p->sumsq);
+        return enqueue_cycle_part(h, k, nullptr);
     });
     if (rc) return rc;
     rc = capture_graph(h, &h->g_resid, [&]() { return enqueue_residual_ss(h, k); });
@@ -530,9 +536,9 @@ static int enqueue_outer_iteration(smg_hierarchy* h)
         if (rc) return rc;
         HIPCHK(hipGraphLaunch(h->g_iter, h->stream));
     } else {
-        int rc = enqueue_residual_ss(h, h->k);
+        int rc = enqueue_residual_ss(h, h->k, true);
         if (rc) return rc;
-        rc = enqueue_cycle_part(h, h->k, &h->d_ctrl.p->sumsq);
+        rc = enqueue_cycle_part(h, h->k, nullptr);
         if (rc) return rc;
     }
     h->iters_enqueued++;

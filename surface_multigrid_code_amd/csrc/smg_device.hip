@@ -42,9 +42,12 @@ template <> struct PanelLoad<2> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wav
 // One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
 template <int MODE, int KB, int RPL>
 __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const double* x,
-                                              const double* b, double* y, int ld, const int* done, double* partials)
+                                              const double* b, double* y, int ld, const int* done, double* partials,
+                                              double* zero_rows)
 {
-    if (done && *done) return;
+    // The convergence flag is loaded up front but only consulted right before the stores: the matrix / vector loads
+    // of a launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
+    const int stop = done ? __builtin_nontemporal_load(done) : 0;
     constexpr int C = 64 * RPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -62,11 +65,18 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
         const int rowb = row0 + RPL * lane;
         double acc[RPL][KB];
         double diag[RPL];
+        double bv[RPL][KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
             diag[r] = 1.0;
+            const bool live = RPL * lane + r < nrow;
 #pragma unroll
-            for (int q = 0; q < KB; q++) acc[r][q] = 0.0;
+            for (int q = 0; q < KB; q++) {
+                acc[r][q] = 0.0;
+                if (MODE == SELL_AX) bv[r][q] = 0.0;
+                else if (MODE == SELL_ADD) bv[r][q] = live ? y[(size_t)(rowb + r) * ld + q] : 0.0;
+                else bv[r][q] = live ? b[(size_t)(rowb + r) * ld + q] : 0.0;
+            }
         }
         constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
@@ -106,15 +116,15 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
         }
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
-            if (RPL * lane + r < nrow) {
+            if (RPL * lane + r < nrow && !stop) {
                 const size_t o = (size_t)(rowb + r) * ld;
 #pragma unroll
                 for (int q = 0; q < KB; q++) {
-                    if (MODE == SELL_AX) y[o + q] = acc[r][q];
-                    else if (MODE == SELL_RESID) y[o + q] = b[o + q] - acc[r][q];
-                    else if (MODE == SELL_ADD) y[o + q] = y[o + q] + acc[r][q];
-                    else if (MODE == SELL_GS) y[o + q] = (b[o + q] - acc[r][q]) / diag[r];
-                    else { const double t = b[o + q] - acc[r][q]; ss += t * t; }
+                    if (MODE == SELL_AX) { y[o + q] = acc[r][q]; if (zero_rows) zero_rows[o + q] = 0.0; }
+                    else if (MODE == SELL_RESID) y[o + q] = bv[r][q] - acc[r][q];
+                    else if (MODE == SELL_ADD) y[o + q] = bv[r][q] + acc[r][q];
+                    else if (MODE == SELL_GS) y[o + q] = (bv[r][q] - acc[r][q]) / diag[r];
+                    else { const double t = bv[r][q] - acc[r][q]; ss += t * t; }
                 }
             }
         }
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0 && !stop) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -133,7 +143,7 @@ int sell_blocks(int n_slices) { return (n_slices + 3) / 4; }
 
 template <int MODE, int RPL>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, const double* x, const double* b, double* y,
-                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, double* zero_rows)
 {
     const int ns = s_end - s_begin;
     const int nb = sell_blocks(ns);
@@ -149,11 +159,12 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
         const double* bb = b ? b + c0 : nullptr;
         double* yy = y ? y + c0 : nullptr;
         double* pp = partials ? partials + (size_t)chunk * nb : nullptr;
+        double* zz = zero_rows ? zero_rows + c0 : nullptr;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = chunk * nb;
@@ -162,23 +173,25 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
 
 template <int RPL>
 static hipError_t launch_sell_rpl(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
-                                  double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+                                  double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
+                                  double* zero_rows)
 {
     switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-        case SELL_GS: return launch_sell_mode<SELL_GS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+        case SELL_AX: return launch_sell_mode<SELL_AX, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_GS: return launch_sell_mode<SELL_GS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
-                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st)
+                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
+                       double* zero_rows)
 {
-    if (A.C == 128) return launch_sell_rpl<2>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
-    return launch_sell_rpl<1>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st);
+    if (A.C == 128) return launch_sell_rpl<2>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+    return launch_sell_rpl<1>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control
@@ -198,11 +211,10 @@ __global__ __launch_bounds__(256) void k_ss_finalize(const double* partials, int
     if (threadIdx.x == 0) ctrl->sumsq = red[0];
 }
 
-__global__ void k_decide(Ctrl* ctrl, const double* sumsq)
+__device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
 {
-    if (ctrl->done) return;
     const double tol = ctrl->tol;
-    const double r = sqrt(*sumsq);
+    const double r = sqrt(sumsq);
     const int i = ctrl->n_his;
     if (i < SMG_MAX_HIS) ctrl->r_his[i] = r;
     ctrl->n_his = i + 1;
@@ -210,10 +222,26 @@ __global__ void k_decide(Ctrl* ctrl, const double* sumsq)
     else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
 }
 
-__global__ void k_count_cycle(Ctrl* ctrl)
+// single-GPU path: reduction of the partials and the break test in one launch
+__global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl)
 {
     if (ctrl->done) return;
-    ctrl->iters += 1;
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { ctrl->sumsq = red[0]; decide_body(ctrl, red[0]); }
+}
+
+__global__ void k_decide(Ctrl* ctrl, const double* sumsq)
+{
+    if (ctrl->done) return;
+    decide_body(ctrl, *sumsq);
 }
 
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
@@ -221,17 +249,16 @@ hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStre
     hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl);
     return hipGetLastError();
 }
+hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ss_finalize_decide, dim3(1), dim3(256), 0, st, partials, n, ctrl);
+    return hipGetLastError();
+}
 hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st)
 {
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, st, ctrl, sumsq);
     return hipGetLastError();
 }
-hipError_t launch_count_cycle(Ctrl* ctrl, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_count_cycle, dim3(1), dim3(1), 0, st, ctrl);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------- coarsest level
 
 // One wavefront per output row; 16 B per lane per load (1 KiB per wave-instruction); deterministic
@@ -240,7 +267,7 @@ template <int KB>
 __global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict__ Ainv, int n, int lda,
                                                         const double* __restrict__ b, double* u, int ld, const int* done)
 {
-    if (done && *done) return;
+    const int stop = done ? *done : 0;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -263,7 +290,7 @@ __global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict
         double s = acc[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) u[(size_t)row * ld + q] = u[(size_t)row * ld + q] + s;
+        if (lane == 0 && !stop) u[(size_t)row * ld + q] = u[(size_t)row * ld + q] + s;
     }
 }
 

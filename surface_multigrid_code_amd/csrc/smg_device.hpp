@@ -19,7 +19,7 @@ struct Ctrl {
     int done;      // 1 once residual < tol (or non-finite) was observed
     int n_his;     // entries of r_his written
     int status;    // 0 ok, -1 non-finite residual
-    int iters;     // V-cycles actually executed
+    int pad_;
     double sumsq;  // sum of squares of the last residual (all-reduced across ranks when column-sharded)
     double tol;    // absolute tolerance of the break test (kept here so captured graphs do not bake it in)
     double r_his[SMG_MAX_HIS];
@@ -46,16 +46,19 @@ enum SellMode {
 // y/x/b: internal layout, ld = number of columns k.  Slices [s_begin, s_end).  `ctrl` may be null (no
 // early-exit test).  For SELL_RESID_SS, `partials` receives one double per launched block; the number of
 // blocks is returned through *n_blocks.
+// zero_rows (SELL_AX only, optional): an n_rows x k block that is set to +0.0 row by row alongside y (the restriction
+// launch also performs `uc.setZero()`, mg_VCycle.cpp:46-47).
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
-                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st);
+                       double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
+                       double* zero_rows = nullptr);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 
 // ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
 // r = sqrt(*sumsq); append to r_his; done = (r < ctrl->tol) or non-finite.  No-op when already done.
 hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st);
-// bookkeeping kernel at the end of a V-cycle (counts executed cycles)
-hipError_t launch_count_cycle(Ctrl* ctrl, hipStream_t st);
+// both of the above in one launch (single-GPU path, no all-reduce in between)
+hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
 
 // u[i,:] += sum_j Ainv[i,j] * b[j,:]   (mg_VCycle.cpp:199-200 with the factorisation pre-inverted)
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,8 @@ struct Level {
     Csr P, PT;              // mg_data::P / PT (unknown-only, maps level lv -> lv-1 / back)
     // ---- device numbering ----
     Ordering ord;           // colour-major numbering of this level's unknowns
+    uint64_t ord_key = 0;   // hash of the sparsity pattern `ord` was built for (time-stepping callers re-precompute
+                            // with the same pattern every step: the colouring is reused)
     Csr A_int, P_int, PT_int;  // host copies in the internal numbering (introspection / tests)
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
