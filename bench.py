@@ -207,6 +207,13 @@ def main():
         prof = mg.prof_table()
         mg.prof_enable(False)
         st = mg.sell_stats(0, "A")
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot profile itself)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         out = {
             "metric": "V-cycles/sec + fine-level SpMV GB/s (% HBM peak), 1M-vert mesh fp64",
             "value": world * K / dt, "unit": "V-cycles/s",
@@ -219,7 +226,8 @@ def main():
                        "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU"},
             "roofline": {"kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm",
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
+                         "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                         "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
                          "sell_padding": st["padded"] / max(st["stored"], 1) - 1.0},
             "roofline_gs_sweep": {"kernel": "k_sell<SELL_GS,1> x colours (one fine-level sweep)", "bound": "hbm",
                                   "achieved": gs_bytes / (gs_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

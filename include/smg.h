@@ -78,6 +78,8 @@ int smg_level_set_prolong_csc(smg_hierarchy *h, int lv, int n_fine, int n_coarse
                               const int *rowidx, const double *val);
 /* mg[lv].V / mg[lv].F (optional; not used by the solve) */
 int smg_level_set_mesh(smg_hierarchy *h, int lv, const double *V, int nV, const int *F, int nF);
+/* read them back (query sizes with NULL arrays first); V: nV x 3 row-major, F: nF x 3 */
+int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double *V, int *F);
 
 /* ---- mg_precompute (src/mg_precompute.h:26-32, src/mg_precompute.cpp:15-87) ------------------------------------ */
 /* Builds the hierarchy from a triangle mesh: level count by the reference's float rule (:27-38), per level

@@ -38,6 +38,7 @@ def load():
         "smg_level_set_prolong": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_prolong_csc": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_mesh": (i, [vp, i, dp, i, ip, i]),
+        "smg_level_get_mesh": (i, [vp, i, ip, ip, dp, ip]),
         "smg_mg_precompute": (i, [dp, i, ip, i, f, i, i, C.POINTER(vp)]),
         "smg_mg_precompute_subdiv": (i, [dp, i, ip, i, i, f, i, i, C.POINTER(vp), dp, ip]),
         "smg_precompute": (i, [vp, i, ip, ip, dp, ip, i]),

@@ -215,6 +215,17 @@ extern "C" int smg_level_set_mesh(smg_hierarchy* h, int lv, const double* V, int
     return SMG_OK;
 }
 
+extern "C" int smg_level_get_mesh(const smg_hierarchy* h, int lv, int* nV, int* nF, double* V, int* F)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_mesh: bad level");
+    const Level& L = h->lv[lv];
+    if (nV) *nV = (int)(L.V.size() / 3);
+    if (nF) *nF = (int)(L.F.size() / 3);
+    if (V) std::copy(L.V.begin(), L.V.end(), V);
+    if (F) std::copy(L.F.begin(), L.F.end(), F);
+    return SMG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ precompute
 // Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
 static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known)

@@ -1,0 +1,38 @@
+"""GPU (-m gpu): the C++ mirror of the reference API (surface_multigrid_code_amd/csrc/mg_api.hpp) through the example
+program examples/03_mg_solver.cpp (the reference's canonical caller, 03_mg_solver/main.cpp)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_example_matches_python_path(smg_mod, oracle_mod):
+    smg, mesh = smg_mod, smg_mod.mesh
+    exe = os.path.join(ROOT, "examples", "03_mg_solver")
+    src = os.path.join(ROOT, "examples", "03_mg_solver.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
+                               "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny.smgm"), "1e-8"], env=env, text=True)
+    res = [float(x) for x in re.findall(r"MG iteration: \d+, residual: ([0-9.eE+-]+)", out)]
+    m = re.search(r"converged: (\d)  iterations: (\d+)  \|z\|\^2: ([0-9.eE+-]+)  unknowns: (\d+)", out)
+    assert m and m.group(1) == "1" and int(m.group(4)) == 9353 - 149
+    # same problem through the python mirror
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    A = (-mesh.cotmatrix(V, F)).tocsr()
+    b = mesh.boundary_loop(F)
+    B = mesh.massmatrix(V, F, "voronoi") @ np.ones(V.shape[0])
+    B[b] = 0.0
+    mg.precompute(A, b)
+    conv, z, rh = mg.solve(B, np.zeros(V.shape[0]), np.zeros(len(b)), smg.SolveOpts(tol=1e-8, max_iter=20))
+    assert conv and len(rh) == len(res) == int(m.group(2))
+    np.testing.assert_allclose(res, rh, rtol=1e-5)          # printed with %g
+    assert abs(float(m.group(3)) - float((z * z).sum())) <= 1e-9 * float((z * z).sum())
