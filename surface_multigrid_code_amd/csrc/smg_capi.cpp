@@ -297,14 +297,22 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     }
     // ---- device numbering (still host work): colour-major ordering of every smoothed level and the operators
     // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.
-    for (int lv = 0; lv < L; lv++) {
+    // coarse to fine, so that a subdivision level can inherit a 4-colouring from its parent
+    for (int lv = L - 1; lv >= 0; lv--) {
         Level& Lv = h->lv[lv];
         uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
         auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
         const int hdr[2] = {Lv.n, lv < L - 1 ? 1 : 0};
         mix(hdr, 2); mix(Lv.A.ptr.data(), Lv.A.ptr.size()); mix(Lv.A.col.data(), Lv.A.col.size());
         if (key == Lv.ord_key && (int)Lv.ord.perm.size() == Lv.n) continue;  // same pattern as last time
-        Lv.ord = (lv < L - 1) ? make_ordering(Lv.A) : identity_ordering(Lv.n);
+        if (lv == L - 1) Lv.ord = identity_ordering(Lv.n);
+        else {
+            std::vector<int> inherited;
+            const Level& Lc = h->lv[lv + 1];
+            const bool ok = (lv + 1 < L - 1) && Lc.ord.n_colors() <= 4 && (int)Lc.ord.color_of.size() == Lc.n &&
+                            subdivision_colors(Lc.P, Lc.ord.color_of, Lv.A, inherited);
+            Lv.ord = make_ordering(Lv.A, 512, ok ? &inherited : nullptr);
+        }
         Lv.ord_key = key;
     }
     for (int lv = 0; lv < L; lv++) {

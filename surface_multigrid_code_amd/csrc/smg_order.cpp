@@ -250,11 +250,18 @@ struct Recolor {
             left.push_back(v);
         }
         // Kempe passes with growing component caps: the expensive caps only ever see the few survivors
-        const int caps[] = {256, 2048, 16384};
-        for (int cap : caps) {
+        // small graphs (coarse levels) get an all-out search: a clean 4-colouring there is inherited by every finer
+        // subdivision level for free (subdivision_colors), and costs little in absolute terms
+        const bool small = A.nr <= 70000 && K <= 4;   // only the 5 -> 4 step is worth an all-out search
+        const int caps_small[] = {256, 2048, 16384, 1 << 30};
+        const int caps_big[] = {256, 2048, 16384};
+        const int* caps = small ? caps_small : caps_big;
+        const int ncaps = small ? 4 : 3;
+        for (int ci = 0; ci < ncaps; ci++) {
+            const int cap = caps[ci];
             if (left.empty()) break;
             todo.swap(left); left.clear();
-            budget = 40L * A.nr + 1000000;
+            budget = (small ? 600L : 40L) * A.nr + 1000000;
             for (int v : todo) {
                 if (color[v] != K) continue;
                 const int d = free_color(v, -1);   // earlier swaps may have freed a colour
@@ -267,8 +274,10 @@ struct Recolor {
         if (left.size() <= 256)
             for (int v : left) {
                 if (color[v] != K) continue;
-                if (ball(v, 2, 50000)) continue;
-                ball(v, 3, 400000);
+                const int d = free_color(v, -1);
+                if (d >= 0) { color[v] = d; continue; }
+                bool ok = false;
+                for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
             }
         for (int v = 0; v < A.nr; v++) if (color[v] == K) return false;
         return true;
@@ -327,13 +336,40 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     return best;
 }
 
-Ordering make_ordering(const Csr& A, int sigma)
+// Colouring of a mid-point-subdivided mesh from a proper 4-colouring of its parent (Tait's construction): the old
+// vertices are pairwise non-adjacent in the subdivided graph (every old edge was split) -> colour 0; the mid-point of
+// the old edge (a,b) gets c_a XOR c_b in {1,2,3}: the three edges of an old face get three different values, and
+// mid-points are adjacent exactly when their edges share a face.  P must have the subdivision structure (rows with one
+// entry 1.0 or two entries 0.5); the result is validated against the pattern of A and rejected otherwise.
+bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, const Csr& A, std::vector<int>& out)
+{
+    if (P.nr != A.nr || (int)coarse_color.size() != P.nc) return false;
+    for (int c : coarse_color) if (c < 0 || c > 3) return false;
+    out.assign(P.nr, -1);
+    for (int i = 0; i < P.nr; i++) {
+        const int b = P.ptr[i], e = P.ptr[i + 1];
+        if (e - b == 1 && P.val[b] == 1.0) out[i] = 0;
+        else if (e - b == 2 && P.val[b] == 0.5 && P.val[b + 1] == 0.5) {
+            const int x = coarse_color[P.col[b]] ^ coarse_color[P.col[b + 1]];
+            if (x == 0) return false;
+            out[i] = x;
+        } else return false;
+    }
+    for (int i = 0; i < A.nr; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (A.col[p] != i && out[A.col[p]] == out[i]) return false;
+    return true;
+}
+
+Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors)
 {
     int n = A.nr;
     Ordering o;
     std::vector<int> rcm = rcm_order(A);  // new -> old
-    std::vector<int> color = color_graph(A, rcm);
+    std::vector<int> color = preset_colors ? *preset_colors : color_graph(A, rcm);
+    if (preset_colors) compact_colors(color);
     int ncol = count_colors(color);
+    o.color_of = color;
     // colour-major, RCM rank inside a colour (counting sort keeps the RCM order stable)
     o.color_ptr.assign(ncol + 1, 0);
     for (int v = 0; v < n; v++) o.color_ptr[color[v] + 1]++;

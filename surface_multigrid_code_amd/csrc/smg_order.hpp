@@ -19,11 +19,14 @@ struct Ordering {
     std::vector<int> perm;       // internal (new) -> caller (old)
     std::vector<int> iperm;      // caller (old) -> internal (new)
     std::vector<int> color_ptr;  // n_colors + 1 row offsets in the internal numbering
+    std::vector<int> color_of;   // colour of every vertex, caller numbering (feeds the next finer level)
     int n_colors() const { return (int)color_ptr.size() - 1; }
 };
 
 std::vector<int> rcm_order(const Csr& A);                    // returns new -> old
-Ordering make_ordering(const Csr& A, int sigma = 512);       // A: square, structurally symmetric
+Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* preset_colors = nullptr);  // A: square, structurally symmetric
+// 4-colouring of a mid-point-subdivided level from a 4-colouring of its parent; false if P / A do not fit
+bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, const Csr& A, std::vector<int>& out);
 Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)
 
 constexpr int SELL_C = 64;  // default slice height = one wavefront (one row per lane); 128 = two rows per lane
