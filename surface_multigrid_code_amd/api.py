@@ -92,7 +92,8 @@ class Hierarchy:
              "smg_level_set_prolong")
 
     def set_stream(self, stream_ptr):
-        _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr)), "smg_hierarchy_set_stream")
+        """Use the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); None / 0 = the default stream."""
+        _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "smg_hierarchy_set_stream")
 
     @classmethod
     def from_prolongs(cls, Ps):
