@@ -102,8 +102,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SMG_BENCH_FORCE_SPLIT=1 exercises the multi-GPU code path (split-phase iteration + RCCL all-reduce) at world size 1
+    force_split = os.environ.get("SMG_BENCH_FORCE_SPLIT") == "1"
+    if world > 1 or force_split:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -138,7 +141,7 @@ def main():
     opts = smg.SolveOpts(tol=0.0, max_iter=min(W + K, 1024), pre=2, post=2)
 
     def run(n_it):
-        if world == 1:
+        if world == 1 and not force_split:
             mg.outer_iterations(n_it)
         else:
             for _ in range(n_it):
@@ -244,7 +247,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mg, A, rhs_h)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_split:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -541,6 +541,9 @@ static int ensure_graphs(smg_hierarchy* h)
     if (rc) return rc;
     rc = capture_graph(h, &h->g_resid, [&]() { return enqueue_residual_ss(h, k); });
     if (rc) return rc;
+    // second half of a split-phase iteration: break test on the (all-reduced) ctrl->sumsq, then the V-cycle
+    rc = capture_graph(h, &h->g_cycle, [&]() { return enqueue_cycle_part(h, k, &h->d_ctrl.p->sumsq); });
+    if (rc) return rc;
     h->g_k = k; h->g_pre = h->pre; h->g_post = h->post;
     return SMG_OK;
 }
@@ -653,10 +656,16 @@ extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
 extern "C" int smg_solve_iter_cycle(smg_hierarchy* h, const double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle: no solve in progress");
-    const double* src = d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq;
-    // (eager: the external sumsq pointer changes the decide kernel's argument, so no cached graph here)
-    int rc = enqueue_cycle_part(h, h->k, src);
-    if (rc) return rc;
+    // the reduced value goes back into the control block so that one cached graph serves every iteration
+    if (d_sumsq) HIPCHK(hipMemcpyAsync(&h->d_ctrl.p->sumsq, d_sumsq, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (graphs_usable(h)) {
+        int rc = ensure_graphs(h);
+        if (rc) return rc;
+        HIPCHK(hipGraphLaunch(h->g_cycle, h->stream));
+    } else {
+        int rc = enqueue_cycle_part(h, h->k, &h->d_ctrl.p->sumsq);
+        if (rc) return rc;
+    }
     h->iters_enqueued++;
     return SMG_OK;
 }
