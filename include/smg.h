@@ -147,6 +147,9 @@ int smg_raw_relax(smg_hierarchy *h, int lv, const double *b, double *u, int k, i
 int smg_raw_outer_iteration(smg_hierarchy *h, int n_iter);   /* residual + decide + V-cycle, n_iter times, on the
                                                                 state loaded by smg_solve_begin; no host sync */
 int smg_synchronize(smg_hierarchy *h);
+/* diagnostic: average time (us, hipEvents on the handle's stream) of one graph-replayed V(pre,post) cycle started at level
+ * lv on whatever the work vectors hold; k columns.  Used to see where a cycle's time goes level by level. */
+int smg_bench_vcycle(smg_hierarchy *h, int lv, int k, int pre, int post, int reps, double *us_per_cycle);
 
 /* ---- introspection (tests, tools) ------------------------------------------------------------------------------ */
 /* which: 0 = A, 1 = P (lv >= 1), 2 = PT (lv >= 1), 3 = P_full (lv >= 1), 4 = Auk (lv == 0).

@@ -274,6 +274,11 @@ class Hierarchy:
     def raw_relax(self, lv, b_ptr, u_ptr, k=1, iters=1):
         _chk(self.L.smg_raw_relax(self.h, lv, b_ptr, u_ptr, k, iters), "smg_raw_relax")
 
+    def bench_vcycle(self, lv=0, k=1, pre=2, post=2, reps=50):
+        out = C.c_double(0)
+        _chk(self.L.smg_bench_vcycle(self.h, lv, k, pre, post, reps, C.byref(out)), "smg_bench_vcycle")
+        return out.value
+
     def synchronize(self):
         _chk(self.L.smg_synchronize(self.h), "smg_synchronize")
 

@@ -16,7 +16,7 @@ LIB = os.path.join(LIBDIR, "libsmg.so")
 SOURCES = ["smg_device.hip", "smg_capi.cpp", "smg_sparse.cpp", "smg_mesh.cpp", "smg_order.cpp", "smg_decimate.cpp"]
 HEADERS = ["smg_device.hpp", "smg_hier.hpp", "smg_sparse.hpp", "smg_mesh.hpp", "smg_order.hpp",
            os.path.join("..", "..", "include", "smg.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"] + os.environ.get("SMG_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

@@ -753,6 +753,31 @@ extern "C" int smg_raw_outer_iteration(smg_hierarchy* h, int n_iter)
     return SMG_OK;
 }
 
+static int piece_prolog(smg_hierarchy* h, int lv, int k, const char* who, bool need_coarser);
+
+extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, int reps, double* us_per_cycle)
+{
+    int rc = piece_prolog(h, lv, k, "smg_bench_vcycle", false);
+    if (rc) return rc;
+    if (reps < 1 || !us_per_cycle) return fail(SMG_ERR_INVALID, "smg_bench_vcycle: bad arguments");
+    hipGraphExec_t g = nullptr;
+    rc = capture_graph(h, &g, [&]() { return enqueue_vcycle(h, lv, k, pre, post, nullptr); });
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) HIPCHK(hipGraphLaunch(g, h->stream));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; i++) HIPCHK(hipGraphLaunch(g, h->stream));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_cycle = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(g);
+    return SMG_OK;
+}
+
 extern "C" int smg_synchronize(smg_hierarchy* h)
 {
     if (!h || h->device < 0) return fail(SMG_ERR_INVALID, "smg_synchronize: no device");

@@ -12,6 +12,8 @@
 //     (build with -ffp-contract=off): bit-identical to the reference's Eigen CPU kernels.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "smg_device.hpp"
 
 namespace smg {
@@ -41,7 +43,7 @@ template <> struct PanelLoad<2> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wav
 
 // One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
 template <int MODE, int KB, int RPL>
-__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const double* x,
+__global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const double* x,
                                               const double* b, double* y, int ld, const int* done, double* partials,
                                               double* zero_rows)
 {
@@ -51,8 +53,9 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
     constexpr int C = 64 * RPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;  // waves (= slices) per block
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
+    const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * wpb + wave);
     double ss = 0.0;
     if (ls < s_end) {
         const int s = use_order ? A.order[ls] : ls;
@@ -130,16 +133,26 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
         }
     }
     if (MODE == SELL_RESID_SS) {
-        __shared__ double red[4];
+        __shared__ double red[16];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (threadIdx.x == 0 && !stop) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0 && !stop) {
+            double t = 0.0;
+            for (int i2 = 0; i2 < wpb; i2++) t += red[i2];
+            partials[blockIdx.x] = t;
+        }
     }
 }
 
-int sell_blocks(int n_slices) { return (n_slices + 3) / 4; }
+static int g_wpb = 0;
+static int sell_wpb()
+{
+    if (!g_wpb) { const char* e = getenv("SMG_WPB"); int v = e ? atoi(e) : 4; g_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }
+    return g_wpb;
+}
+int sell_blocks(int n_slices) { const int w = sell_wpb(); return (n_slices + w - 1) / w; }
 
 template <int MODE, int RPL>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, const double* x, const double* b, double* y,
@@ -161,10 +174,10 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
         double* pp = partials ? partials + (size_t)chunk * nb : nullptr;
         double* zz = zero_rows ? zero_rows + c0 : nullptr;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = chunk * nb;

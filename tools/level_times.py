@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Where does a V-cycle's time go, level by level (graph replay, hipEvents).  usage: tools/level_times.py [workload] [k]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+import surface_multigrid_code_amd as smg
+from surface_multigrid_code_amd import mesh
+wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mg, A, Mb, Vf, Ff, label, _ = B.build_workload(wl, smg, mesh)
+mg.precompute(A)
+print(label, "k =", k)
+prev = None
+ts = []
+for lv in range(mg.n_levels):
+    t = mg.bench_vcycle(lv, k, 2, 2, 100)
+    ts.append(t)
+for lv in range(mg.n_levels):
+    own = ts[lv] - (ts[lv + 1] if lv + 1 < mg.n_levels else 0.0)
+    ncol = len(mg.colors(lv)) - 1 if lv < mg.n_levels - 1 else 0
+    print("level %d rows %8d colours %d: cycle from here %8.1f us, this level alone %7.1f us" % (lv, mg.rows(lv), ncol, ts[lv], own))
