@@ -437,7 +437,7 @@ static int ensure_work(smg_hierarchy* h, int k)
         HIPCHK(hipMemsetAsync(Lv.b.p, 0, rows * k * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
         if (lv < L - 1) HIPCHK(Lv.r.alloc(rows * k));
-        if (lv < L - 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4));
+        if (lv < L - 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
     }
     HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
     h->kcap = k;

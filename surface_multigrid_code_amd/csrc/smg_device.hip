@@ -146,6 +146,120 @@ __global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end,
     }
 }
 
+// ---- wide multi-RHS variant --------------------------------------------------------------------------------------
+// For k >= 8 right-hand sides the lanes run ACROSS COLUMNS: lane = (g, c) with c = lane % KW the column inside a block of
+// KW in {8,16,32,64} columns and g = lane / KW one of G = 64/KW rows handled concurrently.  A neighbour gather is then
+// one contiguous 8*KW-byte segment of the row-major n x k block (the layout was chosen for this), the matrix entry is
+// shared by the KW lanes of a group (one request), and all k columns go through ONE launch instead of k/4.
+// A wave owns 8*G consecutive rows of a slice (KW/8 waves per slice).  Per (row, column) the sum is still sequential in
+// ascending column order: bit-identical to the narrow kernel and to the oracle.
+template <int MODE, int KW>
+__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, const double* x,
+                                                   const double* b, double* y, int ld, const int* done, double* partials,
+                                                   double* zero_rows)
+{
+    const int stop = done ? __builtin_nontemporal_load(done) : 0;
+    constexpr int G = 64 / KW;        // rows in flight per wave-instruction
+    constexpr int R = 2;              // rows per lane
+    constexpr int RW = R * G;         // rows per wave
+    constexpr int SUB = 64 / RW;      // waves per slice
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane % KW, g = lane / KW;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wid = __builtin_amdgcn_readfirstlane(bid * 4 + wave);  // logical wave
+    const int ls = s_begin + wid / SUB;
+    const int sub = wid % SUB;
+    double ss = 0.0;
+    if (ls < s_end) {
+        const int s = use_order ? A.order[ls] : ls;
+        const int row0 = A.slice_row[s];
+        const int nrow = A.slice_row[s + 1] - row0;
+        const int off0 = A.slice_off[s];
+        const int w = A.slice_off[s + 1] - off0;
+        int rl[R];
+        double acc[R], diag[R], bv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            rl[r] = sub * RW + r * G + g;   // row inside the slice
+            acc[r] = 0.0; diag[r] = 1.0;
+            const bool live = rl[r] < nrow;
+            const size_t o = (size_t)(row0 + rl[r]) * ld + c;
+            if (MODE == SELL_AX) bv[r] = 0.0;
+            else if (MODE == SELL_ADD) bv[r] = live ? y[o] : 0.0;
+            else bv[r] = live ? b[o] : 0.0;
+        }
+        const int* cp = A.col + (size_t)off0 * 64;
+        const double* vp = A.val + (size_t)off0 * 64;
+        constexpr int U = 8;
+        for (int j0 = 0; j0 < w; j0 += U) {
+            int cc[U][R];
+            double vv[U][R], xv[U][R];
+#pragma unroll
+            for (int t = 0; t < U; t++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool in = (j0 + t) < w;  // wave-uniform
+                    cc[t][r] = in ? cp[(size_t)(j0 + t) * 64 + rl[r]] : -1;
+                    vv[t][r] = in ? vp[(size_t)(j0 + t) * 64 + rl[r]] : 0.0;
+                }
+#pragma unroll
+            for (int t = 0; t < U; t++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool use = (cc[t][r] >= 0) && !(MODE == SELL_GS && cc[t][r] == row0 + rl[r]);
+                    xv[t][r] = use ? x[(size_t)cc[t][r] * ld + c] : 0.0;
+                }
+#pragma unroll
+            for (int t = 0; t < U; t++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (cc[t][r] >= 0) {
+                        if (MODE == SELL_GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
+                        else acc[r] += vv[t][r] * xv[t][r];
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (rl[r] < nrow && !stop) {
+                const size_t o = (size_t)(row0 + rl[r]) * ld + c;
+                if (MODE == SELL_AX) { y[o] = acc[r]; if (zero_rows) zero_rows[o] = 0.0; }
+                else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
+                else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
+                else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
+                else { const double t = bv[r] - acc[r]; ss += t * t; }
+            }
+        }
+    }
+    if (MODE == SELL_RESID_SS) {
+        __shared__ double red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0 && !stop) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+template <int MODE, int KW>
+static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const double* x, const double* b, double* y,
+                            int k, const int* done, double* partials, double* zero_rows, hipStream_t st, int* nb_out)
+{
+    const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
+    const int nb = (waves + 3) / 4;
+    hipLaunchKernelGGL((k_sell_wide<MODE, KW>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, x, b, y, k, done, partials, zero_rows);
+    *nb_out = nb;
+}
+
+int sell_wide_blocks(int n_slices, int k)
+{
+    // upper bound of the per-block partial sums the wide path writes for k columns
+    int tot = 0, c0 = 0;
+    while (k - c0 >= 8) { int kw = 64; while (kw > k - c0) kw >>= 1; tot += (n_slices * (kw / 2) + 3) / 4; c0 += kw; }
+    return tot;
+}
+
 static int g_wpb = 0;
 static int sell_wpb()
 {
@@ -163,16 +277,38 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
     const int* done = ctrl ? &ctrl->done : nullptr;
     // the region-major launch order only makes sense for whole-matrix launches
     const int use_order = (A.order && s_begin == 0 && s_end == A.n_slices) ? 1 : 0;
-    int chunk = 0;
     if (n_blocks) *n_blocks = 0;
     if (ns <= 0) return hipSuccess;
-    for (int c0 = 0; c0 < k; c0 += 4, chunk++) {
+    int c0 = 0;
+    size_t poff = 0;  // partial sums written so far
+    if (RPL == 1) {
+        while (k - c0 >= 8) {
+            int kw = 64;
+            while (kw > k - c0) kw >>= 1;
+            const double* xx = x ? x + c0 : nullptr;
+            const double* bb = b ? b + c0 : nullptr;
+            double* yy = y ? y + c0 : nullptr;
+            double* pp = partials ? partials + poff : nullptr;
+            double* zz = zero_rows ? zero_rows + c0 : nullptr;
+            int wnb = 0;
+            switch (kw) {
+                case 64: launch_wide_one<MODE, 64>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                case 32: launch_wide_one<MODE, 32>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                case 16: launch_wide_one<MODE, 16>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                default: launch_wide_one<MODE, 8>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+            }
+            poff += (size_t)wnb;
+            c0 += kw;
+        }
+    }
+    for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
         const double* xx = x ? x + c0 : nullptr;
         const double* bb = b ? b + c0 : nullptr;
         double* yy = y ? y + c0 : nullptr;
-        double* pp = partials ? partials + (size_t)chunk * nb : nullptr;
+        double* pp = partials ? partials + poff : nullptr;
         double* zz = zero_rows ? zero_rows + c0 : nullptr;
+        poff += (size_t)nb;
         switch (kb) {
             case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
             case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
@@ -180,7 +316,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
             default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
         }
     }
-    if (n_blocks) *n_blocks = chunk * nb;
+    if (n_blocks) *n_blocks = (int)poff;
     return hipGetLastError();
 }
 
@@ -307,13 +443,77 @@ __global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict
     }
 }
 
+// k >= 16 columns: LDS-tiled GEMM  u[16-row tile, KC cols] += Ainv[tile, :] * b[:, KC cols].  256 threads = 16 rows x 16
+// column groups of KC/16 columns; j is walked in tiles of 32 through LDS.  Per (row, column) the sum is sequential in j.
+// (fp64 FMA-free multiply-add on the vector ALU; an f64 MFMA would fuse and change rounding.)
+template <int KC>
+__global__ __launch_bounds__(256) void k_dense_gemm_tile(const double* __restrict__ Ainv, int n, int lda,
+                                                         const double* __restrict__ b, double* u, int ld, const int* done)
+{
+    constexpr int TR = 16, TJ = 64, CT = KC / 16;
+    constexpr int NA = TR * TJ / 256, NB = TJ * KC / 256;  // staged elements per thread
+    __shared__ double a_s[TR][TJ + 1];
+    __shared__ double b_s[TJ][KC];
+    const int stop = done ? *done : 0;
+    const int t = threadIdx.x, tr = t / 16, tc = t % 16;
+    const int i0 = blockIdx.x * TR;
+    double acc[CT];
+#pragma unroll
+    for (int q = 0; q < CT; q++) acc[q] = 0.0;
+    double ra[NA], rb[NB];  // next tile, prefetched into registers while the current one is consumed from LDS
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int e = 0; e < NA; e++) {
+            const int idx = t + 256 * e, r = idx / TJ, jj = idx % TJ, row = i0 + r;
+            ra[e] = row < n ? Ainv[(size_t)row * lda + j0 + jj] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < NB; e++) {
+            const int idx = t + 256 * e, jj = idx / KC, cc = idx % KC;
+            rb[e] = b[(size_t)(j0 + jj) * ld + cc];
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < lda; j0 += TJ) {
+#pragma unroll
+        for (int e = 0; e < NA; e++) { const int idx = t + 256 * e; a_s[idx / TJ][idx % TJ] = ra[e]; }
+#pragma unroll
+        for (int e = 0; e < NB; e++) { const int idx = t + 256 * e; b_s[idx / KC][idx % KC] = rb[e]; }
+        __syncthreads();
+        if (j0 + TJ < lda) fetch(j0 + TJ);
+#pragma unroll 8
+        for (int jj = 0; jj < TJ; jj++) {
+            const double a = a_s[tr][jj];
+#pragma unroll
+            for (int q = 0; q < CT; q++) acc[q] += a * b_s[jj][tc * CT + q];
+        }
+        __syncthreads();
+    }
+    const int row = i0 + tr;
+    if (row < n && !stop)
+#pragma unroll
+        for (int q = 0; q < CT; q++) u[(size_t)row * ld + tc * CT + q] = u[(size_t)row * ld + tc * CT + q] + acc[q];
+}
+
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
                                  const Ctrl* ctrl, hipStream_t st)
 {
     const int* done = ctrl ? &ctrl->done : nullptr;
     const int nb = (n + 3) / 4;
     if (n <= 0) return hipSuccess;
-    for (int c0 = 0; c0 < k; c0 += 4) {
+    int c0 = 0;
+    while (k - c0 >= 16) {
+        int kc = 64;
+        while (kc > k - c0) kc >>= 1;
+        const int tb = (n + 15) / 16;
+        switch (kc) {
+            case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemm_tile<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+        }
+        c0 += kc;
+    }
+    for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
         switch (kb) {
             case 1: hipLaunchKernelGGL((k_dense_gemv_add<1>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;

@@ -52,6 +52,7 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                        double* zero_rows = nullptr);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
+int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 
 // ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);

@@ -47,7 +47,7 @@ def oracle_on_device_numbering(oracle_mod, mg, lv):
 
 
 # ----------------------------------------------------------------------------------------------- K-level, bitwise
-@pytest.mark.parametrize("kind,k", [("mcf", 1), ("mcf", 3), ("poisson", 2), ("mcf", 6)])
+@pytest.mark.parametrize("kind,k", [("mcf", 1), ("mcf", 3), ("poisson", 2), ("mcf", 6), ("mcf", 8), ("poisson", 27), ("mcf", 64)])
 def test_kernels_bit_exact_in_device_numbering(smg, oracle_mod, kind, k):
     p, mg, orc = build(smg, oracle_mod, kind=kind, k=k, n_sub=2)
     rng = np.random.default_rng(3)
@@ -254,7 +254,8 @@ def test_many_columns(smg, oracle_mod):
     # columns are independent: solving a subset alone gives the same per-column V-cycle iterates
     u_all = mg.vcycle(p["RHS"], p["z0"])
     u_one = mg.vcycle(p["RHS"][:, 5], p["z0"][:, 5])
-    assert np.array_equal(u_all[:, 5], u_one[:, 0])
+    assert abs(u_all[:, 5] - u_one[:, 0]).max() <= 1e-12 * abs(u_one).max()
+    assert np.array_equal(mg.relax(0, p["RHS"], p["z0"], 2)[:, 5], mg.relax(0, p["RHS"][:, 5], p["z0"][:, 5], 2)[:, 0])
 
 
 def test_split_phase_api_equals_fused_solve(smg, oracle_mod):
@@ -359,7 +360,10 @@ def test_c4_mean_curvature_flow_k64(smg, oracle_mod):
     conv2, z2, rh2 = orc.solve(RHS[:, :8], z0[:, :8], tol=1e-12, max_iter=60)      # tight reference on 8 columns
     convt, zt, rht = mg.solve(RHS, z0, None, smg.SolveOpts(tol=1e-11, max_iter=60))
     assert convt and np.linalg.norm(zt[:, :8] - z2) <= 1e-8 * np.linalg.norm(z2)
-    # an 8-way column shard reproduces its columns' V-cycle iterates bit for bit (columns are independent)
+    # an 8-way column shard reproduces its columns' V-cycle iterates (columns are independent); sparse
+    # kernels are bit-identical for any k, the dense coarse solve sums in a k-dependent order => rounding-level slack
     u_all = mg.vcycle(RHS, z0)
     u_blk = mg.vcycle(RHS[:, 16:24], z0[:, 16:24])
-    assert np.array_equal(u_all[:, 16:24], u_blk)
+    assert abs(u_all[:, 16:24] - u_blk).max() <= 1e-12 * abs(u_blk).max()
+    assert np.array_equal(mg.relax(0, RHS, z0, 2)[:, 16:24], mg.relax(0, RHS[:, 16:24], z0[:, 16:24], 2))
+    assert np.array_equal(mg.A(0, z0)[:, 16:24], mg.A(0, z0[:, 16:24]))
