@@ -188,6 +188,7 @@ static int set_prolong(smg_hierarchy* h, int lv, Csr&& P)
     L.P = L.P_full;                   // :74
     L.PT = transpose(L.P);            // :75
     h->precomputed = false;
+    h->p_version++;
     return SMG_OK;
 }
 
@@ -241,8 +242,12 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     }
     if (L > 1 && h->lv[1].P_full.nr != n)
         return fail(SMG_ERR_INVALID, "A is %d x %d but P_1 has %d rows", n, n, h->lv[1].P_full.nr);
+    h->nnz_input = (int)A.nnz();
     if (!h->has_known) {
         // reference src/min_quad_with_fixed_mg.cpp:17-22
+        h->lhs_src.resize(A.nnz());
+        std::iota(h->lhs_src.begin(), h->lhs_src.end(), 0);
+        h->auk_src.clear();
         h->lv[0].A = std::move(A);
         h->Auk = Csr();
         for (int lv = 1; lv < L; lv++) h->lv[lv].PT = transpose(h->lv[lv].P);
@@ -255,8 +260,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         }
         h->known.assign(known, known + n_known);
         for (int i = 0; i < n; i++) if (!isk[i]) h->unknown.push_back(i);
-        h->lv[0].A = slice(A, &h->unknown, &h->unknown);  // LHS = A(unknown, unknown)   (:166-167, :175)
-        h->Auk = slice(A, &h->unknown, &h->known);        // Auk = A(unknown, known)     (:169-170, :176)
+        h->lv[0].A = slice(A, &h->unknown, &h->unknown, &h->lhs_src);  // LHS = A(unknown, unknown)   (:166-167, :175)
+        h->Auk = slice(A, &h->unknown, &h->known, &h->auk_src);        // Auk = A(unknown, known)     (:169-170, :176)
         if (L > 1) {
             h->lv[1].P = slice(h->lv[1].P_full, &h->unknown, nullptr);  // :185
             for (int lv = 1; lv < L; lv++) {
@@ -317,7 +322,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     }
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
-        Lv.A_int = (lv < L - 1) ? permute(Lv.A, Lv.ord.perm, Lv.ord.perm) : Lv.A;
+        if (lv < L - 1) Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
+        else { Lv.A_int = Lv.A; Lv.A_int_src.resize(Lv.A.nnz()); std::iota(Lv.A_int_src.begin(), Lv.A_int_src.end(), 0); }
         if (lv >= 1) {
             const Ordering& of = h->lv[lv - 1].ord;
             Lv.P_int = permute(Lv.P, of.perm, Lv.ord.perm);
@@ -406,18 +412,167 @@ static int precompute_device(smg_hierarchy* h)
     return SMG_OK;
 }
 
+// ---- value-only re-precompute --------------------------------------------------------
+// Time-stepping callers hand in a new matrix with the SAME sparsity every step (05_example_mean_curvature_flow/
+// main.cpp:74, 06_example_balloon_sim/implicit_euler_mg_balloon.h:75).  Then everything structural (unknown set,
+// sliced P, Galerkin patterns, colouring, SELL layout, graphs) is unchanged and the numeric work moves to the GPU:
+// slice gathers, two fixed-recipe SpGEMM stages per level (bit-identical to the host spgemm), SELL value refresh and
+// the dense coarse inverse.
+
+static uint64_t fnv_mix(uint64_t key, const int* p, size_t cnt)
+{
+    for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; }
+    return key;
+}
+
+static uint64_t precompute_key(const smg_hierarchy* h, int n, const int* rowptr, const int* col, const int* known, int n_known)
+{
+    uint64_t key = 1469598103934665603ull;
+    const int hdr[4] = {n, n_known, h->p_version, h->n_levels};
+    key = fnv_mix(key, hdr, 4);
+    key = fnv_mix(key, rowptr, (size_t)n + 1);
+    key = fnv_mix(key, col, (size_t)rowptr[n]);
+    if (known) key = fnv_mix(key, known, (size_t)n_known);
+    return key ? key : 1;
+}
+
+static int build_recipes(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    const int sellC = env_int("SMG_SELL_C", 64) == 128 ? 128 : 64;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);  // the GS launches move to the A^T images on every level
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        HIPCHK(Lv.d_Aval.upload(Lv.A.val));
+        if (lv < L - 1) {
+            // SELL slot -> caller CSR entry, for A and for A^T (the sweep always reads A^T in this mode: whether new
+            // values are bit-symmetric cannot be known in advance)
+            Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
+            std::vector<int> m(S.entry.size());
+            for (size_t i = 0; i < m.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
+            HIPCHK(Lv.mapA.upload(m));
+            std::vector<int> tsrc;
+            Csr AT = transpose(Lv.A_int, &tsrc);
+            if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+            Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
+            if (!Lv.gs_on_transpose) { HIPCHK(Lv.dAT.upload(ST)); Lv.gs_on_transpose = true; }
+            for (size_t i = 0; i < m.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
+            HIPCHK(Lv.mapAT.upload(m));
+        }
+        if (lv >= 1) {
+            const Csr& Af = h->lv[lv - 1].A;
+            Csr T = spgemm(Lv.PT, Af);
+            Recipe r1, r2;
+            spgemm_recipe(Lv.PT, Af, true, T, r1);      // T = PT * A_{lv-1}:  PT constant
+            spgemm_recipe(T, Lv.P, false, Lv.A, r2);    // A_lv = T * P:       P constant
+            Lv.nnzT = (int)T.nnz();
+            HIPCHK(Lv.d_Tval.alloc(T.nnz()));
+            HIPCHK(Lv.r1_ptr.upload(r1.ptr)); HIPCHK(Lv.r1_idx.upload(r1.idx)); HIPCHK(Lv.r1_coef.upload(r1.coef));
+            HIPCHK(Lv.r2_ptr.upload(r2.ptr)); HIPCHK(Lv.r2_idx.upload(r2.idx)); HIPCHK(Lv.r2_coef.upload(r2.coef));
+        }
+    }
+    {
+        const Level& Lc = h->lv[L - 1];
+        std::vector<long long> pos(Lc.A.nnz());
+        std::vector<int> dg;
+        for (int i = 0; i < Lc.n; i++)
+            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) {
+                pos[p] = (long long)i * h->nc_pad + Lc.A.col[p];
+                if (Lc.A.col[p] == i) dg.push_back(p);
+            }
+        HIPCHK(h->d_dense_pos.upload(pos));
+        HIPCHK(h->d_diag_idx.upload(dg));
+    }
+    HIPCHK(h->d_lhs_src.upload(h->lhs_src));
+    if (h->has_known) HIPCHK(h->d_auk_src.upload(h->auk_src));
+    HIPCHK(h->d_Afull.alloc((size_t)std::max(h->nnz_input, 1)));
+    h->recipes_built = true;
+    return SMG_OK;
+}
+
+// d_val: the caller's new values (device, caller CSR order)
+static int precompute_values_device(smg_hierarchy* h, const double* d_val)
+{
+    const int L = h->n_levels;
+    hipStream_t st = h->stream;
+    Level& L0 = h->lv[0];
+    HIPCHK(launch_gather_vals(L0.d_Aval.p, d_val, h->d_lhs_src.p, (size_t)L0.A.nnz(), st));          // LHS = A(unknown, unknown)
+    if (h->has_known) HIPCHK(launch_gather_vals(h->d_auk_val.p, d_val, h->d_auk_src.p, (size_t)h->Auk.nnz(), st));  // Auk
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        if (lv >= 1) {
+            Level& Lf = h->lv[lv - 1];
+            HIPCHK(launch_recipe(Lv.nnzT, Lv.r1_ptr.p, Lv.r1_idx.p, Lv.r1_coef.p, Lf.d_Aval.p, Lv.d_Tval.p, st));
+            HIPCHK(launch_recipe((int)Lv.A.nnz(), Lv.r2_ptr.p, Lv.r2_idx.p, Lv.r2_coef.p, Lv.d_Tval.p, Lv.d_Aval.p, st));
+        }
+        if (lv == L - 1) {
+            HIPCHK(launch_add_at(Lv.d_Aval.p, h->d_diag_idx.p, (int)h->d_diag_idx.n, 1e-12, st));          // :32-36 / :236-241
+        } else {
+            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dA.view.val), Lv.d_Aval.p, Lv.mapA.p, (size_t)Lv.dA.padded, st));
+            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dAT.view.val), Lv.d_Aval.p, Lv.mapAT.p, (size_t)Lv.dAT.padded, st));
+        }
+    }
+    // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254)
+    {
+        const Level& Lc = h->lv[L - 1];
+        HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));
+        DevBuf<double> work;
+        HIPCHK(work.alloc((size_t)2 * h->nc_pad * 32 + 32 * 32));
+        HIPCHK(launch_spd_inverse(h->d_Ainv.p, h->nc_pad, work.p, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    h->host_stale = true;
+    return SMG_OK;
+}
+
+// bring the host copies (mg[l].A, A_diag, Auk, A_int) up to date after a device-side re-precompute
+static int refresh_host_values(smg_hierarchy* h)
+{
+    if (!h->host_stale) return SMG_OK;
+    for (int lv = 0; lv < h->n_levels; lv++) {
+        Level& Lv = h->lv[lv];
+        HIPCHK(hipMemcpy(Lv.A.val.data(), Lv.d_Aval.p, Lv.A.val.size() * sizeof(double), hipMemcpyDeviceToHost));
+        Lv.A_diag = diagonal(Lv.A);
+        for (size_t e = 0; e < Lv.A_int.val.size(); e++) Lv.A_int.val[e] = Lv.A.val[Lv.A_int_src[e]];
+    }
+    if (h->has_known && h->Auk.nnz() > 0)
+        HIPCHK(hipMemcpy(h->Auk.val.data(), h->d_auk_val.p, h->Auk.val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    h->host_stale = false;
+    return SMG_OK;
+}
+
 extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
                               const int* known, int n_known)
 {
     if (!h || n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_precompute: bad arguments");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute called between smg_solve_begin and smg_solve_end");
+    if (known == nullptr) n_known = 0;
+    const uint64_t key = precompute_key(h, n, rowptr, col, known, n_known);
+    if (h->precomputed && h->device >= 0 && key == h->pre_key && h->input_canonical && env_int("SMG_NO_FAST_PRECOMPUTE", 0) == 0) {
+        // same sparsity, same constraints, same prolongations: only the values changed
+        int rc = SMG_OK;
+        if (!h->recipes_built) rc = build_recipes(h);
+        if (rc == SMG_OK) {
+            hipError_t e = hipMemcpyAsync(h->d_Afull.p, val, (size_t)rowptr[n] * sizeof(double), hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) rc = fail(SMG_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+        if (rc == SMG_OK) rc = precompute_values_device(h, h->d_Afull.p);
+        if (rc != SMG_OK) h->precomputed = false;
+        return rc;
+    }
     h->precomputed = false;
-    int rc = precompute_host(h, csr_from_arrays(n, n, rowptr, col, val), known, n_known);
+    h->recipes_built = false;
+    h->host_stale = false;
+    Csr A = csr_from_arrays(n, n, rowptr, col, val);
+    h->input_canonical = (A.nnz() == (long)rowptr[n]) && std::equal(A.col.begin(), A.col.end(), col);
+    int rc = precompute_host(h, std::move(A), known, n_known);
     if (rc != SMG_OK) return rc;
     rc = ensure_device(h);
     if (rc != SMG_OK) return rc;
     rc = precompute_device(h);
     if (rc != SMG_OK) return rc;
+    h->pre_key = key;
     h->precomputed = true;
     return SMG_OK;
 }
@@ -946,6 +1101,7 @@ extern "C" int smg_level_get_matrix(const smg_hierarchy* h, int lv, int which, i
                                     int* nnz, int* rowptr, int* col, double* val)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: bad level");
+    if (h->host_stale) { int rc = refresh_host_values(const_cast<smg_hierarchy*>(h)); if (rc) return rc; }
     const Csr* M = pick_matrix(h, lv, which, internal);
     if (!M) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: no such matrix");
     if (n_rows) *n_rows = M->nr;
@@ -976,6 +1132,7 @@ extern "C" int smg_level_get_colors(const smg_hierarchy* h, int lv, int* n_color
 extern "C" int smg_level_get_Adiag(const smg_hierarchy* h, int lv, double* diag)
 {
     if (!h || lv < 0 || lv >= h->n_levels || !diag) return fail(SMG_ERR_INVALID, "smg_level_get_Adiag: bad arguments");
+    if (h->host_stale) { int rc = refresh_host_values(const_cast<smg_hierarchy*>(h)); if (rc) return rc; }
     std::copy(h->lv[lv].A_diag.begin(), h->lv[lv].A_diag.end(), diag);
     return SMG_OK;
 }

@@ -677,6 +677,69 @@ __global__ void k_csr_sub(int n_rows, const int* ptr, const int* col, const doub
 
 static inline unsigned grid1d(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// ---- value-only re-precompute (fixed sparsity): Galerkin recipes and value scatter maps ------------------------------
+__global__ void k_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_out) return;
+    const int b = ptr[e], en = ptr[e + 1];
+    double acc = 0.0;
+    if (b < en) {
+        acc = coef[b] * src[idx[b]];  // first touch assigns (spgemm), then accumulate in ascending k
+        for (int t = b + 1; t < en; t++) acc += coef[t] * src[idx[t]];
+    }
+    out[e] = acc;
+}
+__global__ void k_gather_vals(double* dst, const double* src, const int* map, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    dst[i] = m >= 0 ? src[m] : 0.0;
+}
+__global__ void k_scatter_dense(double* dense, const double* src, const long long* pos, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dense[pos[i]] = src[i];
+}
+__global__ void k_add_at(double* v, const int* where, int n, double c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[where[i]] += c;
+}
+__global__ void k_dense_identity(double* dense, int np, int n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)np * np) return;
+    const int i = (int)(t / np), j = (int)(t % np);
+    dense[t] = (i == j && i >= n) ? 1.0 : 0.0;
+}
+
+hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out, hipStream_t st)
+{
+    if (n_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_recipe, dim3(grid1d(n_out, 256)), dim3(256), 0, st, n_out, ptr, idx, coef, src, out);
+    return hipGetLastError();
+}
+hipError_t launch_gather_vals(double* dst, const double* src, const int* map, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_vals, dim3(grid1d(n, 256)), dim3(256), 0, st, dst, src, map, n);
+    return hipGetLastError();
+}
+hipError_t launch_dense_from_csr(double* dense, int np, int n, const double* src, const long long* pos, int nnz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dense_identity, dim3(grid1d((size_t)np * np, 256)), dim3(256), 0, st, dense, np, n);
+    if (nnz > 0) hipLaunchKernelGGL(k_scatter_dense, dim3(grid1d(nnz, 256)), dim3(256), 0, st, dense, src, pos, nnz);
+    return hipGetLastError();
+}
+hipError_t launch_add_at(double* v, const int* where, int n, double c, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_at, dim3(grid1d(n, 256)), dim3(256), 0, st, v, where, n, c);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src, hipStream_t st)
 {
     if ((size_t)n * k == 0) return hipSuccess;

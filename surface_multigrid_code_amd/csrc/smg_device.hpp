@@ -68,6 +68,15 @@ hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const doubl
 // blocked Gauss-Jordan elimination without pivoting.  work: 2*n*32 + 32*32 doubles.
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);
 
+// value-only re-precompute (same sparsity as the last full precompute) -------------------------------------------
+// out[e] = sum_t coef[t] * src[idx[t]]  (numeric Galerkin stage with a fixed recipe, smg_sparse.hpp)
+hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out, hipStream_t st);
+// dst[i] = map[i] >= 0 ? src[map[i]] : 0   (refresh of SELL value panels / LHS and Auk slices)
+hipError_t launch_gather_vals(double* dst, const double* src, const int* map, size_t n, hipStream_t st);
+// dense (np x np, row-major) = identity on the padding rows, zero elsewhere, then dense[pos[i]] = src[i]
+hipError_t launch_dense_from_csr(double* dense, int np, int n, const double* src, const long long* pos, int nnz, hipStream_t st);
+hipError_t launch_add_at(double* v, const int* where, int n, double c, hipStream_t st);
+
 // layout helpers ------------------------------------------------------------------------------------------
 // dst[i*k + c] = src[map[i] + c*ld_src]      (column-major caller block -> internal block)
 hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src,

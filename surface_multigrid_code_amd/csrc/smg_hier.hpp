@@ -67,6 +67,14 @@ struct Level {
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
+    // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
+    std::vector<int> A_int_src;   // A_int entry -> index into A.val
+    DevBuf<double> d_Aval;        // values of A in the caller's CSR order: the canonical device copy
+    DevBuf<double> d_Tval;        // stage-1 temporary  PT * A_{lv-1}
+    DevBuf<int> mapA, mapAT;      // SELL slot -> index into d_Aval (-1 = padding)
+    DevBuf<int> r1_ptr, r1_idx, r2_ptr, r2_idx;
+    DevBuf<double> r1_coef, r2_coef;
+    int nnzT = 0;
     // ---- work vectors, internal layout n x kcap ----
     DevBuf<double> b, u, r;
     int n = 0;
@@ -91,6 +99,16 @@ struct smg_hierarchy {
     smg::DevBuf<int> d_unknown, d_known;
     smg::DevBuf<int> d_auk_ptr, d_auk_col;
     smg::DevBuf<double> d_auk_val;
+    // ---- fast re-precompute bookkeeping ----
+    uint64_t pre_key = 0;          // hash of (pattern of A, known list, P version) of the last full precompute
+    int p_version = 0;             // bumped by smg_level_set_prolong
+    bool input_canonical = false;  // the caller's CSR rows were sorted and duplicate-free (entry indices are stable)
+    bool recipes_built = false, host_stale = false;
+    int nnz_input = 0;
+    std::vector<int> lhs_src, auk_src;      // LHS / Auk entry -> index into the caller's value array
+    smg::DevBuf<int> d_lhs_src, d_auk_src, d_diag_idx;
+    smg::DevBuf<long long> d_dense_pos;
+    smg::DevBuf<double> d_Afull;
     // ---- coarse solver: stands in for Eigen::SimplicialLDLT (factorisation pre-inverted on the device) ----
     int nc = 0, nc_pad = 0;
     smg::DevBuf<double> d_Ainv;

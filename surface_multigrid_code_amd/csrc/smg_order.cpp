@@ -420,6 +420,7 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     size_t tot = (size_t)C * (size_t)S.slice_off.back();
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);
+    S.entry.assign(tot, -1);
     for (int s = 0; s < S.n_slices; s++) {
         size_t base = (size_t)C * (size_t)S.slice_off[s];
         for (int r = S.slice_row[s]; r < S.slice_row[s + 1]; r++) {
@@ -428,6 +429,7 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
             for (int p = A.ptr[r]; p < A.ptr[r + 1]; p++, j++) {
                 S.col[base + (size_t)j * C + lane] = A.col[p];
                 S.val[base + (size_t)j * C + lane] = A.val[p];
+                S.entry[base + (size_t)j * C + lane] = p;
             }
         }
     }

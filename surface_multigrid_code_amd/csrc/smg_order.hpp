@@ -48,6 +48,7 @@ struct Sell {
     // Launch order of the slices for whole-matrix kernels: sorted by relative position inside the colour block,
     // so that consecutive logical blocks (= one XCD's share) cover ONE mesh region across all colours.
     std::vector<int> region_order;     // n_slices, or empty (identity)
+    std::vector<int> entry;            // per stored slot: index of the CSR entry it holds (-1 = padding); value refresh map
 };
 
 // row_breaks: optional ascending row offsets (e.g. Ordering::color_ptr) at which a new slice must start.

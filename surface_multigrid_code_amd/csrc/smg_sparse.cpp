@@ -43,9 +43,10 @@ Csr csr_from_csc_arrays(int nr, int nc, const int* colptr, const int* rowidx, co
     return transpose(T);
 }
 
-Csr transpose(const Csr& A)
+Csr transpose(const Csr& A, std::vector<int>* src)
 {
     Csr T;
+    if (src) src->assign(A.nnz(), 0);
     T.nr = A.nc; T.nc = A.nr;
     long nnz = A.nnz();
     T.ptr.assign(T.nr + 1, 0);
@@ -58,6 +59,7 @@ Csr transpose(const Csr& A)
             int q = next[A.col[p]]++;
             T.col[q] = i;
             T.val[q] = A.val[p];
+            if (src) (*src)[q] = p;
         }
     return T;
 }
@@ -103,9 +105,10 @@ Csr spgemm(const Csr& A, const Csr& B)
     return C;
 }
 
-Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols)
+Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols, std::vector<int>* src)
 {
     Csr Y;
+    if (src) src->clear();
     Y.nr = rows ? (int)rows->size() : X.nr;
     Y.nc = cols ? (int)cols->size() : X.nc;
     Y.ptr.assign(Y.nr + 1, 0);
@@ -114,25 +117,54 @@ Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* co
         cmap.assign(X.nc, -1);
         for (int j = 0; j < Y.nc; j++) cmap[(*cols)[j]] = j;
     }
-    std::vector<std::pair<int, double>> row;
+    std::vector<std::pair<int, int>> row;  // (new column, index into X)
     for (int i = 0; i < Y.nr; i++) {
         int r = rows ? (*rows)[i] : i;
         row.clear();
         for (int p = X.ptr[r]; p < X.ptr[r + 1]; p++) {
             int j = cols ? cmap[X.col[p]] : X.col[p];
-            if (j >= 0) row.emplace_back(j, X.val[p]);
+            if (j >= 0) row.emplace_back(j, p);
         }
         if (cols) std::sort(row.begin(), row.end(),
-                            [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-        for (auto& e : row) { Y.col.push_back(e.first); Y.val.push_back(e.second); }
+                            [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+        for (auto& e : row) { Y.col.push_back(e.first); Y.val.push_back(X.val[e.second]); if (src) src->push_back(e.second); }
         Y.ptr[i + 1] = (int)Y.col.size();
     }
     return Y;
 }
 
-Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm)
+Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm, std::vector<int>* src)
 {
-    return slice(A, &rperm, &cperm);
+    return slice(A, &rperm, &cperm, src);
+}
+
+void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, Recipe& R)
+{
+    // position of column j inside row i of C
+    std::vector<int> pos(C.nc, -1);
+    R.ptr.assign(C.nnz() + 1, 0);
+    for (int i = 0; i < A.nr; i++) {
+        for (int e = C.ptr[i]; e < C.ptr[i + 1]; e++) pos[C.col[e]] = e;
+        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+            const int k = A.col[pa];
+            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) R.ptr[pos[B.col[pb]] + 1]++;
+        }
+    }
+    for (long e = 0; e < C.nnz(); e++) R.ptr[e + 1] += R.ptr[e];
+    R.idx.resize(R.ptr[C.nnz()]);
+    R.coef.resize(R.ptr[C.nnz()]);
+    std::vector<int> next(R.ptr.begin(), R.ptr.end() - 1);
+    for (int i = 0; i < A.nr; i++) {
+        for (int e = C.ptr[i]; e < C.ptr[i + 1]; e++) pos[C.col[e]] = e;
+        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {  // ascending k: the accumulation order of spgemm()
+            const int k = A.col[pa];
+            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                const int t = next[pos[B.col[pb]]]++;
+                if (coef_from_A) { R.coef[t] = A.val[pa]; R.idx[t] = pb; }
+                else { R.coef[t] = B.val[pb]; R.idx[t] = pa; }
+            }
+        }
+    }
 }
 
 std::vector<double> diagonal(const Csr& A)

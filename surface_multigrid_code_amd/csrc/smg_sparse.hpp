@@ -24,7 +24,7 @@ Csr csr_from_arrays(int nr, int nc, const int* ptr, const int* col, const double
 // Interpret (ptr,idx,val) as compressed *columns* of an nr x nc matrix and return its CSR.
 Csr csr_from_csc_arrays(int nr, int nc, const int* colptr, const int* rowidx, const double* val);
 
-Csr transpose(const Csr& A);
+Csr transpose(const Csr& A, std::vector<int>* src = nullptr);  // src[e]: index in A.val of output entry e
 
 // C = A * B.  Row i of C accumulates  A(i,k) * B(k,:)  over the stored k of row i in ascending order;
 // the first touch of an output entry assigns.  Entry-wise this is the same sequence of additions as
@@ -33,12 +33,22 @@ Csr transpose(const Csr& A);
 Csr spgemm(const Csr& A, const Csr& B);
 
 // Y(i,j) = X(rows[i], cols[j])  (igl::slice).  A null pointer means "all, in order".  Indices unique.
-Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols);
+Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols, std::vector<int>* src = nullptr);
 
 // B(i,j) = A(rperm[i], cperm[j])  with both lists permutations (new -> old).
-Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm);
+Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>& cperm, std::vector<int>* src = nullptr);
 
 std::vector<double> diagonal(const Csr& A);
+
+// Numeric phase of C = A * B for a FIXED sparsity: out[e] = sum_t coef[t] * src[idx[t]], t in [ptr[e], ptr[e+1]), the terms
+// of an output entry listed in ascending k (the order spgemm accumulates them in), so replaying the recipe with new
+// values of the variable factor reproduces spgemm bit for bit.  coef_from_A: A is the constant factor (its values are
+// baked into coef, idx points into B.val); otherwise B is constant and idx points into A.val.
+struct Recipe {
+    std::vector<int> ptr, idx;
+    std::vector<double> coef;
+};
+void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, Recipe& R);
 
 // y = A x for dense column-major blocks (host; used only by precompute-time checks and tools)
 void spmv_host(const Csr& A, const double* x, double* y);

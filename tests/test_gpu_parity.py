@@ -367,3 +367,48 @@ def test_c4_mean_curvature_flow_k64(smg, oracle_mod):
     assert abs(u_all[:, 16:24] - u_blk).max() <= 1e-12 * abs(u_blk).max()
     assert np.array_equal(mg.relax(0, RHS, z0, 2)[:, 16:24], mg.relax(0, RHS[:, 16:24], z0[:, 16:24], 2))
     assert np.array_equal(mg.A(0, z0)[:, 16:24], mg.A(0, z0[:, 16:24]))
+
+
+@pytest.mark.parametrize("kind", ["mcf", "poisson"])
+def test_value_only_reprecompute_on_device_is_bit_exact(smg, oracle_mod, kind):
+    """a second smg_precompute with the same sparsity runs the Galerkin products, the SELL refresh
+    and the coarse inverse on the GPU.  Every level's matrix must equal the host path (and hence the oracle) bit for bit,
+    and solves on the refreshed handle must equal solves on a freshly built one."""
+    p = subdiv_problem(kind=kind, k=2, n_sub=2)
+    A1 = p["A"]
+    rng = np.random.default_rng(42)
+    D = sp.diags(1.0 + 0.01 * rng.uniform(size=A1.shape[0]))
+    A2 = (D @ A1 @ D + sp.diags(rng.uniform(0, 0.5, A1.shape[0]) * A1.diagonal())).tocsr()   # same pattern, new values, SPD,
+    A2.sort_indices()                               # and NOT bit-symmetric: the sweep must read columns (A^T)
+    assert abs(A2 - A2.T).max() > 0
+    assert np.array_equal(A2.indices, A1.indices)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.precompute(A1, p["known"])                    # full (host + device) path
+    mg.precompute(A2, p["known"])                    # value-only path on the device
+    fresh = smg.Hierarchy.from_prolongs(p["Ps"])
+    fresh.precompute(A2, p["known"])
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(A2, p["known"])
+    for l in range(mg.n_levels):
+        a, b = mg.matrix(l, "A"), fresh.matrix(l, "A")
+        assert np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data), "level %d differs" % l
+        Ao = orc.level_A(l).tocsr()
+        Ao.sort_indices()
+        assert np.array_equal(a.data, Ao.data)
+        assert np.array_equal(mg.Adiag(l), fresh.Adiag(l))
+    o = smg.SolveOpts(tol=1e-9, max_iter=40)
+    r1 = mg.solve(p["RHS"], p["z0"], p["known_val"], o)
+    r2 = fresh.solve(p["RHS"], p["z0"], p["known_val"], o)
+    assert np.array_equal(r1[2], r2[2]) and np.array_equal(r1[1], r2[1]) and (np.diff(r1[2]) < 0).all()
+    # and a third matrix on the same handle, back to back
+    A3 = (A1 + 0.25 * sp.diags(A1.diagonal())).tocsr()
+    A3.sort_indices()
+    mg.precompute(A3, p["known"])
+    fresh.precompute(A3, p["known"])
+    r1 = mg.solve(p["RHS"], p["z0"], p["known_val"], o)
+    r2 = fresh.solve(p["RHS"], p["z0"], p["known_val"], o)
+    assert r1[0] and np.array_equal(r1[2], r2[2]) and np.array_equal(r1[1], r2[1])
+    # a different pattern falls back to the full path
+    pm = subdiv_problem(kind="mcf", k=2, n_sub=2)
+    mg.precompute(pm["A"], None)
+    assert mg.solve(pm["RHS"], pm["z0"], None, o)[0]
