@@ -96,6 +96,17 @@ int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio
 int smg_mg_precompute_subdiv(const double *V, int nV, const int *F, int nF, int n_sub, float ratio, int nVCoarsest,
                              int n_extra_levels, smg_hierarchy **out, double *V_out, int *F_out);
 
+/* mg_precompute_block (src/mg_precompute_block.h, src/mg_precompute_block.cpp:23-95; get_prolong_block,
+ * src/get_prolong.cpp:59-115): same hierarchy with P (x) I_3 for 3-DOF-per-vertex systems, DOF index = 3*vertex + d.
+ * To the V-cycle the block system is a plain sparse matrix. */
+int smg_mg_precompute_block(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
+                            smg_hierarchy **out);
+/* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
+ * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],
+ * and for lv >= 1: i32 n_rows i32 n_cols i32 nnz i32 ptr[n_rows+1] i32 col[nnz] f64 val[nnz]. */
+int smg_hierarchy_save(const smg_hierarchy *h, const char *path);
+int smg_hierarchy_load(const char *path, smg_hierarchy **out);
+
 /* ---- min_quad_with_fixed_mg_precompute (src/min_quad_with_fixed_mg.h:32-36 and :72-77) ------------------------- */
 /* A: n x n symmetric, CSR == CSC.  known == NULL / n_known == 0 selects the no-constraint overload
  * (.cpp:3-51); otherwise the `known` overload (.cpp:137-257): unknown = setdiff, LHS/Auk slices, P re-organised

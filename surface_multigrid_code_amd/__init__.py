@@ -5,9 +5,9 @@ kernels.  This package is a thin ctypes mirror of the reference's operator API f
 (`mg_precompute` -> `min_quad_with_fixed_mg_precompute` -> `min_quad_with_fixed_mg_solve` / `mg_VCycle`),
 used by tests and bench.py.  There is NO CPU fallback: compute calls raise if the library or a GPU is missing.
 """
-from .api import (Hierarchy, SmgError, mg_precompute, mg_precompute_subdiv, min_quad_with_fixed_mg_precompute,
+from .api import (Hierarchy, SmgError, mg_precompute, mg_precompute_block, mg_precompute_subdiv, min_quad_with_fixed_mg_precompute,
                   min_quad_with_fixed_mg_solve, mg_VCycle, SolveOpts)
 from . import mesh
 
-__all__ = ["Hierarchy", "SmgError", "mg_precompute", "mg_precompute_subdiv", "min_quad_with_fixed_mg_precompute",
+__all__ = ["Hierarchy", "SmgError", "mg_precompute", "mg_precompute_block", "mg_precompute_subdiv", "min_quad_with_fixed_mg_precompute",
            "min_quad_with_fixed_mg_solve", "mg_VCycle", "SolveOpts", "mesh"]

@@ -40,6 +40,9 @@ def load():
         "smg_level_set_mesh": (i, [vp, i, dp, i, ip, i]),
         "smg_level_get_mesh": (i, [vp, i, ip, ip, dp, ip]),
         "smg_mg_precompute": (i, [dp, i, ip, i, f, i, i, C.POINTER(vp)]),
+        "smg_mg_precompute_block": (i, [dp, i, ip, i, f, i, i, C.POINTER(vp)]),
+        "smg_hierarchy_save": (i, [vp, C.c_char_p]),
+        "smg_hierarchy_load": (i, [C.c_char_p, C.POINTER(vp)]),
         "smg_mg_precompute_subdiv": (i, [dp, i, ip, i, i, f, i, i, C.POINTER(vp), dp, ip]),
         "smg_precompute": (i, [vp, i, ip, ip, dp, ip, i]),
         "smg_solve": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC), vp, i, dp, ip, ip]),

@@ -95,6 +95,15 @@ class Hierarchy:
         """Use the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); None / 0 = the default stream."""
         _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "smg_hierarchy_set_stream")
 
+    def save(self, path):
+        _chk(self.L.smg_hierarchy_save(self.h, path.encode()), "smg_hierarchy_save")
+
+    @classmethod
+    def load(cls, path):
+        out = C.c_void_p()
+        _chk(_lib.load().smg_hierarchy_load(path.encode(), C.byref(out)), "smg_hierarchy_load")
+        return cls(handle=out.value)
+
     @classmethod
     def from_prolongs(cls, Ps):
         H = cls(len(Ps) + 1)
@@ -294,6 +303,17 @@ def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1):
     out = C.c_void_p()
     _chk(L.smg_mg_precompute(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, C.byref(out)),
          "smg_mg_precompute")
+    return Hierarchy(handle=out.value)
+
+
+def mg_precompute_block(V, F, ratio=0.25, nVCoarsest=500, dec_type=1):
+    """mg_precompute_block (src/mg_precompute_block.cpp:23-95): P (x) I_3, DOF index 3*vertex + d."""
+    L = _lib.load()
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    F = np.ascontiguousarray(F, dtype=np.int32)
+    out = C.c_void_p()
+    _chk(L.smg_mg_precompute_block(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, C.byref(out)),
+         "smg_mg_precompute_block")
     return Hierarchy(handle=out.value)
 
 

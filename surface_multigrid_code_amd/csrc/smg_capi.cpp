@@ -1368,6 +1368,90 @@ extern "C" int smg_mg_precompute(const double* V, int nV, const int* F, int nF, 
     return SMG_OK;
 }
 
+extern "C" int smg_mg_precompute_block(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                       smg_hierarchy** out)
+{
+    int rc = smg_mg_precompute(V, nV, F, nF, ratio, nVCoarsest, dec_type, out);
+    if (rc) return rc;
+    smg_hierarchy* h = *out;
+    for (int lv = 1; lv < h->n_levels; lv++) {
+        const Csr& P = h->lv[lv].P_full;
+        Csr B;
+        B.nr = 3 * P.nr; B.nc = 3 * P.nc;
+        B.ptr.resize((size_t)B.nr + 1);
+        B.col.resize((size_t)3 * P.nnz()); B.val.resize((size_t)3 * P.nnz());
+        int q = 0;
+        for (int r = 0; r < P.nr; r++)
+            for (int d = 0; d < 3; d++) {   // row 3r+d holds P(r,c) at column 3c+d  (src/get_prolong.cpp:108-110)
+                B.ptr[3 * r + d] = q;
+                for (int p = P.ptr[r]; p < P.ptr[r + 1]; p++) { B.col[q] = 3 * P.col[p] + d; B.val[q] = P.val[p]; q++; }
+            }
+        B.ptr[B.nr] = q;
+        set_prolong(h, lv, std::move(B));
+    }
+    return SMG_OK;
+}
+
+extern "C" int smg_hierarchy_save(const smg_hierarchy* h, const char* path)
+{
+    if (!h || !path) return fail(SMG_ERR_INVALID, "smg_hierarchy_save: bad arguments");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(SMG_ERR_IO, "cannot open '%s' for writing", path);
+    const uint32_t ver = 1;
+    const int32_t L = h->n_levels;
+    bool ok = std::fwrite("SMGH", 1, 4, f) == 4 && std::fwrite(&ver, 4, 1, f) == 1 && std::fwrite(&L, 4, 1, f) == 1;
+    for (int lv = 0; lv < L && ok; lv++) {
+        const Level& Lv = h->lv[lv];
+        const int32_t nV = (int32_t)(Lv.V.size() / 3), nF = (int32_t)(Lv.F.size() / 3);
+        ok = std::fwrite(&nV, 4, 1, f) == 1 && std::fwrite(&nF, 4, 1, f) == 1 &&
+             std::fwrite(Lv.V.data(), 8, Lv.V.size(), f) == Lv.V.size() && std::fwrite(Lv.F.data(), 4, Lv.F.size(), f) == Lv.F.size();
+        if (lv >= 1 && ok) {
+            const Csr& P = Lv.P_full;
+            const int32_t hdr[3] = {P.nr, P.nc, (int32_t)P.nnz()};
+            ok = std::fwrite(hdr, 4, 3, f) == 3 && std::fwrite(P.ptr.data(), 4, P.ptr.size(), f) == P.ptr.size() &&
+                 std::fwrite(P.col.data(), 4, P.col.size(), f) == P.col.size() && std::fwrite(P.val.data(), 8, P.val.size(), f) == P.val.size();
+        }
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? SMG_OK : fail(SMG_ERR_IO, "short write to '%s'", path);
+}
+
+extern "C" int smg_hierarchy_load(const char* path, smg_hierarchy** out)
+{
+    if (!path || !out) return fail(SMG_ERR_INVALID, "smg_hierarchy_load: bad arguments");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(SMG_ERR_IO, "cannot open '%s'", path);
+    char magic[4];
+    uint32_t ver = 0;
+    int32_t L = 0;
+    bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "SMGH", 4) == 0 && std::fread(&ver, 4, 1, f) == 1 && ver == 1 &&
+              std::fread(&L, 4, 1, f) == 1 && L >= 1 && L < 64;
+    smg_hierarchy* h = ok ? smg_hierarchy_create(L) : nullptr;
+    for (int lv = 0; lv < L && ok && h; lv++) {
+        int32_t nV = 0, nF = 0;
+        ok = std::fread(&nV, 4, 1, f) == 1 && std::fread(&nF, 4, 1, f) == 1 && nV >= 0 && nF >= 0;
+        if (!ok) break;
+        h->lv[lv].V.resize((size_t)nV * 3); h->lv[lv].F.resize((size_t)nF * 3);
+        ok = std::fread(h->lv[lv].V.data(), 8, h->lv[lv].V.size(), f) == h->lv[lv].V.size() &&
+             std::fread(h->lv[lv].F.data(), 4, h->lv[lv].F.size(), f) == h->lv[lv].F.size();
+        if (lv >= 1 && ok) {
+            int32_t hdr[3];
+            ok = std::fread(hdr, 4, 3, f) == 3 && hdr[0] >= 0 && hdr[1] >= 0 && hdr[2] >= 0;
+            if (!ok) break;
+            Csr P;
+            P.nr = hdr[0]; P.nc = hdr[1];
+            P.ptr.resize((size_t)P.nr + 1); P.col.resize(hdr[2]); P.val.resize(hdr[2]);
+            ok = std::fread(P.ptr.data(), 4, P.ptr.size(), f) == P.ptr.size() && std::fread(P.col.data(), 4, P.col.size(), f) == P.col.size() &&
+                 std::fread(P.val.data(), 8, P.val.size(), f) == P.val.size() && P.ptr.back() == hdr[2];
+            if (ok) set_prolong(h, lv, std::move(P));
+        }
+    }
+    std::fclose(f);
+    if (!ok || !h) { if (h) smg_hierarchy_destroy(h); return fail(SMG_ERR_IO, "'%s' is not a valid hierarchy file", path); }
+    *out = h;
+    return SMG_OK;
+}
+
 extern "C" int smg_mg_precompute_subdiv(const double* V, int nV, const int* F, int nF, int n_sub, float ratio, int nVCoarsest,
                                         int n_extra_levels, smg_hierarchy** out, double* V_out, int* F_out)
 {

@@ -144,3 +144,25 @@ def test_mg_precompute_reproduces_linear_functions(smg_mod):
     # must be reproduced by barycentric interpolation of SOME coarse positions: solve least squares and check fit
     Vc, *_ = np.linalg.lstsq(P.toarray(), V, rcond=None)
     assert abs(P @ Vc - V).max() < 2e-2
+
+
+def test_hierarchy_save_load_roundtrip_and_block_variant(smg_mod, tmp_path):
+    smg, mesh = smg_mod, smg_mod.mesh
+    V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 100, 1)
+    path = str(tmp_path / "ogre_sim.smgh")
+    mg.save(path)
+    mg2 = smg.Hierarchy.load(path)
+    assert mg2.n_levels == mg.n_levels
+    for l in range(1, mg.n_levels):
+        a, b = mg.matrix(l, "P_full"), mg2.matrix(l, "P_full")
+        assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        assert np.array_equal(a.data, b.data)
+    with pytest.raises(smg.SmgError):
+        smg.Hierarchy.load(str(tmp_path / "missing.smgh"))
+    # block variant: P (x) I_3 with DOF index 3*vertex + d (src/get_prolong.cpp:104-114)
+    mb = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    for l in range(1, mg.n_levels):
+        P, Pb = mg.matrix(l, "P_full"), mb.matrix(l, "P_full")
+        assert abs(Pb - sp.kron(P, sp.eye(3), format="csr")).max() == 0
