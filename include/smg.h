@@ -117,6 +117,27 @@ int smg_hierarchy_load(const char *path, smg_hierarchy **out);
 int smg_precompute(smg_hierarchy *h, int n, const int *rowptr, const int *col, const double *val, const int *known,
                    int n_known);
 
+/* Same sparsity / constraints / prolongations as the last smg_precompute on this handle, new VALUES already resident in
+ * HBM (d_val: device pointer, the caller's CSR order): the whole re-precompute runs on the GPU (fixed-recipe Galerkin
+ * products, SELL refresh, coarse inverse).  smg_precompute() takes the same path automatically when it is handed a
+ * matrix with an unchanged pattern. */
+int smg_precompute_values_device(smg_hierarchy *h, const double *d_val);
+
+/* ---- operator assembly on the device for a fixed connectivity -------------------------
+ * What the callers do with libigl around the solve every time step (05_example_mean_curvature_flow/main.cpp:66-69:
+ * massmatrix(U), LHS = M - delta L, RHS = M U; 03_mg_solver/main.cpp:44-61) -- here as three kernels on new vertex
+ * positions that never leave HBM.  Values are bit-identical to smg_mesh_cotmatrix / smg_mesh_massmatrix. */
+typedef struct smg_assembler smg_assembler;
+int smg_assembler_create(const int *F, int nF, int nV, smg_assembler **out);
+void smg_assembler_destroy(smg_assembler *a);
+/* CSR pattern of the assembled matrix (== the pattern of smg_mesh_cotmatrix); query nnz with NULL arrays first */
+int smg_assembler_pattern(const smg_assembler *a, int *nnz, int *rowptr, int *col);
+/* d_V: nV x 3 row-major (device).  d_val[nnz] = mass_coef * M + lap_coef * L with L the (negative semi-definite) cotangent
+ * matrix and M the lumped mass matrix (voronoi != 0: mixed Voronoi areas, else barycentric); d_mass[nV] (optional) = diag M;
+ * d_Lval[nnz] (optional) = L alone.  hip_stream: stream to enqueue on (NULL = default stream). */
+int smg_assemble(smg_assembler *a, const double *d_V, int voronoi, double mass_coef, double lap_coef, double *d_val,
+                 double *d_mass, double *d_Lval, void *hip_stream);
+
 /* ---- min_quad_with_fixed_mg_solve (src/min_quad_with_fixed_mg.h:38-69 and :79-113) ------------------------------ */
 /* RHS, z0, z: n x k column-major (n = full size incl. known rows); known_val: n_known x k (ignored without
  * constraints).  r_his must hold opts->max_iter doubles; *n_his <= max_iter entries are written, one per loop

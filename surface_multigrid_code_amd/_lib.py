@@ -45,6 +45,11 @@ def load():
         "smg_hierarchy_load": (i, [C.c_char_p, C.POINTER(vp)]),
         "smg_mg_precompute_subdiv": (i, [dp, i, ip, i, i, f, i, i, C.POINTER(vp), dp, ip]),
         "smg_precompute": (i, [vp, i, ip, ip, dp, ip, i]),
+        "smg_precompute_values_device": (i, [vp, vp]),
+        "smg_assembler_create": (i, [ip, i, i, C.POINTER(vp)]),
+        "smg_assembler_destroy": (None, [vp]),
+        "smg_assembler_pattern": (i, [vp, ip, ip, ip]),
+        "smg_assemble": (i, [vp, vp, i, d, d, vp, vp, vp, vp]),
         "smg_solve": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC), vp, i, dp, ip, ip]),
         "smg_solve_begin": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC)]),
         "smg_solve_iter_residual": (i, [vp, vp]),

@@ -125,6 +125,10 @@ class Hierarchy:
         _chk(rc, "smg_precompute")
         self.n = n
 
+    def precompute_values_device(self, d_val_ptr):
+        """Same sparsity as the last precompute, new values already in HBM (device pointer, caller CSR order)."""
+        _chk(self.L.smg_precompute_values_device(self.h, d_val_ptr), "smg_precompute_values_device")
+
     # ---- min_quad_with_fixed_mg_solve (host blocks)
     def solve(self, RHS, z0, known_val=None, opts=None):
         opts = opts or SolveOpts()

@@ -542,6 +542,70 @@ static int refresh_host_values(smg_hierarchy* h)
     return SMG_OK;
 }
 
+extern "C" int smg_precompute_values_device(smg_hierarchy* h, const double* d_val)
+{
+    if (!h || !d_val) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: bad arguments");
+    if (!h->precomputed || h->device < 0) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: run a full smg_precompute with this sparsity first");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute_values_device called during a split-phase solve");
+    if (!h->input_canonical) return fail(SMG_ERR_INVALID, "the matrix given to smg_precompute had unsorted or duplicate entries: entry indices are not stable");
+    if (!h->recipes_built) { int rc = build_recipes(h); if (rc) return rc; }
+    int rc = precompute_values_device(h, d_val);
+    if (rc != SMG_OK) h->precomputed = false;
+    return rc;
+}
+
+struct smg_assembler {
+    smg::AssemblyPlan plan;
+    smg::DevBuf<int> F, l_ptr, l_idx, m_ptr, m_idx, diag_of;
+    smg::DevBuf<signed char> l_sgn;
+    smg::DevBuf<double> Qc, Qm, Md;
+};
+
+extern "C" int smg_assembler_create(const int* F, int nF, int nV, smg_assembler** out)
+{
+    if (!F || nF <= 0 || nV <= 0 || !out) return fail(SMG_ERR_INVALID, "smg_assembler_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SMG_ERR_NO_DEVICE, "no HIP device: libsmg has no CPU fallback");
+    smg_assembler* a = new (std::nothrow) smg_assembler();
+    if (!a) return fail(SMG_ERR_ALLOC, "out of memory");
+    std::vector<int> Fv(F, F + (size_t)nF * 3);
+    for (int v : Fv) if (v < 0 || v >= nV) { delete a; return fail(SMG_ERR_INVALID, "face index out of range"); }
+    a->plan = make_assembly_plan(Fv, nV);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = a->F.upload(Fv);
+    if (e == hipSuccess) e = a->l_ptr.upload(a->plan.l_ptr);
+    if (e == hipSuccess) e = a->l_idx.upload(a->plan.l_idx);
+    if (e == hipSuccess) e = a->l_sgn.upload(a->plan.l_sgn);
+    if (e == hipSuccess) e = a->m_ptr.upload(a->plan.m_ptr);
+    if (e == hipSuccess) e = a->m_idx.upload(a->plan.m_idx);
+    if (e == hipSuccess) e = a->diag_of.upload(a->plan.diag_of);
+    if (e == hipSuccess) e = a->Qc.alloc((size_t)nF * 3);
+    if (e == hipSuccess) e = a->Qm.alloc((size_t)nF * 3);
+    if (e == hipSuccess) e = a->Md.alloc((size_t)nV);
+    if (e != hipSuccess) { delete a; return fail(SMG_ERR_HIP, "smg_assembler_create: %s", hipGetErrorString(e)); }
+    *out = a;
+    return SMG_OK;
+}
+extern "C" void smg_assembler_destroy(smg_assembler* a) { delete a; }
+extern "C" int smg_assembler_pattern(const smg_assembler* a, int* nnz, int* rowptr, int* col)
+{
+    if (!a) return fail(SMG_ERR_INVALID, "null assembler");
+    if (nnz) *nnz = (int)a->plan.pattern.nnz();
+    if (rowptr) std::copy(a->plan.pattern.ptr.begin(), a->plan.pattern.ptr.end(), rowptr);
+    if (col) std::copy(a->plan.pattern.col.begin(), a->plan.pattern.col.end(), col);
+    return SMG_OK;
+}
+extern "C" int smg_assemble(smg_assembler* a, const double* d_V, int voronoi, double mass_coef, double lap_coef, double* d_val,
+                            double* d_mass, double* d_Lval, void* hip_stream)
+{
+    if (!a || !d_V || !d_val) return fail(SMG_ERR_INVALID, "smg_assemble: bad arguments");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(launch_assemble(a->plan.nV, a->plan.nF, (int)a->plan.pattern.nnz(), d_V, a->F.p, voronoi, a->l_ptr.p, a->l_idx.p, a->l_sgn.p,
+                           a->m_ptr.p, a->m_idx.p, a->diag_of.p, a->Qc.p, a->Qm.p, a->Md.p, mass_coef, lap_coef, d_val, d_Lval, st));
+    if (d_mass) HIPCHK(hipMemcpyAsync(d_mass, a->Md.p, (size_t)a->plan.nV * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return SMG_OK;
+}
+
 extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
                               const int* known, int n_known)
 {

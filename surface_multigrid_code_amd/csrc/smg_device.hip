@@ -715,6 +715,81 @@ __global__ void k_dense_identity(double* dense, int np, int n)
     dense[t] = (i == j && i >= n) ? 1.0 : 0.0;
 }
 
+// ---- operator assembly for a fixed connectivity (row f-3).  The expressions mirror smg_mesh.cpp (doublearea,
+// edge_lengths, cotmatrix, massmatrix_diag) term by term so the values are bit-identical to the host assembly. ----------
+__global__ void k_face_terms(const double* V, const int* F, int nF, int voronoi, double* Qc, double* Qm)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nF) return;
+    const double* a = V + 3 * (size_t)F[3 * f];
+    const double* b = V + 3 * (size_t)F[3 * f + 1];
+    const double* c = V + 3 * (size_t)F[3 * f + 2];
+    const double ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+    const double vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+    const double wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+    const double dA = sqrt(wx * wx + wy * wy + wz * wz);
+    double d0x = b[0] - c[0], d0y = b[1] - c[1], d0z = b[2] - c[2];
+    double d1x = c[0] - a[0], d1y = c[1] - a[1], d1z = c[2] - a[2];
+    double d2x = a[0] - b[0], d2y = a[1] - b[1], d2z = a[2] - b[2];
+    const double l0 = sqrt(d0x * d0x + d0y * d0y + d0z * d0z);
+    const double l1 = sqrt(d1x * d1x + d1y * d1y + d1z * d1z);
+    const double l2 = sqrt(d2x * d2x + d2y * d2y + d2z * d2z);
+    const double q0 = l0 * l0, q1 = l1 * l1, q2 = l2 * l2;
+    Qc[3 * (size_t)f + 0] = (q1 + q2 - q0) / dA / 4.0;
+    Qc[3 * (size_t)f + 1] = (q2 + q0 - q1) / dA / 4.0;
+    Qc[3 * (size_t)f + 2] = (q0 + q1 - q2) / dA / 4.0;
+    double m0, m1, m2;
+    if (!voronoi) {
+        m0 = m1 = m2 = dA / 6.0;
+    } else {
+        const double cs0 = (l2 * l2 + l1 * l1 - l0 * l0) / (l1 * l2 * 2.0);
+        const double cs1 = (l0 * l0 + l2 * l2 - l1 * l1) / (l2 * l0 * 2.0);
+        const double cs2 = (l1 * l1 + l0 * l0 - l2 * l2) / (l0 * l1 * 2.0);
+        const double b0 = cs0 * l0, b1 = cs1 * l1, b2 = cs2 * l2;
+        const double bs = b0 + b1 + b2;
+        const double p0 = b0 / bs * (dA * 0.5), p1 = b1 / bs * (dA * 0.5), p2 = b2 / bs * (dA * 0.5);
+        m0 = (p1 + p2) * 0.5; m1 = (p2 + p0) * 0.5; m2 = (p0 + p1) * 0.5;
+        if (cs0 < 0) { m0 = 0.25 * dA; m1 = 0.125 * dA; m2 = 0.125 * dA; }
+        if (cs1 < 0) { m0 = 0.125 * dA; m1 = 0.25 * dA; m2 = 0.125 * dA; }
+        if (cs2 < 0) { m0 = 0.125 * dA; m1 = 0.125 * dA; m2 = 0.25 * dA; }
+    }
+    Qm[3 * (size_t)f + 0] = m0; Qm[3 * (size_t)f + 1] = m1; Qm[3 * (size_t)f + 2] = m2;
+}
+__global__ void k_mass_diag(int nV, const int* m_ptr, const int* m_idx, const double* Qm, double* Md)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    double s = 0.0;
+    for (int t = m_ptr[v]; t < m_ptr[v + 1]; t++) s += Qm[m_idx[t]];
+    Md[v] = s;
+}
+// val[e] = mass_coef * M(e) + lap_coef * L(e);  L(e) = sum of +/- cot terms in cotmatrix() order (first term assigns)
+__global__ void k_assemble_vals(int nnz, const int* l_ptr, const int* l_idx, const signed char* l_sgn, const double* Qc,
+                                const int* diag_of, const double* Md, double mass_coef, double lap_coef, double* val, double* Lval)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int b = l_ptr[e], en = l_ptr[e + 1];
+    double L = 0.0;
+    if (b < en) {
+        L = l_sgn[b] > 0 ? Qc[l_idx[b]] : -Qc[l_idx[b]];
+        for (int t = b + 1; t < en; t++) L += l_sgn[t] > 0 ? Qc[l_idx[t]] : -Qc[l_idx[t]];
+    }
+    if (Lval) Lval[e] = L;
+    const int d = diag_of[e];
+    const double x = lap_coef * L;
+    val[e] = d >= 0 ? mass_coef * Md[d] + x : x;
+}
+hipError_t launch_assemble(int nV, int nF, int nnz, const double* V, const int* F, int voronoi, const int* l_ptr, const int* l_idx,
+                           const signed char* l_sgn, const int* m_ptr, const int* m_idx, const int* diag_of, double* Qc, double* Qm,
+                           double* Md, double mass_coef, double lap_coef, double* val, double* Lval, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_face_terms, dim3(grid1d(nF, 256)), dim3(256), 0, st, V, F, nF, voronoi, Qc, Qm);
+    hipLaunchKernelGGL(k_mass_diag, dim3(grid1d(nV, 256)), dim3(256), 0, st, nV, m_ptr, m_idx, Qm, Md);
+    hipLaunchKernelGGL(k_assemble_vals, dim3(grid1d(nnz, 256)), dim3(256), 0, st, nnz, l_ptr, l_idx, l_sgn, Qc, diag_of, Md, mass_coef, lap_coef, val, Lval);
+    return hipGetLastError();
+}
+
 hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out, hipStream_t st)
 {
     if (n_out <= 0) return hipSuccess;

@@ -77,6 +77,12 @@ hipError_t launch_gather_vals(double* dst, const double* src, const int* map, si
 hipError_t launch_dense_from_csr(double* dense, int np, int n, const double* src, const long long* pos, int nnz, hipStream_t st);
 hipError_t launch_add_at(double* v, const int* where, int n, double c, hipStream_t st);
 
+// operator assembly on the device for a fixed connectivity (row f-3): per-face terms, lumped mass, CSR values
+// val = mass_coef * M + lap_coef * L  (L = igl::cotmatrix convention); Lval (optional) receives L alone.
+hipError_t launch_assemble(int nV, int nF, int nnz, const double* V, const int* F, int voronoi, const int* l_ptr, const int* l_idx,
+                           const signed char* l_sgn, const int* m_ptr, const int* m_idx, const int* diag_of, double* Qc, double* Qm,
+                           double* Md, double mass_coef, double lap_coef, double* val, double* Lval, hipStream_t st);
+
 // layout helpers ------------------------------------------------------------------------------------------
 // dst[i*k + c] = src[map[i] + c*ld_src]      (column-major caller block -> internal block)
 hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src,

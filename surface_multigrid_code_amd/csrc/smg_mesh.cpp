@@ -284,6 +284,54 @@ void subdivide(Mesh& m, int n_sub, std::vector<Csr>& Ps)
     for (int s = n_sub - 1; s >= 0; s--) Ps.push_back(std::move(ops[s]));
 }
 
+AssemblyPlan make_assembly_plan(const std::vector<int>& F, int nV)
+{
+    AssemblyPlan P;
+    const int nF = (int)(F.size() / 3);
+    P.nV = nV; P.nF = nF;
+    // same bucketing and insertion order as cotmatrix()
+    std::vector<int> cnt(nV + 1, 0);
+    for (int f = 0; f < nF; f++) for (int c = 0; c < 3; c++) cnt[F[3 * f + c] + 1] += 4;
+    for (int i = 0; i < nV; i++) cnt[i + 1] += cnt[i];
+    struct Trip { int col, term; signed char sgn; };
+    std::vector<Trip> tr(cnt[nV]);
+    std::vector<int> next(cnt.begin(), cnt.end() - 1);
+    static const int es[3] = {1, 2, 0}, ed[3] = {2, 0, 1};
+    for (int f = 0; f < nF; f++)
+        for (int e = 0; e < 3; e++) {
+            const int s = F[3 * f + es[e]], d = F[3 * f + ed[e]], t = 3 * f + e;
+            tr[next[s]++] = {d, t, 1};
+            tr[next[d]++] = {s, t, 1};
+            tr[next[s]++] = {s, t, -1};
+            tr[next[d]++] = {d, t, -1};
+        }
+    P.pattern.nr = P.pattern.nc = nV;
+    P.pattern.ptr.assign(nV + 1, 0);
+    for (int i = 0; i < nV; i++) {
+        std::stable_sort(tr.begin() + cnt[i], tr.begin() + cnt[i + 1], [](const Trip& a, const Trip& b) { return a.col < b.col; });
+        for (int p = cnt[i]; p < cnt[i + 1]; p++) {
+            if (p == cnt[i] || tr[p].col != tr[p - 1].col) {   // new stored entry (csr_from_arrays merges duplicates in this order)
+                P.l_ptr.push_back((int)P.l_idx.size());
+                P.pattern.col.push_back(tr[p].col);
+                P.diag_of.push_back(tr[p].col == i ? i : -1);
+            }
+            P.l_idx.push_back(tr[p].term);
+            P.l_sgn.push_back(tr[p].sgn);
+        }
+        P.pattern.ptr[i + 1] = (int)P.pattern.col.size();
+    }
+    P.l_ptr.push_back((int)P.l_idx.size());
+    P.pattern.val.assign(P.pattern.col.size(), 0.0);
+    // mass: massmatrix_diag() adds the corner terms in face order
+    P.m_ptr.assign(nV + 1, 0);
+    for (int f = 0; f < nF; f++) for (int c = 0; c < 3; c++) P.m_ptr[F[3 * f + c] + 1]++;
+    for (int i = 0; i < nV; i++) P.m_ptr[i + 1] += P.m_ptr[i];
+    P.m_idx.resize(P.m_ptr[nV]);
+    std::vector<int> mn(P.m_ptr.begin(), P.m_ptr.end() - 1);
+    for (int f = 0; f < nF; f++) for (int c = 0; c < 3; c++) P.m_idx[mn[F[3 * f + c]]++] = 3 * f + c;
+    return P;
+}
+
 Mesh make_torus(int nu, int nv, double R, double r)
 {
     Mesh m;

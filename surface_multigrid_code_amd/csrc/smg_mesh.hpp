@@ -38,4 +38,20 @@ void subdivide(Mesh& m, int n_sub, std::vector<Csr>& Ps);
 
 Mesh make_torus(int nu, int nv, double R, double r);           // BASELINE config C5 base mesh
 
+// Assembly plan for a FIXED connectivity: the sparsity of cotmatrix(V, F) and, per stored
+// entry, the ordered list of per-face cotangent terms (+/- C(f,e)) that cotmatrix() sums into it; per vertex the ordered
+// list of per-corner mass terms.  Replaying the plan on new vertex positions reproduces cotmatrix()/massmatrix_diag()
+// bit for bit; the device kernels in smg_device.hip do exactly that.
+struct AssemblyPlan {
+    int nV = 0, nF = 0;
+    Csr pattern;                  // values unused
+    std::vector<int> l_ptr;       // nnz + 1
+    std::vector<int> l_idx;       // term -> 3*f + e   (index into the per-face cot array)
+    std::vector<signed char> l_sgn;
+    std::vector<int> m_ptr;       // nV + 1
+    std::vector<int> m_idx;       // term -> 3*f + corner (index into the per-face mass array)
+    std::vector<int> diag_of;     // per entry: the vertex whose diagonal it is, or -1
+};
+AssemblyPlan make_assembly_plan(const std::vector<int>& F, int nV);
+
 }  // namespace smg

@@ -87,3 +87,44 @@ def torus(nu, nv, R=1.0, r=0.4):
     F = np.zeros((2 * nu * nv, 3), np.int32)
     _chk(_lib.load().smg_mesh_torus(nu, nv, R, r, _dp(V), _ip(F)), "torus")
     return V, F
+
+
+class Assembler:
+    """Operator assembly on the device for a fixed connectivity (include/smg.h, row f-3): per time step
+    `M(U)`, `mass_coef * M + lap_coef * L(U)` and nothing leaves HBM.  Arguments are torch CUDA tensors (float64)."""
+
+    def __init__(self, F, nV):
+        self.L = _lib.load()
+        F = np.ascontiguousarray(F, dtype=np.int32)
+        out = C.c_void_p()
+        _chk(self.L.smg_assembler_create(_ip(F), F.shape[0], int(nV), C.byref(out)), "smg_assembler_create")
+        self.a = out
+        self.nV = int(nV)
+        nnz = C.c_int()
+        _chk(self.L.smg_assembler_pattern(self.a, C.byref(nnz), None, None), "smg_assembler_pattern")
+        self.nnz = nnz.value
+        self.indptr = np.zeros(self.nV + 1, np.int32)
+        self.indices = np.zeros(self.nnz, np.int32)
+        _chk(self.L.smg_assembler_pattern(self.a, None, _ip(self.indptr), _ip(self.indices)), "smg_assembler_pattern")
+
+    def __del__(self):
+        try:
+            if self.a:
+                self.L.smg_assembler_destroy(self.a)
+                self.a = None
+        except Exception:
+            pass
+
+    def assemble(self, V_dev, mass_coef, lap_coef, kind="barycentric", val_out=None, mass_out=None, L_out=None, stream=0):
+        """val = mass_coef * M + lap_coef * L(V); returns (val, mass) device tensors."""
+        import torch
+        assert V_dev.is_cuda and V_dev.dtype == torch.float64 and V_dev.is_contiguous() and V_dev.shape == (self.nV, 3)
+        val = val_out if val_out is not None else torch.empty(self.nnz, dtype=torch.float64, device=V_dev.device)
+        mass = mass_out if mass_out is not None else torch.empty(self.nV, dtype=torch.float64, device=V_dev.device)
+        _chk(self.L.smg_assemble(self.a, V_dev.data_ptr(), int(kind == "voronoi"), float(mass_coef), float(lap_coef), val.data_ptr(),
+                                 mass.data_ptr(), L_out.data_ptr() if L_out is not None else None, C.c_void_p(stream or 0)),
+             "smg_assemble")
+        return val, mass
+
+    def pattern_matrix(self, val_host):
+        return sp.csr_matrix((val_host, self.indices, self.indptr), shape=(self.nV, self.nV))
