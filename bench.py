@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--spmv-reps", type=int, default=500)
+    ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
+                    help="f64 (default): the reference arithmetic; mixed: fp32 V-cycle inside the fp64 outer loop")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +140,7 @@ def main():
     sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
     W, K = args.warmup, args.steps
-    opts = smg.SolveOpts(tol=0.0, max_iter=min(W + K, 1024), pre=2, post=2)
+    opts = smg.SolveOpts(tol=0.0, max_iter=min(W + K, 1024), pre=2, post=2, precision=args.precision)
 
     def run(n_it):
         if world == 1 and not force_split:
@@ -221,7 +223,8 @@ def main():
             "metric": "V-cycles/sec + fine-level SpMV GB/s (% HBM peak), 1M-vert mesh fp64",
             "value": world * K / dt, "unit": "V-cycles/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "f64" else "f64 outer loop + f32 V-cycle (mixed)", "data": "synthetic",
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
                        "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],

@@ -56,6 +56,10 @@ typedef struct {
     int verbosity;     /* 0 silent; 1 prints "MG iteration: i, residual: r" lines like the reference (:111) */
     int check_every;   /* host polls the device-side convergence flag every this many iterations (>=1) */
     int use_graph;     /* 1: replay one captured hipGraph per outer iteration; 0: eager launches */
+    int precision;     /* 0 (default): everything fp64, the reference arithmetic.  1: mixed -- the outer iterate and the
+                          residual (hence r_his and the stopping test) stay fp64, the V-cycle runs on fp32 copies of the
+                          operators as z += V32(RHS - A z): same iteration in exact arithmetic, fp64 accuracy at convergence,
+                          ~2/3 of the bytes (BASELINE config 5: fp32 vs fp64) */
 } smg_solve_opts;
 void smg_solve_opts_default(smg_solve_opts *o);
 
@@ -176,6 +180,8 @@ int smg_residual_norm(smg_hierarchy *h, int lv, const double *B, const double *u
  * internal order (smg_level_get_perm), k columns interleaved.  mode: 0 y=Ax, 1 y=b-Ax, 3 y+=Ax. */
 int smg_raw_spmv(smg_hierarchy *h, int lv, int mode, const double *x, const double *b, double *y, int k);
 int smg_raw_relax(smg_hierarchy *h, int lv, const double *b, double *u, int k, int iters);
+/* fp32 twin of smg_raw_spmv (mode 0 only): x, y are float device vectors; bytes per launch 8 nnz + 4 (n+1) + 8 n k */
+int smg_raw_spmv_f32(smg_hierarchy *h, int lv, const float *x, float *y, int k);
 int smg_raw_outer_iteration(smg_hierarchy *h, int n_iter);   /* residual + decide + V-cycle, n_iter times, on the
                                                                 state loaded by smg_solve_begin; no host sync */
 int smg_synchronize(smg_hierarchy *h);

@@ -10,7 +10,7 @@ SMG_HOST, SMG_DEVICE = 0, 1
 
 class SolveOptsC(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("pre", C.c_int), ("post", C.c_int),
-                ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int)]
+                ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int), ("precision", C.c_int)]
 
 
 _lib = None
@@ -66,6 +66,7 @@ def load():
         "smg_residual_norm": (i, [vp, i, dp, dp, i, dp]),
         "smg_raw_spmv": (i, [vp, i, i, vp, vp, vp, i]),
         "smg_raw_relax": (i, [vp, i, vp, vp, i, i]),
+        "smg_raw_spmv_f32": (i, [vp, i, vp, vp, i]),
         "smg_raw_outer_iteration": (i, [vp, i]),
         "smg_synchronize": (i, [vp]),
         "smg_bench_vcycle": (i, [vp, i, i, i, i, i, dp]),

@@ -55,8 +55,9 @@ def _colmajor(X):
 class SolveOpts:
     """tol / maxIter / pre / post with the reference's defaults (src/min_quad_with_fixed_mg.cpp:63,77,102-103)."""
 
-    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1):
-        self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph)
+    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1, precision="f64"):
+        prec = {"f64": 0, "fp64": 0, 0: 0, "mixed": 1, 1: 1}[precision]
+        self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph, prec)
 
 
 class Hierarchy:
@@ -283,6 +284,9 @@ class Hierarchy:
 
     def raw_spmv(self, lv, mode, x_ptr, b_ptr, y_ptr, k=1):
         _chk(self.L.smg_raw_spmv(self.h, lv, mode, x_ptr, b_ptr, y_ptr, k), "smg_raw_spmv")
+
+    def raw_spmv_f32(self, lv, x_ptr, y_ptr, k=1):
+        _chk(self.L.smg_raw_spmv_f32(self.h, lv, x_ptr, y_ptr, k), "smg_raw_spmv_f32")
 
     def raw_relax(self, lv, b_ptr, u_ptr, k=1, iters=1):
         _chk(self.L.smg_raw_relax(self.h, lv, b_ptr, u_ptr, k, iters), "smg_raw_relax")

@@ -60,6 +60,7 @@ extern "C" void smg_solve_opts_default(smg_solve_opts* o)
     o->verbosity = 0;
     o->check_every = 1;
     o->use_graph = 1;
+    o->precision = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ device plumbing
@@ -351,8 +352,9 @@ static int precompute_device(smg_hierarchy* h)
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
         Lv.b.release(); Lv.u.release(); Lv.r.release();
+        Lv.b32.release(); Lv.u32.release(); Lv.r32.release();
     }
-    h->kcap = 0;
+    h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
         if (lv < L - 1) {
@@ -523,6 +525,7 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
         HIPCHK(hipStreamSynchronize(st));
     }
     h->host_stale = true;
+    h->f32_valid = false;   // the fp32 copies are re-made from the new values when a mixed solve asks for them
     return SMG_OK;
 }
 
@@ -707,6 +710,95 @@ static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, co
     return enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, post, ctrl);  // :57
 }
 
+// ---- mixed precision: fp32 images of the operators and an fp32 V-cycle ------------------------------------------------
+static int ensure_fp32(smg_hierarchy* h, int k)
+{
+    const int L = h->n_levels;
+    if (!h->f32_valid) {
+        drop_graphs(h);
+        auto mk = [&](SellBuf& src, DevBuf<float>& dst, SellDev& view) -> int {
+            view = src.view;
+            if (src.padded == 0) { view.valf = nullptr; return SMG_OK; }
+            HIPCHK(dst.ensure((size_t)src.padded));
+            HIPCHK(launch_cvt_f64_f32(dst.p, src.view.val, (size_t)src.padded, h->stream));
+            view.valf = dst.p;
+            return SMG_OK;
+        };
+        for (int lv = 0; lv < L; lv++) {
+            Level& Lv = h->lv[lv];
+            int rc;
+            if (lv < L - 1) {
+                if ((rc = mk(Lv.dA, Lv.a32, Lv.dA32))) return rc;
+                if (Lv.gs_on_transpose) { if ((rc = mk(Lv.dAT, Lv.at32, Lv.dAT32))) return rc; }
+            }
+            if (lv >= 1) {
+                if ((rc = mk(Lv.dP, Lv.p32, Lv.dP32))) return rc;
+                if ((rc = mk(Lv.dPT, Lv.pt32, Lv.dPT32))) return rc;
+            }
+        }
+        HIPCHK(h->d_Ainv32.ensure((size_t)h->nc_pad * h->nc_pad));
+        HIPCHK(launch_cvt_f64_f32(h->d_Ainv32.p, h->d_Ainv.p, (size_t)h->nc_pad * h->nc_pad, h->stream));
+        h->f32_valid = true;
+    }
+    if (k > h->kcap32) {
+        drop_graphs(h);
+        for (int lv = 0; lv < L; lv++) {
+            Level& Lv = h->lv[lv];
+            const size_t rows = (lv == L - 1) ? (size_t)h->nc_pad : (size_t)Lv.n;
+            HIPCHK(Lv.b32.alloc(rows * k));
+            HIPCHK(Lv.u32.alloc(rows * k));
+            HIPCHK(hipMemsetAsync(Lv.b32.p, 0, rows * k * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(Lv.u32.p, 0, rows * k * sizeof(float), h->stream));
+            if (lv < L - 1) HIPCHK(Lv.r32.alloc(rows * k));
+        }
+        h->kcap32 = k;
+    }
+    return SMG_OK;
+}
+
+static int enqueue_relax32(smg_hierarchy* h, int lv, const float* b, float* u, int k, int iters, const Ctrl* ctrl)
+{
+    Level& Lv = h->lv[lv];
+    ProfGuard pg(h, "MG: relaxation");
+    const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
+    const SellDev& V = Lv.gs_on_transpose ? Lv.dAT32 : Lv.dA32;
+    const std::vector<int>& cs = G.color_slice_ptr;
+    for (int it = 0; it < iters; it++)
+        for (size_t c = 0; c + 1 < cs.size(); c++)
+            HIPCHK(launch_sell_f32(SELL_GS, V, cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
+    return SMG_OK;
+}
+
+// the same cycle as enqueue_vcycle, on the fp32 images and fp32 work vectors
+static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+{
+    const int L = h->n_levels;
+    Level& Lv = h->lv[lv];
+    if (lv == L - 1) {
+        ProfGuard pg(h, "MG: coarse solve");
+        HIPCHK(launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, Lv.b32.p, Lv.u32.p, k, ctrl, h->stream));
+        return SMG_OK;
+    }
+    Level& Lc = h->lv[lv + 1];
+    int rc = enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, pre, ctrl);
+    if (rc) return rc;
+    {
+        ProfGuard pg(h, "MG: residual");
+        HIPCHK(launch_sell_f32(SELL_RESID, Lv.dA32, 0, Lv.dA32.n_slices, Lv.u32.p, Lv.b32.p, Lv.r32.p, k, ctrl, h->stream));
+    }
+    {
+        ProfGuard pg(h, "MG: restrict");
+        HIPCHK(launch_sell_f32(SELL_AX, Lc.dPT32, 0, Lc.dPT32.n_slices, Lv.r32.p, nullptr, Lc.b32.p, k, ctrl, h->stream, Lc.u32.p));
+    }
+    rc = enqueue_vcycle32(h, lv + 1, k, pre, post, ctrl);
+    if (rc) return rc;
+    {
+        ProfGuard pg(h, "MG: prolong");
+        HIPCHK(launch_sell_f32(SELL_ADD, Lc.dP32, 0, Lc.dP32.n_slices, Lc.u32.p, nullptr, Lv.u32.p, k, ctrl, h->stream));
+    }
+    return enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, post, ctrl);
+}
+
 // sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
 static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false)
 {
@@ -714,7 +806,10 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
     ProfGuard pg(h, "MG: outer residual");
     int nb = 0;
     if (h->n_levels == 1) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, mg_precompute.cpp:39)");
-    HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
+    if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
+        HIPCHK(launch_sell(SELL_RESID_BOTH, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
+    else
+        HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     if (fuse_decide) HIPCHK(launch_ss_finalize_decide(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
     else HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
     return SMG_OK;
@@ -726,8 +821,18 @@ static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
     if (d_sumsq) HIPCHK(launch_decide(h->d_ctrl.p, d_sumsq, h->stream));
     {
         ProfGuard pg(h, "MG: total VCycle");  // PROFC_NODE at src/min_quad_with_fixed_mg.cpp:123
-        int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p);
-        if (rc) return rc;
+        if (h->precision == 1) {
+            // z += V32(r): the V-cycle is affine in (B, u), so V(B, z) = z + V(B - A z, 0) in exact arithmetic
+            Level& L0 = h->lv[0];
+            const size_t cnt = (size_t)L0.n * k;
+            HIPCHK(launch_residual_to_f32(L0.b32.p, L0.u32.p, L0.r.p, cnt, h->d_ctrl.p, h->stream));
+            int rc = enqueue_vcycle32(h, 0, k, h->pre, h->post, h->d_ctrl.p);
+            if (rc) return rc;
+            HIPCHK(launch_add_correction(L0.u.p, L0.u32.p, cnt, h->d_ctrl.p, h->stream));
+        } else {
+            int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p);
+            if (rc) return rc;
+        }
     }
     return SMG_OK;
 }
@@ -749,7 +854,7 @@ static int capture_graph(smg_hierarchy* h, hipGraphExec_t* out, Fn&& body)
 
 static int ensure_graphs(smg_hierarchy* h)
 {
-    if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post) return SMG_OK;
+    if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision) return SMG_OK;
     drop_graphs(h);
     const int k = h->k;
     int rc = capture_graph(h, &h->g_iter, [&]() {
@@ -763,7 +868,7 @@ static int ensure_graphs(smg_hierarchy* h)
     // second half of a split-phase iteration: break test on the (all-reduced) ctrl->sumsq, then the V-cycle
     rc = capture_graph(h, &h->g_cycle, [&]() { return enqueue_cycle_part(h, k, &h->d_ctrl.p->sumsq); });
     if (rc) return rc;
-    h->g_k = k; h->g_pre = h->pre; h->g_post = h->post;
+    h->g_k = k; h->g_pre = h->pre; h->g_post = h->post; h->g_prec = h->precision;
     return SMG_OK;
 }
 
@@ -809,8 +914,11 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
     if (h->has_known && (!known_val || ld_kv < (int)h->known.size())) return fail(SMG_ERR_INVALID, "known_val missing or ld_kv too small");
     h->tol = o.tol; h->max_iter = o.max_iter; h->pre = o.pre; h->post = o.post; h->verbosity = o.verbosity;
     h->check_every = std::max(1, o.check_every); h->use_graph = o.use_graph;
+    if (o.precision != 0 && o.precision != 1) return fail(SMG_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
+    h->precision = o.precision;
     rc = ensure_work(h, k);
     if (rc) return rc;
+    if (h->precision == 1 && (rc = ensure_fp32(h, k))) return rc;
     h->k = k;
     const int nk = (int)h->known.size();
     // stage host inputs
@@ -1136,6 +1244,18 @@ extern "C" int smg_raw_spmv(smg_hierarchy* h, int lv, int mode, const double* x,
         return fail(SMG_ERR_INVALID, "smg_raw_spmv: bad level/mode");
     Level& Lv = h->lv[lv];
     HIPCHK(launch_sell((SellMode)mode, Lv.dA.view, 0, Lv.dA.view.n_slices, x, b, y, k, nullptr, nullptr, nullptr, h->stream));
+    return SMG_OK;
+}
+
+extern "C" int smg_raw_spmv_f32(smg_hierarchy* h, int lv, const float* x, float* y, int k)
+{
+    int rc = check_ready(h, "smg_raw_spmv_f32");
+    if (rc) return rc;
+    if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_spmv_f32: bad level");
+    if ((rc = ensure_work(h, k))) return rc;
+    if ((rc = ensure_fp32(h, k))) return rc;
+    Level& Lv = h->lv[lv];
+    HIPCHK(launch_sell_f32(SELL_AX, Lv.dA32, 0, Lv.dA32.n_slices, x, nullptr, y, k, nullptr, h->stream));
     return SMG_OK;
 }
 

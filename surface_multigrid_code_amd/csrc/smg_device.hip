@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "smg_device.hpp"
 
@@ -28,11 +29,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int RPL> struct PanelLoad;
-template <> struct PanelLoad<1> {
-    static __device__ __forceinline__ void ld(const int* cp, const double* vp, int* c, double* v) { c[0] = *cp; v[0] = *vp; }
+template <int RPL, typename T> struct PanelLoad;
+template <typename T> struct PanelLoad<1, T> {
+    static __device__ __forceinline__ void ld(const int* cp, const T* vp, int* c, T* v) { c[0] = *cp; v[0] = *vp; }
 };
-template <> struct PanelLoad<2> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wave-instruction
+template <> struct PanelLoad<2, double> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wave-instruction
     static __device__ __forceinline__ void ld(const int* cp, const double* vp, int* c, double* v)
     {
         const int2 cc = *reinterpret_cast<const int2*>(cp);
@@ -40,12 +41,25 @@ template <> struct PanelLoad<2> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wav
         c[0] = cc.x; c[1] = cc.y; v[0] = vv.x; v[1] = vv.y;
     }
 };
+template <> struct PanelLoad<2, float> {
+    static __device__ __forceinline__ void ld(const int* cp, const float* vp, int* c, float* v)
+    {
+        const int2 cc = *reinterpret_cast<const int2*>(cp);
+        const float2 vv = *reinterpret_cast<const float2*>(vp);
+        c[0] = cc.x; c[1] = cc.y; v[0] = vv.x; v[1] = vv.y;
+    }
+};
+template <typename T> __device__ __forceinline__ const T* sell_vals(const SellDev& A);
+template <> __device__ __forceinline__ const double* sell_vals<double>(const SellDev& A) { return A.val; }
+template <> __device__ __forceinline__ const float* sell_vals<float>(const SellDev& A) { return A.valf; }
 
 // One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
-template <int MODE, int KB, int RPL>
-__global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const double* x,
-                                              const double* b, double* y, int ld, const int* done, double* partials,
-                                              double* zero_rows)
+// T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
+// accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
+template <int MODE, int KB, int RPL, typename T>
+__global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const T* x,
+                                              const T* b, T* y, int ld, const int* done, double* partials,
+                                              T* zero_rows)
 {
     // The convergence flag is loaded up front but only consulted right before the stores: the matrix / vector loads
     // of a launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
@@ -64,44 +78,44 @@ __global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end,
         const int off0 = A.slice_off[s];
         const int w = A.slice_off[s + 1] - off0;
         const int* cp = A.col + (size_t)off0 * C + RPL * lane;
-        const double* vp = A.val + (size_t)off0 * C + RPL * lane;
+        const T* vp = sell_vals<T>(A) + (size_t)off0 * C + RPL * lane;
         const int rowb = row0 + RPL * lane;
-        double acc[RPL][KB];
-        double diag[RPL];
-        double bv[RPL][KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
+        T acc[RPL][KB];
+        T diag[RPL];
+        T bv[RPL][KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
-            diag[r] = 1.0;
+            diag[r] = (T)1;
             const bool live = RPL * lane + r < nrow;
 #pragma unroll
             for (int q = 0; q < KB; q++) {
-                acc[r][q] = 0.0;
-                if (MODE == SELL_AX) bv[r][q] = 0.0;
-                else if (MODE == SELL_ADD) bv[r][q] = live ? y[(size_t)(rowb + r) * ld + q] : 0.0;
-                else bv[r][q] = live ? b[(size_t)(rowb + r) * ld + q] : 0.0;
+                acc[r][q] = (T)0;
+                if (MODE == SELL_AX) bv[r][q] = (T)0;
+                else if (MODE == SELL_ADD) bv[r][q] = live ? y[(size_t)(rowb + r) * ld + q] : (T)0;
+                else bv[r][q] = live ? b[(size_t)(rowb + r) * ld + q] : (T)0;
             }
         }
         constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
             int c[U][RPL];
-            double v[U][RPL];
+            T v[U][RPL];
 #pragma unroll
             for (int t = 0; t < U; t++) {
                 if ((j0 + t) < w) {  // wave-uniform
-                    PanelLoad<RPL>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
+                    PanelLoad<RPL, T>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = 0.0; }
+                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = (T)0; }
                 }
             }
-            double xv[U][RPL][KB];
+            T xv[U][RPL][KB];
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < RPL; r++) {
                     const bool use = (c[t][r] >= 0) && !(MODE == SELL_GS && c[t][r] == rowb + r);
 #pragma unroll
-                    for (int q = 0; q < KB; q++) xv[t][r][q] = use ? x[(size_t)c[t][r] * ld + q] : 0.0;
+                    for (int q = 0; q < KB; q++) xv[t][r][q] = use ? x[(size_t)c[t][r] * ld + q] : (T)0;
                 }
 #pragma unroll
             for (int t = 0; t < U; t++)
@@ -123,16 +137,16 @@ __global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end,
                 const size_t o = (size_t)(rowb + r) * ld;
 #pragma unroll
                 for (int q = 0; q < KB; q++) {
-                    if (MODE == SELL_AX) { y[o + q] = acc[r][q]; if (zero_rows) zero_rows[o + q] = 0.0; }
+                    if (MODE == SELL_AX) { y[o + q] = acc[r][q]; if (zero_rows) zero_rows[o + q] = (T)0; }
                     else if (MODE == SELL_RESID) y[o + q] = bv[r][q] - acc[r][q];
                     else if (MODE == SELL_ADD) y[o + q] = bv[r][q] + acc[r][q];
                     else if (MODE == SELL_GS) y[o + q] = (bv[r][q] - acc[r][q]) / diag[r];
-                    else { const double t = bv[r][q] - acc[r][q]; ss += t * t; }
+                    else { const double t = (double)(bv[r][q] - acc[r][q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[r][q] - acc[r][q]; }
                 }
             }
         }
     }
-    if (MODE == SELL_RESID_SS) {
+    if (MODE == SELL_RESID_SS || MODE == SELL_RESID_BOTH) {
         __shared__ double red[16];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
@@ -153,10 +167,10 @@ __global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end,
 // shared by the KW lanes of a group (one request), and all k columns go through ONE launch instead of k/4.
 // A wave owns 8*G consecutive rows of a slice (KW/8 waves per slice).  Per (row, column) the sum is still sequential in
 // ascending column order: bit-identical to the narrow kernel and to the oracle.
-template <int MODE, int KW>
-__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, const double* x,
-                                                   const double* b, double* y, int ld, const int* done, double* partials,
-                                                   double* zero_rows)
+template <int MODE, int KW, typename T>
+__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, const T* x,
+                                                   const T* b, T* y, int ld, const int* done, double* partials,
+                                                   T* zero_rows)
 {
     const int stop = done ? __builtin_nontemporal_load(done) : 0;
     constexpr int G = 64 / KW;        // rows in flight per wave-instruction
@@ -178,37 +192,37 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
         const int off0 = A.slice_off[s];
         const int w = A.slice_off[s + 1] - off0;
         int rl[R];
-        double acc[R], diag[R], bv[R];
+        T acc[R], diag[R], bv[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             rl[r] = sub * RW + r * G + g;   // row inside the slice
-            acc[r] = 0.0; diag[r] = 1.0;
+            acc[r] = (T)0; diag[r] = (T)1;
             const bool live = rl[r] < nrow;
             const size_t o = (size_t)(row0 + rl[r]) * ld + c;
-            if (MODE == SELL_AX) bv[r] = 0.0;
-            else if (MODE == SELL_ADD) bv[r] = live ? y[o] : 0.0;
-            else bv[r] = live ? b[o] : 0.0;
+            if (MODE == SELL_AX) bv[r] = (T)0;
+            else if (MODE == SELL_ADD) bv[r] = live ? y[o] : (T)0;
+            else bv[r] = live ? b[o] : (T)0;
         }
         const int* cp = A.col + (size_t)off0 * 64;
-        const double* vp = A.val + (size_t)off0 * 64;
+        const T* vp = sell_vals<T>(A) + (size_t)off0 * 64;
         constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
             int cc[U][R];
-            double vv[U][R], xv[U][R];
+            T vv[U][R], xv[U][R];
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool in = (j0 + t) < w;  // wave-uniform
                     cc[t][r] = in ? cp[(size_t)(j0 + t) * 64 + rl[r]] : -1;
-                    vv[t][r] = in ? vp[(size_t)(j0 + t) * 64 + rl[r]] : 0.0;
+                    vv[t][r] = in ? vp[(size_t)(j0 + t) * 64 + rl[r]] : (T)0;
                 }
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool use = (cc[t][r] >= 0) && !(MODE == SELL_GS && cc[t][r] == row0 + rl[r]);
-                    xv[t][r] = use ? x[(size_t)cc[t][r] * ld + c] : 0.0;
+                    xv[t][r] = use ? x[(size_t)cc[t][r] * ld + c] : (T)0;
                 }
 #pragma unroll
             for (int t = 0; t < U; t++)
@@ -224,15 +238,15 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
         for (int r = 0; r < R; r++) {
             if (rl[r] < nrow && !stop) {
                 const size_t o = (size_t)(row0 + rl[r]) * ld + c;
-                if (MODE == SELL_AX) { y[o] = acc[r]; if (zero_rows) zero_rows[o] = 0.0; }
+                if (MODE == SELL_AX) { y[o] = acc[r]; if (zero_rows) zero_rows[o] = (T)0; }
                 else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
                 else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
                 else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
-                else { const double t = bv[r] - acc[r]; ss += t * t; }
+                else { const double t = (double)(bv[r] - acc[r]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o] = bv[r] - acc[r]; }
             }
         }
     }
-    if (MODE == SELL_RESID_SS) {
+    if (MODE == SELL_RESID_SS || MODE == SELL_RESID_BOTH) {
         __shared__ double red[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
@@ -242,13 +256,13 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
     }
 }
 
-template <int MODE, int KW>
-static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const double* x, const double* b, double* y,
-                            int k, const int* done, double* partials, double* zero_rows, hipStream_t st, int* nb_out)
+template <int MODE, int KW, typename T>
+static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const T* x, const T* b, T* y,
+                            int k, const int* done, double* partials, T* zero_rows, hipStream_t st, int* nb_out)
 {
     const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
     const int nb = (waves + 3) / 4;
-    hipLaunchKernelGGL((k_sell_wide<MODE, KW>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, x, b, y, k, done, partials, zero_rows);
+    hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, x, b, y, k, done, partials, zero_rows);
     *nb_out = nb;
 }
 
@@ -268,13 +282,16 @@ static int sell_wpb()
 }
 int sell_blocks(int n_slices) { const int w = sell_wpb(); return (n_slices + w - 1) / w; }
 
-template <int MODE, int RPL>
-static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, const double* x, const double* b, double* y,
-                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, double* zero_rows)
+template <int MODE, int RPL, typename T>
+static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
+                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows)
 {
+    int s_end = s_end_in;
     const int ns = s_end - s_begin;
     const int nb = sell_blocks(ns);
     const int* done = ctrl ? &ctrl->done : nullptr;
+    static const int dbg_empty = getenv("SMG_DEBUG_EMPTY") ? atoi(getenv("SMG_DEBUG_EMPTY")) : 0;  // launch-overhead probe
+    if (dbg_empty == 1) s_end = s_begin;
     // the region-major launch order only makes sense for whole-matrix launches
     const int use_order = (A.order && s_begin == 0 && s_end == A.n_slices) ? 1 : 0;
     if (n_blocks) *n_blocks = 0;
@@ -285,17 +302,17 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
         while (k - c0 >= 8) {
             int kw = 64;
             while (kw > k - c0) kw >>= 1;
-            const double* xx = x ? x + c0 : nullptr;
-            const double* bb = b ? b + c0 : nullptr;
-            double* yy = y ? y + c0 : nullptr;
+            const T* xx = x ? x + c0 : nullptr;
+            const T* bb = b ? b + c0 : nullptr;
+            T* yy = y ? y + c0 : nullptr;
             double* pp = partials ? partials + poff : nullptr;
-            double* zz = zero_rows ? zero_rows + c0 : nullptr;
+            T* zz = zero_rows ? zero_rows + c0 : nullptr;
             int wnb = 0;
             switch (kw) {
-                case 64: launch_wide_one<MODE, 64>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
-                case 32: launch_wide_one<MODE, 32>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
-                case 16: launch_wide_one<MODE, 16>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
-                default: launch_wide_one<MODE, 8>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                case 64: launch_wide_one<MODE, 64, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                case 32: launch_wide_one<MODE, 32, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                case 16: launch_wide_one<MODE, 16, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
+                default: launch_wide_one<MODE, 8, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
             }
             poff += (size_t)wnb;
             c0 += kw;
@@ -303,34 +320,39 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end, con
     }
     for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
-        const double* xx = x ? x + c0 : nullptr;
-        const double* bb = b ? b + c0 : nullptr;
-        double* yy = y ? y + c0 : nullptr;
+        const T* xx = x ? x + c0 : nullptr;
+        const T* bb = b ? b + c0 : nullptr;
+        T* yy = y ? y + c0 : nullptr;
         double* pp = partials ? partials + poff : nullptr;
-        double* zz = zero_rows ? zero_rows + c0 : nullptr;
+        T* zz = zero_rows ? zero_rows + c0 : nullptr;
         poff += (size_t)nb;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = (int)poff;
     return hipGetLastError();
 }
 
-template <int RPL>
-static hipError_t launch_sell_rpl(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
-                                  double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                                  double* zero_rows)
+template <int RPL, typename T>
+static hipError_t launch_sell_rpl(SellMode mode, const SellDev& A, int s_begin, int s_end, const T* x, const T* b,
+                                  T* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
+                                  T* zero_rows)
 {
     switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_RESID_SS: return launch_sell_mode<SELL_RESID_SS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_GS: return launch_sell_mode<SELL_GS, RPL>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_AX: return launch_sell_mode<SELL_AX, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID_SS:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            else return hipErrorInvalidValue;
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_GS: return launch_sell_mode<SELL_GS, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID_BOTH:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -339,8 +361,17 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                        double* zero_rows)
 {
-    if (A.C == 128) return launch_sell_rpl<2>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-    return launch_sell_rpl<1>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+    if (A.C == 128) return launch_sell_rpl<2, double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+    return launch_sell_rpl<1, double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+}
+
+// fp32 twin for the mixed-precision V-cycle (A.valf must be set; the norm modes are fp64-only)
+hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
+                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows)
+{
+    if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
+    if (A.C == 128) return launch_sell_rpl<2, float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
+    return launch_sell_rpl<1, float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control
@@ -412,22 +443,27 @@ hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st)
 
 // One wavefront per output row; 16 B per lane per load (1 KiB per wave-instruction); deterministic
 // shuffle-tree reduction.  n and lda are multiples of 64, b has lda rows (zero padded).
-template <int KB>
-__global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict__ Ainv, int n, int lda,
-                                                        const double* __restrict__ b, double* u, int ld, const int* done)
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <int KB, typename T>
+__global__ __launch_bounds__(256) void k_dense_gemv_add(const T* __restrict__ Ainv, int n, int lda,
+                                                        const T* __restrict__ b, T* u, int ld, const int* done)
 {
     const int stop = done ? *done : 0;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
-    const double2* a2 = reinterpret_cast<const double2*>(Ainv + (size_t)row * lda);
-    double acc[KB];
+    using T2 = typename Vec2<T>::type;
+    const T2* a2 = reinterpret_cast<const T2*>(Ainv + (size_t)row * lda);
+    T acc[KB];
 #pragma unroll
-    for (int q = 0; q < KB; q++) acc[q] = 0.0;
+    for (int q = 0; q < KB; q++) acc[q] = (T)0;
     const int n2 = lda >> 1;
 #pragma unroll 4
     for (int jj = lane; jj < n2; jj += 64) {
-        const double2 a = a2[jj];
+        const T2 a = a2[jj];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
             acc[q] += a.x * b[(size_t)(2 * jj) * ld + q];
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict
     }
 #pragma unroll
     for (int q = 0; q < KB; q++) {
-        double s = acc[q];
+        T s = acc[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if (lane == 0 && !stop) u[(size_t)row * ld + q] = u[(size_t)row * ld + q] + s;
@@ -446,26 +482,26 @@ __global__ __launch_bounds__(256) void k_dense_gemv_add(const double* __restrict
 // k >= 16 columns: LDS-tiled GEMM  u[16-row tile, KC cols] += Ainv[tile, :] * b[:, KC cols].  256 threads = 16 rows x 16
 // column groups of KC/16 columns; j is walked in tiles of 32 through LDS.  Per (row, column) the sum is sequential in j.
 // (fp64 FMA-free multiply-add on the vector ALU; an f64 MFMA would fuse and change rounding.)
-template <int KC>
-__global__ __launch_bounds__(256) void k_dense_gemm_tile(const double* __restrict__ Ainv, int n, int lda,
-                                                         const double* __restrict__ b, double* u, int ld, const int* done)
+template <int KC, typename T>
+__global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ Ainv, int n, int lda,
+                                                         const T* __restrict__ b, T* u, int ld, const int* done)
 {
     constexpr int TR = 16, TJ = 64, CT = KC / 16;
     constexpr int NA = TR * TJ / 256, NB = TJ * KC / 256;  // staged elements per thread
-    __shared__ double a_s[TR][TJ + 1];
-    __shared__ double b_s[TJ][KC];
+    __shared__ T a_s[TR][TJ + 1];
+    __shared__ T b_s[TJ][KC];
     const int stop = done ? *done : 0;
     const int t = threadIdx.x, tr = t / 16, tc = t % 16;
     const int i0 = blockIdx.x * TR;
-    double acc[CT];
+    T acc[CT];
 #pragma unroll
-    for (int q = 0; q < CT; q++) acc[q] = 0.0;
-    double ra[NA], rb[NB];  // next tile, prefetched into registers while the current one is consumed from LDS
+    for (int q = 0; q < CT; q++) acc[q] = (T)0;
+    T ra[NA], rb[NB];  // next tile, prefetched into registers while the current one is consumed from LDS
     auto fetch = [&](int j0) {
 #pragma unroll
         for (int e = 0; e < NA; e++) {
             const int idx = t + 256 * e, r = idx / TJ, jj = idx % TJ, row = i0 + r;
-            ra[e] = row < n ? Ainv[(size_t)row * lda + j0 + jj] : 0.0;
+            ra[e] = row < n ? Ainv[(size_t)row * lda + j0 + jj] : (T)0;
         }
 #pragma unroll
         for (int e = 0; e < NB; e++) {
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const double* __restric
         if (j0 + TJ < lda) fetch(j0 + TJ);
 #pragma unroll 8
         for (int jj = 0; jj < TJ; jj++) {
-            const double a = a_s[tr][jj];
+            const T a = a_s[tr][jj];
 #pragma unroll
             for (int q = 0; q < CT; q++) acc[q] += a * b_s[jj][tc * CT + q];
         }
@@ -495,8 +531,8 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const double* __restric
         for (int q = 0; q < CT; q++) u[(size_t)row * ld + tc * CT + q] = u[(size_t)row * ld + tc * CT + q] + acc[q];
 }
 
-hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
-                                 const Ctrl* ctrl, hipStream_t st)
+template <typename T>
+static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, const Ctrl* ctrl, hipStream_t st)
 {
     const int* done = ctrl ? &ctrl->done : nullptr;
     const int nb = (n + 3) / 4;
@@ -507,21 +543,70 @@ hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const doubl
         while (kc > k - c0) kc >>= 1;
         const int tb = (n + 15) / 16;
         switch (kc) {
-            case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            default: hipLaunchKernelGGL((k_dense_gemm_tile<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemm_tile<16, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
         }
         c0 += kc;
     }
     for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_dense_gemv_add<1>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 2: hipLaunchKernelGGL((k_dense_gemv_add<2>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 3: hipLaunchKernelGGL((k_dense_gemv_add<3>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            default: hipLaunchKernelGGL((k_dense_gemv_add<4>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 1: hipLaunchKernelGGL((k_dense_gemv_add<1, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 2: hipLaunchKernelGGL((k_dense_gemv_add<2, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 3: hipLaunchKernelGGL((k_dense_gemv_add<3, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemv_add<4, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
         }
     }
+    return hipGetLastError();
+}
+hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
+                                 const Ctrl* ctrl, hipStream_t st)
+{
+    return launch_dense_T<double>(Ainv, n, lda, b, u, k, ctrl, st);
+}
+hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
+                                     const Ctrl* ctrl, hipStream_t st)
+{
+    return launch_dense_T<float>(Ainv, n, lda, b, u, k, ctrl, st);
+}
+
+// ---- mixed precision glue: fp64 outer iterate / residual  <->  fp32 V-cycle ----------------------------------------
+__global__ void k_cvt_f64_f32(float* dst, const double* src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+// b32 = (float) r64 ; u32 = 0        (right-hand side and zero initial guess of the correction equation)
+__global__ void k_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const int* done)
+{
+    if (done && *done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { b32[i] = (float)r64[i]; u32[i] = 0.0f; }
+}
+// z64 += (double) e32
+__global__ void k_add_correction(double* z, const float* e, size_t n, const int* done)
+{
+    if (done && *done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = z[i] + (double)e[i];
+}
+hipError_t launch_cvt_f64_f32(float* dst, const double* src, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cvt_f64_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError();
+}
+hipError_t launch_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const Ctrl* ctrl, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_residual_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b32, u32, r64, n, ctrl ? &ctrl->done : nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl* ctrl, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_correction, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, e, n, ctrl ? &ctrl->done : nullptr);
     return hipGetLastError();
 }
 

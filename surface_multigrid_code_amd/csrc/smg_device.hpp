@@ -33,6 +33,7 @@ struct SellDev {
     const int* order = nullptr;      // optional launch order of the slices (region-major), whole-matrix kernels only
     const int* col = nullptr;
     const double* val = nullptr;
+    const float* valf = nullptr;     // fp32 copy of val (same slots), only for the mixed-precision V-cycle
 };
 
 enum SellMode {
@@ -41,6 +42,7 @@ enum SellMode {
     SELL_RESID_SS = 2,  // partial sums of |b - A x|^2   (min_quad_with_fixed_mg.cpp:110 / :332)
     SELL_ADD = 3,       // y = y + A x                   (mg_VCycle.cpp:51-53  u = u + P uc)
     SELL_GS = 4,        // y_i = (b_i - sum_{j != i} A_ij y_j) / A_ii on the given slice range (one colour)
+    SELL_RESID_BOTH = 5,  // y = b - A x AND the partial sums of its squares (outer loop of the mixed-precision mode)
 };
 
 // y/x/b: internal layout, ld = number of columns k.  Slices [s_begin, s_end).  `ctrl` may be null (no
@@ -51,6 +53,8 @@ enum SellMode {
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                        double* zero_rows = nullptr);
+hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
+                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows = nullptr);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 
@@ -64,6 +68,12 @@ hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, 
 // u[i,:] += sum_j Ainv[i,j] * b[j,:]   (mg_VCycle.cpp:199-200 with the factorisation pre-inverted)
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
                                  const Ctrl* ctrl, hipStream_t st);
+hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
+                                     const Ctrl* ctrl, hipStream_t st);
+// mixed precision glue
+hipError_t launch_cvt_f64_f32(float* dst, const double* src, size_t n, hipStream_t st);
+hipError_t launch_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const Ctrl* ctrl, hipStream_t st);
+hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl* ctrl, hipStream_t st);
 // In-place inversion of an SPD matrix (n x n, row-major, leading dimension lda, n % 64 == 0, lda == n) by
 // blocked Gauss-Jordan elimination without pivoting.  work: 2*n*32 + 32*32 doubles.
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);

@@ -75,6 +75,10 @@ struct Level {
     DevBuf<int> r1_ptr, r1_idx, r2_ptr, r2_idx;
     DevBuf<double> r1_coef, r2_coef;
     int nnzT = 0;
+    // ---- fp32 images for the mixed-precision V-cycle (values only; slots, columns, slice tables are shared) ----
+    DevBuf<float> a32, at32, p32, pt32;
+    SellDev dA32, dAT32, dP32, dPT32;
+    DevBuf<float> b32, u32, r32;
     // ---- work vectors, internal layout n x kcap ----
     DevBuf<double> b, u, r;
     int n = 0;
@@ -112,6 +116,9 @@ struct smg_hierarchy {
     // ---- coarse solver: stands in for Eigen::SimplicialLDLT (factorisation pre-inverted on the device) ----
     int nc = 0, nc_pad = 0;
     smg::DevBuf<double> d_Ainv;
+    smg::DevBuf<float> d_Ainv32;
+    bool f32_valid = false;
+    int kcap32 = 0;
     // ---- execution ----
     int device = -1;
     hipStream_t stream = nullptr;
@@ -123,14 +130,14 @@ struct smg_hierarchy {
     bool in_solve = false;
     int k = 0;
     double tol = 1e-3;
-    int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1;
+    int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1, precision = 0;
     int iters_enqueued = 0;
     smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
     const double* cur_kv = nullptr;  // device pointer to known_val (column-major) of the running solve
     int cur_ld_kv = 0;
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
-    int g_k = 0, g_pre = 0, g_post = 0;
+    int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
     // ---- profc mirror ----
     bool prof_on = false;
     std::vector<smg::ProfScope> scopes;

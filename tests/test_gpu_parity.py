@@ -412,3 +412,25 @@ def test_value_only_reprecompute_on_device_is_bit_exact(smg, oracle_mod, kind):
     pm = subdiv_problem(kind="mcf", k=2, n_sub=2)
     mg.precompute(pm["A"], None)
     assert mg.solve(pm["RHS"], pm["z0"], None, o)[0]
+
+
+@pytest.mark.parametrize("kind,k,tol", [("mcf", 3, 1e-10), ("poisson", 1, 1e-10), ("mcf", 16, 5e-7)])
+def test_mixed_precision_reaches_fp64_accuracy(smg, oracle_mod, kind, k, tol):
+    """BASELINE config 5 (fp32 vs fp64): fp32 V-cycle inside an fp64 outer loop.  r_his is measured in fp64, so the same
+    tolerance is reached; the solution agrees with the all-fp64 run (and the oracle) at solver precision."""
+    p, mg, orc = build(smg, oracle_mod, kind=kind, k=k, n_sub=2)
+    c64, z64, r64 = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=tol, max_iter=40))
+    cmx, zmx, rmx = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=tol, max_iter=40, precision="mixed"))
+    assert c64 and cmx and rmx[-1] < tol
+    assert rmx[0] == r64[0]                                   # same fp64 residual of the initial guess
+    assert abs(len(rmx) - len(r64)) <= 2 and (np.diff(rmx) < 0).all()
+    assert np.linalg.norm(zmx - z64) <= (1e-8 if tol <= 1e-9 else 1e-4) * np.linalg.norm(z64)
+    if p["known"] is not None:
+        assert np.array_equal(zmx[p["known"]], p["known_val"])
+    # the first cycle's contraction is the fp64 one to fp32 rounding
+    assert abs(rmx[1] / rmx[0] - r64[1] / r64[0]) < 1e-4
+    # mixed and fp64 solves can alternate on one handle; results are reproducible
+    again = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=tol, max_iter=40, precision="mixed"))
+    assert np.array_equal(again[1], zmx) and np.array_equal(again[2], rmx)
+    back = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=tol, max_iter=40))
+    assert np.array_equal(back[1], z64)
