@@ -344,9 +344,8 @@ static int env_int(const char* name, int dflt)
 static int precompute_device(smg_hierarchy* h)
 {
     const int L = h->n_levels;
-    // tuning knobs (A/B experiments): slice height of the system matrices and region-major launch order
-    const int sellC = env_int("SMG_SELL_C", 64) == 128 ? 128 : 64;
-    const bool region = env_int("SMG_REGION_ORDER", 1) != 0;
+    const int sellC = SELL_C;
+    const bool region = env_int("SMG_REGION_ORDER", 1) != 0;   // A/B knob: region-major launch order
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
     for (int lv = 0; lv < L; lv++) {
@@ -441,7 +440,7 @@ static uint64_t precompute_key(const smg_hierarchy* h, int n, const int* rowptr,
 static int build_recipes(smg_hierarchy* h)
 {
     const int L = h->n_levels;
-    const int sellC = env_int("SMG_SELL_C", 64) == 128 ? 128 : 64;
+    const int sellC = SELL_C;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);  // the GS launches move to the A^T images on every level
     for (int lv = 0; lv < L; lv++) {

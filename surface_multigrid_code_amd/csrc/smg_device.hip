@@ -33,22 +33,6 @@ template <int RPL, typename T> struct PanelLoad;
 template <typename T> struct PanelLoad<1, T> {
     static __device__ __forceinline__ void ld(const int* cp, const T* vp, int* c, T* v) { c[0] = *cp; v[0] = *vp; }
 };
-template <> struct PanelLoad<2, double> {  // 8 B + 16 B per lane: 512 B + 1 KiB per wave-instruction
-    static __device__ __forceinline__ void ld(const int* cp, const double* vp, int* c, double* v)
-    {
-        const int2 cc = *reinterpret_cast<const int2*>(cp);
-        const double2 vv = *reinterpret_cast<const double2*>(vp);
-        c[0] = cc.x; c[1] = cc.y; v[0] = vv.x; v[1] = vv.y;
-    }
-};
-template <> struct PanelLoad<2, float> {
-    static __device__ __forceinline__ void ld(const int* cp, const float* vp, int* c, float* v)
-    {
-        const int2 cc = *reinterpret_cast<const int2*>(cp);
-        const float2 vv = *reinterpret_cast<const float2*>(vp);
-        c[0] = cc.x; c[1] = cc.y; v[0] = vv.x; v[1] = vv.y;
-    }
-};
 template <typename T> __device__ __forceinline__ const T* sell_vals(const SellDev& A);
 template <> __device__ __forceinline__ const double* sell_vals<double>(const SellDev& A) { return A.val; }
 template <> __device__ __forceinline__ const float* sell_vals<float>(const SellDev& A) { return A.valf; }
@@ -57,7 +41,7 @@ template <> __device__ __forceinline__ const float* sell_vals<float>(const SellD
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
 template <int MODE, int KB, int RPL, typename T>
-__global__ __launch_bounds__(512) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const T* x,
+__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const T* x,
                                               const T* b, T* y, int ld, const int* done, double* partials,
                                               T* zero_rows)
 {
@@ -274,13 +258,9 @@ int sell_wide_blocks(int n_slices, int k)
     return tot;
 }
 
-static int g_wpb = 0;
-static int sell_wpb()
-{
-    if (!g_wpb) { const char* e = getenv("SMG_WPB"); int v = e ? atoi(e) : 4; g_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }
-    return g_wpb;
-}
-int sell_blocks(int n_slices) { const int w = sell_wpb(); return (n_slices + w - 1) / w; }
+// 4 slices (waves) per 256-thread block; 1, 2 and 8 measured the same within noise on C3
+static constexpr int sell_wpb() { return 4; }
+int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb(); }
 
 template <int MODE, int RPL, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
@@ -361,7 +341,6 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                        double* zero_rows)
 {
-    if (A.C == 128) return launch_sell_rpl<2, double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
     return launch_sell_rpl<1, double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
 }
 
@@ -370,7 +349,6 @@ hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_e
                            float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows)
 {
     if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
-    if (A.C == 128) return launch_sell_rpl<2, float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
     return launch_sell_rpl<1, float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
 }
 

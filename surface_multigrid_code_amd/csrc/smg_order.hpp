@@ -29,7 +29,7 @@ Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* pr
 bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, const Csr& A, std::vector<int>& out);
 Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)
 
-constexpr int SELL_C = 64;  // default slice height = one wavefront (one row per lane); 128 = two rows per lane
+constexpr int SELL_C = 64;  // slice height = one wavefront, one row per lane (two rows per lane / C = 128 measured slower)
 
 // SELL-C-sigma, C = 64: slice s covers rows [slice_row[s], slice_row[s+1]) (<= 64 of them; a slice never
 // straddles a colour boundary); its entries are stored column-major in a 64-wide panel starting at element
