@@ -182,6 +182,16 @@ extern "C" int smg_hierarchy_set_stream(smg_hierarchy* h, void* hip_stream)
     return SMG_OK;
 }
 
+// CSR/CSC array sanity: monotone pointers, indices in range.  Returns an error string or nullptr.
+static const char* check_compressed(int n_major, int n_minor, const int* ptr, const int* idx)
+{
+    if (ptr[0] != 0) return "pointer array must start at 0";
+    for (int i = 0; i < n_major; i++) if (ptr[i + 1] < ptr[i]) return "pointer array is not monotone";
+    const long nnz = ptr[n_major];
+    for (long p = 0; p < nnz; p++) if (idx[p] < 0 || idx[p] >= n_minor) return "index out of range";
+    return nullptr;
+}
+
 static int set_prolong(smg_hierarchy* h, int lv, Csr&& P)
 {
     Level& L = h->lv[lv];
@@ -198,6 +208,7 @@ extern "C" int smg_level_set_prolong(smg_hierarchy* h, int lv, int n_fine, int n
 {
     if (!h || lv < 1 || lv >= h->n_levels || !rowptr || n_fine < 0 || n_coarse < 0)
         return fail(SMG_ERR_INVALID, "smg_level_set_prolong: bad arguments (lv=%d)", lv);
+    if (const char* e = check_compressed(n_fine, n_coarse, rowptr, col)) return fail(SMG_ERR_INVALID, "smg_level_set_prolong: %s", e);
     return set_prolong(h, lv, csr_from_arrays(n_fine, n_coarse, rowptr, col, val));
 }
 
@@ -206,6 +217,7 @@ extern "C" int smg_level_set_prolong_csc(smg_hierarchy* h, int lv, int n_fine, i
 {
     if (!h || lv < 1 || lv >= h->n_levels || !colptr || n_fine < 0 || n_coarse < 0)
         return fail(SMG_ERR_INVALID, "smg_level_set_prolong_csc: bad arguments (lv=%d)", lv);
+    if (const char* e = check_compressed(n_coarse, n_fine, colptr, rowidx)) return fail(SMG_ERR_INVALID, "smg_level_set_prolong_csc: %s", e);
     return set_prolong(h, lv, csr_from_csc_arrays(n_fine, n_coarse, colptr, rowidx, val));
 }
 
@@ -257,6 +269,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         std::vector<char> isk(n, 0);
         for (int i = 0; i < n_known; i++) {
             if (known[i] < 0 || known[i] >= n) return fail(SMG_ERR_INVALID, "known[%d] = %d out of range", i, known[i]);
+            if (isk[known[i]]) return fail(SMG_ERR_INVALID, "known[%d] = %d appears twice", i, known[i]);
             isk[known[i]] = 1;
         }
         h->known.assign(known, known + n_known);
@@ -283,6 +296,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
     for (int lv = 1; lv < L; lv++) {
         Level& Lv = h->lv[lv];
+        if (Lv.P.nc == 0) return fail(SMG_ERR_INVALID, "level %d has no unknowns left after constraint elimination", lv);
         if (Lv.P.nr != h->lv[lv - 1].A.nr)
             return fail(SMG_ERR_INVALID, "P_%d has %d rows but level %d has %d unknowns", lv, Lv.P.nr, lv - 1, h->lv[lv - 1].A.nr);
         Csr tmp = spgemm(Lv.PT, h->lv[lv - 1].A);
@@ -614,6 +628,9 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
     if (!h || n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_precompute: bad arguments");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute called between smg_solve_begin and smg_solve_end");
     if (known == nullptr) n_known = 0;
+    if (n_known < 0 || n_known >= n) return fail(SMG_ERR_INVALID, "smg_precompute: n_known = %d must be in [0, n)", n_known);
+    if (const char* e = check_compressed(n, n, rowptr, col)) return fail(SMG_ERR_INVALID, "smg_precompute: %s", e);
+    if (h->n_levels < 2) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, src/mg_precompute.cpp:39)");
     const uint64_t key = precompute_key(h, n, rowptr, col, known, n_known);
     if (h->precomputed && h->device >= 0 && key == h->pre_key && h->input_canonical && env_int("SMG_NO_FAST_PRECOMPUTE", 0) == 0) {
         // same sparsity, same constraints, same prolongations: only the values changed

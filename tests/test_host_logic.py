@@ -166,3 +166,46 @@ def test_hierarchy_save_load_roundtrip_and_block_variant(smg_mod, tmp_path):
     for l in range(1, mg.n_levels):
         P, Pb = mg.matrix(l, "P_full"), mb.matrix(l, "P_full")
         assert abs(Pb - sp.kron(P, sp.eye(3), format="csr")).max() == 0
+
+
+def test_malformed_inputs_are_rejected(smg_mod):
+    """Edge cases: out-of-range / duplicate indices, broken pointer arrays, inconsistent sizes, degenerate hierarchies."""
+    import ctypes as C
+    smg = smg_mod
+    L = smg._lib.load()
+    p = subdiv_problem(kind="mcf", k=1, n_sub=1)
+    P = p["Ps"][0].tocsr()
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    h = L.smg_hierarchy_create(2)
+    ptr, col, val = P.indptr.astype(np.int32), P.indices.astype(np.int32), P.data.copy()
+    bad = col.copy(); bad[3] = P.shape[1] + 7
+    assert L.smg_level_set_prolong(h, 1, P.shape[0], P.shape[1], ip(ptr), ip(bad), dp(val)) == -1
+    badptr = ptr.copy(); badptr[5] = badptr[4] - 1
+    assert L.smg_level_set_prolong(h, 1, P.shape[0], P.shape[1], ip(badptr), ip(col), dp(val)) == -1
+    assert L.smg_level_set_prolong(h, 2, P.shape[0], P.shape[1], ip(ptr), ip(col), dp(val)) == -1       # no such level
+    assert L.smg_level_set_prolong(h, 1, P.shape[0], P.shape[1], ip(ptr), ip(col), dp(val)) == 0
+    A = p["A"].tocsr()
+    ap, ac, av = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    badc = ac.copy(); badc[0] = -1
+    assert L.smg_precompute(h, A.shape[0], ip(ap), ip(badc), dp(av), None, 0) == -1
+    kn = np.array([1, 5, 5], dtype=np.int32)
+    assert L.smg_precompute(h, A.shape[0], ip(ap), ip(ac), dp(av), ip(kn), 3) == -1 and b"twice" in L.smg_last_error()
+    kn = np.array([A.shape[0]], dtype=np.int32)
+    assert L.smg_precompute(h, A.shape[0], ip(ap), ip(ac), dp(av), ip(kn), 1) == -1
+    assert L.smg_precompute(h, 100, ip(ap), ip(ac), dp(av), None, 0) == -1                              # size mismatch with P_1
+    L.smg_hierarchy_destroy(h)
+    h1 = L.smg_hierarchy_create(1)
+    assert L.smg_precompute(h1, A.shape[0], ip(ap), ip(ac), dp(av), None, 0) == -1                     # single level unsupported
+    L.smg_hierarchy_destroy(h1)
+    assert not L.smg_hierarchy_create(0)
+    # unsorted rows with duplicate entries are accepted and merged (Eigen setFromTriplets semantics)
+    mgA = smg.Hierarchy.from_prolongs(p["Ps"])
+    coo = A.tocoo()
+    rows = np.concatenate([coo.row, coo.row[:10]]); cols = np.concatenate([coo.col, coo.col[:10]])
+    vals = np.concatenate([coo.data * 1.0, coo.data[:10] * 0.0])
+    order = np.lexsort((-cols, rows))                                       # descending columns inside a row
+    ptr2 = np.zeros(A.shape[0] + 1, np.int32); np.add.at(ptr2, rows + 1, 1); ptr2 = np.cumsum(ptr2).astype(np.int32)
+    rc = L.smg_precompute(mgA.h, A.shape[0], ip(ptr2), ip(cols[order].astype(np.int32)), dp(vals[order].copy()), None, 0)
+    assert rc in (0, -2)                                                    # -2: host half done, no GPU here
+    assert abs(mgA.matrix(0, "A") - A).max() == 0
