@@ -36,3 +36,33 @@ def test_cpp_example_matches_python_path(smg_mod, oracle_mod):
     assert conv and len(rh) == len(res) == int(m.group(2))
     np.testing.assert_allclose(res, rh, rtol=1e-5)          # printed with %g
     assert abs(float(m.group(3)) - float((z * z).sum())) <= 1e-9 * float((z * z).sum())
+
+
+def test_cpp_mean_curvature_flow_example(smg_mod, oracle_mod):
+    """examples/05_mean_curvature_flow.cpp: no-constraint overloads with a 3-column RHS, re-precompute every step
+    (value-only path after the first), mg_VCycle mirror -- against the host/oracle pipeline."""
+    from oracle import mesh_np as M
+    smg, mesh = smg_mod, smg_mod.mesh
+    exe = os.path.join(ROOT, "examples", "05_mean_curvature_flow")
+    src = os.path.join(ROOT, "examples", "05_mean_curvature_flow.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
+                               "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "ogre_sim.smgm"), "3"], env=env, text=True)
+    got = [float(x) for x in re.findall(r"step \d+: converged 1 in \d+ iterations, \|U\|\^2 = ([0-9.eE+-]+)", out)]
+    assert len(got) == 3 and "mg_VCycle: |u|^2" in out
+    V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 100, 1)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    L = M.cotmatrix(V, F)
+    U = V.copy()
+    for s in range(3):
+        Mb = M.massmatrix(U, F, "barycentric")
+        orc = oracle_mod.OracleMG(Ps)
+        orc.precompute((Mb - 0.01 * L).tocsr())
+        conv, z, rh = orc.solve(Mb @ U, U, tol=5e-7, max_iter=20)
+        assert conv
+        U = M.normalize_unit_area(z, F)
+        assert abs(got[s] - float((U * U).sum())) <= 1e-5 * float((U * U).sum())
