@@ -161,6 +161,13 @@ int smg_solve_begin(smg_hierarchy *h, const double *RHS, int ld_rhs, const doubl
                     const double *z0, int ld_z0, int k, int memspace, const smg_solve_opts *opts);
 int smg_solve_iter_residual(smg_hierarchy *h, double *d_sumsq);
 int smg_solve_iter_cycle(smg_hierarchy *h, const double *d_sumsq);
+/* Latency-hiding form of `cycle`: the V-cycle of iteration i does not wait for the all-reduce of residual i.
+ *   cycle_speculative:  saves the iterate, runs the V-cycle in place (independent of the pending reduction);
+ *   commit(d_sumsq):    r = sqrt(*d_sumsq) -> r_his, break test; if THIS test ends the loop the saved iterate is restored.
+ * Results (z, r_his, converged) are bit-identical to residual / cycle.  Usage per iteration:
+ *   residual(d) ; work = all_reduce(d, async) ; cycle_speculative() ; work.wait() ; commit(d)                        */
+int smg_solve_iter_cycle_speculative(smg_hierarchy *h);
+int smg_solve_iter_commit(smg_hierarchy *h, const double *d_sumsq);
 int smg_solve_poll(smg_hierarchy *h, int *done, int *n_his);      /* synchronising read of the control block */
 int smg_solve_end(smg_hierarchy *h, double *z, int ld_z, int memspace, double *r_his, int *n_his, int *converged);
 

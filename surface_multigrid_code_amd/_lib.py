@@ -54,6 +54,8 @@ def load():
         "smg_solve_begin": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC)]),
         "smg_solve_iter_residual": (i, [vp, vp]),
         "smg_solve_iter_cycle": (i, [vp, vp]),
+        "smg_solve_iter_cycle_speculative": (i, [vp]),
+        "smg_solve_iter_commit": (i, [vp, vp]),
         "smg_solve_poll": (i, [vp, ip, ip]),
         "smg_solve_end": (i, [vp, vp, i, i, dp, ip, ip]),
         "smg_level_rows": (i, [vp, i]),

@@ -266,6 +266,12 @@ class Hierarchy:
     def iter_cycle(self, d_sumsq_ptr):
         _chk(self.L.smg_solve_iter_cycle(self.h, d_sumsq_ptr), "smg_solve_iter_cycle")
 
+    def iter_cycle_speculative(self):
+        _chk(self.L.smg_solve_iter_cycle_speculative(self.h), "smg_solve_iter_cycle_speculative")
+
+    def iter_commit(self, d_sumsq_ptr):
+        _chk(self.L.smg_solve_iter_commit(self.h, d_sumsq_ptr), "smg_solve_iter_commit")
+
     def outer_iterations(self, n):
         _chk(self.L.smg_raw_outer_iteration(self.h, n), "smg_raw_outer_iteration")
 

@@ -87,7 +87,8 @@ static void drop_graphs(smg_hierarchy* h)
     if (h->g_iter) (void)hipGraphExecDestroy(h->g_iter);
     if (h->g_resid) (void)hipGraphExecDestroy(h->g_resid);
     if (h->g_cycle) (void)hipGraphExecDestroy(h->g_cycle);
-    h->g_iter = h->g_resid = h->g_cycle = nullptr;
+    if (h->g_spec) (void)hipGraphExecDestroy(h->g_spec);
+    h->g_iter = h->g_resid = h->g_cycle = h->g_spec = nullptr;
     h->g_k = 0;
 }
 
@@ -1010,6 +1011,41 @@ extern "C" int smg_solve_iter_cycle(smg_hierarchy* h, const double* d_sumsq)
         if (rc) return rc;
     }
     h->iters_enqueued++;
+    return SMG_OK;
+}
+
+// save z, V-cycle in place -- nothing here reads the reduced residual
+static int enqueue_cycle_speculative(smg_hierarchy* h)
+{
+    Level& L0 = h->lv[0];
+    const size_t cnt = (size_t)L0.n * h->k;
+    HIPCHK(launch_copy_unless_done(h->d_zsave.p, L0.u.p, cnt, h->d_ctrl.p, h->stream));
+    return enqueue_cycle_part(h, h->k, nullptr);   // nullptr: no decide in front of the cycle
+}
+
+extern "C" int smg_solve_iter_cycle_speculative(smg_hierarchy* h)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle_speculative: no solve in progress");
+    HIPCHK(h->d_zsave.ensure((size_t)h->lv[0].n * h->k));
+    if (graphs_usable(h)) {
+        int rc = ensure_graphs(h);
+        if (rc) return rc;
+        if (!h->g_spec) { rc = capture_graph(h, &h->g_spec, [&]() { return enqueue_cycle_speculative(h); }); if (rc) return rc; }
+        HIPCHK(hipGraphLaunch(h->g_spec, h->stream));
+    } else {
+        int rc = enqueue_cycle_speculative(h);
+        if (rc) return rc;
+    }
+    h->iters_enqueued++;
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_iter_commit(smg_hierarchy* h, const double* d_sumsq)
+{
+    if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_commit: no solve in progress");
+    Level& L0 = h->lv[0];
+    HIPCHK(launch_decide_spec(h->d_ctrl.p, d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq, h->stream));
+    HIPCHK(launch_restore_if_just_done(L0.u.p, h->d_zsave.p, (size_t)L0.n * h->k, h->d_ctrl.p, h->stream));
     return SMG_OK;
 }
 

@@ -407,6 +407,45 @@ hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStre
     hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl);
     return hipGetLastError();
 }
+// Speculative form (multi-GPU: the V-cycle of iteration i runs while the all-reduce of residual i is in flight).
+// decide: like k_decide, and remembers in `just_done` that THIS decision ended the loop; restore then puts the saved
+// iterate back, so the result is exactly what the non-speculative loop returns.
+__global__ void k_decide_spec(Ctrl* ctrl, const double* sumsq)
+{
+    ctrl->just_done = 0;
+    if (ctrl->done) return;
+    decide_body(ctrl, *sumsq);
+    if (ctrl->done) ctrl->just_done = 1;
+}
+__global__ void k_copy_unless_done(double* dst, const double* src, size_t n, const int* done)
+{
+    if (*done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ void k_restore_if_just_done(double* dst, const double* src, size_t n, const Ctrl* ctrl)
+{
+    if (!ctrl->just_done) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+hipError_t launch_decide_spec(Ctrl* ctrl, const double* sumsq, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decide_spec, dim3(1), dim3(1), 0, st, ctrl, sumsq);
+    return hipGetLastError();
+}
+hipError_t launch_copy_unless_done(double* dst, const double* src, size_t n, const Ctrl* ctrl, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_unless_done, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, &ctrl->done);
+    return hipGetLastError();
+}
+hipError_t launch_restore_if_just_done(double* dst, const double* src, size_t n, const Ctrl* ctrl, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_restore_if_just_done, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, ctrl);
+    return hipGetLastError();
+}
 hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
 {
     hipLaunchKernelGGL(k_ss_finalize_decide, dim3(1), dim3(256), 0, st, partials, n, ctrl);

@@ -19,7 +19,7 @@ struct Ctrl {
     int done;      // 1 once residual < tol (or non-finite) was observed
     int n_his;     // entries of r_his written
     int status;    // 0 ok, -1 non-finite residual
-    int pad_;
+    int just_done; // set by the speculative decide when this very decision ended the loop
     double sumsq;  // sum of squares of the last residual (all-reduced across ranks when column-sharded)
     double tol;    // absolute tolerance of the break test (kept here so captured graphs do not bake it in)
     double r_his[SMG_MAX_HIS];
@@ -62,6 +62,10 @@ int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
 // r = sqrt(*sumsq); append to r_his; done = (r < ctrl->tol) or non-finite.  No-op when already done.
 hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st);
+// speculative split-phase iteration (the V-cycle overlaps the all-reduce): see smg.h, smg_solve_iter_cycle_speculative
+hipError_t launch_decide_spec(Ctrl* ctrl, const double* sumsq, hipStream_t st);
+hipError_t launch_copy_unless_done(double* dst, const double* src, size_t n, const Ctrl* ctrl, hipStream_t st);
+hipError_t launch_restore_if_just_done(double* dst, const double* src, size_t n, const Ctrl* ctrl, hipStream_t st);
 // both of the above in one launch (single-GPU path, no all-reduce in between)
 hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
 

@@ -133,6 +133,8 @@ struct smg_hierarchy {
     int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1, precision = 0;
     int iters_enqueued = 0;
     smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
+    smg::DevBuf<double> d_zsave;     // iterate saved by the speculative cycle
+    hipGraphExec_t g_spec = nullptr;  // save + V-cycle (no decide)
     const double* cur_kv = nullptr;  // device pointer to known_val (column-major) of the running solve
     int cur_ld_kv = 0;
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----

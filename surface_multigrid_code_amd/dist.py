@@ -41,12 +41,43 @@ class GpuEngine:
     def cycle(self, sumsq):
         self.mg.iter_cycle(sumsq.data_ptr())
 
+    # latency-hiding pair: the V-cycle is enqueued before the reduction result is needed
+    def cycle_speculative(self):
+        self.mg.iter_cycle_speculative()
+
+    def commit(self, sumsq):
+        self.mg.iter_commit(sumsq.data_ptr())
+
     def poll(self):
         return self.mg.poll()
 
     def end(self):
         conv, r_his = self.mg.solve_end(self.z.data_ptr(), self.n)
         return conv, self.z, r_his
+
+
+def sharded_solve_overlapped(engine, max_iter, all_reduce_async, check_every=1):
+    """Same loop with the all-reduce hidden behind the V-cycle: `all_reduce_async(t)` starts the reduction and returns a
+    handle whose .wait() orders the caller's stream after it (torch.distributed.all_reduce(t, async_op=True)); the
+    engine runs the cycle speculatively and `commit` restores the iterate if the reduced residual says the loop had
+    already ended.  Bit-identical to sharded_solve."""
+    engine.begin()
+    it = 0
+    while it < max_iter:
+        chunk = min(check_every, max_iter - it)
+        for _ in range(chunk):
+            t = engine.residual_sumsq()
+            work = all_reduce_async(t)
+            engine.cycle_speculative()
+            if work is not None:
+                work.wait()
+            engine.commit(t)
+        it += chunk
+        if it < max_iter:
+            done, _ = engine.poll()
+            if done:
+                break
+    return engine.end()
 
 
 def sharded_solve(engine, max_iter, all_reduce, check_every=1):
