@@ -27,6 +27,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _onto_torus(V, R=1.0, r=0.4):
+    """Closest point on the torus (axis z, radii R, r): the subdivided vertices of the C5 / torus workloads are put back
+    on the surface they sample ("mid-point subdivision re-projected onto the torus")."""
+    rho = np.sqrt(V[:, 0] ** 2 + V[:, 1] ** 2)
+    cx, cy = R * V[:, 0] / rho, R * V[:, 1] / rho
+    d = V - np.stack([cx, cy, np.zeros_like(cx)], axis=1)
+    d *= (r / np.linalg.norm(d, axis=1))[:, None]
+    return np.stack([cx, cy, np.zeros_like(cx)], axis=1) + d
+
+
 def build_workload(name, smg, mesh):
     """Returns (mg, A (scipy csr), Vf, Ff, label)."""
     t0 = time.time()
@@ -37,14 +47,14 @@ def build_workload(name, smg, mesh):
         label = "C3: bunny_15K_init x3 midpoint subdivision, 1011330 verts, 5 levels, M_bary+0.01(-L), fp64"
     elif name == "torus1m":
         V, F = mesh.torus(64, 64)
-        V = mesh.normalize_unit_area(V, F)
         mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 4, n_extra_levels=0)
+        Vf = mesh.normalize_unit_area(_onto_torus(Vf), Ff)
         label = "torus 64x64 x4 midpoint subdivision, 1048576 verts, 5 levels, M_bary+0.01(-L), fp64"
     elif name == "C5":
         V, F = mesh.torus(64, 64)
-        V = mesh.normalize_unit_area(V, F)
         mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 5, n_extra_levels=0)
-        label = "C5: torus 64x64 x5 midpoint subdivision, 4194304 verts, 6 levels, M_bary+0.01(-L), fp64"
+        Vf = mesh.normalize_unit_area(_onto_torus(Vf), Ff)
+        label = "C5: torus (R=1, r=0.4) 64x64 x5 midpoint subdivision re-projected onto the torus, 4194304 verts, 6 levels, M_bary+0.01(-L), fp64"
     elif name == "small":
         V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
         V = mesh.normalize_unit_area(V, F)

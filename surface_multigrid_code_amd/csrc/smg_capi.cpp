@@ -315,6 +315,10 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     for (int lv = 0; lv < L; lv++) {                       // A_diag (:39-41, :244-246)
         h->lv[lv].A_diag = diagonal(h->lv[lv].A);
         h->lv[lv].n = h->lv[lv].A.nr;
+        // relax() divides by A_diag (src/mg_VCycle.cpp:157): a missing or zero diagonal would give Inf/NaN there
+        if (lv < L - 1)
+            for (int i = 0; i < h->lv[lv].n; i++)
+                if (h->lv[lv].A_diag[i] == 0.0) return fail(SMG_ERR_INVALID, "level %d: zero or missing diagonal at row %d", lv, i);
     }
     // ---- device numbering (still host work): colour-major ordering of every smoothed level and the operators
     // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.

@@ -18,3 +18,12 @@ for i in range(5):
     t = time.time(); mg.precompute(A3); ts.append(time.time() - t)
 print(label)
 print("full precompute %.3f s | first value-only (recipe build) %.3f s | value-only steady %.1f ms (min %.1f)" % (t_full, t_first, 1e3 * np.median(ts), 1e3 * min(ts)))
+# values already in HBM: no H2D copy
+import torch
+dev = torch.device("cuda", 0)
+vals = torch.from_numpy(A3.data).to(dev)
+torch.cuda.synchronize()
+ts = []
+for i in range(5):
+    t = time.time(); mg.precompute_values_device(vals.data_ptr()); ts.append(time.time() - t)
+print("value-only from HBM (smg_precompute_values_device): %.1f ms (min %.1f)" % (1e3 * np.median(ts), 1e3 * min(ts)))
