@@ -88,9 +88,10 @@ int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double 
 /* ---- mg_precompute (src/mg_precompute.h:26-32, src/mg_precompute.cpp:15-87) ------------------------------------ */
 /* Builds the hierarchy from a triangle mesh: level count by the reference's float rule (:27-38), per level
  * tarF = round(#F * ratio) (:59), edge-collapse decimation + prolongation.  V: nV x 3 row-major, F: nF x 3.
- * NOTE: the decimator/prolongation here is libsmg's own host implementation (shortest-edge mid-point collapse
- * with successive closest-point re-parameterisation), NOT the reference's joint-LSCM self-parameterisation
- * (SURVEY.md section 8 row f-1); same API, same P structure (3 stored entries per row, rows sum to 1). */
+ * NOTE: libsmg's own host implementation of the reference's scheme (shortest-edge mid-point collapse with successive
+ * self-parameterisation: joint conformal flattening of the 1-ring before/after every interior collapse, closest-point
+ * projection for collapses touching the boundary); same API, same P structure (3 stored entries per row, rows sum to 1).
+ * Not a line-by-line restatement of SSP_* / joint_lscm: results differ from the reference's. */
 int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                       smg_hierarchy **out);
 /* Hierarchy of a mid-point-subdivided mesh: the n_sub finest transfer operators are the subdivision operators

@@ -3,12 +3,19 @@
 // fine vertex through the collapse history to barycentric coordinates on the coarse mesh, assemble P with
 // exactly three stored entries per row).
 //
-// THIS IS NOT the reference's successive self-parameterisation (SSP_decimate + joint_lscm + query_fine_to_coarse,
-// ~4.5 kLoC on libigl internals).  It keeps the same contract -- greedy
-// shortest-edge collapse with mid-point placement (dec_type 1) or end-point placement (dec_type 2), link-condition
-// and fold-over rejection, every fine vertex carried along as (face, barycentric) -- but re-parameterises the
-// points of a collapsed 1-ring by closest-point projection onto the post-collapse 1-ring instead of a joint
-// conformal flattening.  Rows of P are non-negative, sum to 1 and reproduce linear functions on flat patches.
+// Same contract as the reference (greedy shortest-edge collapse with mid-point placement, dec_type 1, or end-point
+// placement, dec_type 2; link-condition and fold-over rejection; every fine vertex carried along as (face, barycentric);
+// P with exactly three stored entries per row, non-negative, rows summing to 1).  The per-collapse re-parameterisation:
+//   * interior collapses: the reference's construction -- the 1-rings before and after the collapse are flattened JOINTLY
+//     by least-squares conformal maps with a shared boundary ring (src/joint_lscm.cpp), a collapse whose flattening flips,
+//     folds over or degenerates is rejected (check_valid_UV_lscm), and every point of the 1-ring is located in the
+//     flattened post patch by the largest-minimum-barycentric rule (src/query_fine_to_coarse.cpp:93-116).  Written from the
+//     formulation (energy, pins, checks), not from the reference's code; there is no reference binary to compare with,
+//     so it is validated by invariants and by the V-cycle convergence it yields;
+//   * collapses touching the boundary: closest-point projection onto the post-collapse 1-ring (the reference handles these
+//     with an "infinity vertex" and two more LSCM cases, src/joint_lscm.cpp:642-1131; not restated);
+//   * the libigl-internal edge-flap bookkeeping, the qslim / randomised variants and the coarse-to-fine queries of the
+//     remeshing demos are not restated.
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -56,6 +63,118 @@ void closest_bary(V3 p, V3 a, V3 b, V3 c, double* w)
     double den = 1.0 / (va + vb + vc);
     double v = vb * den, t = vc * den;
     w[0] = 1 - v - t; w[1] = v; w[2] = t;
+}
+
+
+// ---- joint conformal flattening of the pre- and post-collapse 1-rings (interior collapses) -------------------------------
+// The reference's successive self-parameterisation maps a point through a collapse by flattening the 1-ring before and
+// after the collapse JOINTLY (shared boundary ring, least-squares conformal energy of both patches, two pins) and locating
+// the point's UV position in the post patch (src/joint_lscm.cpp:483-555 flatten(), :557-640 interior case;
+// src/query_fine_to_coarse.cpp:85-116).  This is the same construction, written from the formulation:
+//   minimise  E = sum over {pre, post}  1/2 (u^T K u + v^T K v) - Area(u, v),   K = cotangent stiffness of the 3D patch,
+//   subject to  uv(a) = (0,0), uv(b) = (1,0);   unknowns: ring vertices (shared), a, b (pre only), m (post only).
+struct Patch {
+    int n = 0;                                // local vertices: ring..., a = n-3, b = n-2, m = n-1
+    std::vector<std::array<int, 3>> pre, post;  // local faces
+    std::vector<V3> P;                        // local positions (a, b at their pre positions, m at the merged position)
+    std::vector<double> U, Vv;                // solution
+};
+
+static void add_conformal_energy(const Patch& pt, const std::vector<std::array<int, 3>>& F, std::vector<double>& Q)
+{
+    const int n = pt.n, N = 2 * n;
+    for (const auto& f : F) {
+        for (int c = 0; c < 3; c++) {
+            const int i = f[c], j = f[(c + 1) % 3], k = f[(c + 2) % 3];   // edge (i,j), opposite corner k
+            const V3 e1 = pt.P[i] - pt.P[k], e2 = pt.P[j] - pt.P[k];
+            const double cr = norm(cross(e1, e2));
+            const double w = cr > 0 ? 0.5 * dot(e1, e2) / cr : 0.0;       // 1/2 cot(angle at k)
+            for (int d = 0; d < 2; d++) {                                   // K (+)= w (x_i - x_j)^2 for u and v
+                const int I = i + d * n, J = j + d * n;
+                Q[(size_t)I * N + I] += w; Q[(size_t)J * N + J] += w;
+                Q[(size_t)I * N + J] -= w; Q[(size_t)J * N + I] -= w;
+            }
+            // - 2 S:  Area = 1/2 sum over directed face edges (u_i v_j - u_j v_i)
+            Q[(size_t)i * N + (j + n)] -= 0.5; Q[(size_t)(j + n) * N + i] -= 0.5;
+            Q[(size_t)j * N + (i + n)] += 0.5; Q[(size_t)(i + n) * N + j] += 0.5;
+        }
+    }
+}
+
+static bool solve_joint_flattening(Patch& pt)
+{
+    const int n = pt.n, N = 2 * n;
+    std::vector<double> Q((size_t)N * N, 0.0);
+    add_conformal_energy(pt, pt.pre, Q);
+    add_conformal_energy(pt, pt.post, Q);
+    const int a = n - 3, b = n - 2;
+    // pins: u_a = 0, v_a = 0, u_b = 1, v_b = 0
+    std::vector<int> freei;
+    for (int i = 0; i < N; i++) if (i != a && i != b && i != a + n && i != b + n) freei.push_back(i);
+    const int m = (int)freei.size();
+    std::vector<double> M((size_t)m * m), rhs(m);
+    for (int r = 0; r < m; r++) {
+        for (int c = 0; c < m; c++) M[(size_t)r * m + c] = Q[(size_t)freei[r] * N + freei[c]];
+        rhs[r] = -Q[(size_t)freei[r] * N + b] * 1.0;   // only u_b = 1 is non-zero among the pins
+    }
+    // dense Cholesky (the pinned conformal energy is positive definite on a valid patch)
+    for (int j = 0; j < m; j++) {
+        double d = M[(size_t)j * m + j];
+        for (int k = 0; k < j; k++) d -= M[(size_t)j * m + k] * M[(size_t)j * m + k];
+        if (!(d > 1e-14)) return false;
+        d = std::sqrt(d);
+        M[(size_t)j * m + j] = d;
+        for (int i = j + 1; i < m; i++) {
+            double sx = M[(size_t)i * m + j];
+            for (int k = 0; k < j; k++) sx -= M[(size_t)i * m + k] * M[(size_t)j * m + k];
+            M[(size_t)i * m + j] = sx / d;
+        }
+    }
+    for (int i = 0; i < m; i++) { double sx = rhs[i]; for (int k = 0; k < i; k++) sx -= M[(size_t)i * m + k] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
+    for (int i = m - 1; i >= 0; i--) { double sx = rhs[i]; for (int k = i + 1; k < m; k++) sx -= M[(size_t)k * m + i] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
+    std::vector<double> x(N, 0.0);
+    x[b] = 1.0;
+    for (int r = 0; r < m; r++) x[freei[r]] = rhs[r];
+    pt.U.assign(x.begin(), x.begin() + n);
+    pt.Vv.assign(x.begin() + n, x.end());
+    for (double v : x) if (!(v == v)) return false;
+    // every flattened face of both patches must keep its orientation (reference check_valid_UV_lscm: signed area >= 1e-10)
+    auto oriented = [&](const std::vector<std::array<int, 3>>& F) {
+        for (const auto& f : F) {
+            const double ar = (pt.U[f[1]] - pt.U[f[0]]) * (pt.Vv[f[2]] - pt.Vv[f[0]]) - (pt.Vv[f[1]] - pt.Vv[f[0]]) * (pt.U[f[2]] - pt.U[f[0]]);
+            if (!(ar > 1e-10)) return false;
+        }
+        return true;
+    };
+    if (!(oriented(pt.pre) && oriented(pt.post))) return false;
+    // no fold-over: the flattened angles around the collapsing vertices / the merged vertex must not exceed 2 pi
+    // (reference check_valid_UV_lscm, src/joint_lscm.cpp:330-392), and no flattened sliver: quality
+    // 4 sqrt(3) area / (l0^2 + l1^2 + l2^2) >= 0.01 (:394-478)
+    const int la = n - 3, lb = n - 2, lm = n - 1;
+    auto checks = [&](const std::vector<std::array<int, 3>>& F, int v0, int v1) {
+        double ang0 = 0, ang1 = 0;
+        for (const auto& f : F) {
+            double l2[3], ar = 0;
+            for (int c = 0; c < 3; c++) {
+                const int i = f[c], j = f[(c + 1) % 3];
+                const double dx = pt.U[i] - pt.U[j], dy = pt.Vv[i] - pt.Vv[j];
+                l2[c] = dx * dx + dy * dy;
+            }
+            ar = 0.5 * ((pt.U[f[1]] - pt.U[f[0]]) * (pt.Vv[f[2]] - pt.Vv[f[0]]) - (pt.Vv[f[1]] - pt.Vv[f[0]]) * (pt.U[f[2]] - pt.U[f[0]]));
+            const double q = 4.0 * std::sqrt(3.0) * ar / (l2[0] + l2[1] + l2[2]);
+            if (!(q >= 0.01)) return false;
+            for (int c = 0; c < 3; c++) {
+                if (f[c] != v0 && f[c] != v1) continue;
+                const int i = f[c], j = f[(c + 1) % 3], k = f[(c + 2) % 3];
+                const double ax = pt.U[j] - pt.U[i], ay = pt.Vv[j] - pt.Vv[i], bx = pt.U[k] - pt.U[i], by = pt.Vv[k] - pt.Vv[i];
+                const double ang = std::atan2(ax * by - ay * bx, ax * bx + ay * by);
+                (f[c] == v0 ? ang0 : ang1) += ang;
+            }
+        }
+        const double two_pi = 6.283185307179586;
+        return ang0 - two_pi <= 1e-10 && ang1 - two_pi <= 1e-10;
+    };
+    return checks(pt.pre, la, lb) && checks(pt.post, lm, -1);
 }
 
 struct QEntry {
@@ -174,11 +293,53 @@ struct Decimator {
                 if (l1 < 0.02 * e * e) return false;
             }
         }
+        // ---- interior collapse: joint conformal flattening of the 1-ring before / after (reject the collapse if invalid)
+        const bool intrinsic = !ba && !bb;
+        Patch patch;
+        std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
+        std::unordered_map<int, int> loc;                // global vertex -> local
+        if (intrinsic) {
+            std::vector<int> ringv;
+            for (int v : na) if (v != b) ringv.push_back(v);
+            for (int v : nb) if (v != a && !std::binary_search(na.begin(), na.end(), v)) ringv.push_back(v);
+            for (int v : ringv) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
+            const int la = (int)patch.P.size(); patch.P.push_back(pos[a]);
+            const int lb = la + 1; patch.P.push_back(pos[b]);
+            const int lm = lb + 1; patch.P.push_back(m);
+            patch.n = lm + 1;
+            loc[a] = la; loc[b] = lb;
+            auto add_faces = [&](int v) {
+                for (int f : vfaces[v]) {
+                    const auto& fc = faces[f];
+                    if (v == b && has(fc, a)) continue;   // edge faces already taken from a's star
+                    pre_gid.push_back(f);
+                    patch.pre.push_back({loc[fc[0]], loc[fc[1]], loc[fc[2]]});
+                    if (!(has(fc, a) && has(fc, b))) {
+                        post_gid.push_back(f);
+                        std::array<int, 3> g = {loc[fc[0]], loc[fc[1]], loc[fc[2]]};
+                        for (int c2 = 0; c2 < 3; c2++) if (g[c2] == la || g[c2] == lb) g[c2] = lm;
+                        patch.post.push_back(g);
+                    }
+                }
+            };
+            add_faces(a); add_faces(b);
+            if (!solve_joint_flattening(patch)) return false;
+        }
         // ---- gather the fine points of the pre-collapse 1-ring with their positions
         std::vector<int> pts;
         std::vector<V3> ppos;
+        std::vector<std::array<double, 2>> puv;   // position in the joint flattening (interior collapses)
         auto take = [&](int f) {
-            for (int p : fpoints[f]) { pts.push_back(p); ppos.push_back(point_pos(p)); }
+            for (int p : fpoints[f]) {
+                pts.push_back(p); ppos.push_back(point_pos(p));
+                if (intrinsic) {
+                    const auto& fc = faces[f];
+                    const auto& w = pbary[p];
+                    const int l0 = loc[fc[0]], l1 = loc[fc[1]], l2 = loc[fc[2]];
+                    puv.push_back({w[0] * patch.U[l0] + w[1] * patch.U[l1] + w[2] * patch.U[l2],
+                                   w[0] * patch.Vv[l0] + w[1] * patch.Vv[l1] + w[2] * patch.Vv[l2]});
+                }
+            }
             fpoints[f].clear();
             fpoints[f].shrink_to_fit();
         };
@@ -198,6 +359,30 @@ struct Decimator {
         clean(a);
         for (int w : common) clean(w);
         // ---- re-home the points on the post-collapse star of a (closest-point re-parameterisation)
+        if (intrinsic) {
+            // locate every point in the flattened post patch: the face in which its smallest barycentric coordinate is
+            // largest, clamped to >= 0 and renormalised (src/query_fine_to_coarse.cpp:93-116)
+            for (size_t i = 0; i < pts.size(); i++) {
+                double bestmin = -1e300, bw[3] = {1, 0, 0};
+                int bl = -1;
+                for (size_t t = 0; t < patch.post.size(); t++) {
+                    const auto& g = patch.post[t];
+                    const double x0 = patch.U[g[0]], y0 = patch.Vv[g[0]], x1 = patch.U[g[1]], y1 = patch.Vv[g[1]], x2 = patch.U[g[2]], y2 = patch.Vv[g[2]];
+                    const double det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+                    const double w1 = ((puv[i][0] - x0) * (y2 - y0) - (x2 - x0) * (puv[i][1] - y0)) / det;
+                    const double w2 = ((x1 - x0) * (puv[i][1] - y0) - (puv[i][0] - x0) * (y1 - y0)) / det;
+                    const double w0 = 1.0 - w1 - w2, mn = std::min(w0, std::min(w1, w2));
+                    if (mn > bestmin) { bestmin = mn; bl = (int)t; bw[0] = w0; bw[1] = w1; bw[2] = w2; }
+                }
+                double sw = 0;
+                for (int c2 = 0; c2 < 3; c2++) { bw[c2] = std::max(bw[c2], 0.0); sw += bw[c2]; }
+                // patch.post[bl] lists the local vertices in the order of faces[post_gid[bl]] (with a/b -> m): same slots
+                const int p = pts[i], gf = post_gid[bl];
+                pface[p] = gf;
+                pbary[p] = {bw[0] / sw, bw[1] / sw, bw[2] / sw};
+                fpoints[gf].push_back(p);
+            }
+        } else
         for (size_t i = 0; i < pts.size(); i++) {
             double best = 1e300, bw[3] = {1, 0, 0};
             int bf = -1;
