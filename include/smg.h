@@ -196,6 +196,8 @@ int smg_synchronize(smg_hierarchy *h);
 /* diagnostic: average time (us, hipEvents on the handle's stream) of one graph-replayed V(pre,post) cycle started at level
  * lv on whatever the work vectors hold; k columns.  Used to see where a cycle's time goes level by level. */
 int smg_bench_vcycle(smg_hierarchy *h, int lv, int k, int pre, int post, int reps, double *us_per_cycle);
+/* diagnostic: average time (us) of `sweeps` graph-replayed Gauss-Seidel sweeps on level lv */
+int smg_bench_relax(smg_hierarchy *h, int lv, int k, int sweeps, int reps, double *us_per_call);
 
 /* ---- introspection (tests, tools) ------------------------------------------------------------------------------ */
 /* which: 0 = A, 1 = P (lv >= 1), 2 = PT (lv >= 1), 3 = P_full (lv >= 1), 4 = Auk (lv == 0).

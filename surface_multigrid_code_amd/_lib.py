@@ -72,6 +72,7 @@ def load():
         "smg_raw_outer_iteration": (i, [vp, i]),
         "smg_synchronize": (i, [vp]),
         "smg_bench_vcycle": (i, [vp, i, i, i, i, i, dp]),
+        "smg_bench_relax": (i, [vp, i, i, i, i, dp]),
         "smg_level_get_matrix": (i, [vp, i, i, i, ip, ip, ip, ip, ip, dp]),
         "smg_level_get_perm": (i, [vp, i, ip]),
         "smg_level_get_colors": (i, [vp, i, ip, ip]),

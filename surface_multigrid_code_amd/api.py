@@ -302,6 +302,11 @@ class Hierarchy:
         _chk(self.L.smg_bench_vcycle(self.h, lv, k, pre, post, reps, C.byref(out)), "smg_bench_vcycle")
         return out.value
 
+    def bench_relax(self, lv=0, k=1, sweeps=2, reps=50):
+        out = C.c_double(0)
+        _chk(self.L.smg_bench_relax(self.h, lv, k, sweeps, reps, C.byref(out)), "smg_bench_relax")
+        return out.value
+
     def synchronize(self):
         _chk(self.L.smg_synchronize(self.h), "smg_synchronize")
 

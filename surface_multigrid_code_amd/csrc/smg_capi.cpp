@@ -1161,6 +1161,30 @@ extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int po
     return SMG_OK;
 }
 
+extern "C" int smg_bench_relax(smg_hierarchy* h, int lv, int k, int sweeps, int reps, double* us_per_call)
+{
+    int rc = piece_prolog(h, lv, k, "smg_bench_relax", true);
+    if (rc) return rc;
+    if (reps < 1 || sweeps < 1 || !us_per_call) return fail(SMG_ERR_INVALID, "smg_bench_relax: bad arguments");
+    Level& Lv = h->lv[lv];
+    hipGraphExec_t g = nullptr;
+    rc = capture_graph(h, &g, [&]() { return enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, sweeps, nullptr); });
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) HIPCHK(hipGraphLaunch(g, h->stream));
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; i++) HIPCHK(hipGraphLaunch(g, h->stream));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_call = 1e3 * ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(g);
+    return SMG_OK;
+}
+
 extern "C" int smg_synchronize(smg_hierarchy* h)
 {
     if (!h || h->device < 0) return fail(SMG_ERR_INVALID, "smg_synchronize: no device");
