@@ -6,14 +6,15 @@
 // Same contract as the reference (greedy shortest-edge collapse with mid-point placement, dec_type 1, or end-point
 // placement, dec_type 2; link-condition and fold-over rejection; every fine vertex carried along as (face, barycentric);
 // P with exactly three stored entries per row, non-negative, rows summing to 1).  The per-collapse re-parameterisation:
-//   * interior collapses: the reference's construction -- the 1-rings before and after the collapse are flattened JOINTLY
-//     by least-squares conformal maps with a shared boundary ring (src/joint_lscm.cpp), a collapse whose flattening flips,
-//     folds over or degenerates is rejected (check_valid_UV_lscm), and every point of the 1-ring is located in the
-//     flattened post patch by the largest-minimum-barycentric rule (src/query_fine_to_coarse.cpp:93-116).  Written from the
-//     formulation (energy, pins, checks), not from the reference's code; there is no reference binary to compare with,
-//     so it is validated by invariants and by the V-cycle convergence it yields;
-//   * collapses touching the boundary: closest-point projection onto the post-collapse 1-ring (the reference handles these
-//     with an "infinity vertex" and two more LSCM cases, src/joint_lscm.cpp:642-1131; not restated);
+//   * the reference's construction -- the 1-rings before and after the collapse are flattened JOINTLY by least-squares
+//     conformal maps with a shared boundary ring (src/joint_lscm.cpp), a collapse whose flattening flips, folds over or
+//     degenerates is rejected (check_valid_UV_lscm), and every point of the 1-ring is located in the flattened post patch
+//     by the largest-minimum-barycentric rule (src/query_fine_to_coarse.cpp:93-116).  Written from the formulation (energy,
+//     pins, checks), not from the reference's code; there is no reference binary to compare with, so it is validated by
+//     invariants and by the V-cycle convergence it yields;
+//   * collapses touching the boundary go through the same flattening on the open 1-ring (natural boundary conditions); the
+//     reference closes the boundary with an "infinity vertex" and has two more LSCM cases for it (src/joint_lscm.cpp:
+//     642-1131), which are not restated;
 //   * the libigl-internal edge-flap bookkeeping, the qslim / randomised variants and the coarse-to-fine queries of the
 //     remeshing demos are not restated.
 #include <algorithm>
@@ -37,34 +38,6 @@ inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
-
-// closest point of triangle (a,b,c) to p, as barycentric coordinates (Ericson, Real-Time Collision Detection 5.1.5)
-void closest_bary(V3 p, V3 a, V3 b, V3 c, double* w)
-{
-    V3 ab = b - a, ac = c - a, ap = p - a;
-    double d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0 && d2 <= 0) { w[0] = 1; w[1] = 0; w[2] = 0; return; }
-    V3 bp = p - b;
-    double d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0 && d4 <= d3) { w[0] = 0; w[1] = 1; w[2] = 0; return; }
-    double vc = d1 * d4 - d3 * d2;
-    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); w[0] = 1 - v; w[1] = v; w[2] = 0; return; }
-    V3 cp = p - c;
-    double d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0 && d5 <= d6) { w[0] = 0; w[1] = 0; w[2] = 1; return; }
-    double vb = d5 * d2 - d1 * d6;
-    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double t = d2 / (d2 - d6); w[0] = 1 - t; w[1] = 0; w[2] = t; return; }
-    double va = d3 * d6 - d5 * d4;
-    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
-        double t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        w[0] = 0; w[1] = 1 - t; w[2] = t;
-        return;
-    }
-    double den = 1.0 / (va + vb + vc);
-    double v = vb * den, t = vc * den;
-    w[0] = 1 - v - t; w[1] = v; w[2] = t;
-}
-
 
 // ---- joint conformal flattening of the pre- and post-collapse 1-rings (interior collapses) -------------------------------
 // The reference's successive self-parameterisation maps a point through a collapse by flattening the 1-ring before and
@@ -237,13 +210,6 @@ struct Decimator {
         nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
         for (int w : nb) push_edge(v, w);
     }
-    V3 point_pos(int p) const
-    {
-        const auto& f = faces[pface[p]];
-        const auto& w = pbary[p];
-        return w[0] * pos[f[0]] + (w[1] * pos[f[1]] + w[2] * pos[f[2]]);
-    }
-
     // try to collapse (a,b); returns true on success
     bool collapse(int a, int b)
     {
@@ -294,18 +260,19 @@ struct Decimator {
             }
         }
         // ---- interior collapse: joint conformal flattening of the 1-ring before / after (reject the collapse if invalid)
-        const bool intrinsic = !ba && !bb;
+        // (collapses touching the boundary use the same construction on the open 1-ring: the conformal energy has natural
+        //  boundary conditions; when one end point is a boundary vertex the merged vertex sits on that end point)
         Patch patch;
         std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
         std::unordered_map<int, int> loc;                // global vertex -> local
-        if (intrinsic) {
+        {
             std::vector<int> ringv;
             for (int v : na) if (v != b) ringv.push_back(v);
             for (int v : nb) if (v != a && !std::binary_search(na.begin(), na.end(), v)) ringv.push_back(v);
             for (int v : ringv) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
             const int la = (int)patch.P.size(); patch.P.push_back(pos[a]);
             const int lb = la + 1; patch.P.push_back(pos[b]);
-            const int lm = lb + 1; patch.P.push_back(m);
+            const int lm = lb + 1; patch.P.push_back(m);   // a distinct unknown even when m coincides with an end point
             patch.n = lm + 1;
             loc[a] = la; loc[b] = lb;
             auto add_faces = [&](int v) {
@@ -327,12 +294,11 @@ struct Decimator {
         }
         // ---- gather the fine points of the pre-collapse 1-ring with their positions
         std::vector<int> pts;
-        std::vector<V3> ppos;
         std::vector<std::array<double, 2>> puv;   // position in the joint flattening (interior collapses)
         auto take = [&](int f) {
             for (int p : fpoints[f]) {
-                pts.push_back(p); ppos.push_back(point_pos(p));
-                if (intrinsic) {
+                pts.push_back(p);
+                {
                     const auto& fc = faces[f];
                     const auto& w = pbary[p];
                     const int l0 = loc[fc[0]], l1 = loc[fc[1]], l2 = loc[fc[2]];
@@ -359,7 +325,7 @@ struct Decimator {
         clean(a);
         for (int w : common) clean(w);
         // ---- re-home the points on the post-collapse star of a (closest-point re-parameterisation)
-        if (intrinsic) {
+        {
             // locate every point in the flattened post patch: the face in which its smallest barycentric coordinate is
             // largest, clamped to >= 0 and renormalised (src/query_fine_to_coarse.cpp:93-116)
             for (size_t i = 0; i < pts.size(); i++) {
@@ -382,23 +348,6 @@ struct Decimator {
                 pbary[p] = {bw[0] / sw, bw[1] / sw, bw[2] / sw};
                 fpoints[gf].push_back(p);
             }
-        } else
-        for (size_t i = 0; i < pts.size(); i++) {
-            double best = 1e300, bw[3] = {1, 0, 0};
-            int bf = -1;
-            for (int f : vfaces[a]) {
-                const auto& fc = faces[f];
-                double w[3];
-                closest_bary(ppos[i], pos[fc[0]], pos[fc[1]], pos[fc[2]], w);
-                V3 q = w[0] * pos[fc[0]] + (w[1] * pos[fc[1]] + w[2] * pos[fc[2]]);
-                V3 d = q - ppos[i];
-                const double d2 = dot(d, d);
-                if (d2 < best) { best = d2; bf = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
-            }
-            const int p = pts[i];
-            pface[p] = bf;
-            pbary[p] = {bw[0], bw[1], bw[2]};
-            fpoints[bf].push_back(p);
         }
         push_star(a);
         return true;
