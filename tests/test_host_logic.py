@@ -209,3 +209,19 @@ def test_malformed_inputs_are_rejected(smg_mod):
     rc = L.smg_precompute(mgA.h, A.shape[0], ip(ptr2), ip(cols[order].astype(np.int32)), dp(vals[order].copy()), None, 0)
     assert rc in (0, -2)                                                    # -2: host half done, no GPU here
     assert abs(mgA.matrix(0, "A") - A).max() == 0
+
+
+def test_weak_kat_bunny_500_faces(smg_mod):
+    """The only decimation output the reference checks in: 08_subdiv_remesh/output_s0.obj = bunny.obj decimated by
+    mid-point collapse to tarF = 500 -> 261 V / 499 F.  libigl-version dependent on the reference
+    side and a different implementation here, so only the counts are compared (Euler: V = 1 + (F + #boundary edges) / 2)."""
+    import ctypes as C
+    smg, mesh = smg_mod, smg_mod.mesh
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    ratio = float(np.float32(500 / 18555))
+    mg = smg.mg_precompute(V, F, ratio, 200, 1)
+    assert mg.n_levels == 2
+    nV, nF = C.c_int(), C.c_int()
+    smg._lib.load().smg_level_get_mesh(mg.h, 1, C.byref(nV), C.byref(nF), None, None)
+    assert nF.value == 499 and abs(nV.value - 261) <= 3
+    assert mg.matrix(1, "P_full").shape == (9353, nV.value)
