@@ -95,13 +95,30 @@ def test_constraint_cascade_drops_empty_columns(smg_mod, oracle_mod):
 
 
 def test_colour_ordering_is_a_valid_colouring(smg_mod):
+    """The device numbering is computed in the host half: colour-major, no two coupled rows in one colour, 4 colours on
+    subdivision levels (inherited from the coarse 4-colouring), and the internal matrix is the permuted caller matrix."""
     smg = smg_mod
-    p = subdiv_problem(kind="mcf", k=1, n_sub=2)
-    mg = smg.Hierarchy.from_prolongs(p["Ps"])
-    try:
-        mg.precompute(p["A"])
-    except smg.SmgError:
-        pytest.skip("ordering is built in the device half of precompute (needs a GPU)")
+    for kind, known in (("mcf", False), ("poisson", True)):
+        p = subdiv_problem(kind=kind, k=1, n_sub=2)
+        mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"] if known else None)
+        for lv in range(mg.n_levels - 1):
+            A = mg.matrix(lv, "A", internal=True).tocoo()
+            cp = mg.colors(lv)
+            n = mg.rows(lv)
+            assert cp[0] == 0 and cp[-1] == n and (np.diff(cp) > 0).all()
+            col_of = np.searchsorted(cp, np.arange(n), side="right") - 1
+            off = A.row != A.col
+            assert (col_of[A.row[off]] != col_of[A.col[off]]).all()
+            perm = mg.perm(lv)
+            assert sorted(perm) == list(range(n))
+            assert abs(mg.matrix(lv, "A").tocsr()[perm][:, perm] - A.tocsr()).max() == 0
+            if not known:
+                assert len(cp) - 1 == 4, "subdivision levels inherit a 4-colouring"
+        # transfer operators in the device numbering
+        for lv in range(1, mg.n_levels):
+            P, Pi = mg.matrix(lv, "P"), mg.matrix(lv, "P", internal=True)
+            assert abs(P.tocsr()[mg.perm(lv - 1)][:, mg.perm(lv)] - Pi).max() == 0
+            assert abs(mg.matrix(lv, "PT", internal=True) - Pi.T).max() == 0
 
 
 def test_mg_precompute_invariants(smg_mod):
