@@ -97,14 +97,16 @@ hipError_t SellBuf::upload(const Sell& S)
     hipError_t e;
     if ((e = slice_row.upload(S.slice_row)) != hipSuccess) return e;
     if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
+    if ((e = slice_w.upload(S.slice_w)) != hipSuccess) return e;
     if ((e = col.upload(S.col)) != hipSuccess) return e;
     if ((e = val.upload(S.val)) != hipSuccess) return e;
     if ((e = order.upload(S.region_order)) != hipSuccess) return e;
     view.n_rows = S.n_rows; view.n_cols = S.n_cols; view.n_slices = S.n_slices; view.C = S.C;
     view.order = S.region_order.empty() ? nullptr : order.p;
-    view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.col = col.p; view.val = val.p;
+    view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.slice_w = slice_w.p; view.col = col.p; view.val = val.p;
+    view.stride = S.stride; view.w_lo = S.w_lo;
     color_slice_ptr = S.color_slice_ptr;
-    stored = S.nnz; padded = S.padded();
+    stored = S.nnz; padded = S.padded(); used = S.used();
     return hipSuccess;
 }
 
@@ -1418,7 +1420,7 @@ extern "C" int smg_level_sell_stats(const smg_hierarchy* h, int lv, int which, l
     const SellBuf* S = which == 0 ? &h->lv[lv].dA : which == 1 ? &h->lv[lv].dP : which == 2 ? &h->lv[lv].dPT : nullptr;
     if (!S) return fail(SMG_ERR_INVALID, "smg_level_sell_stats: which must be 0,1,2");
     if (stored) *stored = S->stored;
-    if (padded) *padded = S->padded;
+    if (padded) *padded = S->used;   // slots read per pass (the allocation may be larger: fixed-stride panels)
     if (n_slices) *n_slices = S->view.n_slices;
     return SMG_OK;
 }

@@ -29,6 +29,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// `done` is never null (launchers substitute a zero word).  A per-lane (vector) load: the compiler waits for it only
+// where the value is used -- a scalar load of the same word was waited for before anything else was issued.
+__device__ int g_never_done = 0;
+__device__ __forceinline__ int load_flag(const int* done)
+{
+    return __builtin_nontemporal_load(done + (__builtin_amdgcn_mbcnt_lo(~0u, 0u) >> 6));   // + 0, opaque to the optimiser
+}
+static const int* never_done()
+{
+    static const int* p = nullptr;
+    if (!p) { void* q = nullptr; if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_never_done)) == hipSuccess) p = (const int*)q; }
+    return p;
+}
+
 template <int RPL, typename T> struct PanelLoad;
 template <typename T> struct PanelLoad<1, T> {
     static __device__ __forceinline__ void ld(const int* cp, const T* vp, int* c, T* v) { c[0] = *cp; v[0] = *vp; }
@@ -41,28 +55,53 @@ template <> __device__ __forceinline__ const float* sell_vals<float>(const SellD
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
 template <int MODE, int KB, int RPL, typename T>
-__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, const T* x,
+__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, int n_blocks, const T* x,
                                               const T* b, T* y, int ld, const int* done, double* partials,
                                               T* zero_rows)
 {
-    // The convergence flag is loaded up front but only consulted right before the stores: the matrix / vector loads
+    // The convergence flag is requested up front but only consulted right before the stores: the matrix / vector loads
     // of a launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
-    const int stop = done ? __builtin_nontemporal_load(done) : 0;
+    // fetch every kernel argument in one batch of scalar loads (they are otherwise read piecemeal behind the branches below,
+    // each time with its own wait): a value that depends on all of them is made opaque and tested here.  (Not `asm volatile`:
+    // that counts as a possible store and would turn the table reads below from scalar into vector loads.)
+    {
+        size_t keep = (size_t)A.slice_row ^ (size_t)A.slice_off ^ (size_t)A.slice_w ^ (size_t)A.order ^ (size_t)A.col ^
+                      (size_t)sell_vals<T>(A) ^ (size_t)x ^ (size_t)b ^ (size_t)y ^ (size_t)done ^
+                      (size_t)(A.stride + A.w_lo + ld + s_begin + s_end + use_order + n_blocks);
+        asm("" : "+s"(keep));
+        if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
+    }
+    const int stop = load_flag(done);
     constexpr int C = 64 * RPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;  // waves (= slices) per block
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int wpb = 4;            // waves (= slices) per block
+    const int bid = xcd_remap(blockIdx.x, n_blocks);
     const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * wpb + wave);
     double ss = 0.0;
     if (ls < s_end) {
         const int s = use_order ? A.order[ls] : ls;
-        const int row0 = A.slice_row[s];
-        const int nrow = A.slice_row[s + 1] - row0;
-        const int off0 = A.slice_off[s];
-        const int w = A.slice_off[s + 1] - off0;
+        // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (every slice has them) are
+        // requested before the slice's table entries have arrived -- the table reads leave the critical path.
+        const int W0 = A.w_lo < 8 ? A.w_lo : 8;                       // kernel argument; 0 for compact panels
+        const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int* cp = A.col + (size_t)off0 * C + RPL * lane;
         const T* vp = sell_vals<T>(A) + (size_t)off0 * C + RPL * lane;
+        constexpr int U = 8;
+        int c0[U][RPL];
+        T v0[U][RPL];
+#pragma unroll
+        for (int t = 0; t < U; t++) {
+            if (t < W0) {  // wave-uniform
+                PanelLoad<RPL, T>::ld(cp + (size_t)t * C, vp + (size_t)t * C, c0[t], v0[t]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPL; r++) { c0[t][r] = -1; v0[t][r] = (T)0; }
+            }
+        }
+        const int row0 = A.slice_row[s];
+        const int nrow = A.slice_row[s + 1] - row0;
+        const int w = A.slice_w[s];
         const int rowb = row0 + RPL * lane;
         T acc[RPL][KB];
         T diag[RPL];
@@ -79,19 +118,8 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
                 else bv[r][q] = live ? b[(size_t)(rowb + r) * ld + q] : (T)0;
             }
         }
-        constexpr int U = 8;
-        for (int j0 = 0; j0 < w; j0 += U) {
-            int c[U][RPL];
-            T v[U][RPL];
-#pragma unroll
-            for (int t = 0; t < U; t++) {
-                if ((j0 + t) < w) {  // wave-uniform
-                    PanelLoad<RPL, T>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = (T)0; }
-                }
-            }
+        // one batch of U panel columns: gather x for all of them, then accumulate in ascending column order
+        auto consume = [&](const int (&c)[U][RPL], const T (&v)[U][RPL]) {
             T xv[U][RPL][KB];
 #pragma unroll
             for (int t = 0; t < U; t++)
@@ -114,6 +142,21 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
                         }
                     }
                 }
+        };
+        if (W0 > 0) consume(c0, v0);   // columns [0, W0), requested ahead of the table
+        for (int j0 = W0; j0 < w; j0 += U) {
+            int c[U][RPL];
+            T v[U][RPL];
+#pragma unroll
+            for (int t = 0; t < U; t++) {
+                if ((j0 + t) < w) {  // wave-uniform
+                    PanelLoad<RPL, T>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = (T)0; }
+                }
+            }
+            consume(c, v);
         }
 #pragma unroll
         for (int r = 0; r < RPL; r++) {
@@ -152,11 +195,11 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
 // A wave owns 8*G consecutive rows of a slice (KW/8 waves per slice).  Per (row, column) the sum is still sequential in
 // ascending column order: bit-identical to the narrow kernel and to the oracle.
 template <int MODE, int KW, typename T>
-__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, const T* x,
+__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, int n_blocks, const T* x,
                                                    const T* b, T* y, int ld, const int* done, double* partials,
                                                    T* zero_rows)
 {
-    const int stop = done ? __builtin_nontemporal_load(done) : 0;
+    const int stop = load_flag(done);
     constexpr int G = 64 / KW;        // rows in flight per wave-instruction
     constexpr int R = 2;              // rows per lane
     constexpr int RW = R * G;         // rows per wave
@@ -164,7 +207,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane % KW, g = lane / KW;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blockIdx.x, n_blocks);
     const int wid = __builtin_amdgcn_readfirstlane(bid * 4 + wave);  // logical wave
     const int ls = s_begin + wid / SUB;
     const int sub = wid % SUB;
@@ -173,8 +216,8 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
         const int s = use_order ? A.order[ls] : ls;
         const int row0 = A.slice_row[s];
         const int nrow = A.slice_row[s + 1] - row0;
-        const int off0 = A.slice_off[s];
-        const int w = A.slice_off[s + 1] - off0;
+        const int off0 = A.stride ? s * A.stride : A.slice_off[s];
+        const int w = A.slice_w[s];
         int rl[R];
         T acc[R], diag[R], bv[R];
 #pragma unroll
@@ -246,7 +289,7 @@ static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_or
 {
     const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
     const int nb = (waves + 3) / 4;
-    hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, x, b, y, k, done, partials, zero_rows);
+    hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, nb, x, b, y, k, done, partials, zero_rows);
     *nb_out = nb;
 }
 
@@ -269,7 +312,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
     int s_end = s_end_in;
     const int ns = s_end - s_begin;
     const int nb = sell_blocks(ns);
-    const int* done = ctrl ? &ctrl->done : nullptr;
+    const int* done = ctrl ? &ctrl->done : never_done();
     static const int dbg_empty = getenv("SMG_DEBUG_EMPTY") ? atoi(getenv("SMG_DEBUG_EMPTY")) : 0;  // launch-overhead probe
     if (dbg_empty == 1) s_end = s_begin;
     // the region-major launch order only makes sense for whole-matrix launches
@@ -307,10 +350,10 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         T* zz = zero_rows ? zero_rows + c0 : nullptr;
         poff += (size_t)nb;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = (int)poff;

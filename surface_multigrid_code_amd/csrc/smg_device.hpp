@@ -29,7 +29,10 @@ struct SellDev {
     int n_rows = 0, n_cols = 0, n_slices = 0;
     int C = 64;                      // slice height: 64 (one row per lane) or 128 (two adjacent rows per lane)
     const int* slice_row = nullptr;  // n_slices + 1
-    const int* slice_off = nullptr;  // n_slices + 1 (units of C entries)
+    const int* slice_off = nullptr;  // n_slices + 1 (units of C entries); = s * stride when stride > 0
+    const int* slice_w = nullptr;    // n_slices: panel columns used by the slice
+    int stride = 0;                  // > 0: fixed panel pitch, addressing needs no table
+    int w_lo = 0;                    // every slice has at least this many columns (0 when stride == 0)
     const int* order = nullptr;      // optional launch order of the slices (region-major), whole-matrix kernels only
     const int* col = nullptr;
     const double* val = nullptr;

@@ -42,11 +42,11 @@ struct DevBuf {
 };
 
 struct SellBuf {  // device image of one SELL matrix
-    DevBuf<int> slice_row, slice_off, col, order;
+    DevBuf<int> slice_row, slice_off, slice_w, col, order;
     DevBuf<double> val;
     SellDev view;
     std::vector<int> color_slice_ptr;
-    long stored = 0, padded = 0;
+    long stored = 0, padded = 0, used = 0;   // CSR entries / allocated slots / slots the kernels read
     hipError_t upload(const Sell& S);
 };
 

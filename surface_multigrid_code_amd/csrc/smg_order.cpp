@@ -2,6 +2,7 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <numeric>
 #include <queue>
@@ -404,19 +405,26 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     if (row_breaks) breaks = *row_breaks;
     else breaks = {0, A.nr};
     S.slice_row.push_back(0);
-    S.slice_off.push_back(0);
     S.color_slice_ptr.push_back(0);
+    long sum_w = 0;
+    int wmax = 0, wmin = 1 << 30;
     for (size_t c = 0; c + 1 < breaks.size(); c++) {
         for (int r0 = breaks[c]; r0 < breaks[c + 1]; r0 += C) {
             int r1 = std::min(r0 + C, breaks[c + 1]);
             int w = 0;
             for (int r = r0; r < r1; r++) w = std::max(w, A.ptr[r + 1] - A.ptr[r]);
             S.slice_row.push_back(r1);
-            S.slice_off.push_back(S.slice_off.back() + w);
+            S.slice_w.push_back(w);
+            sum_w += w; wmax = std::max(wmax, w); wmin = std::min(wmin, w);
         }
         S.color_slice_ptr.push_back((int)S.slice_row.size() - 1);
     }
     S.n_slices = (int)S.slice_row.size() - 1;
+    // fixed stride unless a few very wide slices would blow the storage up (then: compact panels, table-driven addressing)
+    static const int allow_stride = std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob
+    if (allow_stride && S.n_slices > 0 && wmax > 0 && (long)wmax * S.n_slices <= (5 * sum_w) / 2 + 64) { S.stride = wmax; S.w_lo = wmin; }
+    S.slice_off.assign(S.n_slices + 1, 0);
+    for (int s = 0; s < S.n_slices; s++) S.slice_off[s + 1] = S.stride ? (s + 1) * S.stride : S.slice_off[s] + S.slice_w[s];
     size_t tot = (size_t)C * (size_t)S.slice_off.back();
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);

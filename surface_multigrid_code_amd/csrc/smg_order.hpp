@@ -33,18 +33,26 @@ constexpr int SELL_C = 64;  // slice height = one wavefront, one row per lane (t
 
 // SELL-C-sigma, C = 64: slice s covers rows [slice_row[s], slice_row[s+1]) (<= 64 of them; a slice never
 // straddles a colour boundary); its entries are stored column-major in a 64-wide panel starting at element
-// 64 * slice_off[s]; panel width = slice_off[s+1] - slice_off[s] = longest row of the slice.  Padding has
-// col = -1.  Inside a row the stored order is ascending column index of the *internal* numbering.
+// 64 * slice_off[s]; panel width slice_w[s] = longest row of the slice.  Padding has col = -1.  Inside a row the
+// stored order is ascending column index of the *internal* numbering.
+// Fixed stride: when the widest slice is not much wider than the average (all mesh operators here), every panel gets
+// `stride` columns of room, slice_off[s] = s * stride, and a kernel can address a panel -- and load its first w_lo
+// columns, which every slice has -- without first reading any per-slice table: one dependent memory round trip less per
+// launch.  stride = 0: compact panels, slice_off is a prefix sum of the widths.
 struct Sell {
     int C = SELL_C;                    // slice height: 64 (one row per lane) or 128 (two adjacent rows per lane)
     int n_rows = 0, n_cols = 0, n_slices = 0;
     std::vector<int> slice_row;        // n_slices + 1
     std::vector<int> slice_off;        // n_slices + 1, in units of C entries (panel columns)
+    std::vector<int> slice_w;          // n_slices: panel width actually used by the slice
+    int stride = 0;                    // > 0: slice_off[s] = s * stride
+    int w_lo = 0;                      // min over slices of slice_w (0 when stride == 0 or no slices)
     std::vector<int> col;              // 64 * slice_off[n_slices]
     std::vector<double> val;
     std::vector<int> color_slice_ptr;  // n_colors + 1 slice offsets (single range when uncoloured)
     long nnz = 0;                      // stored (unpadded) entries
-    long padded() const { return (long)C * (slice_off.empty() ? 0 : slice_off.back()); }
+    long padded() const { return (long)C * (slice_off.empty() ? 0 : slice_off.back()); }   // allocated slots
+    long used() const { long t = 0; for (int w : slice_w) t += w; return (long)C * t; }          // slots the kernels read
     // Launch order of the slices for whole-matrix kernels: sorted by relative position inside the colour block,
     // so that consecutive logical blocks (= one XCD's share) cover ONE mesh region across all colours.
     std::vector<int> region_order;     // n_slices, or empty (identity)
