@@ -16,7 +16,11 @@ LIB = os.path.join(LIBDIR, "libsmg.so")
 SOURCES = ["smg_device.hip", "smg_capi.cpp", "smg_sparse.cpp", "smg_mesh.cpp", "smg_order.cpp", "smg_decimate.cpp"]
 HEADERS = ["smg_device.hpp", "smg_hier.hpp", "smg_sparse.hpp", "smg_mesh.hpp", "smg_order.hpp",
            os.path.join("..", "..", "include", "smg.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"] + os.environ.get("SMG_EXTRA_FLAGS", "").split()
+# -amdgpu-kernarg-preload-count: the leading scalar / pointer kernel arguments arrive in SGPRs with the wave (k_sell orders its
+# arguments for this: its first panel loads need no kernarg read at all).  SMG_KERNARG_PRELOAD=0 builds without it (A/B).
+PRELOAD = [] if os.environ.get("SMG_KERNARG_PRELOAD", "1") == "0" else ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"] + PRELOAD +
+         os.environ.get("SMG_EXTRA_FLAGS", "").split())
 
 
 def _hipcc():

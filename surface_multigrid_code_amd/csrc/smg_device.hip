@@ -54,24 +54,19 @@ template <> __device__ __forceinline__ const float* sell_vals<float>(const SellD
 // One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
+// Argument order: the first 16 dwords are what the wave needs to issue its first panel loads; built with
+// -mllvm -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the wave instead of through scalar loads (that only works
+// for leading scalar / pointer arguments, hence no struct up front).  The rest is fetched in one batch.
 template <int MODE, int KB, int RPL, typename T>
-__global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end, int use_order, int n_blocks, const T* x,
-                                              const T* b, T* y, int ld, const int* done, double* partials,
-                                              T* zero_rows)
+__global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
+                                              int a_w_lo, int s_begin, int s_end, int n_blocks, int use_order, const T* x,
+                                              const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld, const int* done,
+                                              double* partials, T* zero_rows)
 {
+    struct { const int *slice_row, *slice_off, *slice_w, *order, *col; int stride, w_lo; } A = {a_slice_row, a_slice_off, a_slice_w, a_order,
+                                                                                               a_col, a_stride, a_w_lo};
     // The convergence flag is requested up front but only consulted right before the stores: the matrix / vector loads
     // of a launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
-    // fetch every kernel argument in one batch of scalar loads (they are otherwise read piecemeal behind the branches below,
-    // each time with its own wait): a value that depends on all of them is made opaque and tested here.  (Not `asm volatile`:
-    // that counts as a possible store and would turn the table reads below from scalar into vector loads.)
-    {
-        size_t keep = (size_t)A.slice_row ^ (size_t)A.slice_off ^ (size_t)A.slice_w ^ (size_t)A.order ^ (size_t)A.col ^
-                      (size_t)sell_vals<T>(A) ^ (size_t)x ^ (size_t)b ^ (size_t)y ^ (size_t)done ^
-                      (size_t)(A.stride + A.w_lo + ld + s_begin + s_end + use_order + n_blocks);
-        asm("" : "+s"(keep));
-        if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
-    }
-    const int stop = load_flag(done);
     constexpr int C = 64 * RPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -79,6 +74,7 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
     const int bid = xcd_remap(blockIdx.x, n_blocks);
     const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * wpb + wave);
     double ss = 0.0;
+    int stop = 0;
     if (ls < s_end) {
         const int s = use_order ? A.order[ls] : ls;
         // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (every slice has them) are
@@ -86,7 +82,7 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
         const int W0 = A.w_lo < 8 ? A.w_lo : 8;                       // kernel argument; 0 for compact panels
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int* cp = A.col + (size_t)off0 * C + RPL * lane;
-        const T* vp = sell_vals<T>(A) + (size_t)off0 * C + RPL * lane;
+        const T* vp = a_val + (size_t)off0 * C + RPL * lane;
         constexpr int U = 8;
         int c0[U][RPL];
         T v0[U][RPL];
@@ -99,6 +95,18 @@ __global__ __launch_bounds__(256) void k_sell(SellDev A, int s_begin, int s_end,
                 for (int r = 0; r < RPL; r++) { c0[t][r] = -1; v0[t][r] = (T)0; }
             }
         }
+        // Now -- with the first panel loads in flight -- fetch the remaining kernel arguments in ONE batch of scalar loads
+        // (they are otherwise read piecemeal behind branches, each time with its own wait): a value that depends on all of
+        // them is made opaque and tested.  (Not `asm volatile`: that counts as a possible store and would turn the table
+        // reads below from scalar into vector loads.)
+        {
+            size_t keep = (size_t)x ^ (size_t)A.slice_row ^ (size_t)A.slice_w ^ (size_t)b ^ (size_t)y ^ (size_t)done ^ (size_t)ld;
+            asm("" : "+s"(keep));
+            if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
+        }
+        // The convergence flag is requested early but only consulted right before the stores: the matrix / vector loads of a
+        // launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
+        stop = load_flag(done);
         const int row0 = A.slice_row[s];
         const int nrow = A.slice_row[s + 1] - row0;
         const int w = A.slice_w[s];
@@ -305,6 +313,10 @@ int sell_wide_blocks(int n_slices, int k)
 static constexpr int sell_wpb() { return 4; }
 int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb(); }
 
+template <typename T> static const T* host_vals(const SellDev& A);
+template <> const double* host_vals<double>(const SellDev& A) { return A.val; }
+template <> const float* host_vals<float>(const SellDev& A) { return A.valf; }
+
 template <int MODE, int RPL, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
                                    int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows)
@@ -350,10 +362,10 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         T* zz = zero_rows ? zero_rows + c0 : nullptr;
         poff += (size_t)nb;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A, s_begin, s_end, use_order, nb, xx, bb, yy, k, done, pp, zz); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = (int)poff;
