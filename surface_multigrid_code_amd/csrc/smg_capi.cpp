@@ -82,6 +82,12 @@ static int ensure_device(smg_hierarchy* h)
     return SMG_OK;
 }
 
+static int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
 static void drop_graphs(smg_hierarchy* h)
 {
     if (h->g_iter) (void)hipGraphExecDestroy(h->g_iter);
@@ -105,6 +111,13 @@ hipError_t SellBuf::upload(const Sell& S)
     view.order = S.region_order.empty() ? nullptr : order.p;
     view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.slice_w = slice_w.p; view.col = col.p; view.val = val.p;
     view.stride = S.stride; view.w_lo = S.w_lo;
+    if (env_int("SMG_DEBUG_SELL", 0)) {
+        int hist[33] = {0};
+        for (int w : S.slice_w) hist[std::min(w, 32)]++;
+        std::fprintf(stderr, "sell %d x %d: %d slices, stride %d, w_lo %d, widths:", S.n_rows, S.n_cols, S.n_slices, S.stride, S.w_lo);
+        for (int w = 0; w <= 32; w++) if (hist[w]) std::fprintf(stderr, " %d:%d", w, hist[w]);
+        std::fprintf(stderr, "\n");
+    }
     color_slice_ptr = S.color_slice_ptr;
     stored = S.nnz; padded = S.padded(); used = S.used();
     return hipSuccess;
@@ -356,12 +369,6 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
 }
 
 // Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
-static int env_int(const char* name, int dflt)
-{
-    const char* v = std::getenv(name);
-    return v && *v ? std::atoi(v) : dflt;
-}
-
 static int precompute_device(smg_hierarchy* h)
 {
     const int L = h->n_levels;

@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
     int stop = 0;
     if (ls < s_end) {
         const int s = use_order ? A.order[ls] : ls;
-        // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (every slice has them) are
-        // requested before the slice's table entries have arrived -- the table reads leave the critical path.
+        // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (what most slices have; a
+        // narrower slice holds padding there) are requested before the slice's table entries have arrived -- the table reads
+        // leave the critical path.
         const int W0 = A.w_lo < 8 ? A.w_lo : 8;                       // kernel argument; 0 for compact panels
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int* cp = A.col + (size_t)off0 * C + RPL * lane;

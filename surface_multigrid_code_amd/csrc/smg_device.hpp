@@ -32,7 +32,7 @@ struct SellDev {
     const int* slice_off = nullptr;  // n_slices + 1 (units of C entries); = s * stride when stride > 0
     const int* slice_w = nullptr;    // n_slices: panel columns used by the slice
     int stride = 0;                  // > 0: fixed panel pitch, addressing needs no table
-    int w_lo = 0;                    // every slice has at least this many columns (0 when stride == 0)
+    int w_lo = 0;                    // columns requested before the slice's width is known, <= stride (0 when stride == 0)
     const int* order = nullptr;      // optional launch order of the slices (region-major), whole-matrix kernels only
     const int* col = nullptr;
     const double* val = nullptr;

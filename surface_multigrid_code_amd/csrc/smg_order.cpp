@@ -422,7 +422,16 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     S.n_slices = (int)S.slice_row.size() - 1;
     // fixed stride unless a few very wide slices would blow the storage up (then: compact panels, table-driven addressing)
     static const int allow_stride = std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob
-    if (allow_stride && S.n_slices > 0 && wmax > 0 && (long)wmax * S.n_slices <= (5 * sum_w) / 2 + 64) { S.stride = wmax; S.w_lo = wmin; }
+    if (allow_stride && S.n_slices > 0 && wmax > 0 && (long)wmax * S.n_slices <= (5 * sum_w) / 2 + 64) {
+        // columns requested before a slice's width is known: the smallest W that covers 90% of the slices (narrower slices read
+        // padding there, which the stride guarantees to exist; wider ones continue table-driven)
+        S.stride = wmax;
+        std::vector<int> hist(wmax + 1, 0);
+        for (int w : S.slice_w) hist[w]++;
+        int cum = 0, W = wmin;
+        for (int w = 0; w <= wmax; w++) { cum += hist[w]; if (10 * (long)cum >= 9 * (long)S.n_slices) { W = w; break; } }
+        S.w_lo = std::max(W, wmin);
+    }
     S.slice_off.assign(S.n_slices + 1, 0);
     for (int s = 0; s < S.n_slices; s++) S.slice_off[s + 1] = S.stride ? (s + 1) * S.stride : S.slice_off[s] + S.slice_w[s];
     size_t tot = (size_t)C * (size_t)S.slice_off.back();

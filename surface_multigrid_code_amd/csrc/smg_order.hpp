@@ -37,7 +37,7 @@ constexpr int SELL_C = 64;  // slice height = one wavefront, one row per lane (t
 // stored order is ascending column index of the *internal* numbering.
 // Fixed stride: when the widest slice is not much wider than the average (all mesh operators here), every panel gets
 // `stride` columns of room, slice_off[s] = s * stride, and a kernel can address a panel -- and load its first w_lo
-// columns, which every slice has -- without first reading any per-slice table: one dependent memory round trip less per
+// columns, which (nearly) every slice has, the others hold padding there -- without first reading any per-slice table: one dependent memory round trip less per
 // launch.  stride = 0: compact panels, slice_off is a prefix sum of the widths.
 struct Sell {
     int C = SELL_C;                    // slice height: 64 (one row per lane) or 128 (two adjacent rows per lane)
@@ -46,7 +46,7 @@ struct Sell {
     std::vector<int> slice_off;        // n_slices + 1, in units of C entries (panel columns)
     std::vector<int> slice_w;          // n_slices: panel width actually used by the slice
     int stride = 0;                    // > 0: slice_off[s] = s * stride
-    int w_lo = 0;                      // min over slices of slice_w (0 when stride == 0 or no slices)
+    int w_lo = 0;                      // columns to request ahead of the table: covers 90% of the slices (0 when stride == 0)
     std::vector<int> col;              // 64 * slice_off[n_slices]
     std::vector<double> val;
     std::vector<int> color_slice_ptr;  // n_colors + 1 slice offsets (single range when uncoloured)
