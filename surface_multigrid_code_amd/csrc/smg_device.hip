@@ -47,9 +47,6 @@ template <int RPL, typename T> struct PanelLoad;
 template <typename T> struct PanelLoad<1, T> {
     static __device__ __forceinline__ void ld(const int* cp, const T* vp, int* c, T* v) { c[0] = *cp; v[0] = *vp; }
 };
-template <typename T> __device__ __forceinline__ const T* sell_vals(const SellDev& A);
-template <> __device__ __forceinline__ const double* sell_vals<double>(const SellDev& A) { return A.val; }
-template <> __device__ __forceinline__ const float* sell_vals<float>(const SellDev& A) { return A.valf; }
 
 // One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
@@ -204,10 +201,13 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
 // A wave owns 8*G consecutive rows of a slice (KW/8 waves per slice).  Per (row, column) the sum is still sequential in
 // ascending column order: bit-identical to the narrow kernel and to the oracle.
 template <int MODE, int KW, typename T>
-__global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s_end, int use_order, int n_blocks, const T* x,
-                                                   const T* b, T* y, int ld, const int* done, double* partials,
-                                                   T* zero_rows)
+__global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
+                                                   int s_begin, int s_end, int n_blocks, int use_order, const T* x,
+                                                   const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld,
+                                                   const int* done, double* partials, T* zero_rows)
 {
+    struct { const int *slice_row, *slice_off, *slice_w, *order, *col; int stride; } A = {a_slice_row, a_slice_off, a_slice_w, a_order, a_col,
+                                                                                        a_stride};
     const int stop = load_flag(done);
     constexpr int G = 64 / KW;        // rows in flight per wave-instruction
     constexpr int R = 2;              // rows per lane
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
             else bv[r] = live ? b[o] : (T)0;
         }
         const int* cp = A.col + (size_t)off0 * 64;
-        const T* vp = sell_vals<T>(A) + (size_t)off0 * 64;
+        const T* vp = a_val + (size_t)off0 * 64;
         constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
             int cc[U][R];
@@ -292,13 +292,18 @@ __global__ __launch_bounds__(256) void k_sell_wide(SellDev A, int s_begin, int s
     }
 }
 
+template <typename T> static const T* host_vals(const SellDev& A);
+template <> const double* host_vals<double>(const SellDev& A) { return A.val; }
+template <> const float* host_vals<float>(const SellDev& A) { return A.valf; }
+
 template <int MODE, int KW, typename T>
 static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const T* x, const T* b, T* y,
                             int k, const int* done, double* partials, T* zero_rows, hipStream_t st, int* nb_out)
 {
     const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
     const int nb = (waves + 3) / 4;
-    hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A, s_begin, s_end, use_order, nb, x, b, y, k, done, partials, zero_rows);
+    hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, s_begin, s_end, nb, use_order, x,
+                       A.slice_row, A.slice_w, b, y, k, done, partials, zero_rows);
     *nb_out = nb;
 }
 
@@ -313,10 +318,6 @@ int sell_wide_blocks(int n_slices, int k)
 // 4 slices (waves) per 256-thread block; 1, 2 and 8 measured the same within noise on C3
 static constexpr int sell_wpb() { return 4; }
 int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb(); }
-
-template <typename T> static const T* host_vals(const SellDev& A);
-template <> const double* host_vals<double>(const SellDev& A) { return A.val; }
-template <> const float* host_vals<float>(const SellDev& A) { return A.valf; }
 
 template <int MODE, int RPL, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
@@ -517,14 +518,14 @@ hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st)
 // One wavefront per output row; 16 B per lane per load (1 KiB per wave-instruction); deterministic
 // shuffle-tree reduction.  n and lda are multiples of 64, b has lda rows (zero padded).
 template <typename T> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<float> { typedef float type __attribute__((ext_vector_type(2))); };
 
 template <int KB, typename T>
 __global__ __launch_bounds__(256) void k_dense_gemv_add(const T* __restrict__ Ainv, int n, int lda,
                                                         const T* __restrict__ b, T* u, int ld, const int* done)
 {
-    const int stop = done ? *done : 0;
+    const int stop = load_flag(done);   // consulted before the store only
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
     constexpr int NA = TR * TJ / 256, NB = TJ * KC / 256;  // staged elements per thread
     __shared__ T a_s[TR][TJ + 1];
     __shared__ T b_s[TJ][KC];
-    const int stop = done ? *done : 0;
+    const int stop = load_flag(done);
     const int t = threadIdx.x, tr = t / 16, tc = t % 16;
     const int i0 = blockIdx.x * TR;
     T acc[CT];
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
 template <typename T>
 static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, const Ctrl* ctrl, hipStream_t st)
 {
-    const int* done = ctrl ? &ctrl->done : nullptr;
+    const int* done = ctrl ? &ctrl->done : never_done();
     const int nb = (n + 3) / 4;
     if (n <= 0) return hipSuccess;
     int c0 = 0;
