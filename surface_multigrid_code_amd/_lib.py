@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsmg.so")
+LIB_PATH = os.environ.get("SMG_LIB") or os.path.join(HERE, "lib", "libsmg.so")   # SMG_LIB: an alternate build (A/B measurements)
 
 SMG_HOST, SMG_DEVICE = 0, 1
 
