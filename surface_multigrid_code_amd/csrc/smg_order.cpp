@@ -421,7 +421,7 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     }
     S.n_slices = (int)S.slice_row.size() - 1;
     // fixed stride unless a few very wide slices would blow the storage up (then: compact panels, table-driven addressing)
-    static const int allow_stride = std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob
+    const int allow_stride = std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob, and the tests' way to the compact layout
     if (allow_stride && S.n_slices > 0 && wmax > 0 && (long)wmax * S.n_slices <= (5 * sum_w) / 2 + 64) {
         // columns requested before a slice's width is known: the smallest W that covers 90% of the slices (narrower slices read
         // padding there, which the stride guarantees to exist; wider ones continue table-driven)

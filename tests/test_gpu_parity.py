@@ -457,3 +457,30 @@ def test_speculative_split_phase_is_bit_identical(smg, oracle_mod):
             assert a[0] == b[0] and np.array_equal(a[2], b[2]) and np.array_equal(za, zb), (tol, max_iter)
         torch.cuda.synchronize()
     mg.set_stream(None)
+
+
+# ----------------------------------------------------------------------------------------------- SELL panel layouts
+@pytest.mark.parametrize("kind,k", [("mcf", 1), ("poisson", 3), ("mcf", 8)])
+def test_compact_and_fixed_pitch_panels_give_the_same_bits(smg, oracle_mod, kind, k, monkeypatch):
+    """Mesh operators are stored with a fixed panel pitch (panel address from the slice number alone, first columns requested
+    ahead of the slice table); matrices with a few very wide slices fall back to compact panels addressed through slice_off.
+    SMG_SELL_STRIDE=0 forces the fallback: kernels, cycles and solves must not change by a bit."""
+    p = subdiv_problem(kind=kind, k=k, n_sub=2)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SMG_SELL_STRIDE", mode)
+        mg = smg.Hierarchy.from_prolongs(p["Ps"])
+        mg.precompute(p["A"], p["known"])
+        res = []
+        for lv in range(mg.n_levels - 1):
+            n = mg.rows(lv)
+            r2 = np.random.default_rng(200 + lv)
+            B, u = r2.uniform(-1, 1, (n, k)), r2.uniform(-1, 1, (n, k))
+            res += [mg.A(lv, u), mg.relax(lv, B, u, 2), mg.vcycle(B, u, lv=lv)]
+            if lv + 1 < mg.n_levels:
+                res += [mg.restrict(lv, B), mg.prolong(lv, r2.uniform(-1, 1, (mg.rows(lv + 1), k)))]
+        conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-11, max_iter=30))
+        assert conv
+        out[mode] = res + [z, rh]
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
