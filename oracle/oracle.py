@@ -63,6 +63,8 @@ def lib():
     L.orc_data_unknown.argtypes = [vp, C.POINTER(ip)]
     L.orc_profile.argtypes = [vp, dp, C.POINTER(C.c_long), dp, C.POINTER(C.c_long)]
     L.orc_profile_reset.argtypes = [vp]
+    L.orc_set_parallel.argtypes = [vp, C.c_int, C.c_int, ip]
+    L.orc_enable_parallel.argtypes = [vp, C.c_int, C.c_int]
     L.orc_csc_times_dense.argtypes = [C.POINTER(_Csc), dp, C.c_int, C.c_int, dp, C.c_int]
     _lib = L
     return L
@@ -137,6 +139,21 @@ class OracleMG:
         if rc != 0:
             raise RuntimeError("oracle precompute failed rc=%d" % rc)
         self.n = n
+
+    # -- all-core comparator (NOT the reference's single-threaded path; SURVEY.md section 8d "fair CPU")
+    def set_parallel(self, color_ptrs, threads=0):
+        """color_ptrs[lv]: row offsets of contiguous, mutually independent row blocks of level lv (a multi-colouring the
+        system is numbered by), for every smoothed level.  Returns the number of OpenMP threads.  Results of sweeps and
+        products are bit-identical to the sequential run; only the residual norm is summed in another order."""
+        for lv, cp in enumerate(color_ptrs):
+            cp = np.ascontiguousarray(cp, dtype=np.int32)
+            rc = self.L.orc_set_parallel(self.h, lv, len(cp) - 1, _ip(cp))
+            if rc != 0:
+                raise RuntimeError("orc_set_parallel(level %d) failed rc=%d (blocks not independent?)" % (lv, rc))
+        return self.L.orc_enable_parallel(self.h, 1, int(threads))
+
+    def set_sequential(self):
+        self.L.orc_enable_parallel(self.h, 0, 0)
 
     # -- min_quad_with_fixed_mg_solve
     def solve(self, RHS, z0, known_val=None, tol=1e-3, max_iter=20):

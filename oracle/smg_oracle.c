@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ utilities */
 
@@ -226,6 +229,25 @@ void orc_csc_times_dense(const orc_csc *A, const double *X, int ldx, int k, doub
     }
 }
 
+/* below this many rows a loop is not worth a fork/join */
+#define ORC_PAR_MIN_ROWS 4096
+
+/* all-core mode only: Y = A X computed row-wise from AT = A^T (column i of AT = row i of A, ascending j): every Y(i,c) is
+ * the same running sum over ascending j as in orc_csc_times_dense, so the result is bit-identical. */
+static void csc_times_dense_rows(const orc_csc *AT, const double *X, int ldx, int k, double *Y, int ldy)
+{
+    for (int c = 0; c < k; c++) {
+        double *y = Y + (size_t)c * (size_t)ldy;
+        const double *x = X + (size_t)c * (size_t)ldx;
+#pragma omp parallel for schedule(static) if (AT->n_cols > ORC_PAR_MIN_ROWS)
+        for (int i = 0; i < AT->n_cols; i++) {
+            double s = 0.0;
+            for (int p = AT->colptr[i]; p < AT->colptr[i + 1]; p++) s += AT->val[p] * x[AT->rowidx[p]];
+            y[i] = s;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ sparse LDL^T */
 
 static void ldlt_free(orc_ldlt *s)
@@ -379,6 +401,11 @@ void orc_mg_destroy(orc_mg *mg)
     free(mg->lv);
     data_free(&mg->data);
     ldlt_free(&mg->solver);
+    for (int l = 0; l < mg->n_levels; l++) {
+        if (mg->color_ptr) free(mg->color_ptr[l]);
+        if (mg->AT) orc_csc_free(&mg->AT[l]);
+    }
+    free(mg->color_ptr); free(mg->n_colors); free(mg->AT);
     free(mg);
 }
 
@@ -427,6 +454,11 @@ static int precompute_tail(orc_mg *mg, int recompute_PT)
         for (int j = 0; j < L->A.n_cols; j++)
             for (int p = L->A.colptr[j]; p < L->A.colptr[j + 1]; p++)
                 if (L->A.rowidx[p] == j) L->A_diag[j] = L->A.val[p];
+    }
+    /* all-core mode: the row-wise images belong to the previous matrices */
+    if (mg->AT) for (int lv = 0; lv < mg->n_levels; lv++) {
+        orc_csc_free(&mg->AT[lv]);
+        if (mg->par) csc_transpose(&mg->AT[lv], &mg->lv[lv].A);
     }
     return ldlt_compute(&mg->solver, &mg->lv[mg->n_levels - 1].A);
 }
@@ -498,18 +530,21 @@ int orc_precompute_known(orc_mg *mg, int n, const int *colptr, const int *rowidx
 void orc_A(const orc_mg *mg, int lv, const double *u, int k, double *Au)
 {
     const orc_csc *A = &mg->lv[lv].A;
+    if (mg->par && mg->AT && mg->AT[lv].colptr) { csc_times_dense_rows(&mg->AT[lv], u, A->n_cols, k, Au, A->n_rows); return; }
     orc_csc_times_dense(A, u, A->n_cols, k, Au, A->n_rows);
 }
 /* mg_VCycle.cpp:72-81   Rx = mg[lv+1].PT * x */
 void orc_restrict(const orc_mg *mg, int lv, const double *x, int k, double *Rx)
 {
     const orc_csc *PT = &mg->lv[lv + 1].PT;
+    if (mg->par) { csc_times_dense_rows(&mg->lv[lv + 1].P, x, PT->n_cols, k, Rx, PT->n_rows); return; }   /* P = (PT)^T */
     orc_csc_times_dense(PT, x, PT->n_cols, k, Rx, PT->n_rows);
 }
 /* mg_VCycle.cpp:83-92   Px = mg[lv+1].P * x */
 void orc_prolong(const orc_mg *mg, int lv, const double *x, int k, double *Px)
 {
     const orc_csc *P = &mg->lv[lv + 1].P;
+    if (mg->par) { csc_times_dense_rows(&mg->lv[lv + 1].PT, x, P->n_cols, k, Px, P->n_rows); return; }   /* PT = P^T */
     orc_csc_times_dense(P, x, P->n_cols, k, Px, P->n_rows);
 }
 
@@ -523,6 +558,27 @@ void orc_relax(orc_mg *mg, int lv, const double *B, int k, int iters, double *u)
     const orc_csc *A = &mg->lv[lv].A;
     const double *diag = mg->lv[lv].A_diag;
     int n = A->n_rows;
+    if (mg->par && mg->color_ptr && mg->color_ptr[lv]) {
+        /* all-core mode: the same sweep, block by block; rows of a block do not reference each other, so sweeping a block
+         * in parallel reads and writes exactly what the sequential loop below does */
+        const int *cp = mg->color_ptr[lv];
+        for (int iter = 0; iter < iters; iter++)
+            for (int ri = 0; ri < k; ri++) {
+                double *uc = u + (size_t)ri * (size_t)n;
+                const double *bc = B + (size_t)ri * (size_t)n;
+                for (int c = 0; c < mg->n_colors[lv]; c++) {
+#pragma omp parallel for schedule(static) if (cp[c + 1] - cp[c] > ORC_PAR_MIN_ROWS)
+                    for (int colIdx = cp[c]; colIdx < cp[c + 1]; colIdx++) {
+                        double sum = 0;
+                        for (int p = A->colptr[colIdx]; p < A->colptr[colIdx + 1]; p++)
+                            if (A->rowidx[p] != colIdx) sum += A->val[p] * uc[A->rowidx[p]];
+                        uc[colIdx] = (bc[colIdx] - sum) / diag[colIdx];
+                    }
+                }
+            }
+        mg->t_relax += now_s() - t0; mg->c_relax++;
+        return;
+    }
     for (int iter = 0; iter < iters; iter++)
         for (int ri = 0; ri < k; ri++) {
             double *uc = u + (size_t)ri * (size_t)n;
@@ -563,14 +619,16 @@ void orc_vcycle(orc_mg *mg, const double *B, int pre, int post, int lv, double *
     double *Au = (double *)xmalloc((size_t)n * (size_t)k * sizeof(double));
     orc_A(mg, lv, u, k, Au);                           /* :40-41 */
     double *r = Au;                                    /* r = B - Au, :42 */
-    for (size_t t = 0; t < (size_t)n * (size_t)k; t++) r[t] = B[t] - Au[t];
+#pragma omp parallel for schedule(static) if (mg->par && n > ORC_PAR_MIN_ROWS)
+    for (long t = 0; t < (long)n * (long)k; t++) r[t] = B[t] - Au[t];
     double *rc = (double *)xmalloc((size_t)nc * (size_t)k * sizeof(double));
     orc_restrict(mg, lv, r, k, rc);                    /* :43-44 */
     double *uc = (double *)xcalloc((size_t)nc * (size_t)k, sizeof(double)); /* :46-47 */
     orc_vcycle(mg, rc, pre, post, lv + 1, uc, k);      /* :48 */
     double *puc = r;                                   /* reuse the buffer */
     orc_prolong(mg, lv, uc, k, puc);                   /* :51-52 */
-    for (size_t t = 0; t < (size_t)n * (size_t)k; t++) u[t] = u[t] + puc[t]; /* :53 */
+#pragma omp parallel for schedule(static) if (mg->par && n > ORC_PAR_MIN_ROWS)
+    for (long t = 0; t < (long)n * (long)k; t++) u[t] = u[t] + puc[t]; /* :53 */
     free(rc); free(uc); free(Au);
     orc_relax(mg, lv, B, k, post, u);                  /* :57 */
 }
@@ -582,6 +640,14 @@ static double residual_norm(const orc_mg *mg, const double *RHS, const double *z
     int n = mg->lv[0].A.n_rows;
     orc_A(mg, 0, z, k, tmp);
     double ss = 0.0;
+    if (mg->par) {   /* all-core mode: a parallel reduction (summation order differs from Eigen's in the last digits) */
+#pragma omp parallel for schedule(static) reduction(+ : ss)
+        for (long t = 0; t < (long)n * (long)k; t++) {
+            double d = RHS[t] - tmp[t];
+            ss += d * d;
+        }
+        return sqrt(ss);
+    }
     for (size_t t = 0; t < (size_t)n * (size_t)k; t++) {
         double d = RHS[t] - tmp[t];
         ss += d * d;
@@ -673,4 +739,46 @@ void orc_profile(const orc_mg *mg, double *t_relax, long *c_relax, double *t_vcy
 {
     *t_relax = mg->t_relax; *c_relax = mg->c_relax; *t_vcycle = mg->t_vcycle; *c_vcycle = mg->c_vcycle;
 }
+/* ---- all-core mode (see header) */
+int orc_set_parallel(orc_mg *mg, int lv, int n_colors, const int *color_ptr)
+{
+    if (!mg || lv < 0 || lv >= mg->n_levels || n_colors < 1 || !color_ptr) return -1;
+    if (!mg->color_ptr) {
+        mg->color_ptr = (int **)xcalloc((size_t)mg->n_levels, sizeof(int *));
+        mg->n_colors = (int *)xcalloc((size_t)mg->n_levels, sizeof(int));
+        mg->AT = (orc_csc *)xcalloc((size_t)mg->n_levels, sizeof(orc_csc));
+    }
+    const orc_csc *A = &mg->lv[lv].A;
+    if (color_ptr[0] != 0 || color_ptr[n_colors] != A->n_rows) return -1;
+    /* the blocks must really be independent sets, or the parallel sweep would not be the sequential one */
+    for (int c = 0; c < n_colors; c++)
+        for (int j = color_ptr[c]; j < color_ptr[c + 1]; j++)
+            for (int p = A->colptr[j]; p < A->colptr[j + 1]; p++) {
+                int i = A->rowidx[p];
+                if (i != j && i >= color_ptr[c] && i < color_ptr[c + 1]) return -2;
+            }
+    free(mg->color_ptr[lv]);
+    mg->color_ptr[lv] = (int *)xmalloc((size_t)(n_colors + 1) * sizeof(int));
+    memcpy(mg->color_ptr[lv], color_ptr, (size_t)(n_colors + 1) * sizeof(int));
+    mg->n_colors[lv] = n_colors;
+    orc_csc_free(&mg->AT[lv]);
+    csc_transpose(&mg->AT[lv], A);
+    return 0;
+}
+int orc_enable_parallel(orc_mg *mg, int on, int threads)
+{
+    mg->par = on ? 1 : 0;
+    if (on) for (int lv = 0; lv < mg->n_levels; lv++) {   /* every level's A needs its row-wise image */
+        if (!mg->AT) mg->AT = (orc_csc *)xcalloc((size_t)mg->n_levels, sizeof(orc_csc));
+        if (!mg->AT[lv].colptr && mg->lv[lv].A.colptr) csc_transpose(&mg->AT[lv], &mg->lv[lv].A);
+    }
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    return on ? omp_get_max_threads() : 1;
+#else
+    (void)threads;
+    return 1;
+#endif
+}
+
 void orc_profile_reset(orc_mg *mg) { mg->t_relax = mg->t_vcycle = 0.0; mg->c_relax = mg->c_vcycle = 0; }

@@ -68,6 +68,11 @@ typedef struct {
     int verbose;            /* 0: silent (the reference prints unconditionally) */
     /* PROFC_NODE accumulators (profc.h): seconds + counts */
     double t_relax, t_vcycle; long c_relax, c_vcycle;
+    /* "fair CPU" comparator, off by default: see orc_set_parallel */
+    int par;                /* 1: OpenMP all-core mode */
+    int **color_ptr;        /* per level: n_colors + 1 row offsets of the independent blocks, or NULL */
+    int *n_colors;
+    orc_csc *AT;            /* per level: A^T (the row-wise image of A), built by orc_set_parallel */
 } orc_mg;
 
 /* ---- hierarchy container ---- */
@@ -114,6 +119,16 @@ const orc_csc *orc_data_LHS(const orc_mg *mg);
 const orc_csc *orc_data_Auk(const orc_mg *mg);
 int orc_data_unknown(const orc_mg *mg, const int **idx);
 void orc_profile(const orc_mg *mg, double *t_relax, long *c_relax, double *t_vcycle, long *c_vcycle);
+
+/* ---- all-core mode: NOT a restatement of the reference (whose solve is single-threaded), but the comparator SURVEY.md
+ * section 8d asks for beside it.  The caller hands in, per smoothed level, a partition of the rows into contiguous blocks
+ * whose rows are mutually independent (a multi-colouring in whose order the system is numbered -- then the reference's
+ * lexicographic sweep IS the multi-colour sweep and each block can be swept in parallel without changing a bit).  Sparse
+ * products run row-wise over the stored transposes (same ascending-column accumulation per output element, same bits);
+ * only the residual norm (parallel reduction) may differ in the last digits.  Call after orc_precompute*.  threads <= 0:
+ * the OpenMP default.  Returns the number of threads in use (1 if built without OpenMP). */
+int orc_set_parallel(orc_mg *mg, int lv, int n_colors, const int *color_ptr);
+int orc_enable_parallel(orc_mg *mg, int on, int threads);
 void orc_profile_reset(orc_mg *mg);
 
 /* ---- generic sparse helpers (Eigen / libigl semantics), exported for tests ---- */

@@ -76,3 +76,51 @@ def test_outer_loop_bookkeeping(oracle_mod):
         assert np.array_equal(u[:, c], o3.relax(0, p3["RHS"][:, c], p3["z0"][:, c], 2)[:, 0])
     prof = o3.profile()
     assert prof["MG: relaxation"][0] == 4
+
+
+def test_all_core_mode_of_the_oracle_is_the_same_arithmetic(oracle_mod):
+    """bench.py's `cpu_allcore` leg runs the oracle with OpenMP over the colour blocks of a colour-major numbering.  Rows of a
+    block are independent, products run row-wise in the same ascending order: the iterate must be bit-identical to the
+    sequential (reference-order) run on the same renumbered system; only the residual norm is reduced in another order."""
+    import scipy.sparse as sp
+    from problems import subdiv_problem
+    p = subdiv_problem(kind="mcf", k=2, n_sub=2)
+    o = oracle_mod.OracleMG(p["Ps"])
+    o.precompute(p["A"])
+    L = o.n_levels
+
+    def greedy(A):
+        A = A.tocsr()
+        col = -np.ones(A.shape[0], int)
+        for i in range(A.shape[0]):
+            used = set(col[A.indices[A.indptr[i]:A.indptr[i + 1]]])
+            c = 0
+            while c in used:
+                c += 1
+            col[i] = c
+        return col
+
+    perms, cps = [], []
+    for lv in range(L - 1):
+        c = greedy(o.level_A(lv))
+        perms.append(np.argsort(c, kind="stable"))
+        cps.append(np.concatenate([[0], np.cumsum(np.bincount(c))]))
+    perms.append(np.arange(o.rows(L - 1)))
+    A0 = sp.csr_matrix(p["A"])[perms[0]][:, perms[0]]
+    Ps = [sp.csr_matrix(p["Ps"][l])[perms[l]][:, perms[l + 1]] for l in range(L - 1)]
+    o2 = oracle_mod.OracleMG(Ps)
+    o2.precompute(A0)
+    rhs, z0 = p["RHS"][perms[0]], p["z0"][perms[0]]
+    seq = o2.solve(rhs, z0, tol=1e-10, max_iter=30)
+    assert o2.set_parallel(cps, 4) >= 1
+    par = o2.solve(rhs, z0, tol=1e-10, max_iter=30)
+    assert seq[0] and par[0] and len(seq[2]) == len(par[2])
+    assert np.array_equal(seq[1], par[1])
+    assert np.allclose(seq[2], par[2], rtol=1e-10, atol=0)
+    # blocks that are not independent sets are refused
+    with pytest.raises(RuntimeError):
+        o2.set_parallel([np.array([0, o2.rows(0)])] + cps[1:], 2)
+    # and the renumbered problem is the same problem
+    back = np.empty_like(seq[1]); back[perms[0]] = seq[1]
+    ref = o.solve(p["RHS"], p["z0"], tol=1e-10, max_iter=30)
+    assert np.linalg.norm(back - ref[1]) <= 1e-7 * np.linalg.norm(ref[1])
