@@ -2,6 +2,7 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstdint>
 #include <numeric>
@@ -362,11 +363,11 @@ bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, cons
     return true;
 }
 
-Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors)
+Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors, const std::vector<int>* rcm_in)
 {
     int n = A.nr;
     Ordering o;
-    std::vector<int> rcm = rcm_order(A);  // new -> old
+    std::vector<int> rcm = rcm_in ? *rcm_in : rcm_order(A);  // new -> old
     std::vector<int> color = preset_colors ? *preset_colors : color_graph(A, rcm);
     if (preset_colors) compact_colors(color);
     int ncol = count_colors(color);
@@ -394,6 +395,30 @@ Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_c
     for (int i = 0; i < n; i++) o.iperm[o.perm[i]] = i;
     if (n == 0) o.color_ptr = {0, 0};
     return o;
+}
+
+std::vector<int> induced_order(const Csr& P, const std::vector<int>& coarse_rank)
+{
+    const int n = P.nr, nc = P.nc;
+    std::vector<int> key(n);
+    parallel_for(n, 65536, [&](long r0, long r1) {
+        for (long i = r0; i < r1; i++) {
+            int par = -1;
+            double best = -1.0;
+            for (int p = P.ptr[i]; p < P.ptr[i + 1]; p++) {
+                const double w = std::fabs(P.val[p]);
+                if (w > best) { best = w; par = P.col[p]; }
+            }
+            key[i] = par >= 0 ? coarse_rank[par] : nc;   // rows without a parent go last
+        }
+    });
+    // stable counting sort by parent position
+    std::vector<int> start(nc + 2, 0);
+    for (int i = 0; i < n; i++) start[key[i] + 1]++;
+    for (int k = 0; k <= nc; k++) start[k + 1] += start[k];
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[start[key[i]]++] = i;
+    return order;
 }
 
 Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order)
@@ -438,18 +463,20 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);
     S.entry.assign(tot, -1);
-    for (int s = 0; s < S.n_slices; s++) {
-        size_t base = (size_t)C * (size_t)S.slice_off[s];
-        for (int r = S.slice_row[s]; r < S.slice_row[s + 1]; r++) {
-            int lane = r - S.slice_row[s];
-            int j = 0;
-            for (int p = A.ptr[r]; p < A.ptr[r + 1]; p++, j++) {
-                S.col[base + (size_t)j * C + lane] = A.col[p];
-                S.val[base + (size_t)j * C + lane] = A.val[p];
-                S.entry[base + (size_t)j * C + lane] = p;
+    parallel_for(S.n_slices, 512, [&](long s0, long s1) {
+        for (long s = s0; s < s1; s++) {
+            size_t base = (size_t)C * (size_t)S.slice_off[s];
+            for (int r = S.slice_row[s]; r < S.slice_row[s + 1]; r++) {
+                int lane = r - S.slice_row[s];
+                int j = 0;
+                for (int p = A.ptr[r]; p < A.ptr[r + 1]; p++, j++) {
+                    S.col[base + (size_t)j * C + lane] = A.col[p];
+                    S.val[base + (size_t)j * C + lane] = A.val[p];
+                    S.entry[base + (size_t)j * C + lane] = p;
+                }
             }
         }
-    }
+    });
     if (region_order && S.color_slice_ptr.size() > 2) {
         // key = position of the slice inside its colour block, in [0,1): rows of a colour are in RCM order, so equal
         // keys across colours are the same region of the mesh

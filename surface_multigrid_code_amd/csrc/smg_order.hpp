@@ -24,7 +24,12 @@ struct Ordering {
 };
 
 std::vector<int> rcm_order(const Csr& A);                    // returns new -> old
-Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* preset_colors = nullptr);  // A: square, structurally symmetric
+// Locality order of a fine level induced by its coarse level: fine vertex i goes where its parent -- the column of the largest
+// weight in row i of P (fine x coarse) -- sits in the coarse order (coarse_rank: old -> position), children of one parent
+// together.  O(nnz(P)), against a sequential breadth-first search over the fine matrix for RCM.
+std::vector<int> induced_order(const Csr& P, const std::vector<int>& coarse_rank);
+// A: square, structurally symmetric.  rcm: a precomputed rcm_order(A) (lets callers run the per-level RCMs concurrently).
+Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* preset_colors = nullptr, const std::vector<int>* rcm = nullptr);
 // 4-colouring of a mid-point-subdivided level from a 4-colouring of its parent; false if P / A do not fit
 bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, const Csr& A, std::vector<int>& out);
 Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)

@@ -2,10 +2,57 @@
 #include "smg_sparse.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 #include <utility>
 
 namespace smg {
+
+// ---------------------------------------------------------------------------------------------- host parallelism
+int host_threads()
+{
+    static const int n = [] {
+        const char* v = std::getenv("SMG_HOST_THREADS");
+        int t = v && *v ? std::atoi(v) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, t);
+    }();
+    return n;
+}
+static thread_local bool tl_inside_parallel = false;
+
+void parallel_for(long n, long grain, const std::function<void(long, long)>& fn)
+{
+    if (n <= 0) return;
+    const int T = (int)std::min<long>(host_threads(), (n + grain - 1) / std::max<long>(grain, 1));
+    if (T <= 1 || tl_inside_parallel) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    auto body = [&](int t) {
+        tl_inside_parallel = true;
+        const long b = n * t / T, e = n * (t + 1) / T;
+        if (e > b) fn(b, e);
+        tl_inside_parallel = false;
+    };
+    for (int t = 1; t < T; t++) th.emplace_back(body, t);
+    body(0);
+    for (auto& x : th) x.join();
+}
+
+void parallel_tasks(const std::vector<std::function<void()>>& tasks)
+{
+    if (tasks.empty()) return;
+    if (tasks.size() == 1 || host_threads() <= 1 || tl_inside_parallel) { for (auto& f : tasks) f(); return; }
+    // tasks keep the right to parallel_for themselves: they run on plain threads, not flagged as "inside"
+    std::atomic<size_t> next{0};
+    const int T = (int)std::min<size_t>(tasks.size(), (size_t)host_threads());
+    auto worker = [&] { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) tasks[i](); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+}
 
 Csr csr_from_arrays(int nr, int nc, const int* ptr, const int* col, const double* val)
 {
@@ -69,46 +116,51 @@ Csr spgemm(const Csr& A, const Csr& B)
     Csr C;
     C.nr = A.nr; C.nc = B.nc;
     C.ptr.assign(C.nr + 1, 0);
-    std::vector<int> mark(B.nc, -1);
-    std::vector<double> acc(B.nc, 0.0);
-    std::vector<int> idx;
-    idx.reserve(64);
-    // symbolic pass (row sizes)
-    for (int i = 0; i < A.nr; i++) {
-        int cnt = 0;
-        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
-            int k = A.col[pa];
-            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
-                int j = B.col[pb];
-                if (mark[j] != i) { mark[j] = i; cnt++; }
+    // symbolic pass (row sizes), rows in parallel: every thread owns a marker array
+    parallel_for(A.nr, 4096, [&](long r0, long r1) {
+        std::vector<int> mark(B.nc, -1);
+        for (long i = r0; i < r1; i++) {
+            int cnt = 0;
+            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+                const int k = A.col[pa];
+                for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                    const int j = B.col[pb];
+                    if (mark[j] != (int)i) { mark[j] = (int)i; cnt++; }
+                }
             }
+            C.ptr[i + 1] = cnt;
         }
-        C.ptr[i + 1] = C.ptr[i] + cnt;
-    }
+    });
+    for (int i = 0; i < C.nr; i++) C.ptr[i + 1] += C.ptr[i];
     C.col.resize(C.ptr[C.nr]); C.val.resize(C.ptr[C.nr]);
-    std::fill(mark.begin(), mark.end(), -1);
-    for (int i = 0; i < A.nr; i++) {
-        idx.clear();
-        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
-            int k = A.col[pa];
-            double a = A.val[pa];
-            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
-                int j = B.col[pb];
-                if (mark[j] != i) { mark[j] = i; acc[j] = a * B.val[pb]; idx.push_back(j); }
-                else acc[j] += a * B.val[pb];
+    // numeric pass: per row the same ascending-k accumulation as before
+    parallel_for(A.nr, 4096, [&](long r0, long r1) {
+        std::vector<int> mark(B.nc, -1);
+        std::vector<double> acc(B.nc, 0.0);
+        std::vector<int> idx;
+        idx.reserve(64);
+        for (long i = r0; i < r1; i++) {
+            idx.clear();
+            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+                const int k = A.col[pa];
+                const double a = A.val[pa];
+                for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                    const int j = B.col[pb];
+                    if (mark[j] != (int)i) { mark[j] = (int)i; acc[j] = a * B.val[pb]; idx.push_back(j); }
+                    else acc[j] += a * B.val[pb];
+                }
             }
+            std::sort(idx.begin(), idx.end());
+            const int base = C.ptr[i];
+            for (size_t t = 0; t < idx.size(); t++) { C.col[base + t] = idx[t]; C.val[base + t] = acc[idx[t]]; }
         }
-        std::sort(idx.begin(), idx.end());
-        int base = C.ptr[i];
-        for (size_t t = 0; t < idx.size(); t++) { C.col[base + t] = idx[t]; C.val[base + t] = acc[idx[t]]; }
-    }
+    });
     return C;
 }
 
 Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* cols, std::vector<int>* src)
 {
     Csr Y;
-    if (src) src->clear();
     Y.nr = rows ? (int)rows->size() : X.nr;
     Y.nc = cols ? (int)cols->size() : X.nc;
     Y.ptr.assign(Y.nr + 1, 0);
@@ -117,19 +169,36 @@ Csr slice(const Csr& X, const std::vector<int>* rows, const std::vector<int>* co
         cmap.assign(X.nc, -1);
         for (int j = 0; j < Y.nc; j++) cmap[(*cols)[j]] = j;
     }
-    std::vector<std::pair<int, int>> row;  // (new column, index into X)
-    for (int i = 0; i < Y.nr; i++) {
-        int r = rows ? (*rows)[i] : i;
-        row.clear();
-        for (int p = X.ptr[r]; p < X.ptr[r + 1]; p++) {
-            int j = cols ? cmap[X.col[p]] : X.col[p];
-            if (j >= 0) row.emplace_back(j, p);
+    // pass 1: row sizes
+    parallel_for(Y.nr, 16384, [&](long r0, long r1) {
+        for (long i = r0; i < r1; i++) {
+            const int r = rows ? (*rows)[i] : (int)i;
+            int cnt = 0;
+            if (!cols) cnt = X.ptr[r + 1] - X.ptr[r];
+            else for (int p = X.ptr[r]; p < X.ptr[r + 1]; p++) cnt += cmap[X.col[p]] >= 0;
+            Y.ptr[i + 1] = cnt;
         }
-        if (cols) std::sort(row.begin(), row.end(),
-                            [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
-        for (auto& e : row) { Y.col.push_back(e.first); Y.val.push_back(X.val[e.second]); if (src) src->push_back(e.second); }
-        Y.ptr[i + 1] = (int)Y.col.size();
-    }
+    });
+    for (int i = 0; i < Y.nr; i++) Y.ptr[i + 1] += Y.ptr[i];
+    const long nnz = Y.ptr[Y.nr];
+    Y.col.resize(nnz); Y.val.resize(nnz);
+    if (src) src->assign(nnz, 0);
+    // pass 2: fill, rows sorted by new column
+    parallel_for(Y.nr, 16384, [&](long r0, long r1) {
+        std::vector<std::pair<int, int>> row;  // (new column, index into X)
+        for (long i = r0; i < r1; i++) {
+            const int r = rows ? (*rows)[i] : (int)i;
+            row.clear();
+            for (int p = X.ptr[r]; p < X.ptr[r + 1]; p++) {
+                const int j = cols ? cmap[X.col[p]] : X.col[p];
+                if (j >= 0) row.emplace_back(j, p);
+            }
+            if (cols) std::sort(row.begin(), row.end(),
+                                [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+            long o = Y.ptr[i];
+            for (auto& e : row) { Y.col[o] = e.first; Y.val[o] = X.val[e.second]; if (src) (*src)[o] = e.second; o++; }
+        }
+    });
     return Y;
 }
 

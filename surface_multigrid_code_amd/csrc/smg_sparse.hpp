@@ -5,6 +5,7 @@
 // matrices CSR == CSC; P and PT are both kept explicitly, as the reference does.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace smg {
@@ -49,6 +50,14 @@ struct Recipe {
     std::vector<double> coef;
 };
 void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, Recipe& R);
+
+// Host parallelism for the precompute (the reference's precompute is single-threaded Eigen; here it must not dwarf a solve
+// that takes milliseconds).  fn(begin, end) is called on disjoint chunks of [0, n) from up to host_threads() threads; chunks are
+// contiguous and their outputs position-independent, so every result is identical to the sequential one.
+int host_threads();   // SMG_HOST_THREADS, default min(hardware threads, 32)
+void parallel_for(long n, long grain, const std::function<void(long, long)>& fn);
+// run independent tasks concurrently (each may itself call parallel_for: nested calls run inline)
+void parallel_tasks(const std::vector<std::function<void()>>& tasks);
 
 // y = A x for dense column-major blocks (host; used only by precompute-time checks and tools)
 void spmv_host(const Csr& A, const double* x, double* y);
