@@ -307,6 +307,30 @@ static void compact_colors(std::vector<int>& color)
     for (int& c : color) c = remap[c];
 }
 
+// A vertex whose neighbours form closed cycles (every neighbour has exactly two neighbours inside the neighbourhood: a closed
+// fan of triangles) of odd total length sits at the hub of an odd wheel, which needs 4 colours.  Almost every triangle mesh has
+// one (any interior vertex of odd valence), and then trying to dissolve the fourth class is a search that cannot succeed.
+static bool has_odd_wheel(const Csr& A)
+{
+    std::vector<char> in(A.nr, 0);
+    for (int v = 0; v < A.nr; v++) {
+        int d = 0;
+        for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) if (A.col[p] != v) { in[A.col[p]] = 1; d++; }
+        bool wheel = (d % 2 == 1) && d >= 3;
+        if (wheel)
+            for (int p = A.ptr[v]; p < A.ptr[v + 1] && wheel; p++) {
+                const int u = A.col[p];
+                if (u == v) continue;
+                int ring = 0;
+                for (int q = A.ptr[u]; q < A.ptr[u + 1]; q++) if (A.col[q] != u && A.col[q] != v && in[A.col[q]]) ring++;
+                if (ring != 2) wheel = false;
+            }
+        for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) in[A.col[p]] = 0;
+        if (wheel) return true;
+    }
+    return false;
+}
+
 static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
 {
     std::vector<int> best, cur;
@@ -326,8 +350,9 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
         if (greedy_color(A, order, cur) <= nc) { best = cur; compact_colors(best); }
     }
     nbest = count_colors(best);
-    // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle)
-    for (int guard = 0; guard < 6 && nbest > 3; guard++) {
+    // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle, 4 with an odd wheel)
+    const int floor_colors = (nbest > 3 && has_odd_wheel(A)) ? 4 : 3;
+    for (int guard = 0; guard < 6 && nbest > floor_colors; guard++) {
         cur = best;
         const bool emptied = dissolve_top_class(A, cur, nbest - 1);
         best = cur;  // partial progress is kept: the colouring stays valid
