@@ -308,10 +308,19 @@ def main():
                 out["cpu_allcore"] = cpu_allcore(mg, A, rhs_h)
             except Exception as e:  # the comparator is informational: never lose the bench line over it
                 out["cpu_allcore"] = {"error": str(e)}
-        print(json.dumps(out), flush=True)
+    # tear the process group down BEFORE the line is printed: RCCL may write to stdout when a communicator is created or
+    # destroyed, and the JSON must be the last line
     if world > 1 or force_split:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:   # C-level stdio of the libraries (RCCL prints its path there) is block-buffered on a pipe: drain it first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
