@@ -484,3 +484,44 @@ def test_compact_and_fixed_pitch_panels_give_the_same_bits(smg, oracle_mod, kind
         out[mode] = res + [z, rh]
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------------- tiny and ragged systems
+def _path_matrix(n):
+    return sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(n, n)).tocsr()
+
+
+def _path_interp(n):
+    nc = (n + 1) // 2
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        if i % 2 == 0:
+            rows.append(i); cols.append(i // 2); vals.append(1.0)
+        else:
+            rows += [i, i]; cols += [i // 2, min(i // 2 + 1, nc - 1)]; vals += [0.5, 0.5]
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n, nc))
+
+
+@pytest.mark.parametrize("n,levels,k,known", [(3, 2, 1, None), (10, 2, 1, None), (63, 2, 1, None), (64, 2, 2, None), (65, 2, 1, None),
+                                              (129, 2, 3, None), (37, 3, 5, None), (50, 2, 2, [0, 7, 49]), (30, 2, 1, "all but 3")])
+def test_tiny_and_ragged_systems(smg, oracle_mod, n, levels, k, known):
+    """Systems smaller than one slice, sizes around the 64-row slice boundary, a 19-row coarsest level, and constraint sets that
+    leave three unknowns: same answers as the reference algorithm (iteration counts within 2: multi-colour vs lexicographic)."""
+    Ps, m = [], n
+    for _ in range(levels - 1):
+        Ps.append(_path_interp(m)); m = (m + 1) // 2
+    A = _path_matrix(n)
+    if known == "all but 3":
+        known = np.setdiff1d(np.arange(n), [3, 4, 20])
+    kn = None if known is None else np.asarray(known, np.int32)
+    rng = np.random.default_rng(1)
+    mg = smg.Hierarchy.from_prolongs(Ps); mg.precompute(A, kn)
+    o = oracle_mod.OracleMG(Ps); o.precompute(A, kn)
+    rhs, z0 = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+    kv = rng.uniform(-1, 1, (len(kn), k)) if kn is not None else None
+    a = mg.solve(rhs, z0, kv, smg.SolveOpts(tol=1e-10, max_iter=60))
+    b = o.solve(rhs, z0, kv, tol=1e-10, max_iter=60)
+    assert a[0] and b[0] and abs(len(a[2]) - len(b[2])) <= 2
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-8 * max(np.linalg.norm(b[1]), 1e-300)
+    if kn is not None:
+        assert np.array_equal(a[1][kn], kv)
