@@ -684,47 +684,59 @@ hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl
     return hipGetLastError();
 }
 
-// Blocked Gauss-Jordan inversion (no pivoting; the matrix is SPD), block size 32, 64x64 update tiles.
-constexpr int GJ_NB = 32;
+// Blocked Gauss-Jordan inversion (no pivoting; the matrix is SPD), block size 64, 64x64 update tiles.  Every step streams
+// the whole matrix once (read + write), so the block size is the number of passes: 64 halves the traffic of 32; the update
+// walks the 64 pivot columns in two halves of 32 to stay inside 64 KB of LDS.
+constexpr int GJ_NB = 64;
+constexpr int GJ_H = 32;   // sub-panel width staged through LDS
 
+// inverse of the 64 x 64 pivot block, one workgroup, 4 elements per thread
 __global__ __launch_bounds__(1024) void k_gj_diag(const double* M, int n, int kb, double* dinv)
 {
     __shared__ double a[GJ_NB][GJ_NB + 1];
-    const int i = threadIdx.x / GJ_NB, j = threadIdx.x % GJ_NB;
     const int K = kb * GJ_NB;
-    a[i][j] = M[(size_t)(K + i) * n + K + j];
+    const int j = threadIdx.x % GJ_NB, i0 = threadIdx.x / GJ_NB;   // rows i0, i0 + 16, i0 + 32, i0 + 48
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[i0 + 16 * q][j] = M[(size_t)(K + i0 + 16 * q) * n + K + j];
     __syncthreads();
     for (int p = 0; p < GJ_NB; p++) {
-        const double piv = a[p][p], f = a[i][p], r = a[p][j], cur = a[i][j];
+        const double d = 1.0 / a[p][p], r = a[p][j];
+        double f[4], cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { f[q] = a[i0 + 16 * q][p]; cur[q] = a[i0 + 16 * q][j]; }
         __syncthreads();
-        const double d = 1.0 / piv;
-        double val;
-        if (i == p) val = (j == p) ? d : r * d;
-        else val = (j == p) ? -(f * d) : cur - f * (r * d);
-        a[i][j] = val;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + 16 * q;
+            double val;
+            if (i == p) val = (j == p) ? d : r * d;
+            else val = (j == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
+            a[i][j] = val;
+        }
         __syncthreads();
     }
-    dinv[i * GJ_NB + j] = a[i][j];
+#pragma unroll
+    for (int q = 0; q < 4; q++) dinv[(i0 + 16 * q) * GJ_NB + j] = a[i0 + 16 * q][j];
 }
 
-// block x handles columns [64x, 64x+64) of the scaled pivot row panel and rows [64x, 64x+64) of the column panel
+// block x handles columns [32x, 32x+32) of the scaled pivot row panel and rows [32x, 32x+32) of the column panel
 __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int kb, const double* dinv, double* rowp,
                                                    double* colp)
 {
     __shared__ double d_s[GJ_NB][GJ_NB + 1];
-    __shared__ double m_s[GJ_NB][64 + 1];
+    __shared__ double m_s[GJ_NB][GJ_H + 1];
     const int K = kb * GJ_NB;
-    const int j0 = blockIdx.x * 64;
+    const int j0 = blockIdx.x * GJ_H;
     for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += 256) d_s[t / GJ_NB][t % GJ_NB] = dinv[t];
-    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) m_s[t / 64][t % 64] = M[(size_t)(K + t / 64) * n + j0 + t % 64];
-    // column panel copy: rows j0..j0+63, columns K..K+31
-    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) {
+    for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) m_s[t / GJ_H][t % GJ_H] = M[(size_t)(K + t / GJ_H) * n + j0 + t % GJ_H];
+    // column panel copy: rows j0..j0+31, columns K..K+63
+    for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) {
         const int i = j0 + t / GJ_NB, c = t % GJ_NB;
         colp[(size_t)i * GJ_NB + c] = M[(size_t)i * n + K + c];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) {
-        const int r = t / 64, c = t % 64, j = j0 + c;
+    for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) {
+        const int r = t / GJ_H, c = t % GJ_H, j = j0 + c;
         double v;
         if (j >= K && j < K + GJ_NB) v = d_s[r][j - K];
         else {
@@ -738,41 +750,47 @@ __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int k
 
 __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* rowp, const double* colp)
 {
-    __shared__ double c_s[64][GJ_NB + 1];
-    __shared__ double r_s[GJ_NB][64 + 1];
+#pragma clang fp contract(fast)   // the inverse is compared against LDL^T to 1e-11, not bit for bit: let the compiler fuse here
+    __shared__ double c_s[64][GJ_H + 1];
+    __shared__ double r_s[GJ_H][64 + 1];
     const int K = kb * GJ_NB;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-    for (int t = threadIdx.x; t < 64 * GJ_NB; t += 256) c_s[t / GJ_NB][t % GJ_NB] = colp[(size_t)(i0 + t / GJ_NB) * GJ_NB + t % GJ_NB];
-    for (int t = threadIdx.x; t < GJ_NB * 64; t += 256) r_s[t / 64][t % 64] = rowp[(size_t)(t / 64) * n + j0 + t % 64];
-    __syncthreads();
     const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[a][c] = 0.0;
+    const bool tile_in_pivot_rows = (i0 >= K && i0 < K + GJ_NB);   // 64-row tiles never straddle the 64-row pivot block
+    for (int h = 0; h < GJ_NB; h += GJ_H) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 64 * GJ_H; t += 256) c_s[t / GJ_H][t % GJ_H] = colp[(size_t)(i0 + t / GJ_H) * GJ_NB + h + t % GJ_H];
+        for (int t = threadIdx.x; t < GJ_H * 64; t += 256) r_s[t / 64][t % 64] = rowp[(size_t)(h + t / 64) * n + j0 + t % 64];
+        __syncthreads();
+        if (!tile_in_pivot_rows) {
 #pragma unroll 2
-    for (int t = 0; t < GJ_NB; t++) {
-        double cv[4], rv[4];
+            for (int t = 0; t < GJ_H; t++) {
+                double cv[4], rv[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) cv[a] = c_s[ti + 16 * a][t];
+                for (int a = 0; a < 4; a++) cv[a] = c_s[ti + 16 * a][t];
 #pragma unroll
-        for (int c = 0; c < 4; c++) rv[c] = r_s[t][tj + 16 * c];
+                for (int c = 0; c < 4; c++) rv[c] = r_s[t][tj + 16 * c];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+                for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[a][c] += cv[a] * rv[c];
+                    for (int c = 0; c < 4; c++) acc[a][c] += cv[a] * rv[c];
+            }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = i0 + ti + 16 * a;
-        const bool ipiv = (i >= K && i < K + GJ_NB);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int j = j0 + tj + 16 * c;
             const bool jpiv = (j >= K && j < K + GJ_NB);
             double* m = M + (size_t)i * n + j;
-            if (ipiv) *m = r_s[i - K][tj + 16 * c];
+            if (tile_in_pivot_rows) *m = rowp[(size_t)(i - K) * n + j];
             else *m = (jpiv ? 0.0 : *m) - acc[a][c];
         }
     }
@@ -787,7 +805,7 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
     double* dinv = colp + (size_t)n * GJ_NB;
     for (int kb = 0; kb < n / GJ_NB; kb++) {
         hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(1024), 0, st, M, n, kb, dinv);
-        hipLaunchKernelGGL(k_gj_panels, dim3(n / 64), dim3(256), 0, st, M, n, kb, dinv, rowp, colp);
+        hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv, rowp, colp);
         hipLaunchKernelGGL(k_gj_update, dim3(n / 64, n / 64), dim3(256), 0, st, M, n, kb, rowp, colp);
     }
     return hipGetLastError();
