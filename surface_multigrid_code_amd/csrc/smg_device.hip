@@ -690,7 +690,8 @@ hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl
 constexpr int GJ_NB = 64;
 constexpr int GJ_H = 32;   // sub-panel width staged through LDS
 
-// inverse of the 64 x 64 pivot block, one workgroup, 4 elements per thread
+// inverse of the 64 x 64 pivot block, one workgroup, 4 elements per thread.  (A variant that keeps the elements in registers and
+// passes only row p / column p through LDS with one barrier per pivot measured slower: 53 vs 35 us.)
 __global__ __launch_bounds__(1024) void k_gj_diag(const double* M, int n, int kb, double* dinv)
 {
     __shared__ double a[GJ_NB][GJ_NB + 1];
@@ -748,50 +749,52 @@ __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int k
     }
 }
 
-__global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* rowp, const double* colp)
+// Trailing update  M -= colp (n x 64) * rowp (64 x n)  on the fp64 matrix cores: the one GEMM-shaped piece of the library.
+// A workgroup owns a 64 x 64 tile, wave w its rows [16 w, 16 w + 16) as four 16 x 16 MFMA tiles; K = 64 is walked in 16 steps of
+// v_mfma_f64_16x16x4_f64 (A: lane -> A[lane & 15][lane >> 4], B: lane -> B[lane >> 4][lane & 15], C/D: register r of lane ->
+// row (lane >> 4) + 4 r, column lane & 15).  Operands come straight from the two panels (L1/L2-resident: 2 MB each); the matrix
+// itself is read and written once per step, which is what bounds the step.  The result is compared with LDL^T to 1e-11, not
+// bit for bit, so the fused multiply-adds are fine here.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// (a 128 x 64 tile per workgroup, one B operand feeding two MFMA tiles, measured slower: 9.1 vs 8.5 ms per inversion)
+__global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp)
 {
-#pragma clang fp contract(fast)   // the inverse is compared against LDL^T to 1e-11, not bit for bit: let the compiler fuse here
-    __shared__ double c_s[64][GJ_H + 1];
-    __shared__ double r_s[GJ_H][64 + 1];
     const int K = kb * GJ_NB;
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
-    double acc[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    if (i0 >= K && i0 < K + GJ_NB) {   // the pivot rows take the scaled row panel (64-row tiles never straddle the pivot block)
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+        for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[a][c] = 0.0;
-    const bool tile_in_pivot_rows = (i0 >= K && i0 < K + GJ_NB);   // 64-row tiles never straddle the 64-row pivot block
-    for (int h = 0; h < GJ_NB; h += GJ_H) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < 64 * GJ_H; t += 256) c_s[t / GJ_H][t % GJ_H] = colp[(size_t)(i0 + t / GJ_H) * GJ_NB + h + t % GJ_H];
-        for (int t = threadIdx.x; t < GJ_H * 64; t += 256) r_s[t / 64][t % 64] = rowp[(size_t)(h + t / 64) * n + j0 + t % 64];
-        __syncthreads();
-        if (!tile_in_pivot_rows) {
-#pragma unroll 2
-            for (int t = 0; t < GJ_H; t++) {
-                double cv[4], rv[4];
-#pragma unroll
-                for (int a = 0; a < 4; a++) cv[a] = c_s[ti + 16 * a][t];
-#pragma unroll
-                for (int c = 0; c < 4; c++) rv[c] = r_s[t][tj + 16 * c];
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) acc[a][c] += cv[a] * rv[c];
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + 16 * wave + lr + 4 * r, j = j0 + 16 * c + lc;
+                M[(size_t)i * n + j] = rowp[(size_t)(i - K) * n + j];
             }
+        return;
+    }
+    v4f64 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
+    const double* bp = rowp + (size_t)lr * n + j0 + lc;
+#pragma unroll 4
+    for (int s = 0; s < GJ_NB / 4; s++) {
+        const double a = ap[4 * s];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double b = bp[(size_t)(4 * s) * n + 16 * c];
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int i = i0 + ti + 16 * a;
+    for (int c = 0; c < 4; c++) {
+        const int j = j0 + 16 * c + lc;
+        const bool jpiv = (j >= K && j < K + GJ_NB);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int j = j0 + tj + 16 * c;
-            const bool jpiv = (j >= K && j < K + GJ_NB);
-            double* m = M + (size_t)i * n + j;
-            if (tile_in_pivot_rows) *m = rowp[(size_t)(i - K) * n + j];
-            else *m = (jpiv ? 0.0 : *m) - acc[a][c];
+        for (int r = 0; r < 4; r++) {
+            double* m = M + (size_t)(i0 + 16 * wave + lr + 4 * r) * n + j;
+            *m = (jpiv ? 0.0 : *m) - acc[c][r];
         }
     }
 }
