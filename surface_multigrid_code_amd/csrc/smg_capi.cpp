@@ -539,7 +539,7 @@ static int precompute_device(smg_hierarchy* h)
             for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) dense[(size_t)i * np + Lc.A.col[p]] = Lc.A.val[p];
         HIPCHK(h->d_Ainv.upload(dense));
         DevBuf<double> work;
-        HIPCHK(work.alloc((size_t)2 * np * 64 + 64 * 64));
+        HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
         HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -675,7 +675,7 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
         const Level& Lc = h->lv[L - 1];
         HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));
         DevBuf<double> work;
-        HIPCHK(work.alloc((size_t)2 * h->nc_pad * 64 + 64 * 64));
+        HIPCHK(work.alloc((size_t)2 * h->nc_pad * 64 + 2 * 64 * 64));
         HIPCHK(launch_spd_inverse(h->d_Ainv.p, h->nc_pad, work.p, st));
         HIPCHK(hipStreamSynchronize(st));
     }

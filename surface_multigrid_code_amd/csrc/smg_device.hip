@@ -757,10 +757,22 @@ __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int k
 // bit for bit, so the fused multiply-adds are fine here.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // (a 128 x 64 tile per workgroup, one B operand feeding two MFMA tiles, measured slower: 9.1 vs 8.5 ms per inversion)
-__global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp)
+// Look-ahead: the workgroup that updates the NEXT pivot block (it is dispatched first: block (0,0) trades tiles with it) goes on
+// to invert that block and leaves the result in dinv_next, so the 35 us pivot-block inversion no longer runs alone between the
+// steps but in the shadow of this kernel.
+__global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp,
+                                                   double* dinv_next)
 {
+    __shared__ double a[GJ_NB][GJ_NB + 1];
     const int K = kb * GJ_NB;
-    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int nb = n / 64, nxt = kb + 1;                  // tile index of the next pivot block (none after the last step)
+    int by = blockIdx.y, bx = blockIdx.x;
+    if (nxt < nb) {                                       // swap tile (0,0) with tile (nxt, nxt)
+        if (by == 0 && bx == 0) { by = nxt; bx = nxt; }
+        else if (by == nxt && bx == nxt) { by = 0; bx = 0; }
+    }
+    const bool lookahead = (nxt < nb) && by == nxt && bx == nxt;
+    const int i0 = by * 64, j0 = bx * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
     if (i0 >= K && i0 < K + GJ_NB) {   // the pivot rows take the scaled row panel (64-row tiles never straddle the pivot block)
@@ -780,11 +792,11 @@ __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, con
     const double* bp = rowp + (size_t)lr * n + j0 + lc;
 #pragma unroll 4
     for (int s = 0; s < GJ_NB / 4; s++) {
-        const double a = ap[4 * s];
+        const double av = ap[4 * s];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const double b = bp[(size_t)(4 * s) * n + 16 * c];
-            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[c], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -794,9 +806,34 @@ __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, con
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             double* m = M + (size_t)(i0 + 16 * wave + lr + 4 * r) * n + j;
-            *m = (jpiv ? 0.0 : *m) - acc[c][r];
+            const double v = (jpiv ? 0.0 : *m) - acc[c][r];
+            *m = v;
+            if (lookahead) a[16 * wave + lr + 4 * r][16 * c + lc] = v;
         }
     }
+    if (!lookahead) return;   // uniform per workgroup
+    // invert the freshly updated next pivot block: 256 threads, 16 elements each (rows ti + 4 q, column tj).  (Keeping the
+    // elements in registers and passing only row / column p through LDS measured slower, here as in k_gj_diag.)
+    __syncthreads();
+    const int tj = threadIdx.x % GJ_NB, ti = threadIdx.x / GJ_NB;
+    for (int p = 0; p < GJ_NB; p++) {
+        const double d = 1.0 / a[p][p], r = a[p][tj];
+        double f[16], cur[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { f[q] = a[ti + 4 * q][p]; cur[q] = a[ti + 4 * q][tj]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = ti + 4 * q;
+            double val;
+            if (i == p) val = (tj == p) ? d : r * d;
+            else val = (tj == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
+            a[i][tj] = val;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) dinv_next[(ti + 4 * q) * GJ_NB + tj] = a[ti + 4 * q][tj];
 }
 
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
@@ -805,11 +842,11 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
     if (n % 64) return hipErrorInvalidValue;
     double* rowp = work;
     double* colp = work + (size_t)n * GJ_NB;
-    double* dinv = colp + (size_t)n * GJ_NB;
+    double* dinv[2] = {colp + (size_t)n * GJ_NB, colp + (size_t)n * GJ_NB + GJ_NB * GJ_NB};
+    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(1024), 0, st, M, n, 0, dinv[0]);   // only the first pivot block; the others: look-ahead
     for (int kb = 0; kb < n / GJ_NB; kb++) {
-        hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(1024), 0, st, M, n, kb, dinv);
-        hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv, rowp, colp);
-        hipLaunchKernelGGL(k_gj_update, dim3(n / 64, n / 64), dim3(256), 0, st, M, n, kb, rowp, colp);
+        hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv[kb & 1], rowp, colp);
+        hipLaunchKernelGGL(k_gj_update, dim3(n / 64, n / 64), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
     }
     return hipGetLastError();
 }

@@ -82,7 +82,7 @@ hipError_t launch_cvt_f64_f32(float* dst, const double* src, size_t n, hipStream
 hipError_t launch_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const Ctrl* ctrl, hipStream_t st);
 hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl* ctrl, hipStream_t st);
 // In-place inversion of an SPD matrix (n x n, row-major, leading dimension lda, n % 64 == 0, lda == n) by
-// blocked Gauss-Jordan elimination without pivoting.  work: 2*n*64 + 64*64 doubles.
+// blocked Gauss-Jordan elimination without pivoting.  work: 2*n*64 + 2*64*64 doubles.
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);
 
 // value-only re-precompute (same sparsity as the last full precompute) -------------------------------------------
