@@ -43,18 +43,14 @@ static const int* never_done()
     return p;
 }
 
-template <int RPL, typename T> struct PanelLoad;
-template <typename T> struct PanelLoad<1, T> {
-    static __device__ __forceinline__ void ld(const int* cp, const T* vp, int* c, T* v) { c[0] = *cp; v[0] = *vp; }
-};
 
-// One wavefront per slice of C = 64*RPL rows; lane l owns rows row0 + RPL*l .. +RPL-1.
+// One wavefront per slice of 64 rows; lane l owns row row0 + l.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
 // Argument order: the first 16 dwords are what the wave needs to issue its first panel loads; built with
 // -mllvm -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the wave instead of through scalar loads (that only works
 // for leading scalar / pointer arguments, hence no struct up front).  The rest is fetched in one batch.
-template <int MODE, int KB, int RPL, typename T>
+template <int MODE, int KB, typename T>
 __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                               int a_w_lo, int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                               const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld, const int* done,
@@ -64,7 +60,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                                                                                                a_col, a_stride, a_w_lo};
     // The convergence flag is requested up front but only consulted right before the stores: the matrix / vector loads
     // of a launch must not wait for that round trip (a launch after convergence does the work and writes nothing).
-    constexpr int C = 64 * RPL;
+    constexpr int C = 64;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     constexpr int wpb = 4;            // waves (= slices) per block
@@ -79,19 +75,16 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         // leave the critical path.
         const int W0 = A.w_lo < 8 ? A.w_lo : 8;                       // kernel argument; 0 for compact panels
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
-        const int* cp = A.col + (size_t)off0 * C + RPL * lane;
-        const T* vp = a_val + (size_t)off0 * C + RPL * lane;
+        const int* cp = A.col + (size_t)off0 * C + lane;
+        const T* vp = a_val + (size_t)off0 * C + lane;
         constexpr int U = 8;
-        int c0[U][RPL];
-        T v0[U][RPL];
+        int c0[U];
+        T v0[U];
 #pragma unroll
         for (int t = 0; t < U; t++) {
-            if (t < W0) {  // wave-uniform
-                PanelLoad<RPL, T>::ld(cp + (size_t)t * C, vp + (size_t)t * C, c0[t], v0[t]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < RPL; r++) { c0[t][r] = -1; v0[t][r] = (T)0; }
-            }
+            const bool in = t < W0;  // wave-uniform
+            c0[t] = in ? cp[(size_t)t * C] : -1;
+            v0[t] = in ? vp[(size_t)t * C] : (T)0;
         }
         // Now -- with the first panel loads in flight -- fetch the remaining kernel arguments in ONE batch of scalar loads
         // (they are otherwise read piecemeal behind branches, each time with its own wait): a value that depends on all of
@@ -108,74 +101,60 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         const int row0 = A.slice_row[s];
         const int nrow = A.slice_row[s + 1] - row0;
         const int w = A.slice_w[s];
-        const int rowb = row0 + RPL * lane;
-        T acc[RPL][KB];
-        T diag[RPL];
-        T bv[RPL][KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
+        const int rowb = row0 + lane;
+        T acc[KB];
+        T diag = (T)1;
+        T bv[KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
+        const bool live = lane < nrow;
 #pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            diag[r] = (T)1;
-            const bool live = RPL * lane + r < nrow;
-#pragma unroll
-            for (int q = 0; q < KB; q++) {
-                acc[r][q] = (T)0;
-                if (MODE == SELL_AX) bv[r][q] = (T)0;
-                else if (MODE == SELL_ADD) bv[r][q] = live ? y[(size_t)(rowb + r) * ld + q] : (T)0;
-                else bv[r][q] = live ? b[(size_t)(rowb + r) * ld + q] : (T)0;
-            }
+        for (int q = 0; q < KB; q++) {
+            acc[q] = (T)0;
+            if (MODE == SELL_AX) bv[q] = (T)0;
+            else if (MODE == SELL_ADD) bv[q] = live ? y[(size_t)rowb * ld + q] : (T)0;
+            else bv[q] = live ? b[(size_t)rowb * ld + q] : (T)0;
         }
         // one batch of U panel columns: gather x for all of them, then accumulate in ascending column order
-        auto consume = [&](const int (&c)[U][RPL], const T (&v)[U][RPL]) {
-            T xv[U][RPL][KB];
+        auto consume = [&](const int (&c)[U], const T (&v)[U]) {
+            T xv[U][KB];
 #pragma unroll
-            for (int t = 0; t < U; t++)
+            for (int t = 0; t < U; t++) {
+                const bool use = (c[t] >= 0) && !(MODE == SELL_GS && c[t] == rowb);
 #pragma unroll
-                for (int r = 0; r < RPL; r++) {
-                    const bool use = (c[t][r] >= 0) && !(MODE == SELL_GS && c[t][r] == rowb + r);
+                for (int q = 0; q < KB; q++) xv[t][q] = use ? x[(size_t)c[t] * ld + q] : (T)0;
+            }
 #pragma unroll
-                    for (int q = 0; q < KB; q++) xv[t][r][q] = use ? x[(size_t)c[t][r] * ld + q] : (T)0;
-                }
+            for (int t = 0; t < U; t++) {
+                if (c[t] >= 0) {
+                    if (MODE == SELL_GS && c[t] == rowb) {
+                        diag = v[t];
+                    } else {
 #pragma unroll
-            for (int t = 0; t < U; t++)
-#pragma unroll
-                for (int r = 0; r < RPL; r++) {
-                    if (c[t][r] >= 0) {
-                        if (MODE == SELL_GS && c[t][r] == rowb + r) {
-                            diag[r] = v[t][r];
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < KB; q++) acc[r][q] += v[t][r] * xv[t][r][q];
-                        }
+                        for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
                     }
                 }
+            }
         };
         if (W0 > 0) consume(c0, v0);   // columns [0, W0), requested ahead of the table
         for (int j0 = W0; j0 < w; j0 += U) {
-            int c[U][RPL];
-            T v[U][RPL];
+            int c[U];
+            T v[U];
 #pragma unroll
             for (int t = 0; t < U; t++) {
-                if ((j0 + t) < w) {  // wave-uniform
-                    PanelLoad<RPL, T>::ld(cp + (size_t)(j0 + t) * C, vp + (size_t)(j0 + t) * C, c[t], v[t]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < RPL; r++) { c[t][r] = -1; v[t][r] = (T)0; }
-                }
+                const bool in = (j0 + t) < w;  // wave-uniform
+                c[t] = in ? cp[(size_t)(j0 + t) * C] : -1;
+                v[t] = in ? vp[(size_t)(j0 + t) * C] : (T)0;
             }
             consume(c, v);
         }
+        if (live && !stop) {
+            const size_t o = (size_t)rowb * ld;
 #pragma unroll
-        for (int r = 0; r < RPL; r++) {
-            if (RPL * lane + r < nrow && !stop) {
-                const size_t o = (size_t)(rowb + r) * ld;
-#pragma unroll
-                for (int q = 0; q < KB; q++) {
-                    if (MODE == SELL_AX) { y[o + q] = acc[r][q]; if (zero_rows) zero_rows[o + q] = (T)0; }
-                    else if (MODE == SELL_RESID) y[o + q] = bv[r][q] - acc[r][q];
-                    else if (MODE == SELL_ADD) y[o + q] = bv[r][q] + acc[r][q];
-                    else if (MODE == SELL_GS) y[o + q] = (bv[r][q] - acc[r][q]) / diag[r];
-                    else { const double t = (double)(bv[r][q] - acc[r][q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[r][q] - acc[r][q]; }
-                }
+            for (int q = 0; q < KB; q++) {
+                if (MODE == SELL_AX) { y[o + q] = acc[q]; if (zero_rows) zero_rows[o + q] = (T)0; }
+                else if (MODE == SELL_RESID) y[o + q] = bv[q] - acc[q];
+                else if (MODE == SELL_ADD) y[o + q] = bv[q] + acc[q];
+                else if (MODE == SELL_GS) y[o + q] = (bv[q] - acc[q]) / diag;
+                else { const double t = (double)(bv[q] - acc[q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[q] - acc[q]; }
             }
         }
     }
@@ -319,7 +298,7 @@ int sell_wide_blocks(int n_slices, int k)
 static constexpr int sell_wpb() { return 4; }
 int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb(); }
 
-template <int MODE, int RPL, typename T>
+template <int MODE, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
                                    int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows)
 {
@@ -335,7 +314,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
     if (ns <= 0) return hipSuccess;
     int c0 = 0;
     size_t poff = 0;  // partial sums written so far
-    if (RPL == 1) {
+    {
         while (k - c0 >= 8) {
             int kw = 64;
             while (kw > k - c0) kw >>= 1;
@@ -364,31 +343,31 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         T* zz = zero_rows ? zero_rows + c0 : nullptr;
         poff += (size_t)nb;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, RPL, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            default: hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
         }
     }
     if (n_blocks) *n_blocks = (int)poff;
     return hipGetLastError();
 }
 
-template <int RPL, typename T>
-static hipError_t launch_sell_rpl(SellMode mode, const SellDev& A, int s_begin, int s_end, const T* x, const T* b,
+template <typename T>
+static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, int s_end, const T* x, const T* b,
                                   T* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                                   T* zero_rows)
 {
     switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
         case SELL_RESID_SS:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
             else return hipErrorInvalidValue;
-        case SELL_ADD: return launch_sell_mode<SELL_ADD, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_GS: return launch_sell_mode<SELL_GS, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_GS: return launch_sell_mode<SELL_GS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
         case SELL_RESID_BOTH:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, RPL, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
             else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
@@ -398,7 +377,7 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
                        double* zero_rows)
 {
-    return launch_sell_rpl<1, double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+    return launch_sell_any<double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
 }
 
 // fp32 twin for the mixed-precision V-cycle (A.valf must be set; the norm modes are fp64-only)
@@ -406,7 +385,7 @@ hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_e
                            float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows)
 {
     if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
-    return launch_sell_rpl<1, float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
+    return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control
@@ -440,10 +419,13 @@ __device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
 // single-GPU path: reduction of the partials and the break test in one launch
 __global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl)
 {
-    if (ctrl->done) return;
+    // the partial sums are requested before the convergence flag is looked at: one round trip instead of two on a kernel that
+    // is nothing but latency (same summation order as before)
     __shared__ double red[256];
     double s = 0.0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    if (ctrl->done) return;   // uniform
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
