@@ -2,6 +2,7 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -121,7 +122,8 @@ static int dsatur_color(const Csr& A, std::vector<int>& color)
         const int v = e.v;
         if (color[v] >= 0 || e.sat != sat[v]) continue;
         int c = 0;
-        while (c < 63 && ((seen[v] >> c) & 1)) c++;
+        while (c < 64 && ((seen[v] >> c) & 1)) c++;
+        if (c >= 63) return INT_MAX;   // the 64-bit colour sets of this routine are exhausted: leave dense graphs to plain greedy
         color[v] = c;
         ncol = std::max(ncol, c + 1);
         for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) {
@@ -144,7 +146,8 @@ struct Recolor {
     int K;
     std::vector<char> mark;
     long budget;
-    Recolor(const Csr& A_, std::vector<int>& c, int K_) : A(A_), color(c), K(K_), mark(A_.nr, 0), budget(40L * A_.nr + 100000) {}
+    long ball_budget;   // elementary steps all ball searches of this object may take together
+    Recolor(const Csr& A_, std::vector<int>& c, int K_) : A(A_), color(c), K(K_), mark(A_.nr, 0), budget(40L * A_.nr + 100000), ball_budget(400L * A_.nr + 20000000L) {}
 
     int free_color(int u, int avoid) const
     {
@@ -209,6 +212,9 @@ struct Recolor {
             const int u = B[h];
             for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) { const int w = A.col[p]; if (!mark[w]) { mark[w] = 1; B.push_back(w); dist.push_back(dist[h] + 1); } }
         }
+        // the search below costs O(|ball| * degree) per node: it is meant for mesh neighbourhoods (a few dozen vertices), not for
+        // the balls of an expander, which hold most of the graph after three hops
+        if (B.size() > 192 || ball_budget <= 0) { for (int w : B) mark[w] = 0; return false; }
         std::vector<int> saved(B.size());
         for (size_t i = 0; i < B.size(); i++) { saved[i] = color[B[i]]; color[B[i]] = -1; }
         long nodes = 0;
@@ -224,6 +230,8 @@ struct Recolor {
         stackv.push_back(u); stackc.push_back(0);
         while (!stackv.empty()) {
             if (++nodes > node_limit) break;
+            ball_budget -= (long)B.size();
+            if (ball_budget <= 0) break;
             const int cu = stackv.back();
             int& next = stackc.back();
             color[cu] = -1;
@@ -331,11 +339,24 @@ static bool has_odd_wheel(const Csr& A)
     return false;
 }
 
+static bool coloring_is_valid(const Csr& A, const std::vector<int>& color)
+{
+    for (int i = 0; i < A.nr; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (A.col[p] != i && color[A.col[p]] == color[i]) return false;
+    return true;
+}
+
 static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
 {
     std::vector<int> best, cur;
     int nbest = greedy_color(A, rcm, best);
     if (A.nr == 0) return best;
+    // The refinement below works with 64-bit colour sets and local searches whose cost grows with the degree: it is for
+    // mesh-like graphs.  Dense or high-chromatic graphs (Galerkin operators of aggressive aggregations, say) keep the plain
+    // first-fit colouring, which is always valid.
+    if (nbest > 32 || A.nnz() > 64L * A.nr) return best;
+    const std::vector<int> fallback = best;
     if (dsatur_color(A, cur) <= nbest) best = cur;
     compact_colors(best);
     nbest = count_colors(best);
@@ -360,7 +381,7 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
         nbest = count_colors(best);
         if (!emptied) break;
     }
-    return best;
+    return coloring_is_valid(A, best) ? best : fallback;   // belt and braces: a wrong colouring would be a data race in the sweep
 }
 
 // Colouring of a mid-point-subdivided mesh from a proper 4-colouring of its parent (Tait's construction): the old

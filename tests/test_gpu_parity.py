@@ -525,3 +525,66 @@ def test_tiny_and_ragged_systems(smg, oracle_mod, n, levels, k, known):
     assert np.linalg.norm(a[1] - b[1]) <= 1e-8 * max(np.linalg.norm(b[1]), 1e-300)
     if kn is not None:
         assert np.array_equal(a[1][kn], kv)
+
+
+# ----------------------------------------------------------------------------------------------- random non-mesh systems
+def _random_spd_hierarchy(rng, n, levels, hub):
+    """A random sparse SPD matrix (irregular degrees; optionally a few hub rows so that SELL slices get very wide and the
+    compact-panel fallback and > 4 colours are exercised) with a random aggregation-type prolongation hierarchy."""
+    deg = rng.integers(2, 9, n)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, rows.size)
+    if hub:
+        hubs = rng.choice(n, 3, replace=False)
+        extra = rng.choice(n, (3, min(n - 1, 120)))
+        rows = np.concatenate([rows, np.repeat(hubs, extra.shape[1])]); cols = np.concatenate([cols, extra.ravel()])
+    W = sp.coo_matrix((-rng.uniform(0.1, 1.0, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    W.setdiag(0); W.eliminate_zeros()
+    W = W + W.T
+    A = (W + sp.diags(np.asarray(-W.sum(axis=1)).ravel() + rng.uniform(0.05, 0.5, n))).tocsr()   # strictly diagonally dominant
+    A.sort_indices()
+    Ps, m = [], n
+    for _ in range(levels - 1):
+        mc = max(2, m // 3)
+        agg = rng.integers(0, mc, m); agg[:mc] = np.arange(mc)          # every coarse vertex has a child
+        second = rng.integers(0, mc, m)
+        w = rng.uniform(0.5, 1.0, m)
+        P = sp.coo_matrix((np.concatenate([w, 1 - w]), (np.concatenate([np.arange(m)] * 2), np.concatenate([agg, second]))), shape=(m, mc)).tocsr()
+        P.sum_duplicates(); P.sort_indices()
+        Ps.append(P); m = mc
+    return A, Ps
+
+
+@pytest.mark.parametrize("seed,n,levels,k,hub", [(1, 200, 2, 1, False), (2, 777, 3, 2, False), (3, 1500, 3, 1, True), (4, 4000, 4, 3, True),
+                                                (5, 65, 2, 9, False), (6, 2600, 3, 1, False)])
+def test_random_non_mesh_systems_match_the_oracle(smg, oracle_mod, seed, n, levels, k, hub):
+    """Nothing in the library may depend on the operators coming from a triangle mesh: irregular random graphs (many colours,
+    hub rows => very wide SELL slices => compact panels), random prolongations.  Kernels stay bit-exact against the oracle on the
+    level matrices in the device numbering; solves agree with the reference algorithm."""
+    rng = np.random.default_rng(seed)
+    A, Ps = _random_spd_hierarchy(rng, n, levels, hub)
+    mg = smg.Hierarchy.from_prolongs(Ps); mg.precompute(A)
+    o = oracle_mod.OracleMG(Ps); o.precompute(A)
+    for lv in range(mg.n_levels - 1):
+        m = mg.rows(lv)
+        cp = mg.colors(lv)
+        Ai = mg.matrix(lv, "A", internal=True)
+        # a valid colouring: no entry inside a diagonal colour block except the diagonal
+        for c in range(len(cp) - 1):
+            blk = sp.csr_matrix(Ai[cp[c]:cp[c + 1], cp[c]:cp[c + 1]]); blk.setdiag(0); blk.eliminate_zeros()
+            assert blk.nnz == 0
+        x = rng.uniform(-1, 1, (m, k)); b = rng.uniform(-1, 1, (m, k))
+        perm = mg.perm(lv)
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm]))
+        assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2))
+        permc = mg.perm(lv + 1)
+        assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm]))
+        xc = rng.uniform(-1, 1, (mg.rows(lv + 1), k))
+        assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc]))
+    rhs, z0 = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+    a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=200))
+    bb = o.solve(rhs, z0, tol=1e-10, max_iter=200)
+    assert a[0] and bb[0]
+    assert np.linalg.norm(a[1] - bb[1]) <= 1e-7 * np.linalg.norm(bb[1])
+    assert abs(len(a[2]) - len(bb[2])) <= max(3, len(bb[2]) // 4)
