@@ -588,3 +588,43 @@ def test_random_non_mesh_systems_match_the_oracle(smg, oracle_mod, seed, n, leve
     assert a[0] and bb[0]
     assert np.linalg.norm(a[1] - bb[1]) <= 1e-7 * np.linalg.norm(bb[1])
     assert abs(len(a[2]) - len(bb[2])) <= max(3, len(bb[2]) // 4)
+
+
+def test_unsorted_duplicate_input_and_explicit_zeros(smg, oracle_mod):
+    """Eigen's setFromTriplets semantics at the boundary: the caller's CSR rows may be unsorted and hold duplicate (row, col)
+    pairs (summed), prolongation rows may carry explicit zeros (the [1, 0, 0] rows of get_prolong.cpp:48-54); k = 100 columns
+    go through one wide launch of 64, one of 32 and a narrow remainder."""
+    p = subdiv_problem(kind="mcf", k=1, n_sub=2)
+    A = sp.csr_matrix(p["A"])
+    n = A.shape[0]
+    rng = np.random.default_rng(11)
+    # split every entry into two halves and shuffle each row
+    ptr, col, val = [0], [], []
+    for i in range(n):
+        c = A.indices[A.indptr[i]:A.indptr[i + 1]]; v = A.data[A.indptr[i]:A.indptr[i + 1]]
+        cc = np.concatenate([c, c]); vv = np.concatenate([0.25 * v, 0.75 * v])
+        o = rng.permutation(len(cc))
+        col.append(cc[o]); val.append(vv[o]); ptr.append(ptr[-1] + len(cc))
+    ptr, col, val = np.asarray(ptr, np.int32), np.concatenate(col).astype(np.int32), np.concatenate(val)
+    # explicit zeros in P: add a zero entry to every row of every P
+    Ps = []
+    for P in p["Ps"]:
+        P = sp.csr_matrix(P)
+        extra = sp.csr_matrix((np.zeros(P.shape[0]), (np.arange(P.shape[0]), rng.integers(0, P.shape[1], P.shape[0]))), shape=P.shape)
+        Q = sp.csr_matrix(P + extra)       # scipy drops nothing here: the zeros land on new positions or on existing ones
+        Ps.append(Q)
+    mg = smg.Hierarchy.from_prolongs(Ps)
+    rc = mg.L.smg_precompute(mg.h, n, ptr.ctypes.data_as(mg.L.smg_precompute.argtypes[2]), col.ctypes.data_as(mg.L.smg_precompute.argtypes[3]),
+                             val.ctypes.data_as(mg.L.smg_precompute.argtypes[4]), None, 0)
+    assert rc == 0
+    # 0.25 v + 0.75 v is not bit-exactly v: compare with the oracle fed the same summed matrix
+    Asum = sp.csr_matrix((val, col, ptr), shape=(n, n)); Asum.sum_duplicates(); Asum.sort_indices()
+    o = oracle_mod.OracleMG(Ps); o.precompute(Asum)
+    k = 100
+    rhs, z0 = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+    a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=40))
+    b = o.solve(rhs, z0, tol=1e-9, max_iter=40)
+    assert a[0] and b[0] and abs(len(a[2]) - len(b[2])) <= 2
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-7 * np.linalg.norm(b[1])
+    x = rng.uniform(-1, 1, (n, 3))
+    assert np.allclose(mg.A(0, x), Asum @ x, rtol=0, atol=1e-13 * abs(Asum).sum(axis=1).max())
