@@ -18,6 +18,7 @@
 //   * the libigl-internal edge-flap bookkeeping, the qslim / randomised variants and the coarse-to-fine queries of the
 //     remeshing demos are not restated.
 #include <algorithm>
+#include <cstdlib>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -408,11 +409,24 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
     // greedy loop (src/SSP_midpoint.cpp:188-220): pop the cheapest valid edge until #faces <= tarF
     // Rejected edges are parked and offered again once the queue runs dry after at least one success (their
     // validity can change when a neighbouring collapse rewires the link).
+    // Absorption cap (not in the reference): shortest-edge-first decimation coarsens the densely sampled parts of a mesh far
+    // beyond the global ratio before it touches the rest (ogre.obj: coarse triangles holding 50 fine vertices next to regions
+    // left untouched), and a smooth error bump inside such a triangle is invisible to the coarse level: the V-cycle stalls at
+    // 0.6 per cycle there.  A surviving vertex may therefore stand for at most `cap` input vertices (twice the average of the
+    // requested ratio); edges that would exceed it wait, and the cap is relaxed only when nothing else is left to collapse.
+    // SMG_DECIMATE_CAP=0 switches it off (the reference's behaviour); another value sets the factor in tenths (default 20 = 2.0).
+    const int cap_mode = [] { const char* v = std::getenv("SMG_DECIMATE_CAP"); return v && *v ? std::atoi(v) : 20; }();
+    int cap = cap_mode ? std::max(3, (int)std::lround(0.1 * cap_mode * (double)nF / (double)std::max(tarF, 1))) : (1 << 30);
+    std::vector<int> weight(nV, 1);
     std::vector<QEntry> parked;
     bool progressed = false;
     while (D.n_alive_faces > tarF) {
         if (D.pq.empty()) {
-            if (!progressed || parked.empty()) break;
+            if (parked.empty()) break;
+            if (!progressed) {
+                if (cap >= (1 << 29)) break;
+                cap *= 2;   // nothing moved under the current cap: relax it
+            }
             for (const QEntry& e : parked)
                 if (D.valive[e.a] && D.valive[e.b]) D.push_edge(e.a, e.b);
             parked.clear();
@@ -422,7 +436,8 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
         QEntry e = D.pq.top();
         D.pq.pop();
         if (!D.valive[e.a] || !D.valive[e.b] || D.version[e.a] != e.va || D.version[e.b] != e.vb) continue;
-        if (D.collapse(e.a, e.b)) progressed = true;
+        if (weight[e.a] + weight[e.b] > cap) { parked.push_back(e); continue; }
+        if (D.collapse(e.a, e.b)) { progressed = true; weight[e.a] += weight[e.b]; }   // b merges into a
         else parked.push_back(e);
     }
     // compact
