@@ -242,3 +242,29 @@ def test_weak_kat_bunny_500_faces(smg_mod):
     smg._lib.load().smg_level_get_mesh(mg.h, 1, C.byref(nV), C.byref(nF), None, None)
     assert nF.value == 499 and abs(nV.value - 261) <= 3
     assert mg.matrix(1, "P_full").shape == (9353, nV.value)
+
+
+@pytest.mark.parametrize("mesh_name,bound", [("bunny.smgm", 0.12), ("ogre.smgm", 0.36), ("bunny_15K_init.smgm", 0.12)])
+def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, bound):
+    """no reference binary to compare the hierarchy builder with, so it is judged by what it is for --
+    the V-cycle convergence factor of the reference algorithm (CPU oracle) on its hierarchy, expected <~ 0.3 (ogre.obj, strongly
+    non-uniform sampling, needs the absorption cap of the decimator for that: 0.62 without)."""
+    V, F = M.read_smgm(mesh_name)
+    V = M.normalize_unit_area(V, F)
+    mg = smg_mod.mg_precompute(V, F, ratio=0.25, nVCoarsest=500)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    sizes = [Ps[0].shape[0]] + [P.shape[1] for P in Ps]
+    assert all(0.2 < sizes[i + 1] / sizes[i] < 0.3 for i in range(len(sizes) - 1))
+    A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    o = oracle_mod.OracleMG(Ps)
+    o.precompute(A)
+    rng = np.random.default_rng(0)
+    e = rng.uniform(-1, 1, (V.shape[0], 1))
+    zero = np.zeros_like(e)
+    factor = 1.0
+    for _ in range(25):   # power iteration on the error propagation of one V(2,2) cycle
+        e2 = o.vcycle(zero, e)
+        factor = np.linalg.norm(e2) / np.linalg.norm(e)
+        e = e2 / np.linalg.norm(e2)
+    assert factor < bound
