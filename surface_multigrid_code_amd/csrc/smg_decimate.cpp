@@ -273,8 +273,18 @@ struct Decimator {
             for (int v : ringv) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
             const int la = (int)patch.P.size(); patch.P.push_back(pos[a]);
             const int lb = la + 1; patch.P.push_back(pos[b]);
-            const int lm = lb + 1; patch.P.push_back(m);   // a distinct unknown even when m coincides with an end point
-            patch.n = lm + 1;
+            // The merged vertex is its own unknown of the flattening when it is a new point (mid-point placement).  When it IS one of
+            // the end points (vertex removal; a boundary vertex that stays put) it shares that end point's unknown: otherwise the
+            // two would be flattened to different places and the surviving vertex's own record -- the fine vertex sitting exactly
+            // on the coarse vertex -- would be re-located into the interior of a face (coarse vertices nobody interpolates from,
+            // i.e. zero rows in the Galerkin operator, were the symptom).
+            const bool m_is_a = (m.x == pos[a].x && m.y == pos[a].y && m.z == pos[a].z);
+            const bool m_is_b = !m_is_a && (m.x == pos[b].x && m.y == pos[b].y && m.z == pos[b].z);
+            int lm = lb + 1;
+            if (m_is_a) lm = la;
+            else if (m_is_b) lm = lb;
+            else patch.P.push_back(m);
+            patch.n = (int)patch.P.size();
             loc[a] = la; loc[b] = lb;
             auto add_faces = [&](int v) {
                 for (int f : vfaces[v]) {
@@ -453,6 +463,36 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
     for (int v = 0; v < nV; v++) if (vmap[v] >= 0) { coarse.V[3 * vmap[v]] = D.pos[v].x; coarse.V[3 * vmap[v] + 1] = D.pos[v].y; coarse.V[3 * vmap[v] + 2] = D.pos[v].z; }
     coarse.F.clear();
     for (int f = 0; f < nF; f++) if (D.falive[f]) for (int c = 0; c < 3; c++) coarse.F.push_back(vmap[D.faces[f][c]]);
+    // Every coarse vertex must be interpolated from by somebody: a column of P without a positive entry is a zero row and column
+    // of the Galerkin operator, and the smoother divides by its diagonal.  (Possible in principle with mid-point placement: all
+    // points of the incident faces may sit on the opposite edges.)  Repair: the fine point of an incident face that lies closest
+    // to the orphaned vertex is snapped onto it.
+    {
+        std::vector<char> used(nV, 0);
+        for (int p = 0; p < nV; p++)
+            for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 1e-12) used[D.faces[D.pface[p]][c]] = 1;
+        for (int v = 0; v < nV; v++) {
+            if (vmap[v] < 0 || used[v]) continue;
+            int best = -1, bf = -1, bc = -1;
+            double bd = 1e300;
+            for (int f : D.vfaces[v]) {
+                if (!D.falive[f]) continue;
+                int cv = 0;
+                while (D.faces[f][cv] != v) cv++;
+                for (int p : D.fpoints[f]) {
+                    // position of the point on the coarse face
+                    V3 q = {0, 0, 0};
+                    for (int c = 0; c < 3; c++) q = q + D.pbary[p][c] * D.pos[D.faces[f][c]];
+                    const double d = norm(q - D.pos[v]);
+                    // do not orphan another vertex: the point must not be the only user of a vertex it currently leans on fully
+                    bool sole = false;
+                    for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 0.999999) sole = true;
+                    if (!sole && d < bd) { bd = d; best = p; bf = f; bc = cv; }
+                }
+            }
+            if (best >= 0) { D.pface[best] = bf; D.pbary[best] = {0, 0, 0}; D.pbary[best][bc] = 1.0; used[v] = 1; }
+        }
+    }
     // P: three stored entries per row (explicit zeros kept), src/get_prolong.cpp:45-56
     std::vector<int> ptr(nV + 1), col((size_t)nV * 3);
     std::vector<double> val((size_t)nV * 3);

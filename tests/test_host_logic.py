@@ -142,6 +142,16 @@ def test_mg_precompute_invariants(smg_mod):
     V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
     mg2 = smg.mg_precompute(mesh.normalize_unit_area(V, F), F, 0.25, 100, 2)
     assert mg2.n_levels == 3
+    # vertex removal keeps the surviving end point where it is: the fine vertex sitting on a coarse vertex interpolates from it
+    # alone (regression: the merged vertex used to be flattened apart from that end point, 8 levels of ogre.obj at ratio 0.5 then
+    # had coarse vertices nobody interpolated from -- zero rows in the Galerkin operator)
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    mg3 = smg.mg_precompute(mesh.normalize_unit_area(V, F), F, 0.5, 100, 2)
+    assert mg3.n_levels == 8
+    for l in range(1, mg3.n_levels):
+        P = mg3.matrix(l, "P_full")
+        assert (np.asarray((P > 1e-12).sum(axis=0)).ravel() > 0).all()
+        assert (np.asarray((P > 1 - 1e-12).sum(axis=0)).ravel() > 0).all()   # ... by a one-hot row, even
     with pytest.raises(smg.SmgError):
         smg.mg_precompute(V, F, 0.25, 500, 0)                     # qslim is not implemented
 
