@@ -419,20 +419,29 @@ __device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
 // single-GPU path: reduction of the partials and the break test in one launch
 __global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl)
 {
-    // the partial sums are requested before the convergence flag is looked at: one round trip instead of two on a kernel that
-    // is nothing but latency (same summation order as before)
+    // a kernel that is nothing but latency: everything it will need -- the partial sums, the flag, the tolerance, the history
+    // length -- is requested up front, in one round trip (same summation order as before)
     __shared__ double red[256];
+    const int done = ctrl->done, n_his = ctrl->n_his;
+    const double tol = ctrl->tol;
     double s = 0.0;
 #pragma unroll 8
     for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
-    if (ctrl->done) return;   // uniform
+    if (done) return;   // uniform
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { ctrl->sumsq = red[0]; decide_body(ctrl, red[0]); }
+    if (threadIdx.x == 0) {
+        const double sumsq = red[0], r = sqrt(sumsq);
+        ctrl->sumsq = sumsq;
+        if (n_his < SMG_MAX_HIS) ctrl->r_his[n_his] = r;
+        ctrl->n_his = n_his + 1;
+        if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
+        else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
+    }
 }
 
 __global__ void k_decide(Ctrl* ctrl, const double* sumsq)
