@@ -82,9 +82,10 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         T v0[U];
 #pragma unroll
         for (int t = 0; t < U; t++) {
-            const bool in = t < W0;  // wave-uniform
-            c0[t] = in ? cp[(size_t)t * C] : -1;
-            v0[t] = in ? vp[(size_t)t * C] : (T)0;
+            // one wave-uniform branch per column, both loads behind it: as two selects this compiled to two branches per column
+            // and the longer issue sequence cost 2.5 % of the V-cycle (every launch pays it before its loads are out)
+            if (t < W0) { c0[t] = cp[(size_t)t * C]; v0[t] = vp[(size_t)t * C]; }
+            else { c0[t] = -1; v0[t] = (T)0; }
         }
         // Now -- with the first panel loads in flight -- fetch the remaining kernel arguments in ONE batch of scalar loads
         // (they are otherwise read piecemeal behind branches, each time with its own wait): a value that depends on all of
@@ -140,9 +141,8 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
             T v[U];
 #pragma unroll
             for (int t = 0; t < U; t++) {
-                const bool in = (j0 + t) < w;  // wave-uniform
-                c[t] = in ? cp[(size_t)(j0 + t) * C] : -1;
-                v[t] = in ? vp[(size_t)(j0 + t) * C] : (T)0;
+                if ((j0 + t) < w) { c[t] = cp[(size_t)(j0 + t) * C]; v[t] = vp[(size_t)(j0 + t) * C]; }   // wave-uniform
+                else { c[t] = -1; v[t] = (T)0; }
             }
             consume(c, v);
         }
