@@ -50,7 +50,9 @@ static const int* never_done()
 // Argument order: the first 16 dwords are what the wave needs to issue its first panel loads; built with
 // -mllvm -amdgpu-kernarg-preload-count=16 they arrive in SGPRs with the wave instead of through scalar loads (that only works
 // for leading scalar / pointer arguments, hence no struct up front).  The rest is fetched in one batch.
-template <int MODE, int KB, typename T>
+// W0C: the number of panel columns requested ahead, fixed at compile time (7: the one-ring of a regular mesh vertex plus the
+// diagonal, by far the most common slice width of A) -- straight-line loads, no branch per column; -1: taken from a_w_lo.
+template <int MODE, int KB, typename T, int W0C = -1>
 __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                               int a_w_lo, int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                               const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld, const int* done,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (what most slices have; a
         // narrower slice holds padding there) are requested before the slice's table entries have arrived -- the table reads
         // leave the critical path.
-        const int W0 = A.w_lo < 8 ? A.w_lo : 8;                       // kernel argument; 0 for compact panels
+        const int W0 = W0C >= 0 ? W0C : (A.w_lo < 8 ? A.w_lo : 8);   // compile-time, or the kernel argument (0 for compact panels)
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int* cp = A.col + (size_t)off0 * C + lane;
         const T* vp = a_val + (size_t)off0 * C + lane;
@@ -343,10 +345,27 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         T* zz = zero_rows ? zero_rows + c0 : nullptr;
         poff += (size_t)nb;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            case 2: hipLaunchKernelGGL((k_sell<MODE, 2, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            case 3: hipLaunchKernelGGL((k_sell<MODE, 3, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
-            default: hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz); break;
+            case 1: {
+                // the usual widths get kernels with the look-ahead count fixed at compile time (no branch per panel column)
+                const int w0 = A.stride > 0 ? (A.w_lo < 8 ? A.w_lo : 8) : -1;
+                if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 2) hipLaunchKernelGGL((k_sell<MODE, 1, T, 2>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                break;
+            }
+            case 2:
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 2, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 2, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                break;
+            case 3:
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 3, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 3, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                break;
+            default:
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 4, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                break;
         }
     }
     if (n_blocks) *n_blocks = (int)poff;
