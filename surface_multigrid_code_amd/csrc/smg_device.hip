@@ -25,8 +25,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 {
     // block b runs on XCD b % 8 (observed dispatch order; used for locality only, never for correctness):
     // give every XCD one contiguous range of logical block ids.  Bijective for any nb.
+    // XCD x owns q blocks, the first r XCDs one more: its range starts at x q + min(x, r)  (branch-free: this sits in front of
+    // the first load of every launch)
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
 // `done` is never null (launchers substitute a zero word).  A per-lane (vector) load: the compiler waits for it only
@@ -71,12 +73,12 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
     double ss = 0.0;
     int stop = 0;
     if (ls < s_end) {
-        const int s = use_order ? A.order[ls] : ls;
+        const int s = (MODE != SELL_GS && use_order) ? A.order[ls] : ls;   // colour sweeps never walk the region order
         // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (what most slices have; a
         // narrower slice holds padding there) are requested before the slice's table entries have arrived -- the table reads
         // leave the critical path.
         const int W0 = W0C >= 0 ? W0C : (A.w_lo < 8 ? A.w_lo : 8);   // compile-time, or the kernel argument (0 for compact panels)
-        const int off0 = A.stride ? s * A.stride : A.slice_off[s];
+        const int off0 = (W0C >= 0 || A.stride) ? s * A.stride : A.slice_off[s];   // W0C >= 0: launched on fixed-pitch matrices only
         const int* cp = A.col + (size_t)off0 * C + lane;
         const T* vp = a_val + (size_t)off0 * C + lane;
         constexpr int U = 8;
