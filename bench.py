@@ -161,9 +161,12 @@ def main():
     if world > 1 or force_split:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # "nccl" is RCCL.  SMG_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
+        # (ranks then share devices: RCCL refuses that)
+        dist.init_process_group(os.environ.get("SMG_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
 
     from surface_multigrid_code_amd import build as smg_build
     if rank == 0:
