@@ -628,3 +628,28 @@ def test_unsorted_duplicate_input_and_explicit_zeros(smg, oracle_mod):
     assert np.linalg.norm(a[1] - b[1]) <= 1e-7 * np.linalg.norm(b[1])
     x = rng.uniform(-1, 1, (n, 3))
     assert np.allclose(mg.A(0, x), Asum @ x, rtol=0, atol=1e-13 * abs(Asum).sum(axis=1).max())
+
+
+def test_block_hierarchy_solves_a_3dof_system(smg, oracle_mod):
+    """mg_precompute_block (P (x) I_3, DOF = 3 vertex + d; 06_example_balloon_sim's hierarchy): a vector-valued SPD system with
+    coupling between the three components of a vertex, solved on the GPU and by the reference algorithm on the same hierarchy."""
+    from oracle import mesh_np as M
+    V, F = M.read_smgm("ogre_sim.smgm")
+    V = M.normalize_unit_area(V, F)
+    n = V.shape[0]
+    mg = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    assert Ps[0].shape[0] == 3 * n
+    S = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+    rng = np.random.default_rng(5)
+    B3 = rng.uniform(-1, 1, (3, 3)); C3 = B3 @ B3.T + 3.0 * np.eye(3)            # SPD 3 x 3 coupling
+    A = sp.kron(S, sp.csr_matrix(C3), format="csr")                              # DOF index 3 v + d
+    A.sort_indices()
+    rhs, z0 = rng.uniform(-1, 1, (3 * n, 2)), np.zeros((3 * n, 2))
+    mg.precompute(A)
+    o = oracle_mod.OracleMG(Ps); o.precompute(A)
+    a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=60))
+    b = o.solve(rhs, z0, tol=1e-10, max_iter=60)
+    assert a[0] and b[0] and abs(len(a[2]) - len(b[2])) <= 2
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-8 * np.linalg.norm(b[1])
+    assert np.linalg.norm(rhs - A @ a[1]) < 1.5e-10
