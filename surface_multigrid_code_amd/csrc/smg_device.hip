@@ -124,8 +124,28 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
 #pragma unroll
             for (int t = 0; t < U; t++) {
                 const bool use = (c[t] >= 0) && !(MODE == SELL_GS && c[t] == rowb);
+                if constexpr (KB == 1) {
+                    xv[t][0] = use ? x[(size_t)c[t] * ld] : (T)0;
+                } else {
+                    // the KB columns of a neighbour are contiguous: one (KB = 2) or two wide loads instead of KB narrow ones -- the
+                    // gathers are what a small-level launch waits for (element-aligned only: gfx950 global loads do not need more)
+                    typedef T V2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+                    const T* px = x + (size_t)c[t] * ld;
+                    if constexpr (KB == 3) {   // a 3-vector would be padded to 4 elements: the load would run past the row
+                        V2 g = {(T)0, (T)0};
+                        T g2 = (T)0;
+                        if (use) { g = *reinterpret_cast<const V2*>(px); g2 = px[2]; }
+                        xv[t][0] = g[0]; xv[t][1] = g[1]; xv[t][2] = g2;
+                    } else {
+                        typedef T VK __attribute__((ext_vector_type(KB), aligned(sizeof(T))));
+                        VK g;
 #pragma unroll
-                for (int q = 0; q < KB; q++) xv[t][q] = use ? x[(size_t)c[t] * ld + q] : (T)0;
+                        for (int q = 0; q < KB; q++) g[q] = (T)0;
+                        if (use) g = *reinterpret_cast<const VK*>(px);
+#pragma unroll
+                        for (int q = 0; q < KB; q++) xv[t][q] = g[q];
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < U; t++) {
