@@ -538,6 +538,7 @@ static int precompute_device(smg_hierarchy* h)
         for (int i = 0; i < nc; i++)
             for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) dense[(size_t)i * np + Lc.A.col[p]] = Lc.A.val[p];
         HIPCHK(h->d_Ainv.upload(dense));
+        if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(h->d_sympart.ensure((size_t)(np / 64) * (np / 64) * 64)); else h->d_sympart.release();
         DevBuf<double> work;
         HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
         HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
@@ -844,7 +845,7 @@ static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, co
     Level& Lv = h->lv[lv];
     if (lv == L - 1) {  // coarseSolve: u = u + solver.solve(B)  (:28-33, :199-200)
         ProfGuard pg(h, "MG: coarse solve");
-        HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, ctrl, h->stream));
+        HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, ctrl, h->stream, h->d_sympart.p));
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
@@ -934,7 +935,7 @@ static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, 
     Level& Lv = h->lv[lv];
     if (lv == L - 1) {
         ProfGuard pg(h, "MG: coarse solve");
-        HIPCHK(launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, Lv.b32.p, Lv.u32.p, k, ctrl, h->stream));
+        HIPCHK(launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, Lv.b32.p, Lv.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p));
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
@@ -1417,7 +1418,7 @@ extern "C" int smg_coarse_solve(smg_hierarchy* h, const double* B, int k, double
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
-    HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, nullptr, h->stream));
+    HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, nullptr, h->stream, h->d_sympart.p));
     return get_block(h, lv, Lv.u.p, k, u);
 }
 

@@ -637,12 +637,65 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
         for (int q = 0; q < CT; q++) u[(size_t)row * ld + tc * CT + q] = u[(size_t)row * ld + tc * CT + q] + acc[q];
 }
 
+// ---- k = 1, symmetric: the inverse of an SPD matrix is symmetric, so one column's product needs only the lower triangle of
+// tiles -- half the bytes of the (bandwidth-bound) coarse solve.  Tile (I, J), I >= J, yields A_IJ b_J (a share of y_I) and, off the
+// diagonal, A_IJ^T b_I (a share of y_J); the 64-row shares are summed per row in ascending block order by a second small launch:
+// deterministic, independent of scheduling.  (The two halves of the stored inverse agree to rounding; using the lower one for
+// both is the same operator to 1e-16.)
 template <typename T>
-static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, const Ctrl* ctrl, hipStream_t st)
+__global__ __launch_bounds__(256) void k_sym_gemv_tiles(const T* __restrict__ Ainv, int lda, const T* __restrict__ b, T* __restrict__ part, int nb)
+{
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (J > I) return;
+    __shared__ T tile[64][65];
+    __shared__ T bI[64], bJ[64];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int idx = e * 256 + t, r = idx >> 6, c = idx & 63;
+        tile[r][c] = Ainv[(size_t)(I * 64 + r) * lda + J * 64 + c];
+    }
+    if (t < 64) bJ[t] = b[J * 64 + t];
+    else if (t < 128) bI[t - 64] = b[I * 64 + t - 64];
+    __syncthreads();
+    if (t < 64) {
+        T s = (T)0;
+#pragma unroll 8
+        for (int c = 0; c < 64; c++) s += tile[t][c] * bJ[c];
+        part[((size_t)I * nb + J) * 64 + t] = s;
+    } else if (t < 128 && I != J) {
+        const int j = t - 64;
+        T s = (T)0;
+#pragma unroll 8
+        for (int r = 0; r < 64; r++) s += tile[r][j] * bI[r];
+        part[((size_t)J * nb + I) * 64 + j] = s;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_sym_gemv_sum(const T* __restrict__ part, int nb, int n, T* u, const int* done)
+{
+    const int stop = load_flag(done);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int a = i >> 6, l = i & 63;
+    T s = (T)0;
+#pragma unroll 8
+    for (int bidx = 0; bidx < nb; bidx++) s += part[((size_t)a * nb + bidx) * 64 + l];
+    if (!stop) u[i] = u[i] + s;
+}
+
+template <typename T>
+static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, const Ctrl* ctrl, hipStream_t st, void* sym_work)
 {
     const int* done = ctrl ? &ctrl->done : never_done();
     const int nb = (n + 3) / 4;
     if (n <= 0) return hipSuccess;
+    if (k == 1 && sym_work && lda % 64 == 0 && lda >= 512) {
+        const int nt = lda / 64;
+        hipLaunchKernelGGL((k_sym_gemv_tiles<T>), dim3(nt, nt), dim3(256), 0, st, Ainv, lda, b, (T*)sym_work, nt);
+        hipLaunchKernelGGL((k_sym_gemv_sum<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const T*)sym_work, nt, n, u, done);
+        return hipGetLastError();
+    }
     int c0 = 0;
     while (k - c0 >= 16) {
         int kc = 64;
@@ -667,14 +720,14 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
     return hipGetLastError();
 }
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
-                                 const Ctrl* ctrl, hipStream_t st)
+                                 const Ctrl* ctrl, hipStream_t st, double* sym_work)
 {
-    return launch_dense_T<double>(Ainv, n, lda, b, u, k, ctrl, st);
+    return launch_dense_T<double>(Ainv, n, lda, b, u, k, ctrl, st, sym_work);
 }
 hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
-                                     const Ctrl* ctrl, hipStream_t st)
+                                     const Ctrl* ctrl, hipStream_t st, float* sym_work)
 {
-    return launch_dense_T<float>(Ainv, n, lda, b, u, k, ctrl, st);
+    return launch_dense_T<float>(Ainv, n, lda, b, u, k, ctrl, st, sym_work);
 }
 
 // ---- mixed precision glue: fp64 outer iterate / residual  <->  fp32 V-cycle ----------------------------------------

@@ -73,10 +73,12 @@ hipError_t launch_restore_if_just_done(double* dst, const double* src, size_t n,
 hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
 
 // u[i,:] += sum_j Ainv[i,j] * b[j,:]   (mg_VCycle.cpp:199-200 with the factorisation pre-inverted)
+// sym_work (optional, (lda/64)^2 * 64 elements): with it, a single column (k = 1) is multiplied through the lower triangle of
+// tiles only (the inverse is symmetric): half the bytes, two launches, deterministic per-row summation in block order.
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
-                                 const Ctrl* ctrl, hipStream_t st);
+                                 const Ctrl* ctrl, hipStream_t st, double* sym_work = nullptr);
 hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
-                                     const Ctrl* ctrl, hipStream_t st);
+                                     const Ctrl* ctrl, hipStream_t st, float* sym_work = nullptr);
 // mixed precision glue
 hipError_t launch_cvt_f64_f32(float* dst, const double* src, size_t n, hipStream_t st);
 hipError_t launch_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const Ctrl* ctrl, hipStream_t st);

@@ -117,6 +117,7 @@ struct smg_hierarchy {
     int nc = 0, nc_pad = 0;
     smg::DevBuf<double> d_Ainv;
     smg::DevBuf<float> d_Ainv32;
+    smg::DevBuf<double> d_sympart;  // (nc_pad/64)^2 x 64 partial products of the symmetric k = 1 coarse solve (also used as float)
     bool f32_valid = false;
     int kcap32 = 0;
     // ---- execution ----
