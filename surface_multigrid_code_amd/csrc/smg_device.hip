@@ -645,8 +645,12 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
 template <typename T>
 __global__ __launch_bounds__(256) void k_sym_gemv_tiles(const T* __restrict__ Ainv, int lda, const T* __restrict__ b, T* __restrict__ part, int nb)
 {
-    const int I = blockIdx.y, J = blockIdx.x;
-    if (J > I) return;
+    // blockIdx.x enumerates the lower triangle row by row: idx = I (I + 1) / 2 + J
+    const int idx = blockIdx.x;
+    int I = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    I -= (I * (I + 1) / 2 > idx);
+    I += ((I + 1) * (I + 2) / 2 <= idx);
+    const int J = idx - I * (I + 1) / 2;
     __shared__ T tile[64][65];
     __shared__ T bI[64], bJ[64];
     const int t = threadIdx.x;
@@ -658,30 +662,37 @@ __global__ __launch_bounds__(256) void k_sym_gemv_tiles(const T* __restrict__ Ai
     if (t < 64) bJ[t] = b[J * 64 + t];
     else if (t < 128) bI[t - 64] = b[I * 64 + t - 64];
     __syncthreads();
-    if (t < 64) {
-        T s = (T)0;
+    // waves 0/1: rows of the tile against b_J (columns 0..31 / 32..63); waves 2/3: columns of the tile against b_I (rows 0..31 / 32..63)
+    __shared__ T red[4][64];
+    const int g = t >> 6, l = t & 63, h0 = (g & 1) * 32;
+    T s = (T)0;
+    if (g < 2) {
 #pragma unroll 8
-        for (int c = 0; c < 64; c++) s += tile[t][c] * bJ[c];
-        part[((size_t)I * nb + J) * 64 + t] = s;
-    } else if (t < 128 && I != J) {
-        const int j = t - 64;
-        T s = (T)0;
+        for (int c = h0; c < h0 + 32; c++) s += tile[l][c] * bJ[c];
+    } else {
 #pragma unroll 8
-        for (int r = 0; r < 64; r++) s += tile[r][j] * bI[r];
-        part[((size_t)J * nb + I) * 64 + j] = s;
+        for (int r = h0; r < h0 + 32; r++) s += tile[r][l] * bI[r];
     }
+    red[g][l] = s;
+    __syncthreads();
+    if (t < 64) part[((size_t)I * nb + J) * 64 + t] = red[0][t] + red[1][t];
+    else if (t < 128 && I != J) part[((size_t)J * nb + I) * 64 + (t - 64)] = red[2][t - 64] + red[3][t - 64];
 }
+// one workgroup per 64-row block: four waves sum a quarter of the block shares each (ascending), combined in a fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void k_sym_gemv_sum(const T* __restrict__ part, int nb, int n, T* u, const int* done)
 {
     const int stop = load_flag(done);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int a = i >> 6, l = i & 63;
+    __shared__ T red[4][64];
+    const int a = blockIdx.x, g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int q = (nb + 3) / 4, b0 = g * q, b1 = min(nb, b0 + q);
     T s = (T)0;
 #pragma unroll 8
-    for (int bidx = 0; bidx < nb; bidx++) s += part[((size_t)a * nb + bidx) * 64 + l];
-    if (!stop) u[i] = u[i] + s;
+    for (int bidx = b0; bidx < b1; bidx++) s += part[((size_t)a * nb + bidx) * 64 + l];
+    red[g][l] = s;
+    __syncthreads();
+    const int i = a * 64 + l;
+    if (g == 0 && i < n && !stop) u[i] = u[i] + ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
 }
 
 template <typename T>
@@ -692,8 +703,8 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
     if (n <= 0) return hipSuccess;
     if (k == 1 && sym_work && lda % 64 == 0 && lda >= 512) {
         const int nt = lda / 64;
-        hipLaunchKernelGGL((k_sym_gemv_tiles<T>), dim3(nt, nt), dim3(256), 0, st, Ainv, lda, b, (T*)sym_work, nt);
-        hipLaunchKernelGGL((k_sym_gemv_sum<T>), dim3((n + 255) / 256), dim3(256), 0, st, (const T*)sym_work, nt, n, u, done);
+        hipLaunchKernelGGL((k_sym_gemv_tiles<T>), dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Ainv, lda, b, (T*)sym_work, nt);
+        hipLaunchKernelGGL((k_sym_gemv_sum<T>), dim3(nt), dim3(256), 0, st, (const T*)sym_work, nt, n, u, done);
         return hipGetLastError();
     }
     int c0 = 0;
