@@ -783,66 +783,148 @@ hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl
 // Blocked Gauss-Jordan inversion (no pivoting; the matrix is SPD), block size 64, 64x64 update tiles.  Every step streams
 // the whole matrix once (read + write), so the block size is the number of passes: 64 halves the traffic of 32; the update
 // walks the 64 pivot columns in two halves of 32 to stay inside 64 KB of LDS.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int GJ_NB = 64;
 constexpr int GJ_H = 32;   // sub-panel width staged through LDS
 
-// inverse of the 64 x 64 pivot block, one workgroup, 4 elements per thread.  (A variant that keeps the elements in registers and
-// passes only row p / column p through LDS with one barrier per pivot measured slower: 53 vs 35 us.)
-__global__ __launch_bounds__(1024) void k_gj_diag(const double* M, int n, int kb, double* dinv)
+// In-place inverse of a 64 x 64 (SPD) block held in LDS, by a workgroup of 256 threads: Gauss-Jordan in four steps of 16 -- the
+// 16 x 16 pivot is inverted by one wave on its own (16 eliminations, no workgroup barrier), the row panel and the rank-16 update
+// run on the matrix cores -- 12 workgroup barriers instead of the 128 of the element-wise elimination, and far fewer LDS reads
+// (35 us -> 17 us for the stand-alone kernel; what remains is the chain of 64 dependent eliminations).
+// Must be entered by all threads, with `a` complete (barrier before the call is the caller's).
+__device__ __forceinline__ void gj_invert64(double (*a)[GJ_NB + 1], double (*Rb)[GJ_NB + 1], double (*Cb)[17])
 {
-    __shared__ double a[GJ_NB][GJ_NB + 1];
-    const int K = kb * GJ_NB;
-    const int j = threadIdx.x % GJ_NB, i0 = threadIdx.x / GJ_NB;   // rows i0, i0 + 16, i0 + 32, i0 + 48
+    const int t = threadIdx.x;
+    for (int kk = 0; kk < 4; kk++) {
+        const int P = 16 * kk;
+        if (t < 64) {
+            const int jj = t & 15, ig = t >> 4;           // rows ig + 4 q of the pivot, column jj
+            for (int p = 0; p < 16; p++) {
+                // reciprocal of the pivot: hardware estimate + two Newton steps (the IEEE division sequence is several times longer
+                // and sits on the one serial chain of the whole inversion)
+                const double piv = a[P + p][P + p], r = a[P + p][P + jj];
+                double d = __builtin_amdgcn_rcp(piv);
+                d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
+                d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
+                double f[4], cur[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) a[i0 + 16 * q][j] = M[(size_t)(K + i0 + 16 * q) * n + K + j];
-    __syncthreads();
-    for (int p = 0; p < GJ_NB; p++) {
-        const double d = 1.0 / a[p][p], r = a[p][j];
-        double f[4], cur[4];
+                for (int q = 0; q < 4; q++) { f[q] = a[P + ig + 4 * q][P + p]; cur[q] = a[P + ig + 4 * q][P + jj]; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 4; q++) { f[q] = a[i0 + 16 * q][p]; cur[q] = a[i0 + 16 * q][j]; }
+                for (int q = 0; q < 4; q++) {
+                    const int i = ig + 4 * q;
+                    double val;
+                    if (i == p) val = (jj == p) ? d : r * d;
+                    else val = (jj == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
+                    a[P + i][P + jj] = val;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         __syncthreads();
+        // row panel D^-1 a[P.., :] (one 16 x 16 tile per wave; the inverse itself in the pivot columns) and a copy of the column panel
+        const int w = t >> 6, lane = t & 63, lr = lane >> 4, lc = lane & 15;
+        {
+            if (w == kk) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = i0 + 16 * q;
-            double val;
-            if (i == p) val = (j == p) ? d : r * d;
-            else val = (j == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
-            a[i][j] = val;
+                for (int r = 0; r < 4; r++) Rb[lr + 4 * r][16 * w + lc] = a[P + lr + 4 * r][16 * w + lc];
+            } else {
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[P + lc][P + 4 * q + lr], a[P + 4 * q + lr][16 * w + lc], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) Rb[lr + 4 * r][16 * w + lc] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = t + 256 * q; Cb[e >> 4][e & 15] = a[e >> 4][P + (e & 15)]; }
+        __syncthreads();
+        // rank-16 update, four 16 x 16 tiles (tix >> 2, tix & 3) per wave; the pivot rows take the row panel
+#pragma unroll
+        for (int tix = w; tix < 16; tix += 4) {
+            const int ti = tix >> 2, tj = tix & 3;
+            if (ti == kk) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) a[P + lr + 4 * r][16 * tj + lc] = Rb[lr + 4 * r][16 * tj + lc];
+            } else {
+                v4f64 acc;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = tj == kk ? 0.0 : a[16 * ti + lr + 4 * r][16 * tj + lc];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cb[16 * ti + lc][4 * q + lr], Rb[4 * q + lr][16 * tj + lc], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) a[16 * ti + lr + 4 * r][16 * tj + lc] = acc[r];
+            }
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) dinv[(i0 + 16 * q) * GJ_NB + j] = a[i0 + 16 * q][j];
 }
 
-// block x handles columns [32x, 32x+32) of the scaled pivot row panel and rows [32x, 32x+32) of the column panel
+// inverse of the first 64 x 64 pivot block (the later ones are inverted by the look-ahead of k_gj_update)
+__global__ __launch_bounds__(256) void k_gj_diag(const double* M, int n, int kb, double* dinv)
+{
+    __shared__ double a[GJ_NB][GJ_NB + 1];
+    __shared__ double Rb[16][GJ_NB + 1];
+    __shared__ double Cb[GJ_NB][17];
+    const int K = kb * GJ_NB;
+    for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 256) a[e / GJ_NB][e % GJ_NB] = M[(size_t)(K + e / GJ_NB) * n + K + e % GJ_NB];
+    __syncthreads();
+    gj_invert64(a, Rb, Cb);
+    for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 256) dinv[e] = a[e / GJ_NB][e % GJ_NB];
+}
+
+// Only the lower triangle of tiles is kept up to date (the iterates of Gauss-Jordan on a symmetric matrix are symmetric up to the
+// sign of the blocks that couple an already inverted block with one still to come), which halves the traffic and the flops of
+// every step; SimplicialLDLT reads the lower triangle only, too.  With pivot block K (tile index kb):
+//   column panel  C_I = M[I,K]  = stored tile (I,K) for I > K,   = -(stored tile (K,I))^T for I < K  (I already inverted)
+//   row panel     R_J = D^-1 M[K,J],  M[K,J] = stored tile (K,J) for J < K,  = (stored tile (J,K))^T for J > K
+// so one source tile per 64 indices feeds both panels.  Block x handles indices [32x, 32x+32).
 __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int kb, const double* dinv, double* rowp,
                                                    double* colp)
 {
     __shared__ double d_s[GJ_NB][GJ_NB + 1];
-    __shared__ double m_s[GJ_NB][GJ_H + 1];
+    __shared__ double m_s[GJ_NB][GJ_H + 1];   // m_s[r][c] = M[K + r][j0 + c] (as a full symmetric-iterate matrix would hold it)
     const int K = kb * GJ_NB;
     const int j0 = blockIdx.x * GJ_H;
+    const int J = j0 / GJ_NB;
     for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += 256) d_s[t / GJ_NB][t % GJ_NB] = dinv[t];
-    for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) m_s[t / GJ_H][t % GJ_H] = M[(size_t)(K + t / GJ_H) * n + j0 + t % GJ_H];
-    // column panel copy: rows j0..j0+31, columns K..K+63
-    for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) {
-        const int i = j0 + t / GJ_NB, c = t % GJ_NB;
-        colp[(size_t)i * GJ_NB + c] = M[(size_t)i * n + K + c];
+    if (J < kb) {
+        for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) m_s[t / GJ_H][t % GJ_H] = M[(size_t)(K + t / GJ_H) * n + j0 + t % GJ_H];
+    } else if (J > kb) {
+        for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) m_s[t % GJ_NB][t / GJ_NB] = M[(size_t)(j0 + t / GJ_NB) * n + K + t % GJ_NB];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) {
-        const int r = t / GJ_H, c = t % GJ_H, j = j0 + c;
-        double v;
-        if (j >= K && j < K + GJ_NB) v = d_s[r][j - K];
-        else {
-            v = 0.0;
-#pragma unroll 8
-            for (int s = 0; s < GJ_NB; s++) v += d_s[r][s] * m_s[s][c];
+    if (J != kb) {
+        const double sgn = J < kb ? -1.0 : 1.0;
+        for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) {
+            const int c = t / GJ_NB, r = t % GJ_NB;
+            colp[(size_t)(j0 + c) * GJ_NB + r] = sgn * m_s[r][c];
         }
-        rowp[(size_t)r * n + j] = v;
     }
+    if (J == kb) {
+        for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) {
+            const int r = t / GJ_H, c = t % GJ_H;
+            rowp[(size_t)r * n + j0 + c] = d_s[r][j0 + c - K];
+        }
+        return;
+    }
+    // D^-1 (64 x 64) times the 64 x 32 slab on the matrix cores: wave w -> rows 16 w .. 16 w + 15, two 16 x 16 tiles
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane >> 4, lc = lane & 15;
+    v4f64 acc[2] = {(v4f64){0.0, 0.0, 0.0, 0.0}, (v4f64){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll 4
+    for (int q = 0; q < GJ_NB / 4; q++) {
+        const double av = d_s[16 * w + lc][4 * q + lr];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, m_s[4 * q + lr][16 * ct + lc], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) rowp[(size_t)(16 * w + lr + 4 * r) * n + j0 + 16 * ct + lc] = acc[ct][r];
 }
 
 // Trailing update  M -= colp (n x 64) * rowp (64 x n)  on the fp64 matrix cores: the one GEMM-shaped piece of the library.
@@ -851,27 +933,34 @@ __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int k
 // row (lane >> 4) + 4 r, column lane & 15).  Operands come straight from the two panels (L1/L2-resident: 2 MB each); the matrix
 // itself is read and written once per step, which is what bounds the step.  The result is compared with LDL^T to 1e-11, not
 // bit for bit, so the fused multiply-adds are fine here.
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 // (a 128 x 64 tile per workgroup, one B operand feeding two MFMA tiles, measured slower: 9.1 vs 8.5 ms per inversion)
 // Look-ahead: the workgroup that updates the NEXT pivot block (it is dispatched first: block (0,0) trades tiles with it) goes on
-// to invert that block and leaves the result in dinv_next, so the 35 us pivot-block inversion no longer runs alone between the
-// steps but in the shadow of this kernel.
+// to invert that block and leaves the result in dinv_next, so the pivot-block inversion does not run alone between the
+// steps but in the shadow of this kernel.  (1024-thread workgroups of four tiles measured slower: 55 vs 43 us per step.)
 __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp,
-                                                   double* dinv_next)
+                                                    double* dinv_next)
 {
     __shared__ double a[GJ_NB][GJ_NB + 1];
+    __shared__ double Rb[16][GJ_NB + 1];
+    __shared__ double Cb[GJ_NB][17];
     const int K = kb * GJ_NB;
     const int nb = n / 64, nxt = kb + 1;                  // tile index of the next pivot block (none after the last step)
-    int by = blockIdx.y, bx = blockIdx.x;
-    if (nxt < nb) {                                       // swap tile (0,0) with tile (nxt, nxt)
-        if (by == 0 && bx == 0) { by = nxt; bx = nxt; }
-        else if (by == nxt && bx == nxt) { by = 0; bx = 0; }
+    // one workgroup per tile of the lower triangle, enumerated row by row: idx = by (by + 1) / 2 + bx, bx <= by
+    int idx = blockIdx.x;
+    if (nxt < nb) {                                       // tile (0,0) trades places with tile (nxt, nxt): that one is dispatched first
+        const int inx = nxt * (nxt + 1) / 2 + nxt;
+        if (idx == 0) idx = inx;
+        else if (idx == inx) idx = 0;
     }
-    const bool lookahead = (nxt < nb) && by == nxt && bx == nxt;
+    int by = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    by -= (by * (by + 1) / 2 > idx);
+    by += ((by + 1) * (by + 2) / 2 <= idx);
+    const int bx = idx - by * (by + 1) / 2;
+    const bool lookahead = (nxt < nb) && blockIdx.x == 0; // uniform per workgroup: this one goes on to invert the next pivot block
     const int i0 = by * 64, j0 = bx * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane >> 4, lc = lane & 15;
-    if (i0 >= K && i0 < K + GJ_NB) {   // the pivot rows take the scaled row panel (64-row tiles never straddle the pivot block)
+    if (by == kb) {   // the pivot rows take the scaled row panel (64-row tiles never straddle the pivot block)
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -879,71 +968,81 @@ __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, con
                 const int i = i0 + 16 * wave + lr + 4 * r, j = j0 + 16 * c + lc;
                 M[(size_t)i * n + j] = rowp[(size_t)(i - K) * n + j];
             }
-        return;
-    }
-    v4f64 acc[4];
+    } else {
+        const bool jpiv = bx == kb;
+        double* mp = M + (size_t)(i0 + 16 * wave + lr) * n + j0 + lc;
+        v4f64 old[4];                                     // the tile's old values: requested before the panel operands
 #pragma unroll
-    for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
-    const double* bp = rowp + (size_t)lr * n + j0 + lc;
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) old[c][r] = jpiv ? 0.0 : mp[(size_t)(4 * r) * n + 16 * c];
+        v4f64 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
+        const double* bp = rowp + (size_t)lr * n + j0 + lc;
 #pragma unroll 4
-    for (int s = 0; s < GJ_NB / 4; s++) {
-        const double av = ap[4 * s];
+        for (int s = 0; s < GJ_NB / 4; s++) {
+            const double av = ap[4 * s];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const double b = bp[(size_t)(4 * s) * n + 16 * c];
-            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[c], 0, 0, 0);
+            for (int c = 0; c < 4; c++) {
+                const double b = bp[(size_t)(4 * s) * n + 16 * c];
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[c], 0, 0, 0);
+            }
         }
-    }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int j = j0 + 16 * c + lc;
-        const bool jpiv = (j >= K && j < K + GJ_NB);
+        for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            double* m = M + (size_t)(i0 + 16 * wave + lr + 4 * r) * n + j;
-            const double v = (jpiv ? 0.0 : *m) - acc[c][r];
-            *m = v;
-            if (lookahead) a[16 * wave + lr + 4 * r][16 * c + lc] = v;
-        }
+            for (int r = 0; r < 4; r++) {
+                const double v = old[c][r] - acc[c][r];
+                mp[(size_t)(4 * r) * n + 16 * c] = v;
+                if (lookahead) a[16 * wave + lr + 4 * r][16 * c + lc] = v;
+            }
     }
-    if (!lookahead) return;   // uniform per workgroup
-    // invert the freshly updated next pivot block: 256 threads, 16 elements each (rows ti + 4 q, column tj).  (Keeping the
-    // elements in registers and passing only row / column p through LDS measured slower, here as in k_gj_diag.)
+    if (!lookahead) return;
+    // invert the freshly updated next pivot block with the whole workgroup
     __syncthreads();
-    const int tj = threadIdx.x % GJ_NB, ti = threadIdx.x / GJ_NB;
-    for (int p = 0; p < GJ_NB; p++) {
-        const double d = 1.0 / a[p][p], r = a[p][tj];
-        double f[16], cur[16];
+    gj_invert64(a, Rb, Cb);
+    for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 256) dinv_next[e] = a[e / GJ_NB][e % GJ_NB];
+}
+
+// upper triangle of tiles <- transpose of the lower one (the multi-column coarse solves read whole rows)
+__global__ __launch_bounds__(256) void k_mirror_lower(double* M, int n)
+{
+    __shared__ double a[64][65];
+    const int idx = blockIdx.x;                            // strictly lower tiles: idx = I (I - 1) / 2 + J, J < I
+    int I = (int)((sqrtf(8.0f * (float)idx + 1.0f) + 1.0f) * 0.5f);
+    I -= (I * (I - 1) / 2 > idx);
+    I += ((I + 1) * I / 2 <= idx);
+    const int J = idx - I * (I - 1) / 2;
+    const int t = threadIdx.x;
 #pragma unroll
-        for (int q = 0; q < 16; q++) { f[q] = a[ti + 4 * q][p]; cur[q] = a[ti + 4 * q][tj]; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = ti + 4 * q;
-            double val;
-            if (i == p) val = (tj == p) ? d : r * d;
-            else val = (tj == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
-            a[i][tj] = val;
-        }
-        __syncthreads();
+    for (int e = 0; e < 16; e++) {
+        const int q = e * 256 + t, r = q >> 6, c = q & 63;
+        a[r][c] = M[(size_t)(I * 64 + r) * n + J * 64 + c];
     }
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; q++) dinv_next[(ti + 4 * q) * GJ_NB + tj] = a[ti + 4 * q][tj];
+    for (int e = 0; e < 16; e++) {
+        const int q = e * 256 + t, r = q >> 6, c = q & 63;
+        M[(size_t)(J * 64 + r) * n + I * 64 + c] = a[c][r];
+    }
 }
 
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     if (n % 64) return hipErrorInvalidValue;
+    const int nt = n / 64;
     double* rowp = work;
     double* colp = work + (size_t)n * GJ_NB;
     double* dinv[2] = {colp + (size_t)n * GJ_NB, colp + (size_t)n * GJ_NB + GJ_NB * GJ_NB};
-    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(1024), 0, st, M, n, 0, dinv[0]);   // only the first pivot block; the others: look-ahead
-    for (int kb = 0; kb < n / GJ_NB; kb++) {
+    hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, M, n, 0, dinv[0]);   // only the first pivot block; the others: look-ahead
+    for (int kb = 0; kb < nt; kb++) {
         hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv[kb & 1], rowp, colp);
-        hipLaunchKernelGGL(k_gj_update, dim3(n / 64, n / 64), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
+        hipLaunchKernelGGL(k_gj_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
     }
+    if (nt > 1) hipLaunchKernelGGL(k_mirror_lower, dim3(nt * (nt - 1) / 2), dim3(256), 0, st, M, n);
     return hipGetLastError();
 }
 
