@@ -136,6 +136,28 @@ hipError_t SellBuf::upload(const Sell& S)
     }
     color_slice_ptr = S.color_slice_ptr;
     stored = S.nnz; padded = S.padded(); used = S.used();
+    // where the diagonal of each first-colour row sits in the value array (restriction launches with a fused first colour)
+    n_first = 0;
+    if (S.n_rows == S.n_cols && S.color_slice_ptr.size() >= 3) {
+        const int s1 = S.color_slice_ptr[1];
+        const int nf = S.slice_row[s1];
+        std::vector<int> slot((size_t)nf, -1);
+        bool ok = true;
+        for (int sl = 0; sl < s1 && ok; sl++) {
+            const int r0 = S.slice_row[sl], r1 = S.slice_row[sl + 1];
+            for (int r = r0; r < r1; r++) {
+                for (int j = 0; j < S.slice_w[sl]; j++) {
+                    const size_t at = ((size_t)S.slice_off[sl] + j) * S.C + (r - r0);
+                    if (S.col[at] == r) { slot[r] = (int)at; break; }
+                }
+                if (slot[r] < 0) { ok = false; break; }
+            }
+        }
+        if (ok && nf > 0) {
+            if ((e = first_diag_slot.upload(slot)) != hipSuccess) return e;
+            n_first = nf;
+        }
+    }
     return hipSuccess;
 }
 
@@ -826,20 +848,23 @@ static int ensure_work(smg_hierarchy* h, int k)
 }
 
 // `iters` forward Gauss-Seidel sweeps: one launch per colour (reference relax(), src/mg_VCycle.cpp:113-178)
-static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl)
+// first_done: the first colour of the first sweep was already produced by the restriction launch (FirstColour)
+static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
     const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
     const std::vector<int>& cs = G.color_slice_ptr;
     for (int it = 0; it < iters; it++)
-        for (size_t c = 0; c + 1 < cs.size(); c++)
+        for (size_t c = (it == 0 && first_done) ? 1 : 0; c + 1 < cs.size(); c++)
             HIPCHK(launch_sell(SELL_GS, G.view, cs[c], cs[c + 1], u, b, u, k, ctrl, nullptr, nullptr, h->stream));
     return SMG_OK;
 }
 
 // reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
-static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+static bool fuse_first_colour() { static const int on = env_int("SMG_FUSE_FIRST", 1); return on != 0; }
+
+static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
 {
     const int L = h->n_levels;
     Level& Lv = h->lv[lv];
@@ -849,18 +874,25 @@ static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, co
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
-    int rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, pre, ctrl);  // :36
+    int rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, pre, ctrl, first_done);  // :36
     if (rc) return rc;
     {   // r = B - A u  (:40-42)
         ProfGuard pg(h, "MG: residual");
         HIPCHK(launch_sell(SELL_RESID, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, Lv.r.p, k, ctrl, nullptr, nullptr, h->stream));
     }
+    // With uc = 0 the first colour launch of the coarse level's first pre-smoothing sweep computes (rc_i - 0) / a_ii: the
+    // restriction launch writes that into uc itself (bit for bit the same value) and the sweep starts at the second colour.
+    const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
+    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Gc.n_first > 0;
     {   // rc = PT r  (:43-44, :80)
         ProfGuard pg(h, "MG: restrict");
         // rc = PT r (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
-        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream, Lc.u.p));
+        FirstColour fc;
+        if (fuse) { fc.diag_slot = Gc.first_diag_slot.p; fc.n_first = Gc.n_first; fc.val = Gc.view.val; }
+        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream, Lc.u.p,
+                           fuse ? &fc : nullptr));
     }
-    rc = enqueue_vcycle(h, lv + 1, k, pre, post, ctrl);  // :48
+    rc = enqueue_vcycle(h, lv + 1, k, pre, post, ctrl, fuse);  // :48
     if (rc) return rc;
     {   // u = u + P uc  (:51-53, :91)
         ProfGuard pg(h, "MG: prolong");
@@ -915,7 +947,7 @@ static int ensure_fp32(smg_hierarchy* h, int k)
     return SMG_OK;
 }
 
-static int enqueue_relax32(smg_hierarchy* h, int lv, const float* b, float* u, int k, int iters, const Ctrl* ctrl)
+static int enqueue_relax32(smg_hierarchy* h, int lv, const float* b, float* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");
@@ -923,13 +955,13 @@ static int enqueue_relax32(smg_hierarchy* h, int lv, const float* b, float* u, i
     const SellDev& V = Lv.gs_on_transpose ? Lv.dAT32 : Lv.dA32;
     const std::vector<int>& cs = G.color_slice_ptr;
     for (int it = 0; it < iters; it++)
-        for (size_t c = 0; c + 1 < cs.size(); c++)
+        for (size_t c = (it == 0 && first_done) ? 1 : 0; c + 1 < cs.size(); c++)
             HIPCHK(launch_sell_f32(SELL_GS, V, cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
     return SMG_OK;
 }
 
 // the same cycle as enqueue_vcycle, on the fp32 images and fp32 work vectors
-static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
 {
     const int L = h->n_levels;
     Level& Lv = h->lv[lv];
@@ -939,17 +971,22 @@ static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, 
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
-    int rc = enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, pre, ctrl);
+    int rc = enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, pre, ctrl, first_done);
     if (rc) return rc;
     {
         ProfGuard pg(h, "MG: residual");
         HIPCHK(launch_sell_f32(SELL_RESID, Lv.dA32, 0, Lv.dA32.n_slices, Lv.u32.p, Lv.b32.p, Lv.r32.p, k, ctrl, h->stream));
     }
+    const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
+    const SellDev& Vc = Lc.gs_on_transpose ? Lc.dAT32 : Lc.dA32;
+    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Gc.n_first > 0 && Vc.valf;
     {
         ProfGuard pg(h, "MG: restrict");
-        HIPCHK(launch_sell_f32(SELL_AX, Lc.dPT32, 0, Lc.dPT32.n_slices, Lv.r32.p, nullptr, Lc.b32.p, k, ctrl, h->stream, Lc.u32.p));
+        FirstColour fc;
+        if (fuse) { fc.diag_slot = Gc.first_diag_slot.p; fc.n_first = Gc.n_first; fc.valf = Vc.valf; }
+        HIPCHK(launch_sell_f32(SELL_AX, Lc.dPT32, 0, Lc.dPT32.n_slices, Lv.r32.p, nullptr, Lc.b32.p, k, ctrl, h->stream, Lc.u32.p, fuse ? &fc : nullptr));
     }
-    rc = enqueue_vcycle32(h, lv + 1, k, pre, post, ctrl);
+    rc = enqueue_vcycle32(h, lv + 1, k, pre, post, ctrl, fuse);
     if (rc) return rc;
     {
         ProfGuard pg(h, "MG: prolong");

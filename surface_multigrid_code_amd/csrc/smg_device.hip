@@ -46,6 +46,9 @@ static const int* never_done()
 }
 
 
+// what a restriction launch leaves in the coarse level's u (see FirstColour in smg_device.hpp)
+template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; };
+
 // One wavefront per slice of 64 rows; lane l owns row row0 + l.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
@@ -58,7 +61,7 @@ template <int MODE, int KB, typename T, int W0C = -1>
 __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                               int a_w_lo, int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                               const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld, const int* done,
-                                              double* partials, T* zero_rows)
+                                              double* partials, CoarseInit<T> z)
 {
     struct { const int *slice_row, *slice_off, *slice_w, *order, *col; int stride, w_lo; } A = {a_slice_row, a_slice_off, a_slice_w, a_order,
                                                                                                a_col, a_stride, a_w_lo};
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         // reads below from scalar into vector loads.)
         {
             size_t keep = (size_t)x ^ (size_t)A.slice_row ^ (size_t)A.slice_w ^ (size_t)b ^ (size_t)y ^ (size_t)done ^ (size_t)ld;
+            if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first;
             asm("" : "+s"(keep));
             if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
         }
@@ -111,6 +115,8 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         T diag = (T)1;
         T bv[KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
         const bool live = lane < nrow;
+        T zd = (T)1;   // restriction with a fused first colour: the coarse diagonal, requested now
+        if (MODE == SELL_AX && live && rowb < z.n_first) zd = z.gs_val[z.diag_slot[rowb]];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
             acc[q] = (T)0;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
             const size_t o = (size_t)rowb * ld;
 #pragma unroll
             for (int q = 0; q < KB; q++) {
-                if (MODE == SELL_AX) { y[o + q] = acc[q]; if (zero_rows) zero_rows[o + q] = (T)0; }
+                if (MODE == SELL_AX) { y[o + q] = acc[q]; if (z.u) z.u[o + q] = rowb < z.n_first ? acc[q] / zd : (T)0; }
                 else if (MODE == SELL_RESID) y[o + q] = bv[q] - acc[q];
                 else if (MODE == SELL_ADD) y[o + q] = bv[q] + acc[q];
                 else if (MODE == SELL_GS) y[o + q] = (bv[q] - acc[q]) / diag;
@@ -207,7 +213,7 @@ template <int MODE, int KW, typename T>
 __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                                    int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                                    const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld,
-                                                   const int* done, double* partials, T* zero_rows)
+                                                   const int* done, double* partials, CoarseInit<T> z)
 {
     struct { const int *slice_row, *slice_off, *slice_w, *order, *col; int stride; } A = {a_slice_row, a_slice_off, a_slice_w, a_order, a_col,
                                                                                         a_stride};
@@ -231,12 +237,14 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int w = A.slice_w[s];
         int rl[R];
-        T acc[R], diag[R], bv[R];
+        T acc[R], diag[R], bv[R], zd[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             rl[r] = sub * RW + r * G + g;   // row inside the slice
             acc[r] = (T)0; diag[r] = (T)1;
             const bool live = rl[r] < nrow;
+            zd[r] = (T)1;
+            if (MODE == SELL_AX && live && row0 + rl[r] < z.n_first) zd[r] = z.gs_val[z.diag_slot[row0 + rl[r]]];
             const size_t o = (size_t)(row0 + rl[r]) * ld + c;
             if (MODE == SELL_AX) bv[r] = (T)0;
             else if (MODE == SELL_ADD) bv[r] = live ? y[o] : (T)0;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         for (int r = 0; r < R; r++) {
             if (rl[r] < nrow && !stop) {
                 const size_t o = (size_t)(row0 + rl[r]) * ld + c;
-                if (MODE == SELL_AX) { y[o] = acc[r]; if (zero_rows) zero_rows[o] = (T)0; }
+                if (MODE == SELL_AX) { y[o] = acc[r]; if (z.u) z.u[o] = row0 + rl[r] < z.n_first ? acc[r] / zd[r] : (T)0; }
                 else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
                 else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
                 else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
@@ -296,12 +304,22 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
 }
 
 template <typename T> static const T* host_vals(const SellDev& A);
+template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, const FirstColour* first)
+{
+    CoarseInit<T> z{zero_rows ? zero_rows + c0 : nullptr, nullptr, nullptr, 0};
+    if (zero_rows && first && first->n_first > 0) {
+        if constexpr (std::is_same<T, double>::value) z.gs_val = first->val; else z.gs_val = first->valf;
+        z.diag_slot = first->diag_slot;
+        z.n_first = (z.gs_val && z.diag_slot) ? first->n_first : 0;
+    }
+    return z;
+}
 template <> const double* host_vals<double>(const SellDev& A) { return A.val; }
 template <> const float* host_vals<float>(const SellDev& A) { return A.valf; }
 
 template <int MODE, int KW, typename T>
 static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const T* x, const T* b, T* y,
-                            int k, const int* done, double* partials, T* zero_rows, hipStream_t st, int* nb_out)
+                            int k, const int* done, double* partials, CoarseInit<T> zero_rows, hipStream_t st, int* nb_out)
 {
     const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
     const int nb = (waves + 3) / 4;
@@ -324,7 +342,7 @@ int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb();
 
 template <int MODE, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
-                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows)
+                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows, const FirstColour* first)
 {
     int s_end = s_end_in;
     const int ns = s_end - s_begin;
@@ -346,7 +364,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             const T* bb = b ? b + c0 : nullptr;
             T* yy = y ? y + c0 : nullptr;
             double* pp = partials ? partials + poff : nullptr;
-            T* zz = zero_rows ? zero_rows + c0 : nullptr;
+            const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first);
             int wnb = 0;
             switch (kw) {
                 case 64: launch_wide_one<MODE, 64, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
@@ -364,7 +382,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         const T* bb = b ? b + c0 : nullptr;
         T* yy = y ? y + c0 : nullptr;
         double* pp = partials ? partials + poff : nullptr;
-        T* zz = zero_rows ? zero_rows + c0 : nullptr;
+        const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first);
         poff += (size_t)nb;
         switch (kb) {
             case 1: {
@@ -397,18 +415,18 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
 template <typename T>
 static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, int s_end, const T* x, const T* b,
                                   T* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                                  T* zero_rows)
+                                  T* zero_rows, const FirstColour* first)
 {
     switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
         case SELL_RESID_SS:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
             else return hipErrorInvalidValue;
-        case SELL_ADD: return launch_sell_mode<SELL_ADD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
-        case SELL_GS: return launch_sell_mode<SELL_GS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+        case SELL_GS: return launch_sell_mode<SELL_GS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
         case SELL_RESID_BOTH:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
             else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
@@ -416,17 +434,17 @@ static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, 
 
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                       double* zero_rows)
+                       double* zero_rows, const FirstColour* first)
 {
-    return launch_sell_any<double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows);
+    return launch_sell_any<double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
 }
 
 // fp32 twin for the mixed-precision V-cycle (A.valf must be set; the norm modes are fp64-only)
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
-                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows)
+                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows, const FirstColour* first)
 {
     if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
-    return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows);
+    return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows, first);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control

@@ -53,11 +53,21 @@ enum SellMode {
 // blocks is returned through *n_blocks.
 // zero_rows (SELL_AX only, optional): an n_rows x k block that is set to +0.0 row by row alongside y (the restriction
 // launch also performs `uc.setZero()`, mg_VCycle.cpp:46-47).
+// first (with zero_rows, optional): the rows of the coarse level's first colour get, instead of +0.0, what the first colour
+// launch of the first pre-smoothing sweep would leave there -- y_i / a_ii: with a zero initial guess every product of that
+// launch is a_ij * 0, so (b_i - 0) / a_ii is bit for bit the sweep's value, and the cycle skips that launch.
+struct FirstColour {
+    const int* diag_slot = nullptr;   // per row of the first colour: slot of the diagonal in the sweep's SELL value array
+    int n_first = 0;                  // rows of the first colour (they lead the colour-major numbering)
+    const double* val = nullptr;      // the sweep's SELL values (A or A^T) ...
+    const float* valf = nullptr;      // ... and their fp32 image
+};
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                       double* zero_rows = nullptr);
+                       double* zero_rows = nullptr, const FirstColour* first = nullptr);
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
-                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows = nullptr);
+                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows = nullptr,
+                           const FirstColour* first = nullptr);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

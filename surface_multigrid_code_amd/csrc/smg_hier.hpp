@@ -46,6 +46,8 @@ struct SellBuf {  // device image of one SELL matrix
     DevBuf<double> val;
     SellDev view;
     std::vector<int> color_slice_ptr;
+    DevBuf<int> first_diag_slot;             // coloured square matrices: slot of a_ii for the rows of the first colour ...
+    int n_first = 0;                         // ... and their number (0: not available), see FirstColour in smg_device.hpp
     long stored = 0, padded = 0, used = 0;   // CSR entries / allocated slots / slots the kernels read
     hipError_t upload(const Sell& S);
 };
