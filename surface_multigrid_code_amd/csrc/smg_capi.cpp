@@ -486,53 +486,53 @@ static int precompute_device(smg_hierarchy* h)
     }
     h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
     StageTimer tm;
-    // host: all SELL images concurrently; then the uploads
-    struct Images { Sell A, AT, P, PT; bool has_AT = false, bad = false; };
-    std::vector<Images> img(L);
+    // all SELL images concurrently on host threads, each uploaded by the task that built it (pageable-memory copies are bound by
+    // the host-side staging copy, so they overlap with the other tasks' work and with each other)
+    std::vector<int> bad(L, 0);
     {
         std::vector<std::function<void()>> tasks;
+        std::vector<hipError_t> errs;
+        errs.reserve((size_t)4 * L);
         for (int lv = 0; lv < L; lv++) {
-            Level& Lv = h->lv[lv];
             if (lv < L - 1) {
-                tasks.push_back([&, lv] { img[lv].A = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region); });
+                errs.push_back(hipSuccess);
+                hipError_t* eA = &errs.back();
+                tasks.push_back([&, lv, eA] {
+                    Sell S = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region);
+                    *eA = h->lv[lv].dA.upload(S);
+                });
                 // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
                 // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
                 // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
-                tasks.push_back([&, lv] {
+                errs.push_back(hipSuccess);
+                hipError_t* eT = &errs.back();
+                tasks.push_back([&, lv, eT] {
                     Level& Lw = h->lv[lv];
                     Csr AT = transpose(Lw.A_int);
                     Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
+                    Lw.dAT = SellBuf();
                     if (Lw.gs_on_transpose) {
-                        if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { img[lv].bad = true; return; }
-                        img[lv].AT = build_sell(AT, &Lw.ord.color_ptr, sellC, false);
-                        img[lv].has_AT = true;
+                        if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad[lv] = 1; return; }
+                        Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false);
+                        *eT = Lw.dAT.upload(S);
                     }
                 });
             }
             if (lv >= 1) {
-                tasks.push_back([&, lv] { img[lv].P = build_sell(h->lv[lv].P_int, nullptr); });
-                tasks.push_back([&, lv] { img[lv].PT = build_sell(h->lv[lv].PT_int, nullptr); });
+                errs.push_back(hipSuccess);
+                hipError_t* eP = &errs.back();
+                tasks.push_back([&, lv, eP] { Sell S = build_sell(h->lv[lv].P_int, nullptr); *eP = h->lv[lv].dP.upload(S); });
+                errs.push_back(hipSuccess);
+                hipError_t* eQ = &errs.back();
+                tasks.push_back([&, lv, eQ] { Sell S = build_sell(h->lv[lv].PT_int, nullptr); *eQ = h->lv[lv].dPT.upload(S); });
             }
-            (void)Lv;
         }
         parallel_tasks(tasks);
+        for (int lv = 0; lv < L; lv++)
+            if (bad[lv]) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+        for (hipError_t e : errs) HIPCHK(e);
     }
-    tm.lap("device: SELL images built (host)");
-    for (int lv = 0; lv < L; lv++) {
-        Level& Lv = h->lv[lv];
-        if (lv < L - 1) {
-            if (img[lv].bad) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
-            HIPCHK(Lv.dA.upload(img[lv].A));
-            Lv.dAT = SellBuf();
-            if (img[lv].has_AT) HIPCHK(Lv.dAT.upload(img[lv].AT));
-        }
-        if (lv >= 1) {
-            HIPCHK(Lv.dP.upload(img[lv].P));
-            HIPCHK(Lv.dPT.upload(img[lv].PT));
-        }
-        img[lv] = Images();
-    }
-    tm.lap("device: SELL images uploaded");
+    tm.lap("device: SELL images built and uploaded");
     // level-0 index maps
     {
         const Level& L0 = h->lv[0];
@@ -555,11 +555,16 @@ static int precompute_device(smg_hierarchy* h)
         const int nc = Lc.n;
         const int np = ((nc + 63) / 64) * 64;
         h->nc = nc; h->nc_pad = np;
-        std::vector<double> dense((size_t)np * np, 0.0);
-        for (int i = nc; i < np; i++) dense[(size_t)i * np + i] = 1.0;
+        // dense image on the device: the few entries travel, not n^2 zeros
+        std::vector<long long> pos(Lc.A.nnz());
         for (int i = 0; i < nc; i++)
-            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) dense[(size_t)i * np + Lc.A.col[p]] = Lc.A.val[p];
-        HIPCHK(h->d_Ainv.upload(dense));
+            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) pos[p] = (long long)i * np + Lc.A.col[p];
+        DevBuf<long long> d_pos;
+        DevBuf<double> d_val;
+        HIPCHK(d_pos.upload(pos));
+        HIPCHK(d_val.upload(Lc.A.val));
+        HIPCHK(h->d_Ainv.ensure((size_t)np * np));
+        HIPCHK(launch_dense_from_csr(h->d_Ainv.p, np, nc, d_val.p, d_pos.p, (int)Lc.A.nnz(), h->stream));
         if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(h->d_sympart.ensure((size_t)(np / 64) * (np / 64) * 64)); else h->d_sympart.release();
         DevBuf<double> work;
         HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
@@ -600,58 +605,57 @@ static int build_recipes(smg_hierarchy* h)
     const int sellC = SELL_C;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);  // the GS launches move to the A^T images on every level
-    // host work first, all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes), then uploads
-    struct Host { std::vector<int> mA, mAT; Sell ST; bool bad = false; Recipe r1, r2; long nnzT = 0; };
-    std::vector<Host> hw(L);
+    // all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes); every task uploads what it built
+    std::vector<int> bad(L, 0);
+    std::vector<hipError_t> errs((size_t)2 * L, hipSuccess);
     StageTimer tm;
     {
         std::vector<std::function<void()>> tasks;
+        auto up = [](hipError_t& acc, hipError_t e) { if (acc == hipSuccess) acc = e; };
         for (int lv = 0; lv < L; lv++) {
             if (lv < L - 1) tasks.push_back([&, lv] {
                 // SELL slot -> caller CSR entry, for A and for A^T (the sweep always reads A^T in this mode: whether new
                 // values are bit-symmetric cannot be known in advance)
                 Level& Lv = h->lv[lv];
-                Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
-                hw[lv].mA.resize(S.entry.size());
-                for (size_t i = 0; i < S.entry.size(); i++) hw[lv].mA[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
+                hipError_t& er = errs[2 * lv];
+                std::vector<int> m;
+                {
+                    Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
+                    m.resize(S.entry.size());
+                    for (size_t i = 0; i < S.entry.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
+                }
+                up(er, Lv.mapA.upload(m));
                 std::vector<int> tsrc;
                 Csr AT = transpose(Lv.A_int, &tsrc);
-                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) { hw[lv].bad = true; return; }
-                hw[lv].ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
-                const Sell& ST = hw[lv].ST;
-                hw[lv].mAT.resize(ST.entry.size());
-                for (size_t i = 0; i < ST.entry.size(); i++) hw[lv].mAT[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
+                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) { bad[lv] = 1; return; }
+                Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
+                m.resize(ST.entry.size());
+                for (size_t i = 0; i < ST.entry.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
+                up(er, Lv.mapAT.upload(m));
+                if (!Lv.gs_on_transpose) { up(er, Lv.dAT.upload(ST)); Lv.gs_on_transpose = true; }
             });
-            if (lv >= 1) tasks.push_back([&, lv] {
+            tasks.push_back([&, lv] {
                 Level& Lv = h->lv[lv];
+                hipError_t& er = errs[2 * lv + 1];
+                up(er, Lv.d_Aval.upload(Lv.A.val));
+                if (lv == 0) return;
                 const Csr& Af = h->lv[lv - 1].A;
                 Csr T = spgemm(Lv.PT, Af);
-                spgemm_recipe(Lv.PT, Af, true, T, hw[lv].r1);      // T = PT * A_{lv-1}:  PT constant
-                spgemm_recipe(T, Lv.P, false, Lv.A, hw[lv].r2);    // A_lv = T * P:       P constant
-                hw[lv].nnzT = T.nnz();
+                Recipe r;
+                spgemm_recipe(Lv.PT, Af, true, T, r);      // T = PT * A_{lv-1}:  PT constant
+                up(er, Lv.r1_ptr.upload(r.ptr)); up(er, Lv.r1_idx.upload(r.idx)); up(er, Lv.r1_coef.upload(r.coef));
+                spgemm_recipe(T, Lv.P, false, Lv.A, r);    // A_lv = T * P:       P constant
+                up(er, Lv.r2_ptr.upload(r.ptr)); up(er, Lv.r2_idx.upload(r.idx)); up(er, Lv.r2_coef.upload(r.coef));
+                Lv.nnzT = (int)T.nnz();
+                up(er, Lv.d_Tval.alloc(T.nnz()));
             });
         }
         parallel_tasks(tasks);
     }
-    tm.lap("recipes: host work");
-    for (int lv = 0; lv < L; lv++) {
-        Level& Lv = h->lv[lv];
-        HIPCHK(Lv.d_Aval.upload(Lv.A.val));
-        if (lv < L - 1) {
-            if (hw[lv].bad) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
-            HIPCHK(Lv.mapA.upload(hw[lv].mA));
-            if (!Lv.gs_on_transpose) { HIPCHK(Lv.dAT.upload(hw[lv].ST)); Lv.gs_on_transpose = true; }
-            HIPCHK(Lv.mapAT.upload(hw[lv].mAT));
-        }
-        if (lv >= 1) {
-            Lv.nnzT = (int)hw[lv].nnzT;
-            HIPCHK(Lv.d_Tval.alloc(hw[lv].nnzT));
-            HIPCHK(Lv.r1_ptr.upload(hw[lv].r1.ptr)); HIPCHK(Lv.r1_idx.upload(hw[lv].r1.idx)); HIPCHK(Lv.r1_coef.upload(hw[lv].r1.coef));
-            HIPCHK(Lv.r2_ptr.upload(hw[lv].r2.ptr)); HIPCHK(Lv.r2_idx.upload(hw[lv].r2.idx)); HIPCHK(Lv.r2_coef.upload(hw[lv].r2.coef));
-        }
-        hw[lv] = Host();
-    }
-    tm.lap("recipes: uploads");
+    for (int lv = 0; lv < L; lv++)
+        if (bad[lv]) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+    for (hipError_t e : errs) HIPCHK(e);
+    tm.lap("recipes: host work + uploads");
     {
         const Level& Lc = h->lv[L - 1];
         std::vector<long long> pos(Lc.A.nnz());
