@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     constexpr int wpb = 4;            // waves (= slices) per block
-    const int bid = xcd_remap(blockIdx.x, n_blocks);
+    // n_blocks < 0 (small colour sweeps only): the launch has 8x the workgroups and only those that land on XCD 0 work, so the
+    // values one colour launch writes are still in that XCD's L2 when the next launch gathers them -- a small level's launch chain
+    // is pure latency, and this takes the trip to the Infinity Cache out of it (tools/micro/xcd_local.hip: 3.6 -> 2.85 us per launch)
+    int bid;
+    if (MODE == SELL_GS && n_blocks < 0) { if (blockIdx.x & 7) return; bid = blockIdx.x >> 3; }
+    else bid = xcd_remap(blockIdx.x, n_blocks);
     const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * wpb + wave);
     double ss = 0.0;
     int stop = 0;
@@ -376,6 +381,10 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             c0 += kw;
         }
     }
+    // small colour sweeps run on one XCD (see k_sell): grid 8 nb, n_blocks passed negated
+    static const int one_xcd_max = getenv("SMG_ONE_XCD_MAX") ? atoi(getenv("SMG_ONE_XCD_MAX")) : 32;
+    const bool one_xcd = MODE == SELL_GS && nb <= one_xcd_max;
+    const int grid = one_xcd ? nb * 8 : nb, nbarg = one_xcd ? -nb : nb;
     for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
         const T* xx = x ? x + c0 : nullptr;
@@ -388,23 +397,23 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             case 1: {
                 // the usual widths get kernels with the look-ahead count fixed at compile time (no branch per panel column)
                 const int w0 = A.stride > 0 ? (A.w_lo < 8 ? A.w_lo : 8) : -1;
-                if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else if (w0 == 2) hipLaunchKernelGGL((k_sell<MODE, 1, T, 2>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 2) hipLaunchKernelGGL((k_sell<MODE, 1, T, 2>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 break;
             }
             case 2:
-                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 2, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else hipLaunchKernelGGL((k_sell<MODE, 2, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 2, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 2, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 break;
             case 3:
-                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 3, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else hipLaunchKernelGGL((k_sell<MODE, 3, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 3, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 3, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 break;
             default:
-                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 4, T, 7>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
-                else hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(nb), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nb, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 4, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 break;
         }
     }

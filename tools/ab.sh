@@ -6,7 +6,7 @@ for r in $(seq 1 ${5:-2}); do
 if [ $((r % 2)) = 1 ]; then order="$2 $3"; else order="$3 $2"; fi
 for v in $order; do
 echo "--- $1=$v (round $r)"
-env $1=$v timeout 300 bash tools/quick.sh ${4:-C3} 2000
+env $1=$v timeout 300 bash tools/quick.sh ${4:-C3} 900
 done
 done
 for v in $2 $3; do
