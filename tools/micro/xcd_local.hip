@@ -8,12 +8,12 @@
 #pragma clang diagnostic ignored "-Wunused-value"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr int W = 8;
-template <int NX>   // XCDs used: workgroup g runs on XCD g % 8
-__global__ __launch_bounds__(256) void k_sweep(const int* __restrict__ col, const double* __restrict__ val, double* u, const double* __restrict__ b, int r0, int r1, int n)
+template <int NX, int BS = 256>   // XCDs used: workgroup g runs on XCD g % 8; BS threads per workgroup
+__global__ __launch_bounds__(BS) void k_sweep(const int* __restrict__ col, const double* __restrict__ val, double* u, const double* __restrict__ b, int r0, int r1, int n)
 {
     int bid = blockIdx.x;
     if (NX < 8) { if ((bid & 7) >= NX) return; bid = (bid >> 3) * NX + (bid & 7); }
-    const int i = r0 + bid * 256 + threadIdx.x;
+    const int i = r0 + bid * BS + threadIdx.x;
     if (i >= r1) return;
     double acc = 0.0, d = 1.0;
 #pragma unroll
@@ -65,6 +65,22 @@ int main()
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double chk = 0; std::vector<double> hu(n); CK(hipMemcpy(hu.data(), du, n * 8, hipMemcpyDeviceToHost)); for (double x : hu) chk += x;
             printf("n=%7d rows (%4d workgroups per launch) on %d XCD(s): %.2f us per launch   (checksum %.9f)\n", n, nb, nx, ms * 1000.0 / (20 * sweeps * ncol), chk);
+            hipGraphExecDestroy(ge); hipGraphDestroy(g);
+        }
+        {   // one XCD, 1024-thread workgroups: 4x fewer workgroups to dispatch
+            const int sweeps = 16, nb = (per + 1023) / 1024, grid = nb * 8;
+            CK(hipMemset(du, 0, n * 8));
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int s = 0; s < sweeps; s++)
+                for (int c = 0; c < ncol; c++) hipLaunchKernelGGL((k_sweep<1, 1024>), dim3(grid), dim3(1024), 0, st, dcol, dval, du, db, c * per, (c + 1) * per, n);
+            CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, st); for (int r = 0; r < 20; r++) hipGraphLaunch(ge, st); hipEventRecord(e1, st); CK(hipStreamSynchronize(st));
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double chk = 0; std::vector<double> hu(n); CK(hipMemcpy(hu.data(), du, n * 8, hipMemcpyDeviceToHost)); for (double x : hu) chk += x;
+            printf("n=%7d rows (%4d workgroups of 1024 per launch) on 1 XCD: %.2f us per launch   (checksum %.9f)\n", n, nb, ms * 1000.0 / (20 * sweeps * ncol), chk);
             hipGraphExecDestroy(ge); hipGraphDestroy(g);
         }
         hipFree(dcol); hipFree(dval); hipFree(du); hipFree(db);
