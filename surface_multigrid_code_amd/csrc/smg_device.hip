@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         const int off0 = (W0C >= 0 || A.stride) ? s * A.stride : A.slice_off[s];   // W0C >= 0: launched on fixed-pitch matrices only
         const int* cp = A.col + (size_t)off0 * C + lane;
         const T* vp = a_val + (size_t)off0 * C + lane;
-        constexpr int U = 8;
+        constexpr int U = W0C > 8 ? W0C : 8;   // W0C = 12: the whole pitch of the usual matrices in ONE batch (small launches only)
         int c0[U];
         T v0[U];
 #pragma unroll
@@ -397,7 +397,9 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             case 1: {
                 // the usual widths get kernels with the look-ahead count fixed at compile time (no branch per panel column)
                 const int w0 = A.stride > 0 ? (A.w_lo < 8 ? A.w_lo : 8) : -1;
-                if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                static const int pitch_max = getenv("SMG_PITCH_SPEC_MAX") ? atoi(getenv("SMG_PITCH_SPEC_MAX")) : 32;
+                if (nb <= pitch_max && A.stride == 12 && w0 >= 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 12>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 2) hipLaunchKernelGGL((k_sell<MODE, 1, T, 2>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else hipLaunchKernelGGL((k_sell<MODE, 1, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
