@@ -18,6 +18,7 @@
 #include <functional>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/smg.h"
@@ -357,6 +358,30 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         }
     }
     tm.lap("host: slices / transposes of P");
+    // The locality order of the finest level is the longest sequential piece of the whole precompute (a Cuthill-McKee search over
+    // all rows) and needs nothing but A_0's pattern: it starts now, on its own thread, beside the Galerkin products.
+    auto pattern_key = [&](int lv) {
+        const Csr& M = h->lv[lv].A;
+        uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
+        auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
+        const int hdr[2] = {M.nr, lv < L - 1 ? 1 : 0};
+        mix(hdr, 2); mix(M.ptr.data(), M.ptr.size()); mix(M.col.data(), M.col.size());
+        return key;
+    };
+    static const bool use_rcm = [] { const char* v = std::getenv("SMG_ORDER"); return !(v && std::string(v) == "induced"); }();
+    std::vector<int> rcm0;
+    std::thread rcm0_thread;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } rcm0_joiner{rcm0_thread};
+    uint64_t key0 = 0;
+    if (L >= 3 && use_rcm && host_threads() > 1) {
+        key0 = pattern_key(0);
+        const Level& L0 = h->lv[0];
+        if (!(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) rcm0_thread = std::thread([&] {
+            const auto t0 = std::chrono::steady_clock::now();
+            rcm0 = rcm_order(h->lv[0].A);
+            if (tm.on) std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        });
+    }
     // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
     for (int lv = 1; lv < L; lv++) {
         Level& Lv = h->lv[lv];
@@ -395,10 +420,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         std::vector<std::function<void()>> tasks;
         for (int lv = 0; lv < L; lv++) tasks.push_back([&, lv] {
             Level& Lv = h->lv[lv];
-            uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
-            auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
-            const int hdr[2] = {Lv.n, lv < L - 1 ? 1 : 0};
-            mix(hdr, 2); mix(Lv.A.ptr.data(), Lv.A.ptr.size()); mix(Lv.A.col.data(), Lv.A.col.size());
+            const uint64_t key = (lv == 0 && key0) ? key0 : pattern_key(lv);
             keys[lv] = key;
             need[lv] = !(key == Lv.ord_key && (int)Lv.ord.perm.size() == Lv.n);   // else: same pattern as last time
         });
@@ -412,20 +434,23 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     std::vector<std::vector<int>> rcm(L);
     const bool any_need = std::any_of(need.begin(), need.end(), [](char c) { return c != 0; });
     if (any_need) {
-        static const bool use_rcm = [] { const char* v = std::getenv("SMG_ORDER"); return !(v && std::string(v) == "induced"); }();
         if (use_rcm) {
             // the coarsest smoothed level is coloured from scratch (a search that can take longer than all the RCMs together):
             // it goes first in the task list and runs beside the finer levels' searches
             std::vector<std::function<void()>> tasks;
             if (L >= 2 && need[L - 2]) tasks.push_back([&] {
                 Level& Lv = h->lv[L - 2];
+                const auto t0 = std::chrono::steady_clock::now();
                 rcm[L - 2] = rcm_order(Lv.A);
                 Lv.ord = make_ordering(Lv.A, 512, nullptr, &rcm[L - 2]);
+                if (tm.on) std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring from scratch %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 Lv.ord_key = keys[L - 2];
                 need[L - 2] = 0;
             });
-            for (int lv = 0; lv < L - 2; lv++) if (need[lv]) tasks.push_back([&, lv] { rcm[lv] = rcm_order(h->lv[lv].A); });
+            const bool early0 = rcm0_thread.joinable();
+            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(h->lv[lv].A); });
             parallel_tasks(tasks);
+            if (early0) { rcm0_thread.join(); rcm[0] = std::move(rcm0); }
         } else {
             std::vector<int> rank;
             for (int lv = L - 2; lv >= 0; lv--) {
