@@ -2,7 +2,9 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -280,6 +282,20 @@ struct Recolor {
                 if (budget > 0 && kempe(v, cap)) continue;
                 left.push_back(v);
             }
+            // after the cheapest Kempe pass the survivors first get the small exhaustive ball searches: on meshes those settle
+            // nearly all of them in about a millisecond, where the passes with large component caps walk half the graph per
+            // attempt (C3's 15.8 k-vertex level: 18 stragglers, 137 ms of large-cap passes without a single success)
+            if (ci == 0 && left.size() <= 256) {
+                todo.swap(left); left.clear();
+                for (int v : todo) {
+                    if (color[v] != K) continue;
+                    const int d = free_color(v, -1);
+                    if (d >= 0) { color[v] = d; continue; }
+                    bool ok = false;
+                    for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
+                    if (!ok) left.push_back(v);
+                }
+            }
         }
         if (left.size() <= 256)
             for (int v : left) {
@@ -349,6 +365,9 @@ static bool coloring_is_valid(const Csr& A, const std::vector<int>& color)
 
 static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
 {
+    const bool tm_on = std::getenv("SMG_TIMING_COLOR") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what, int nc) { if (!tm_on) return; auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[colour] %-28s %7.1f ms  (%d colours)\n", what, 1e3 * std::chrono::duration<double>(t - t_last).count(), nc); t_last = t; };
     std::vector<int> best, cur;
     int nbest = greedy_color(A, rcm, best);
     if (A.nr == 0) return best;
@@ -357,9 +376,11 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     // first-fit colouring, which is always valid.
     if (nbest > 32 || A.nnz() > 64L * A.nr) return best;
     const std::vector<int> fallback = best;
+    lap("greedy", nbest);
     if (dsatur_color(A, cur) <= nbest) best = cur;
     compact_colors(best);
     nbest = count_colors(best);
+    lap("dsatur", nbest);
     // two rounds of iterated greedy (Culberson): revisit class by class, can only lower the count
     for (int it = 0; it < 2; it++) {
         const int nc = count_colors(best);
@@ -371,6 +392,7 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
         if (greedy_color(A, order, cur) <= nc) { best = cur; compact_colors(best); }
     }
     nbest = count_colors(best);
+    lap("iterated greedy", nbest);
     // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle, 4 with an odd wheel)
     const int floor_colors = (nbest > 3 && has_odd_wheel(A)) ? 4 : 3;
     for (int guard = 0; guard < 6 && nbest > floor_colors; guard++) {
@@ -379,6 +401,7 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
         best = cur;  // partial progress is kept: the colouring stays valid
         compact_colors(best);
         nbest = count_colors(best);
+        lap("dissolve top class", nbest);
         if (!emptied) break;
     }
     return coloring_is_valid(A, best) ? best : fallback;   // belt and braces: a wrong colouring would be a data race in the sweep
