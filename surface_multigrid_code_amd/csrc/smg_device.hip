@@ -915,40 +915,50 @@ __global__ __launch_bounds__(256) void k_gj_diag(const double* M, int n, int kb,
 __global__ __launch_bounds__(256) void k_gj_panels(const double* M, int n, int kb, const double* dinv, double* rowp,
                                                    double* colp)
 {
-    __shared__ double d_s[GJ_NB][GJ_NB + 1];
     __shared__ double m_s[GJ_NB][GJ_H + 1];   // m_s[r][c] = M[K + r][j0 + c] (as a full symmetric-iterate matrix would hold it)
     const int K = kb * GJ_NB;
     const int j0 = blockIdx.x * GJ_H;
     const int J = j0 / GJ_NB;
-    for (int t = threadIdx.x; t < GJ_NB * GJ_NB; t += 256) d_s[t / GJ_NB][t % GJ_NB] = dinv[t];
-    if (J < kb) {
-        for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) m_s[t / GJ_H][t % GJ_H] = M[(size_t)(K + t / GJ_H) * n + j0 + t % GJ_H];
-    } else if (J > kb) {
-        for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) m_s[t % GJ_NB][t / GJ_NB] = M[(size_t)(j0 + t / GJ_NB) * n + K + t % GJ_NB];
-    }
-    __syncthreads();
-    if (J != kb) {
-        const double sgn = J < kb ? -1.0 : 1.0;
-        for (int t = threadIdx.x; t < GJ_H * GJ_NB; t += 256) {
-            const int c = t / GJ_NB, r = t % GJ_NB;
-            colp[(size_t)(j0 + c) * GJ_NB + r] = sgn * m_s[r][c];
-        }
-    }
-    if (J == kb) {
-        for (int t = threadIdx.x; t < GJ_NB * GJ_H; t += 256) {
-            const int r = t / GJ_H, c = t % GJ_H;
-            rowp[(size_t)r * n + j0 + c] = d_s[r][j0 + c - K];
+    const int t = threadIdx.x;
+    if (J == kb) {   // the pivot columns of the row panel hold D^-1 itself
+        for (int e = t; e < GJ_NB * GJ_H; e += 256) {
+            const int r = e / GJ_H, c = e % GJ_H;
+            rowp[(size_t)r * n + j0 + c] = dinv[r * GJ_NB + j0 + c - K];
         }
         return;
     }
-    // D^-1 (64 x 64) times the 64 x 32 slab on the matrix cores: wave w -> rows 16 w .. 16 w + 15, two 16 x 16 tiles
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane >> 4, lc = lane & 15;
-    v4f64 acc[2] = {(v4f64){0.0, 0.0, 0.0, 0.0}, (v4f64){0.0, 0.0, 0.0, 0.0}};
-#pragma unroll 4
-    for (int q = 0; q < GJ_NB / 4; q++) {
-        const double av = d_s[16 * w + lc][4 * q + lr];
+    // all loads of the block are requested up front: the A operands (rows 16 w .. 16 w + 15 of D^-1, straight from L2 into the
+    // MFMA operand registers) and the 64 x 32 slab (transposed through LDS when it comes from the column side)
+    const int lane = t & 63, w = t >> 6, lr = lane >> 4, lc = lane & 15;
+    double av[GJ_NB / 4], mr[8];
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, m_s[4 * q + lr][16 * ct + lc], acc[ct], 0, 0, 0);
+    for (int q = 0; q < GJ_NB / 4; q++) av[q] = dinv[(16 * w + lc) * GJ_NB + 4 * q + lr];
+    if (J < kb) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int x = t + 256 * e; mr[e] = M[(size_t)(K + x / GJ_H) * n + j0 + x % GJ_H]; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int x = t + 256 * e; m_s[x / GJ_H][x % GJ_H] = mr[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int x = t + 256 * e; mr[e] = M[(size_t)(j0 + x / GJ_NB) * n + K + x % GJ_NB]; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int x = t + 256 * e; m_s[x % GJ_NB][x / GJ_NB] = mr[e]; }
+    }
+    __syncthreads();
+    {
+        const double sgn = J < kb ? -1.0 : 1.0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int x = t + 256 * e, c = x / GJ_NB, r = x % GJ_NB;
+            colp[(size_t)(j0 + c) * GJ_NB + r] = sgn * m_s[r][c];
+        }
+    }
+    // D^-1 (64 x 64) times the 64 x 32 slab on the matrix cores: wave w -> rows 16 w .. 16 w + 15, two 16 x 16 tiles
+    v4f64 acc[2] = {(v4f64){0.0, 0.0, 0.0, 0.0}, (v4f64){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < GJ_NB / 4; q++) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], m_s[4 * q + lr][16 * ct + lc], acc[ct], 0, 0, 0);
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
