@@ -1015,20 +1015,29 @@ __global__ __launch_bounds__(256) void k_gj_update(double* M, int n, int kb, con
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int r = 0; r < 4; r++) old[c][r] = jpiv ? 0.0 : mp[(size_t)(4 * r) * n + 16 * c];
+        // operands: this wave's 16 rows of the column panel straight into registers; the 64 x 64 slab of the row panel, which all
+        // four waves need, once through LDS (`a` is free until the look-ahead writes its results into it)
+        double av[GJ_NB / 4];
+        const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
+#pragma unroll
+        for (int s = 0; s < GJ_NB / 4; s++) av[s] = ap[4 * s];
+        {
+            double br[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) { const int x = threadIdx.x + 256 * e; br[e] = rowp[(size_t)(x >> 6) * n + j0 + (x & 63)]; }
+#pragma unroll
+            for (int e = 0; e < 16; e++) { const int x = threadIdx.x + 256 * e; a[x >> 6][x & 63] = br[e]; }
+        }
+        __syncthreads();   // workgroup-uniform branch
         v4f64 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
-        const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
-        const double* bp = rowp + (size_t)lr * n + j0 + lc;
-#pragma unroll 4
-        for (int s = 0; s < GJ_NB / 4; s++) {
-            const double av = ap[4 * s];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const double b = bp[(size_t)(4 * s) * n + 16 * c];
-                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[c], 0, 0, 0);
-            }
+        for (int s = 0; s < GJ_NB / 4; s++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], a[4 * s + lr][16 * c + lc], acc[c], 0, 0, 0);
         }
+        if (lookahead) __syncthreads();   // every wave is done with the slab before the results overwrite it
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
