@@ -653,3 +653,46 @@ def test_block_hierarchy_solves_a_3dof_system(smg, oracle_mod):
     assert a[0] and b[0] and abs(len(a[2]) - len(b[2])) <= 2
     assert np.linalg.norm(a[1] - b[1]) <= 1e-8 * np.linalg.norm(b[1])
     assert np.linalg.norm(rhs - A @ a[1]) < 1.5e-10
+
+
+# ----------------------------------------------------------------------------------------------- launch shortcuts
+_SHORTCUT_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import surface_multigrid_code_amd as smg
+from problems import subdiv_problem
+for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2)):
+    p = subdiv_problem(kind=kind, k=k, n_sub=3)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.precompute(p["A"], p["known"])
+    rng = np.random.default_rng(3)
+    n = mg.rows(0)
+    B, u = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+    v = mg.vcycle(B, u)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-9, max_iter=30))
+    print(kind, k, mg.n_levels, hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest(),
+          hashlib.sha256(np.ascontiguousarray(z).tobytes()).hexdigest(), len(rh))
+"""
+
+
+def test_launch_shortcuts_do_not_change_a_bit(smg):
+    """The launch-count / latency shortcuts of the cycle -- the restriction launch producing the first colour of the coarse level's
+    first sweep (SMG_FUSE_FIRST), small colour sweeps confined to one XCD (SMG_ONE_XCD_MAX), the whole panel pitch requested
+    ahead on tiny launches (SMG_PITCH_SPEC_MAX) -- are re-orderings of WHERE and WHEN the same arithmetic runs: a full-depth
+    V-cycle and a solve on a 4-level hierarchy give identical bits with all of them off.  (The knobs are read once per process,
+    hence the two child processes.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0")
+        r = subprocess.run([sys.executable, "-c", _SHORTCUT_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("mcf", "poisson"))]
+        assert len(lines) == 3, r.stdout
+        outs.append(lines)
+    assert all(int(ln.split()[2]) >= 4 for ln in outs[0])   # deep enough for the fused restriction to be in play
+    assert outs[0] == outs[1]
