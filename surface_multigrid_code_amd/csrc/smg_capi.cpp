@@ -1025,7 +1025,7 @@ static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, 
 }
 
 // sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
-static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false)
+static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false, double* sumsq_out = nullptr)
 {
     Level& L0 = h->lv[0];
     ProfGuard pg(h, "MG: outer residual");
@@ -1036,7 +1036,7 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
     else
         HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     if (fuse_decide) HIPCHK(launch_ss_finalize_decide(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
-    else HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+    else HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream, sumsq_out));
     return SMG_OK;
 }
 
@@ -1077,6 +1077,22 @@ static int capture_graph(smg_hierarchy* h, hipGraphExec_t* out, Fn&& body)
     return SMG_OK;
 }
 
+// The two halves of a split-phase iteration work on ONE buffer that the caller all-reduces in between: the residual graph leaves
+// the local sum of squares there, the cycle graph's break test reads the reduced value from there (no staging copies: an 8-byte
+// device-to-device copy costs several microseconds of stream time).  Re-captured when the caller hands in another buffer.
+static int capture_split_graphs(smg_hierarchy* h, double* buf)
+{
+    if (h->g_resid) { (void)hipGraphExecDestroy(h->g_resid); h->g_resid = nullptr; }
+    if (h->g_cycle) { (void)hipGraphExecDestroy(h->g_cycle); h->g_cycle = nullptr; }
+    const int k = h->k;
+    int rc = capture_graph(h, &h->g_resid, [&]() { return enqueue_residual_ss(h, k, false, buf); });
+    if (rc) return rc;
+    rc = capture_graph(h, &h->g_cycle, [&]() { return enqueue_cycle_part(h, k, buf); });
+    if (rc) return rc;
+    h->g_sumsq_ptr = buf;
+    return SMG_OK;
+}
+
 static int ensure_graphs(smg_hierarchy* h)
 {
     if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision) return SMG_OK;
@@ -1088,10 +1104,7 @@ static int ensure_graphs(smg_hierarchy* h)
         return enqueue_cycle_part(h, k, nullptr);
     });
     if (rc) return rc;
-    rc = capture_graph(h, &h->g_resid, [&]() { return enqueue_residual_ss(h, k); });
-    if (rc) return rc;
-    // second half of a split-phase iteration: break test on the (all-reduced) ctrl->sumsq, then the V-cycle
-    rc = capture_graph(h, &h->g_cycle, [&]() { return enqueue_cycle_part(h, k, &h->d_ctrl.p->sumsq); });
+    rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
     if (rc) return rc;
     h->g_k = k; h->g_pre = h->pre; h->g_post = h->post; h->g_prec = h->precision;
     return SMG_OK;
@@ -1193,29 +1206,30 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
 extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_residual: no solve in progress");
+    double* buf = d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq;
     if (graphs_usable(h)) {
         int rc = ensure_graphs(h);
         if (rc) return rc;
+        if (h->g_sumsq_ptr != buf) { rc = capture_split_graphs(h, buf); if (rc) return rc; }
         HIPCHK(hipGraphLaunch(h->g_resid, h->stream));
     } else {
-        int rc = enqueue_residual_ss(h, h->k);
+        int rc = enqueue_residual_ss(h, h->k, false, buf);
         if (rc) return rc;
     }
-    if (d_sumsq) HIPCHK(hipMemcpyAsync(d_sumsq, &h->d_ctrl.p->sumsq, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return SMG_OK;
 }
 
 extern "C" int smg_solve_iter_cycle(smg_hierarchy* h, const double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle: no solve in progress");
-    // the reduced value goes back into the control block so that one cached graph serves every iteration
-    if (d_sumsq) HIPCHK(hipMemcpyAsync(&h->d_ctrl.p->sumsq, d_sumsq, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    double* buf = d_sumsq ? const_cast<double*>(d_sumsq) : &h->d_ctrl.p->sumsq;
     if (graphs_usable(h)) {
         int rc = ensure_graphs(h);
         if (rc) return rc;
+        if (h->g_sumsq_ptr != buf) { rc = capture_split_graphs(h, buf); if (rc) return rc; }
         HIPCHK(hipGraphLaunch(h->g_cycle, h->stream));
     } else {
-        int rc = enqueue_cycle_part(h, h->k, &h->d_ctrl.p->sumsq);
+        int rc = enqueue_cycle_part(h, h->k, buf);
         if (rc) return rc;
     }
     h->iters_enqueued++;

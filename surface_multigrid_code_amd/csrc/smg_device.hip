@@ -460,7 +460,7 @@ hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_e
 
 // ---------------------------------------------------------------------------------------------- solve-loop control
 
-__global__ __launch_bounds__(256) void k_ss_finalize(const double* partials, int n, Ctrl* ctrl)
+__global__ __launch_bounds__(256) void k_ss_finalize(const double* partials, int n, Ctrl* ctrl, double* out)
 {
     if (ctrl->done) return;
     __shared__ double red[256];
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_ss_finalize(const double* partials, int
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) ctrl->sumsq = red[0];
+    if (threadIdx.x == 0) *out = red[0];
 }
 
 __device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
@@ -520,9 +520,9 @@ __global__ void k_decide(Ctrl* ctrl, const double* sumsq)
     decide_body(ctrl, *sumsq);
 }
 
-hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
+hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st, double* out)
 {
-    hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl);
+    hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl, out ? out : &ctrl->sumsq);
     return hipGetLastError();
 }
 // Speculative form (multi-GPU: the V-cycle of iteration i runs while the all-reduce of residual i is in flight).

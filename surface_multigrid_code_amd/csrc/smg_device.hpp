@@ -72,7 +72,7 @@ int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 
 // ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
-hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st);
+hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st, double* out = nullptr);   // out: where the sum goes (default ctrl->sumsq)
 // r = sqrt(*sumsq); append to r_his; done = (r < ctrl->tol) or non-finite.  No-op when already done.
 hipError_t launch_decide(Ctrl* ctrl, const double* sumsq, hipStream_t st);
 // speculative split-phase iteration (the V-cycle overlaps the all-reduce): see smg.h, smg_solve_iter_cycle_speculative

@@ -142,6 +142,7 @@ struct smg_hierarchy {
     int cur_ld_kv = 0;
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
+    double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
     int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
     // ---- profc mirror ----
     bool prof_on = false;
