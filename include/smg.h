@@ -156,7 +156,9 @@ int smg_solve(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *kno
  *   begin:     gathers RHS/z0 (device, column-major) into the handle, resets the control block;
  *   residual:  *d_sumsq (device double) = sum over the local columns of |RHS_u - A_0 z_u|^2   (.cpp:110/:332);
  *   cycle:     r = sqrt(*d_sumsq) -> r_his, break test, then one V-cycle (skipped on the device once done);
- *   end:       scatters z, copies r_his back, reports convergence. */
+ *   end:       scatters z, copies r_his back, reports convergence.
+ * residual and cycle run as cached graphs that write / read *d_sumsq in place (no staging copy): hand the SAME device buffer to
+ * both, every iteration (another buffer is honoured, at the price of re-capturing the two graphs).  NULL = the handle's own word. */
 int smg_solve_begin(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *known_val, int ld_kv,
                     const double *z0, int ld_z0, int k, int memspace, const smg_solve_opts *opts);
 int smg_solve_iter_residual(smg_hierarchy *h, double *d_sumsq);
