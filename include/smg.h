@@ -88,7 +88,9 @@ int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double 
 /* ---- mg_precompute (src/mg_precompute.h:26-32, src/mg_precompute.cpp:15-87) ------------------------------------ */
 /* Builds the hierarchy from a triangle mesh: level count by the reference's float rule (:27-38), per level
  * tarF = round(#F * ratio) (:59), edge-collapse decimation + prolongation.  V: nV x 3 row-major, F: nF x 3.
- * NOTE: libsmg's own host implementation of the reference's scheme (shortest-edge mid-point collapse with successive
+ * dec_type (src/mg_precompute.cpp:10): 0 qslim (quadric error metric, merged vertex at the quadric's minimiser), 1 mid-point
+ * (shortest edge first), 2 vertex removal (shortest edge first, merged vertex on an end point).
+ * NOTE: libsmg's own host implementation of the reference's scheme (greedy edge collapse with successive
  * self-parameterisation: joint conformal flattening of the 1-ring before/after every collapse); same API, same P structure (3 stored entries per row, rows sum to 1).
  * Not a line-by-line restatement of SSP_* / joint_lscm: results differ from the reference's. */
 int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,

@@ -3,8 +3,8 @@
 // fine vertex through the collapse history to barycentric coordinates on the coarse mesh, assemble P with
 // exactly three stored entries per row).
 //
-// Same contract as the reference (greedy shortest-edge collapse with mid-point placement, dec_type 1, or end-point
-// placement, dec_type 2; link-condition and fold-over rejection; every fine vertex carried along as (face, barycentric);
+// Same contract as the reference (greedy collapse: shortest edge first with mid-point placement, dec_type 1, or end-point
+// placement, dec_type 2; smallest quadric error first with the quadric's minimiser as placement, dec_type 0 "qslim"; link-condition and fold-over rejection; every fine vertex carried along as (face, barycentric);
 // P with exactly three stored entries per row, non-negative, rows summing to 1).  The per-collapse re-parameterisation:
 //   * the reference's construction -- the 1-rings before and after the collapse are flattened JOINTLY by least-squares
 //     conformal maps with a shared boundary ring (src/joint_lscm.cpp), a collapse whose flattening flips, folds over or
@@ -15,7 +15,7 @@
 //   * collapses touching the boundary go through the same flattening on the open 1-ring (natural boundary conditions); the
 //     reference closes the boundary with an "infinity vertex" and has two more LSCM cases for it (src/joint_lscm.cpp:
 //     642-1131), which are not restated;
-//   * the libigl-internal edge-flap bookkeeping, the qslim / randomised variants and the coarse-to-fine queries of the
+//   * the libigl-internal edge-flap bookkeeping, the randomised variants and the coarse-to-fine queries of the
 //     remeshing demos are not restated.
 #include <algorithm>
 #include <cstdlib>
@@ -175,6 +175,78 @@ struct Decimator {
     std::priority_queue<QEntry> pq;
     int n_alive_faces = 0;
     int dec_type = 1;
+    // dec_type 0 (the reference's "qslim", src/SSP_qslim.cpp): quadric error metric -- every vertex carries the area-weighted
+    // sum of the squared distances to the planes of its input faces, Q(v) = v^T A v + 2 b^T v + c stored as
+    // (a11 a12 a13 a22 a23 a33 b1 b2 b3 c); an edge costs the minimum of Q_a + Q_b and the merged vertex goes to the minimiser
+    // (Garland & Heckbert).  Boundary edges add a plane through the edge perpendicular to their face, so borders keep their shape
+    // (the reference reaches the same end by connecting the boundary to a vertex at infinity).
+    std::vector<std::array<double, 10>> quad;
+
+    static void add_plane(std::array<double, 10>& q, V3 n, double d, double w)
+    {
+        q[0] += w * n.x * n.x; q[1] += w * n.x * n.y; q[2] += w * n.x * n.z;
+        q[3] += w * n.y * n.y; q[4] += w * n.y * n.z; q[5] += w * n.z * n.z;
+        q[6] += w * d * n.x; q[7] += w * d * n.y; q[8] += w * d * n.z; q[9] += w * d * d;
+    }
+    static double qeval(const std::array<double, 10>& q, V3 v)
+    {
+        return q[0] * v.x * v.x + 2 * q[1] * v.x * v.y + 2 * q[2] * v.x * v.z + q[3] * v.y * v.y + 2 * q[4] * v.y * v.z + q[5] * v.z * v.z +
+               2 * (q[6] * v.x + q[7] * v.y + q[8] * v.z) + q[9];
+    }
+    void init_quadrics()
+    {
+        quad.assign(pos.size(), std::array<double, 10>{});
+        for (size_t f = 0; f < faces.size(); f++) {
+            const auto& fc = faces[f];
+            const V3 p0 = pos[fc[0]], p1 = pos[fc[1]], p2 = pos[fc[2]];
+            const V3 cr = cross(p1 - p0, p2 - p0);
+            const double l = norm(cr);
+            if (!(l > 0)) continue;
+            const V3 n = (1.0 / l) * cr;
+            for (int c = 0; c < 3; c++) add_plane(quad[fc[c]], n, -dot(n, p0), 0.5 * l);
+            for (int c = 0; c < 3; c++) {   // boundary edges: a constraint plane through the edge, perpendicular to the face
+                const int a = fc[c], b = fc[(c + 1) % 3];
+                int ef[3];
+                if (edge_faces(a, b, ef) != 1) continue;
+                const V3 e = pos[b] - pos[a];
+                const V3 nb0 = cross(e, n);
+                const double lb = norm(nb0);
+                if (!(lb > 0)) continue;
+                const V3 nb = (1.0 / lb) * nb0;
+                const double w = 10.0 * dot(e, e);   // length^2: the scale of an area, weighted up so that the border wins
+                add_plane(quad[a], nb, -dot(nb, pos[a]), w);
+                add_plane(quad[b], nb, -dot(nb, pos[a]), w);
+            }
+        }
+    }
+    // minimiser and minimum of Q_a + Q_b; falls back to the better of the end points / the mid-point when the 3 x 3 system is
+    // (nearly) singular -- flat or straight neighbourhoods -- or the minimiser runs away from the edge
+    double qem(int a, int b, V3* where) const
+    {
+        std::array<double, 10> q;
+        for (int i = 0; i < 10; i++) q[i] = quad[a][i] + quad[b][i];
+        const double a11 = q[0], a12 = q[1], a13 = q[2], a22 = q[3], a23 = q[4], a33 = q[5];
+        const double c11 = a22 * a33 - a23 * a23, c12 = a13 * a23 - a12 * a33, c13 = a12 * a23 - a13 * a22;
+        const double det = a11 * c11 + a12 * c12 + a13 * c13;
+        const double tr = (a11 + a22 + a33) / 3.0;
+        const V3 mid = 0.5 * (pos[a] + pos[b]);
+        V3 best = mid;
+        double cost = qeval(q, mid);
+        bool have_opt = false;
+        if (std::fabs(det) > 1e-6 * tr * tr * tr && tr > 0) {
+            const double c22 = a11 * a33 - a13 * a13, c23 = a12 * a13 - a11 * a23, c33 = a11 * a22 - a12 * a12;
+            const V3 v = {-(c11 * q[6] + c12 * q[7] + c13 * q[8]) / det, -(c12 * q[6] + c22 * q[7] + c23 * q[8]) / det,
+                          -(c13 * q[6] + c23 * q[7] + c33 * q[8]) / det};
+            if (norm(v - mid) <= 2.0 * norm(pos[a] - pos[b])) { best = v; cost = qeval(q, v); have_opt = true; }
+        }
+        if (!have_opt) {
+            const double ca = qeval(q, pos[a]), cb = qeval(q, pos[b]);
+            if (ca < cost) { cost = ca; best = pos[a]; }
+            if (cb < cost) { cost = cb; best = pos[b]; }
+        }
+        if (where) *where = best;
+        return cost;
+    }
 
     void clean(int v)
     {
@@ -201,7 +273,7 @@ struct Decimator {
     void push_edge(int a, int b)
     {
         if (a > b) std::swap(a, b);
-        pq.push({norm(pos[a] - pos[b]), a, b, version[a], version[b]});
+        pq.push({dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]});
     }
     void push_star(int v)
     {
@@ -239,6 +311,7 @@ struct Decimator {
         // placement
         V3 m;
         if (dec_type == 2) m = pos[a];                       // vertex removal: keep an end point
+        else if (dec_type == 0 && ba == bb) (void)qem(a, b, &m);  // quadric-optimal placement (boundary: see below)
         else if (ba && !bb) m = pos[a];                      // keep the boundary where it is
         else if (bb && !ba) m = pos[b];
         else m = 0.5 * (pos[a] + pos[b]);                    // mid-point (dec_type 1)
@@ -332,6 +405,7 @@ struct Decimator {
         vfaces[b].clear();
         valive[b] = 0;
         pos[a] = m;
+        if (dec_type == 0) for (int i = 0; i < 10; i++) quad[a][i] += quad[b][i];
         version[a]++; version[b]++;
         clean(a);
         for (int w : common) clean(w);
@@ -370,7 +444,7 @@ struct Decimator {
 int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& P, std::string& err)
 {
     const int nV = fine.nV(), nF = fine.nF();
-    if (dec_type != 1 && dec_type != 2) { err = "dec_type must be 1 (mid-point) or 2 (vertex removal); qslim (0) is not implemented"; return -1; }
+    if (dec_type < 0 || dec_type > 2) { err = "dec_type must be 0 (qslim), 1 (mid-point) or 2 (vertex removal)"; return -1; }
     if (nV < 4 || nF < 4) { err = "mesh too small to decimate"; return -1; }
     Decimator D;
     D.dec_type = dec_type;
@@ -392,6 +466,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
         }
         if (D.faces[f][0] == D.faces[f][1] || D.faces[f][1] == D.faces[f][2] || D.faces[f][0] == D.faces[f][2]) { err = "degenerate face"; return -1; }
     }
+    if (dec_type == 0) D.init_quadrics();
     // manifoldness (the reference bails out on non-manifold input, src/SSP_decimate.cpp:20-23)
     {
         std::unordered_map<uint64_t, int> ecount;

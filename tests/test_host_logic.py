@@ -152,8 +152,18 @@ def test_mg_precompute_invariants(smg_mod):
         P = mg3.matrix(l, "P_full")
         assert (np.asarray((P > 1e-12).sum(axis=0)).ravel() > 0).all()
         assert (np.asarray((P > 1 - 1e-12).sum(axis=0)).ravel() > 0).all()   # ... by a one-hot row, even
+    # dec_type 0 ("qslim": quadric error metric, merged vertex at the quadric's minimiser): same structure of P
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    mg0 = smg.mg_precompute(mesh.normalize_unit_area(V, F), F, 0.25, 500, 0)
+    assert mg0.n_levels == 3
+    for l in range(1, mg0.n_levels):
+        P = mg0.matrix(l, "P_full")
+        assert np.all(np.diff(P.indptr) == 3) and P.data.min() >= 0.0
+        np.testing.assert_allclose(np.asarray(P.sum(axis=1)).ravel(), 1.0, atol=1e-14)
+        assert 0.2 < P.shape[1] / P.shape[0] < 0.3
+        assert (np.asarray((P > 0).sum(axis=0)).ravel() > 0).all()
     with pytest.raises(smg.SmgError):
-        smg.mg_precompute(V, F, 0.25, 500, 0)                     # qslim is not implemented
+        smg.mg_precompute(V, F, 0.25, 500, 3)                     # no such decimation type
 
 
 def test_mg_precompute_reproduces_linear_functions(smg_mod):
@@ -254,14 +264,15 @@ def test_weak_kat_bunny_500_faces(smg_mod):
     assert mg.matrix(1, "P_full").shape == (9353, nV.value)
 
 
-@pytest.mark.parametrize("mesh_name,bound", [("bunny.smgm", 0.12), ("ogre.smgm", 0.36), ("bunny_15K_init.smgm", 0.12)])
-def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, bound):
+@pytest.mark.parametrize("mesh_name,bound,dec_type", [("bunny.smgm", 0.12, 1), ("ogre.smgm", 0.36, 1), ("bunny_15K_init.smgm", 0.12, 1),
+                                                      ("bunny.smgm", 0.35, 0), ("bunny.smgm", 0.3, 2)])
+def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, bound, dec_type):
     """no reference binary to compare the hierarchy builder with, so it is judged by what it is for --
     the V-cycle convergence factor of the reference algorithm (CPU oracle) on its hierarchy, expected <~ 0.3 (ogre.obj, strongly
     non-uniform sampling, needs the absorption cap of the decimator for that: 0.62 without)."""
     V, F = M.read_smgm(mesh_name)
     V = M.normalize_unit_area(V, F)
-    mg = smg_mod.mg_precompute(V, F, ratio=0.25, nVCoarsest=500)
+    mg = smg_mod.mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=dec_type)
     Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
     sizes = [Ps[0].shape[0]] + [P.shape[1] for P in Ps]
     assert all(0.2 < sizes[i + 1] / sizes[i] < 0.3 for i in range(len(sizes) - 1))
