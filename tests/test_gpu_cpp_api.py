@@ -66,3 +66,37 @@ def test_cpp_mean_curvature_flow_example(smg_mod, oracle_mod):
         assert conv
         U = M.normalize_unit_area(z, F)
         assert abs(got[s] - float((U * U).sum())) <= 1e-5 * float((U * U).sum())
+
+
+def test_cpp_closed_mesh_with_pins_example(smg_mod, oracle_mod):
+    """examples/04_mg_solver_nobd.cpp (the reference's 04_mg_solver_nobd/main.cpp: closed surface, pinned vertices, random initial
+    guess, tol 1e-10) against the same problem through the python mirror."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    exe = os.path.join(ROOT, "examples", "04_mg_solver_nobd")
+    src = os.path.join(ROOT, "examples", "04_mg_solver_nobd.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
+                               "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny_15K_init.smgm"), "346"], env=env, text=True)
+    m = re.search(r"converged: (\d)  iterations: (\d+)  \|z\|\^2: ([0-9.eE+-]+)  unknowns: (\d+)", out)
+    assert m and m.group(1) == "1" and int(m.group(4)) == 15804 - 346
+    V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    n = V.shape[0]
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    A = (-mesh.cotmatrix(V, F)).tocsr()
+    b = (np.arange(346) * (n // 346)).astype(np.int32)
+    B = mesh.massmatrix(V, F, "voronoi") @ np.ones(n)
+    B[b] = 0.0
+    z0 = np.empty(n)
+    x = 12345
+    for i in range(n):
+        x = (1103515245 * x + 12345) % 2147483648
+        z0[i] = x / 1073741824.0 - 1.0
+    mg.precompute(A, b)
+    conv, z, rh = mg.solve(B, z0, np.zeros(len(b)), smg.SolveOpts(tol=1e-10, max_iter=20))
+    assert conv and len(rh) == int(m.group(2))
+    assert abs(float(m.group(3)) - float((z * z).sum())) <= 1e-9 * float((z * z).sum())
+    unk = np.setdiff1d(np.arange(n), b)
+    assert np.linalg.norm((B - A @ z[:, 0])[unk]) < 1e-10 and abs(z[b, 0]).max() == 0.0
