@@ -210,6 +210,14 @@ def main():
             # (a latency-hiding variant exists -- iter_cycle_speculative / iter_commit, dist.sharded_solve_overlapped --
             #  but its extra graph launch and copies cost as much as the 8-byte all-reduce it hides: measured 0.533 vs
             #  0.503 ms per iteration with the reduction forced on at world size 1)
+            if os.environ.get("SMG_BENCH_SPECULATIVE", "0") == "1":
+                for _ in range(n_it):             # the all-reduce hidden behind the cycle (smg.h: speculative / commit)
+                    mg.iter_residual(sumsq.data_ptr())
+                    work = dist.all_reduce(sumsq, async_op=True)
+                    mg.iter_cycle_speculative()
+                    work.wait()
+                    mg.iter_commit(sumsq.data_ptr())
+                return
             for _ in range(n_it):
                 mg.iter_residual(sumsq.data_ptr())
                 dist.all_reduce(sumsq)            # RCCL, 8 bytes: the Frobenius norm couples the columns
