@@ -194,6 +194,23 @@ def main():
     z = torch.empty(n, dtype=torch.float64, device=dev)
     sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
+    # multi-GPU: the 8-byte all-reduce runs on the solve's stream through RCCL directly (dist.StreamAllReduce); torch's collective
+    # is the fallback when that cannot be set up (SMG_BENCH_TORCH_ALLREDUCE=1 forces it)
+    stream_ar = None
+    if (world > 1 or force_split) and os.environ.get("SMG_BENCH_TORCH_ALLREDUCE", "0") != "1" and os.environ.get("SMG_BENCH_BACKEND", "nccl") == "nccl":
+        from surface_multigrid_code_amd.dist import StreamAllReduce
+
+        def all_agree(flag):
+            t = torch.tensor([1 if flag else 0], device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        sar = StreamAllReduce(rank, world, stream.cuda_stream, device=dev)
+        if all_agree(sar.ready) and all_agree(sar.connect()):
+            stream_ar = sar
+        elif rank == 0:
+            print("bench: direct RCCL all-reduce unavailable (%s), using torch.distributed" % sar.err, file=sys.stderr)
     W, K = args.warmup, args.steps
     # tol = 0: the loop never converges, every step is a full outer iteration (residual + norm + break test + V(2,2) cycle) that
     # stores its results.  The device-side residual history holds 1024 entries (= the largest max_iter), and launches after the
@@ -218,9 +235,15 @@ def main():
                     work.wait()
                     mg.iter_commit(sumsq.data_ptr())
                 return
+            if stream_ar is not None:
+                for _ in range(n_it):
+                    mg.iter_residual(sumsq.data_ptr())
+                    stream_ar(sumsq.data_ptr())   # RCCL, 8 bytes, on the solve's own stream: the Frobenius norm couples the columns
+                    mg.iter_cycle(sumsq.data_ptr())
+                return
             for _ in range(n_it):
                 mg.iter_residual(sumsq.data_ptr())
-                dist.all_reduce(sumsq)            # RCCL, 8 bytes: the Frobenius norm couples the columns
+                dist.all_reduce(sumsq)            # the same through torch.distributed (its own stream)
                 mg.iter_cycle(sumsq.data_ptr())
 
     def run(n_it):
@@ -316,7 +339,8 @@ def main():
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
                        "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],
                        "rhs_columns_per_gpu": 1, "cycle": "V(2,2), multi-colour Gauss-Seidel, dense coarsest solve",
-                       "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU"},
+                       "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU",
+                       "allreduce": ("RCCL on the solve stream (dist.StreamAllReduce)" if stream_ar is not None else "torch.distributed") if (world > 1 or force_split) else None},
             "roofline": {"kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm",
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
@@ -343,6 +367,9 @@ def main():
     # tear the process group down BEFORE the line is printed: RCCL may write to stdout when a communicator is created or
     # destroyed, and the JSON must be the last line
     if world > 1 or force_split:
+        torch.cuda.synchronize()
+        if stream_ar is not None:
+            stream_ar.close()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
