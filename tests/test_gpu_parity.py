@@ -696,3 +696,51 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
         outs.append(lines)
     assert all(int(ln.split()[2]) >= 4 for ln in outs[0])   # deep enough for the fused restriction to be in play
     assert outs[0] == outs[1]
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+import numpy as np, torch, torch.distributed as dist
+import surface_multigrid_code_amd as smg
+from surface_multigrid_code_amd.dist import StreamAllReduce
+from problems import subdiv_problem
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream()
+t = torch.tensor([1.5, -2.0, 4.25], dtype=torch.float64, device=dev)
+with torch.cuda.stream(stream):
+    sar = StreamAllReduce(0, 1, stream.cuda_stream, device=dev)
+    assert sar.ready and sar.connect(), sar.err
+    sar(t.data_ptr(), 3)
+    stream.synchronize()
+    assert t.tolist() == [1.5, -2.0, 4.25]
+    # the split-phase loop with the reduction on the solve stream == the fused solve, bit for bit
+    p = subdiv_problem(kind="mcf", k=1, n_sub=2)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"]); mg.precompute(p["A"], p["known"])
+    mg.set_stream(stream.cuda_stream)
+    n = mg.rows(0)
+    conv, z_ref, rh_ref = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-9, max_iter=30))
+    rhs = torch.from_numpy(np.ascontiguousarray(p["RHS"][:, 0])).to(dev); z0 = torch.from_numpy(np.ascontiguousarray(p["z0"][:, 0])).to(dev)
+    z = torch.empty(n, dtype=torch.float64, device=dev); ss = torch.zeros(1, dtype=torch.float64, device=dev)
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=1e-9, max_iter=30))
+    for _ in range(30):
+        mg.iter_residual(ss.data_ptr()); sar(ss.data_ptr()); mg.iter_cycle(ss.data_ptr())
+    conv2, rh = mg.solve_end(z.data_ptr(), n, max_iter=30)
+    assert conv2 and len(rh) == len(rh_ref) and np.array_equal(np.asarray(rh), np.asarray(rh_ref))
+    assert np.array_equal(z.cpu().numpy(), z_ref[:, 0])
+    sar.close()
+dist.destroy_process_group()
+print("RCCL_STREAM_OK")
+"""
+
+
+def test_allreduce_on_the_solve_stream(smg):
+    """dist.StreamAllReduce (ncclAllReduce through ctypes on the solve's own stream, world size 1 here): values pass through
+    unchanged, and the split-phase loop driven with it reproduces the fused solve bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_STREAM_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
