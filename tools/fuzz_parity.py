@@ -18,6 +18,7 @@ for seed in range(seed0, seed0 + ncases):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(5, 5000)); levels = int(rng.integers(2, 5)); k = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17, 40])); hub = bool(rng.integers(0, 2)) and n > 200
     while n // (3 ** (levels - 1)) < 2: levels -= 1
+    if levels < 2: continue   # single-level hierarchies are rejected by design (reference TODO, src/mg_precompute.cpp:39)
     A, Ps = ns["_random_spd_hierarchy"](rng, n, levels, hub)
     known = None
     if rng.integers(0, 2):
