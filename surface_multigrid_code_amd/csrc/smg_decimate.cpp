@@ -181,6 +181,7 @@ struct Decimator {
     // (Garland & Heckbert).  Boundary edges add a plane through the edge perpendicular to their face, so borders keep their shape
     // (the reference reaches the same end by connecting the boundary to a vertex at infinity).
     std::vector<std::array<double, 10>> quad;
+    std::vector<int> locmap;                 // scratch of collapse(): global vertex -> local index of the current patch (-1 outside)
 
     static void add_plane(std::array<double, 10>& q, V3 n, double d, double w)
     {
@@ -262,12 +263,30 @@ struct Decimator {
         for (int f : vfaces[a]) if (falive[f] && has(faces[f], b)) { if (n < 3) out[n] = f; n++; }
         return n;
     }
-    bool on_boundary(int v)
+    bool on_boundary_big(int v)   // valence > 64
     {
-        // v is a boundary vertex iff one of its edges has a single incident face
         std::unordered_map<int, int> cnt;
         for (int f : vfaces[v]) if (falive[f]) for (int c = 0; c < 3; c++) if (faces[f][c] != v) cnt[faces[f][c]]++;
         for (auto& kv : cnt) if (kv.second == 1) return true;
+        return false;
+    }
+    bool on_boundary(int v)
+    {
+        // v is a boundary vertex iff one of its edges has a single incident face
+        // (a one-ring holds a dozen vertices: a flat list beats a hash map, and this runs twice per attempted collapse)
+        int nbv[64], nbc[64], nn = 0;
+        for (int f : vfaces[v]) {
+            if (!falive[f]) continue;
+            for (int c = 0; c < 3; c++) {
+                const int w = faces[f][c];
+                if (w == v) continue;
+                int i = 0;
+                while (i < nn && nbv[i] != w) i++;
+                if (i == nn) { if (nn == 64) return on_boundary_big(v); nbv[nn] = w; nbc[nn] = 0; nn++; }
+                nbc[i]++;
+            }
+        }
+        for (int i = 0; i < nn; i++) if (nbc[i] == 1) return true;
         return false;
     }
     void push_edge(int a, int b)
@@ -338,7 +357,13 @@ struct Decimator {
         //  boundary conditions; when one end point is a boundary vertex the merged vertex sits on that end point)
         Patch patch;
         std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
-        std::unordered_map<int, int> loc;                // global vertex -> local
+        // global vertex -> local: a scratch array over all vertices, touched entries reset on every way out of this function
+        if (locmap.size() != pos.size()) locmap.assign(pos.size(), -1);
+        struct LocGuard {
+            std::vector<int>& m; std::vector<int> touched;
+            int& operator[](int v) { if (m[v] < 0) touched.push_back(v); return m[v]; }
+            ~LocGuard() { for (int v : touched) m[v] = -1; }
+        } loc{locmap, {}};
         {
             std::vector<int> ringv;
             for (int v : na) if (v != b) ringv.push_back(v);
@@ -390,8 +415,7 @@ struct Decimator {
                                    w[0] * patch.Vv[l0] + w[1] * patch.Vv[l1] + w[2] * patch.Vv[l2]});
                 }
             }
-            fpoints[f].clear();
-            fpoints[f].shrink_to_fit();
+            fpoints[f].clear();   // (capacity kept: re-homed points come straight back to the surviving faces)
         };
         for (int f : vfaces[a]) take(f);
         for (int f : vfaces[b]) if (!has(faces[f], a)) take(f);
