@@ -493,17 +493,21 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
     if (dec_type == 0) D.init_quadrics();
     // manifoldness (the reference bails out on non-manifold input, src/SSP_decimate.cpp:20-23)
     {
-        std::unordered_map<uint64_t, int> ecount;
-        ecount.reserve((size_t)nF * 3);
+        // sorted edge keys: equal keys are adjacent (a hash map over 3 #F edges cost a tenth of the whole decimation)
+        std::vector<uint64_t> ekeys;
+        ekeys.reserve((size_t)nF * 3);
         for (int f = 0; f < nF; f++)
             for (int c = 0; c < 3; c++) {
                 int a = D.faces[f][c], b = D.faces[f][(c + 1) % 3];
-                uint64_t key = ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
-                if (++ecount[key] > 2) { err = "input mesh is not edge-manifold"; return -1; }
+                ekeys.push_back(((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b));
             }
-        for (auto& kv : ecount) {
-            int a = (int)(kv.first >> 32), b = (int)(kv.first & 0xffffffffu);
-            D.push_edge(a, b);
+        std::sort(ekeys.begin(), ekeys.end());
+        for (size_t i = 0; i < ekeys.size();) {
+            size_t j = i;
+            while (j < ekeys.size() && ekeys[j] == ekeys[i]) j++;
+            if (j - i > 2) { err = "input mesh is not edge-manifold"; return -1; }
+            D.push_edge((int)(ekeys[i] >> 32), (int)(ekeys[i] & 0xffffffffu));
+            i = j;
         }
     }
     // every fine vertex starts as a one-hot barycentric point on one of its faces (src/get_prolong.cpp:23-39)
