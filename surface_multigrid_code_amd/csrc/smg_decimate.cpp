@@ -78,15 +78,18 @@ static void add_conformal_energy(const Patch& pt, const std::vector<std::array<i
 static bool solve_joint_flattening(Patch& pt)
 {
     const int n = pt.n, N = 2 * n;
-    std::vector<double> Q((size_t)N * N, 0.0);
+    // (scratch vectors live across calls: a collapse is a few microseconds of arithmetic, allocation would be a good part of it)
+    static thread_local std::vector<double> Q, M, rhs, x;
+    static thread_local std::vector<int> freei;
+    Q.assign((size_t)N * N, 0.0);
     add_conformal_energy(pt, pt.pre, Q);
     add_conformal_energy(pt, pt.post, Q);
     const int a = n - 3, b = n - 2;
     // pins: u_a = 0, v_a = 0, u_b = 1, v_b = 0
-    std::vector<int> freei;
+    freei.clear();
     for (int i = 0; i < N; i++) if (i != a && i != b && i != a + n && i != b + n) freei.push_back(i);
     const int m = (int)freei.size();
-    std::vector<double> M((size_t)m * m), rhs(m);
+    M.resize((size_t)m * m); rhs.resize(m);
     for (int r = 0; r < m; r++) {
         for (int c = 0; c < m; c++) M[(size_t)r * m + c] = Q[(size_t)freei[r] * N + freei[c]];
         rhs[r] = -Q[(size_t)freei[r] * N + b] * 1.0;   // only u_b = 1 is non-zero among the pins
@@ -106,7 +109,7 @@ static bool solve_joint_flattening(Patch& pt)
     }
     for (int i = 0; i < m; i++) { double sx = rhs[i]; for (int k = 0; k < i; k++) sx -= M[(size_t)i * m + k] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
     for (int i = m - 1; i >= 0; i--) { double sx = rhs[i]; for (int k = i + 1; k < m; k++) sx -= M[(size_t)k * m + i] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
-    std::vector<double> x(N, 0.0);
+    x.assign(N, 0.0);
     x[b] = 1.0;
     for (int r = 0; r < m; r++) x[freei[r]] = rhs[r];
     pt.U.assign(x.begin(), x.begin() + n);
@@ -296,7 +299,8 @@ struct Decimator {
     }
     void push_star(int v)
     {
-        std::vector<int> nb;
+        static thread_local std::vector<int> nb;
+        nb.clear();
         for (int f : vfaces[v]) if (falive[f]) for (int c = 0; c < 3; c++) if (faces[f][c] != v) nb.push_back(faces[f][c]);
         std::sort(nb.begin(), nb.end());
         nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
@@ -313,12 +317,12 @@ struct Decimator {
         const bool ba = on_boundary(a), bb = on_boundary(b);
         if (ba && bb && !edge_is_boundary) return false;  // interior chord between two boundary vertices
         // link condition: common neighbours == vertices opposite to the edge
-        std::vector<int> na, nb;
+        static thread_local std::vector<int> na, nb, common;
+        na.clear(); nb.clear(); common.clear();
         for (int f : vfaces[a]) for (int c = 0; c < 3; c++) if (faces[f][c] != a) na.push_back(faces[f][c]);
         for (int f : vfaces[b]) for (int c = 0; c < 3; c++) if (faces[f][c] != b) nb.push_back(faces[f][c]);
         std::sort(na.begin(), na.end()); na.erase(std::unique(na.begin(), na.end()), na.end());
         std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
-        std::vector<int> common;
         std::set_intersection(na.begin(), na.end(), nb.begin(), nb.end(), std::back_inserter(common));
         if ((int)common.size() != nef) return false;
         for (int i = 0; i < nef; i++) {
@@ -355,17 +359,22 @@ struct Decimator {
         // ---- interior collapse: joint conformal flattening of the 1-ring before / after (reject the collapse if invalid)
         // (collapses touching the boundary use the same construction on the open 1-ring: the conformal energy has natural
         //  boundary conditions; when one end point is a boundary vertex the merged vertex sits on that end point)
-        Patch patch;
-        std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
+        static thread_local Patch patch;
+        static thread_local std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
+        patch.pre.clear(); patch.post.clear(); patch.P.clear(); patch.U.clear(); patch.Vv.clear(); patch.n = 0;
+        pre_gid.clear(); post_gid.clear();
         // global vertex -> local: a scratch array over all vertices, touched entries reset on every way out of this function
         if (locmap.size() != pos.size()) locmap.assign(pos.size(), -1);
+        static thread_local std::vector<int> loc_touched;
+        loc_touched.clear();
         struct LocGuard {
-            std::vector<int>& m; std::vector<int> touched;
+            std::vector<int>& m; std::vector<int>& touched;
             int& operator[](int v) { if (m[v] < 0) touched.push_back(v); return m[v]; }
             ~LocGuard() { for (int v : touched) m[v] = -1; }
-        } loc{locmap, {}};
+        } loc{locmap, loc_touched};
         {
-            std::vector<int> ringv;
+            static thread_local std::vector<int> ringv;
+            ringv.clear();
             for (int v : na) if (v != b) ringv.push_back(v);
             for (int v : nb) if (v != a && !std::binary_search(na.begin(), na.end(), v)) ringv.push_back(v);
             for (int v : ringv) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
@@ -402,8 +411,9 @@ struct Decimator {
             if (!solve_joint_flattening(patch)) return false;
         }
         // ---- gather the fine points of the pre-collapse 1-ring with their positions
-        std::vector<int> pts;
-        std::vector<std::array<double, 2>> puv;   // position in the joint flattening (interior collapses)
+        static thread_local std::vector<int> pts;
+        static thread_local std::vector<std::array<double, 2>> puv;   // position in the joint flattening (interior collapses)
+        pts.clear(); puv.clear();
         auto take = [&](int f) {
             for (int p : fpoints[f]) {
                 pts.push_back(p);
