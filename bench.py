@@ -207,7 +207,16 @@ def main():
             return int(t.item()) == 1
 
         sar = StreamAllReduce(rank, world, stream.cuda_stream, device=dev)
-        if all_agree(sar.ready) and all_agree(sar.connect()):
+        good = all_agree(sar.ready) and all_agree(sar.connect())
+        if good:   # known answer before it is trusted: sum over ranks of (rank + 1)
+            probe = torch.tensor([rank + 1.0], dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            sar(probe.data_ptr())
+            stream.synchronize()
+            good = all_agree(float(probe.item()) == world * (world + 1) / 2.0)
+            if not good:
+                sar.err = "known-answer all-reduce gave %r" % float(probe.item())
+        if good:
             stream_ar = sar
         elif rank == 0:
             print("bench: direct RCCL all-reduce unavailable (%s), using torch.distributed" % sar.err, file=sys.stderr)
