@@ -176,6 +176,25 @@ struct Decimator {
     std::vector<int> pface;
     std::vector<std::array<double, 3>> pbary;
     std::priority_queue<QEntry> pq;
+    // The edges of the input mesh -- most of what the queue ever holds -- are sorted once and consumed front to back; the heap only
+    // takes the edges created or re-offered later.  pop_next() returns the better of the two fronts: the same sequence one heap
+    // holding everything would produce (the order of QEntry is total), at a fraction of the cache misses.
+    std::vector<QEntry> initial;
+    size_t ihead = 0;
+    bool filling = true;
+    void seal_initial()
+    {
+        std::sort(initial.begin(), initial.end(), [](const QEntry& x, const QEntry& y) { return y < x; });   // best first
+        filling = false;
+    }
+    bool queue_empty() const { return pq.empty() && ihead == initial.size(); }
+    QEntry pop_next()
+    {
+        if (pq.empty() || (ihead < initial.size() && !(initial[ihead] < pq.top()))) return initial[ihead++];
+        QEntry e = pq.top();
+        pq.pop();
+        return e;
+    }
     int n_alive_faces = 0;
     int dec_type = 1;
     // dec_type 0 (the reference's "qslim", src/SSP_qslim.cpp): quadric error metric -- every vertex carries the area-weighted
@@ -295,7 +314,8 @@ struct Decimator {
     void push_edge(int a, int b)
     {
         if (a > b) std::swap(a, b);
-        pq.push({dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]});
+        const QEntry e{dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]};
+        if (filling) initial.push_back(e); else pq.push(e);
     }
     void push_star(int v)
     {
@@ -520,6 +540,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
             i = j;
         }
     }
+    D.seal_initial();
     // every fine vertex starts as a one-hot barycentric point on one of its faces (src/get_prolong.cpp:23-39)
     D.pface.assign(nV, -1);
     D.pbary.assign(nV, {0, 0, 0});
@@ -544,7 +565,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
     std::vector<QEntry> parked;
     bool progressed = false;
     while (D.n_alive_faces > tarF) {
-        if (D.pq.empty()) {
+        if (D.queue_empty()) {
             if (parked.empty()) break;
             if (!progressed) {
                 if (cap >= (1 << 29)) break;
@@ -556,8 +577,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
             progressed = false;
             continue;
         }
-        QEntry e = D.pq.top();
-        D.pq.pop();
+        QEntry e = D.pop_next();
         if (!D.valive[e.a] || !D.valive[e.b] || D.version[e.a] != e.va || D.version[e.b] != e.vb) continue;
         if (weight[e.a] + weight[e.b] > cap) { parked.push_back(e); continue; }
         if (D.collapse(e.a, e.b)) { progressed = true; weight[e.a] += weight[e.b]; }   // b merges into a
