@@ -546,10 +546,23 @@ static int precompute_device(smg_hierarchy* h)
             if (lv >= 1) {
                 errs.push_back(hipSuccess);
                 hipError_t* eP = &errs.back();
-                tasks.push_back([&, lv, eP] { Sell S = build_sell(h->lv[lv].P_int, nullptr); *eP = h->lv[lv].dP.upload(S); });
+                // P and PT are launched whole: with their rows cut at the colour boundaries of the level they belong to, the slices get
+                // the same region-major launch order as A, and the workgroups an XCD receives (a contiguous piece of that order) read
+                // their gathers from one region of the mesh instead of from all over it (restriction at C3: 54 MB of HBM traffic per
+                // launch for 33 MB of algorithmic bytes before)
+                static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
+                tasks.push_back([&, lv, eP] {
+                    const bool cut = tr_region && region && h->lv[lv - 1].ord.color_ptr.size() > 2;
+                    Sell S = build_sell(h->lv[lv].P_int, cut ? &h->lv[lv - 1].ord.color_ptr : nullptr, sellC, cut);
+                    *eP = h->lv[lv].dP.upload(S);
+                });
                 errs.push_back(hipSuccess);
                 hipError_t* eQ = &errs.back();
-                tasks.push_back([&, lv, eQ] { Sell S = build_sell(h->lv[lv].PT_int, nullptr); *eQ = h->lv[lv].dPT.upload(S); });
+                tasks.push_back([&, lv, eQ] {
+                    const bool cut = tr_region && region && lv < L - 1 && h->lv[lv].ord.color_ptr.size() > 2;
+                    Sell S = build_sell(h->lv[lv].PT_int, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                    *eQ = h->lv[lv].dPT.upload(S);
+                });
             }
         }
         parallel_tasks(tasks);
