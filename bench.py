@@ -146,6 +146,11 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--spmv-reps", type=int, default=500)
+    ap.add_argument("--smoother", default="hybrid", choices=["gs", "jacobi", "hybrid"],
+                    help="gs (default): the reference's Gauss-Seidel on every level; hybrid: GS on the big levels, damped Jacobi on "
+                         "those with <= --jacobi-max-rows unknowns; jacobi: Jacobi everywhere")
+    ap.add_argument("--omega", type=float, default=0.8)
+    ap.add_argument("--jacobi-max-rows", type=int, default=100000)
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
                     help="f64 (default): the reference arithmetic; mixed: fp32 V-cycle inside the fp64 outer loop")
     args = ap.parse_args()
@@ -226,7 +231,8 @@ def main():
     # last allowed iteration would run without storing anything -- so longer runs restart the solve (a gather launch and two
     # small copies, inside the timed region) every 1024 steps instead of silently timing such launches.
     HIS = 1024
-    opts = smg.SolveOpts(tol=0.0, max_iter=HIS, pre=2, post=2, precision=args.precision)
+    sm_kw = dict(smoother=args.smoother, omega=args.omega, jacobi_max_rows=args.jacobi_max_rows)
+    opts = smg.SolveOpts(tol=0.0, max_iter=HIS, pre=2, post=2, precision=args.precision, **sm_kw)
     state = {"left": 0, "his": None}
 
     def step_block(n_it):
@@ -293,6 +299,40 @@ def main():
     if rank == 0:
         ms_step = 1e3 * dt / K
         vcyc_bytes = mg.vcycle_bytes(1, 2, 2)
+        # ---- smoother comparison: the reference's Gauss-Seidel everywhere vs the timed configuration.  What counts is the time
+        # to the tolerance: cycles needed to 1e-10 (the drop-in solve on resident vectors, device-side break test, host polling
+        # every iteration) x the steady-state time of an outer iteration.
+        def smoother_line(kw, ms_known=None):
+            o = smg.SolveOpts(tol=1e-10, max_iter=100, pre=2, post=2, precision=args.precision, **kw)
+            mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)       # warm (graph capture)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            cv, rh_ = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+            wall = 1e3 * (time.perf_counter() - tw)
+            ms = ms_known
+            if ms is None:      # steady-state time of one outer iteration with this smoother (HIP events on the solve stream)
+                oo = smg.SolveOpts(tol=0.0, max_iter=HIS, pre=2, post=2, precision=args.precision, **kw)
+                mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=oo)
+                mg.outer_iterations(50)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(stream)
+                mg.outer_iterations(300)
+                eb.record(stream)
+                torch.cuda.synchronize()
+                mg.solve_end(z.data_ptr(), n, max_iter=HIS)
+                ms = ea.elapsed_time(eb) / 300
+            cyc = len(rh_) - 1
+            return {"smoother": kw["smoother"], "omega": kw.get("omega"), "jacobi_max_rows": kw.get("jacobi_max_rows"),
+                    "jacobi_levels": [l for l in range(mg.n_levels - 1) if kw["smoother"] == "jacobi" or
+                                      (kw["smoother"] == "hybrid" and mg.rows(l) <= kw["jacobi_max_rows"])],
+                    "converged": bool(cv), "cycles_to_tol": cyc, "tol": 1e-10, "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms,
+                    "time_to_tol_ms": cyc * ms, "solve_wall_ms": wall, "final_residual": float(rh_[-1]) if len(rh_) else None}
+        smoothers = None
+        if world == 1 and not force_split:
+            smoothers = {"timed": smoother_line(sm_kw, ms_step)}
+            if args.smoother != "gs":
+                smoothers["reference_gs"] = smoother_line(dict(smoother="gs", omega=args.omega, jacobi_max_rows=args.jacobi_max_rows))
+            mg.set_smoother("gs")   # the kernel-level measurements below are of the reference smoother
         # ---- roofline of the fine-level SpMV kernel (k_sell<SELL_AX,1> on A_0), HIP events on the launch stream
         x = torch.from_numpy(rng.uniform(-1.0, 1.0, n)).to(dev)
         y = torch.empty_like(x)
@@ -325,7 +365,7 @@ def main():
         gs_bytes = 12 * nnz0 + 4 * (n + 1) + 24 * n
         # ---- per-scope timing of the V-cycle (profc mirror; eager launches with hipEvents)
         mg.prof_enable(True)
-        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=8))
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=8, **sm_kw))
         mg.outer_iterations(8)
         mg.solve_end(z.data_ptr(), n, max_iter=8)
         prof = mg.prof_table()
@@ -347,7 +387,11 @@ def main():
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
                        "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],
-                       "rhs_columns_per_gpu": 1, "cycle": "V(2,2), multi-colour Gauss-Seidel, dense coarsest solve",
+                       "rhs_columns_per_gpu": 1,
+                       "cycle": {"gs": "V(2,2), multi-colour Gauss-Seidel on every level (the reference's relax()), dense coarsest solve",
+                                 "hybrid": "V(2,2), multi-colour Gauss-Seidel on levels > %d rows, damped Jacobi (omega %.2f) below, dense coarsest solve" % (args.jacobi_max_rows, args.omega),
+                                 "jacobi": "V(2,2), damped Jacobi (omega %.2f) on every level, dense coarsest solve" % args.omega}[args.smoother],
+                       "smoother": args.smoother,
                        "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU",
                        "allreduce": ("RCCL on the solve stream (dist.StreamAllReduce)" if stream_ar is not None else "torch.distributed") if (world > 1 or force_split) else None},
             "roofline": {"kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm",
@@ -362,6 +406,9 @@ def main():
             "roofline_vcycle": {"bound": "hbm", "bytes_per_step": int(vcyc_bytes),
                                 "achieved": vcyc_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": vcyc_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "smoothers": smoothers,
+            "time_to_tol_ms": smoothers["timed"]["time_to_tol_ms"] if smoothers else None,
+            "cycles_to_tol": smoothers["timed"]["cycles_to_tol"] if smoothers else None,
             "profc": {k: {"count": v[0], "ms_total": v[1]} for k, v in prof.items()},
             "residual_history_head": [float(v) for v in r_his[:6]],
             "setup_s": {"mesh_hierarchy_host": t_host, "precompute": t_pre},

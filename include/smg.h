@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMG_VERSION 100
+#define SMG_VERSION 200
 
 enum {
     SMG_OK = 0,
@@ -45,6 +45,14 @@ enum { SMG_HOST = 0, SMG_DEVICE = 1 };         /* where the dense blocks handed 
 /* decimation types of mg_precompute (src/mg_precompute.h:9: 0 qslim, 1 midpoint, 2 vertex removal) */
 enum { SMG_DEC_QSLIM = 0, SMG_DEC_MIDPOINT = 1, SMG_DEC_VERTEX_REMOVAL = 2 };
 
+/* smoother of the V-cycle (the slot of relax(), src/mg_VCycle.cpp:113-178).  The reference only has Gauss-Seidel; damped Jacobi is
+ * the "Gauss-Seidel/Jacobi smoothing" of this build's brief: one whole-matrix launch per sweep instead of one launch per colour.
+ *   GS      forward Gauss-Seidel on every level: the reference's sweep on the colour-major numbering (default)
+ *   JACOBI  damped Jacobi on every level:  u_i <- u_i + omega * ((b_i - sum_{j != i} A(j,i) u_j) / A_diag_i - u_i), all rows from the old u
+ *   HYBRID  Gauss-Seidel on the levels with more than `jacobi_max_rows` unknowns (bandwidth-bound: a sweep costs its bytes),
+ *           Jacobi on the smaller ones (launch-latency-bound: a sweep costs its launches) */
+enum { SMG_SMOOTH_GS = 0, SMG_SMOOTH_JACOBI = 1, SMG_SMOOTH_HYBRID = 2 };
+
 typedef struct smg_hierarchy smg_hierarchy;
 
 /* Parameters the reference hard-codes or passes through default-argument overloads:
@@ -60,6 +68,9 @@ typedef struct {
                           residual (hence r_his and the stopping test) stay fp64, the V-cycle runs on fp32 copies of the
                           operators as z += V32(RHS - A z): same iteration in exact arithmetic, fp64 accuracy at convergence,
                           ~2/3 of the bytes (BASELINE config 5: fp32 vs fp64) */
+    int smoother;      /* SMG_SMOOTH_GS (default, the reference) / SMG_SMOOTH_JACOBI / SMG_SMOOTH_HYBRID */
+    double omega;      /* Jacobi damping factor (default 0.8) */
+    int jacobi_max_rows; /* HYBRID: levels with at most this many unknowns are smoothed by Jacobi (default 100000) */
 } smg_solve_opts;
 void smg_solve_opts_default(smg_solve_opts *o);
 
@@ -74,6 +85,9 @@ void smg_hierarchy_destroy(smg_hierarchy *h);
 int smg_hierarchy_levels(const smg_hierarchy *h);
 /* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) instead of the handle's own. */
 int smg_hierarchy_set_stream(smg_hierarchy *h, void *hip_stream);
+/* Smoother used by smg_vcycle / smg_relax and the raw / bench entry points (which take no smg_solve_opts); smg_solve* set the same
+ * state from their opts.  omega <= 0 keeps the current value, jacobi_max_rows < 0 likewise. */
+int smg_hierarchy_set_smoother(smg_hierarchy *h, int smoother, double omega, int jacobi_max_rows);
 /* mg[lv].P_full = mg[lv].P = P; mg[lv].PT = P^T  (what mg_precompute stores per level, src/mg_precompute.cpp:71-77).
  * P is #V_{lv-1} x #V_lv for lv = 1 .. n_levels-1 (the operator lives on the COARSER level, mg_VCycle.cpp:80,:91). */
 int smg_level_set_prolong(smg_hierarchy *h, int lv, int n_fine, int n_coarse, const int *rowptr, const int *col,
@@ -146,7 +160,7 @@ int smg_assemble(smg_assembler *a, const double *d_V, int voronoi, double mass_c
 
 /* ---- min_quad_with_fixed_mg_solve (src/min_quad_with_fixed_mg.h:38-69 and :79-113) ------------------------------ */
 /* RHS, z0, z: n x k column-major (n = full size incl. known rows); known_val: n_known x k (ignored without
- * constraints).  r_his must hold opts->max_iter doubles; *n_his <= max_iter entries are written, one per loop
+ * constraints).  r_his must hold opts->max_iter doubles (any max_iter >= 0, as in the reference, .cpp:77); *n_his <= max_iter entries are written, one per loop
  * entry incl. the one that triggers the break (.cpp:108-116).  *converged = !(last measured residual > tol)
  * (.cpp:131-134).  memspace: SMG_HOST or SMG_DEVICE for RHS/known_val/z0/z (r_his is always host). */
 int smg_solve(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *known_val, int ld_kv, const double *z0,

@@ -65,6 +65,7 @@ def lib():
     L.orc_profile_reset.argtypes = [vp]
     L.orc_set_parallel.argtypes = [vp, C.c_int, C.c_int, ip]
     L.orc_enable_parallel.argtypes = [vp, C.c_int, C.c_int]
+    L.orc_set_smoother.argtypes = [vp, C.c_int, C.c_int, C.c_double]
     L.orc_csc_times_dense.argtypes = [C.POINTER(_Csc), dp, C.c_int, C.c_int, dp, C.c_int]
     _lib = L
     return L
@@ -151,6 +152,12 @@ class OracleMG:
             if rc != 0:
                 raise RuntimeError("orc_set_parallel(level %d) failed rc=%d (blocks not independent?)" % (lv, rc))
         return self.L.orc_enable_parallel(self.h, 1, int(threads))
+
+    # -- smoother per level (extension: damped Jacobi, see smg_oracle.h)
+    def set_smoother(self, lv, kind="gs", omega=1.0):
+        rc = self.L.orc_set_smoother(self.h, lv, {"gs": 0, "jacobi": 1}[kind], float(omega))
+        if rc != 0:
+            raise RuntimeError("orc_set_smoother failed rc=%d" % rc)
 
     def set_sequential(self):
         self.L.orc_enable_parallel(self.h, 0, 0)

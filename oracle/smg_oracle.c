@@ -406,6 +406,7 @@ void orc_mg_destroy(orc_mg *mg)
         if (mg->AT) orc_csc_free(&mg->AT[l]);
     }
     free(mg->color_ptr); free(mg->n_colors); free(mg->AT);
+    free(mg->smoother); free(mg->omega);
     free(mg);
 }
 
@@ -552,12 +553,54 @@ void orc_prolong(const orc_mg *mg, int lv, const double *x, int k, double *Px)
  * Column colIdx of the (symmetric) CSC matrix is walked instead of row colIdx (:149-150);
  * the diagonal is skipped by index test (:153); division by the cached A_diag (:157).
  * dim > 1: the dense-column loop is outermost (:161-177) => k independent sweeps. */
+/* Damped Jacobi (extension, see smg_oracle.h: orc_set_smoother): `iters` sweeps, every row from the old iterate. */
+static void relax_jacobi(orc_mg *mg, int lv, const double *B, int k, int iters, double *u, double omega)
+{
+    const orc_csc *A = &mg->lv[lv].A;
+    const double *diag = mg->lv[lv].A_diag;
+    int n = A->n_rows;
+    double *tmp = (double *)xmalloc((size_t)n * sizeof(double));
+    for (int ri = 0; ri < k; ri++) {
+        double *uc = u + (size_t)ri * (size_t)n;
+        const double *bc = B + (size_t)ri * (size_t)n;
+        for (int iter = 0; iter < iters; iter++) {
+#pragma omp parallel for schedule(static) if (mg->par && n > ORC_PAR_MIN_ROWS)
+            for (int colIdx = 0; colIdx < n; colIdx++) {
+                double sum = 0;
+                for (int p = A->colptr[colIdx]; p < A->colptr[colIdx + 1]; p++)
+                    if (A->rowidx[p] != colIdx) sum += A->val[p] * uc[A->rowidx[p]];
+                double t = (bc[colIdx] - sum) / diag[colIdx];
+                tmp[colIdx] = uc[colIdx] + omega * (t - uc[colIdx]);
+            }
+            memcpy(uc, tmp, (size_t)n * sizeof(double));
+        }
+    }
+    free(tmp);
+}
+
+int orc_set_smoother(orc_mg *mg, int lv, int kind, double omega)
+{
+    if (!mg || lv < 0 || lv >= mg->n_levels || (kind != ORC_SMOOTH_GS && kind != ORC_SMOOTH_JACOBI)) return -1;
+    if (!mg->smoother) {
+        mg->smoother = (int *)xcalloc((size_t)mg->n_levels, sizeof(int));
+        mg->omega = (double *)xcalloc((size_t)mg->n_levels, sizeof(double));
+    }
+    mg->smoother[lv] = kind;
+    mg->omega[lv] = omega;
+    return 0;
+}
+
 void orc_relax(orc_mg *mg, int lv, const double *B, int k, int iters, double *u)
 {
     double t0 = now_s();
     const orc_csc *A = &mg->lv[lv].A;
     const double *diag = mg->lv[lv].A_diag;
     int n = A->n_rows;
+    if (mg->smoother && mg->smoother[lv] == ORC_SMOOTH_JACOBI) {
+        relax_jacobi(mg, lv, B, k, iters, u, mg->omega[lv]);
+        mg->t_relax += now_s() - t0; mg->c_relax++;
+        return;
+    }
     if (mg->par && mg->color_ptr && mg->color_ptr[lv]) {
         /* all-core mode: the same sweep, block by block; rows of a block do not reference each other, so sweeping a block
          * in parallel reads and writes exactly what the sequential loop below does */

@@ -73,6 +73,9 @@ typedef struct {
     int **color_ptr;        /* per level: n_colors + 1 row offsets of the independent blocks, or NULL */
     int *n_colors;
     orc_csc *AT;            /* per level: A^T (the row-wise image of A), built by orc_set_parallel */
+    /* per-level smoother selection (extension named by BASELINE.json's north_star, see orc_set_smoother) */
+    int *smoother;          /* NULL or per level: ORC_SMOOTH_GS (the reference's relax()) / ORC_SMOOTH_JACOBI */
+    double *omega;          /* per level: damping factor of the Jacobi sweep */
 } orc_mg;
 
 /* ---- hierarchy container ---- */
@@ -108,6 +111,16 @@ void orc_restrict(const orc_mg *mg, int lv, const double *x, int k, double *Rx);
 void orc_prolong(const orc_mg *mg, int lv, const double *x, int k, double *Px);  /* :83-92  */
 void orc_relax(orc_mg *mg, int lv, const double *B, int k, int iters, double *u); /* :113-178 */
 void orc_coarse_solve(orc_mg *mg, int lv, const double *B, int k, double *u);    /* :181-201 */
+
+/* ---- damped-Jacobi smoother: NOT in the reference (its relax() is Gauss-Seidel only, mg_VCycle.cpp:113-178); it is the
+ * "Gauss-Seidel/Jacobi smoothing" of BASELINE.json's north_star and fills the same slot.  Defined so that the HIP kernel and
+ * this loop agree bit for bit.  One sweep, for every row i from the OLD iterate (all rows simultaneously):
+ *     s = sum_{j != i, ascending j} A(j,i) * u_old[j]      (column i of the CSC matrix, like relax(), :149-155)
+ *     t = (B[i] - s) / A_diag[i]
+ *     u_new[i] = u_old[i] + omega * (t - u_old[i])
+ * kind: ORC_SMOOTH_GS (default on every level) or ORC_SMOOTH_JACOBI.  orc_relax() dispatches on the level's setting. */
+enum { ORC_SMOOTH_GS = 0, ORC_SMOOTH_JACOBI = 1 };
+int orc_set_smoother(orc_mg *mg, int lv, int kind, double omega);
 
 /* ---- introspection for tests ---- */
 int orc_level_rows(const orc_mg *mg, int lv);

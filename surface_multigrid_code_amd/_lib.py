@@ -10,7 +10,8 @@ SMG_HOST, SMG_DEVICE = 0, 1
 
 class SolveOptsC(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("pre", C.c_int), ("post", C.c_int),
-                ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int), ("precision", C.c_int)]
+                ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int), ("precision", C.c_int),
+                ("smoother", C.c_int), ("omega", C.c_double), ("jacobi_max_rows", C.c_int)]
 
 
 _lib = None
@@ -35,6 +36,7 @@ def load():
         "smg_hierarchy_destroy": (None, [vp]),
         "smg_hierarchy_levels": (i, [vp]),
         "smg_hierarchy_set_stream": (i, [vp, vp]),
+        "smg_hierarchy_set_smoother": (i, [vp, i, d, i]),
         "smg_level_set_prolong": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_prolong_csc": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_mesh": (i, [vp, i, dp, i, ip, i]),

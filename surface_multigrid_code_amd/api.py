@@ -52,12 +52,19 @@ def _colmajor(X):
     return np.asfortranarray(X)
 
 
+SMOOTHERS = {"gs": 0, "jacobi": 1, "hybrid": 2, 0: 0, 1: 1, 2: 2}
+
+
 class SolveOpts:
     """tol / maxIter / pre / post with the reference's defaults (src/min_quad_with_fixed_mg.cpp:63,77,102-103)."""
 
-    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1, precision="f64"):
+    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1, precision="f64",
+                 smoother="gs", omega=0.8, jacobi_max_rows=100000):
+        """smoother: "gs" (the reference's relax(), default) / "jacobi" (damped Jacobi on every level) / "hybrid" (Gauss-Seidel on
+        the levels with more than `jacobi_max_rows` unknowns, Jacobi below)."""
         prec = {"f64": 0, "fp64": 0, 0: 0, "mixed": 1, 1: 1}[precision]
-        self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph, prec)
+        self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph, prec, SMOOTHERS[smoother], omega,
+                            jacobi_max_rows)
 
 
 class Hierarchy:
@@ -95,6 +102,10 @@ class Hierarchy:
     def set_stream(self, stream_ptr):
         """Use the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); None / 0 = the default stream."""
         _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "smg_hierarchy_set_stream")
+
+    def set_smoother(self, smoother="gs", omega=0.0, jacobi_max_rows=-1):
+        """Smoother of vcycle()/relax() and the raw entry points (solve() takes it from its SolveOpts)."""
+        _chk(self.L.smg_hierarchy_set_smoother(self.h, SMOOTHERS[smoother], omega, jacobi_max_rows), "smg_hierarchy_set_smoother")
 
     def save(self, path):
         _chk(self.L.smg_hierarchy_save(self.h, path.encode()), "smg_hierarchy_save")
@@ -146,6 +157,16 @@ class Hierarchy:
                               C.byref(opts.c), z.ctypes.data, n, _dp(r_his), C.byref(n_his), C.byref(conv))
         _chk(rc, "smg_solve")
         return bool(conv.value), z, r_his[: n_his.value].copy()
+
+    def solve_device(self, rhs_ptr, z0_ptr, z_ptr, n, k=1, known_val_ptr=None, ld_kv=0, opts=None):
+        """min_quad_with_fixed_mg_solve on column-major blocks already resident in HBM (device pointers, leading dimension n):
+        the drop-in call, polling the device-side convergence flag every opts.check_every iterations."""
+        opts = opts or SolveOpts()
+        r_his = np.zeros(max(opts.c.max_iter, 1))
+        n_his, conv = C.c_int(0), C.c_int(0)
+        _chk(self.L.smg_solve(self.h, rhs_ptr, n, known_val_ptr, ld_kv, z0_ptr, n, k, SMG_DEVICE, C.byref(opts.c), z_ptr, n,
+                              _dp(r_his), C.byref(n_his), C.byref(conv)), "smg_solve")
+        return bool(conv.value), r_his[: n_his.value].copy()
 
     # ---- mg_VCycle.h pieces (host blocks in the level's caller numbering)
     def rows(self, lv):

@@ -64,6 +64,9 @@ extern "C" void smg_solve_opts_default(smg_solve_opts* o)
     o->check_every = 1;
     o->use_graph = 1;
     o->precision = 0;
+    o->smoother = SMG_SMOOTH_GS;   // the reference's relax()
+    o->omega = 0.8;
+    o->jacobi_max_rows = 100000;
 }
 
 // ------------------------------------------------------------------------------------------------ device plumbing
@@ -82,8 +85,23 @@ static int ensure_device(smg_hierarchy* h)
     }
     HIPCHK(h->d_ctrl.alloc(1));
     HIPCHK(hipMemset(h->d_ctrl.p, 0, sizeof(Ctrl)));
+    HIPCHK(h->d_rhis.alloc(1));
     return SMG_OK;
 }
+
+// The current HIP device is a per-thread setting: every entry point that touches the device -- and every worker thread of the
+// precompute -- runs on the handle's device, whatever the calling thread had selected (one process may drive several GPUs, and a
+// std::thread starts on device 0).  Restores the caller's selection on scope exit.
+struct DeviceScope {
+    int prev = -1, dev = -1;
+    explicit DeviceScope(int d) : dev(d)
+    {
+        if (d < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) (void)hipSetDevice(d);
+    }
+    ~DeviceScope() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 
 static int env_int(const char* name, int dflt)
 {
@@ -137,26 +155,28 @@ hipError_t SellBuf::upload(const Sell& S)
     }
     color_slice_ptr = S.color_slice_ptr;
     stored = S.nnz; padded = S.padded(); used = S.used();
-    // where the diagonal of each first-colour row sits in the value array (restriction launches with a fused first colour)
-    n_first = 0;
-    if (S.n_rows == S.n_cols && S.color_slice_ptr.size() >= 3) {
-        const int s1 = S.color_slice_ptr[1];
+    // where the diagonal of each row sits in the value array (restriction launches that produce the first launch of the coarse
+    // level's first sweep themselves: the first colour of a Gauss-Seidel sweep / the whole first Jacobi sweep)
+    n_first = 0; n_all = 0;
+    if (S.n_rows == S.n_cols && S.color_slice_ptr.size() >= 2) {
+        const int s1 = S.color_slice_ptr.size() >= 3 ? S.color_slice_ptr[1] : S.n_slices;
         const int nf = S.slice_row[s1];
-        std::vector<int> slot((size_t)nf, -1);
-        bool ok = true;
-        for (int sl = 0; sl < s1 && ok; sl++) {
+        std::vector<int> slot((size_t)S.n_rows, -1);
+        int first_missing = S.n_rows;
+        for (int sl = 0; sl < S.n_slices; sl++) {
             const int r0 = S.slice_row[sl], r1 = S.slice_row[sl + 1];
             for (int r = r0; r < r1; r++) {
                 for (int j = 0; j < S.slice_w[sl]; j++) {
                     const size_t at = ((size_t)S.slice_off[sl] + j) * S.C + (r - r0);
                     if (S.col[at] == r) { slot[r] = (int)at; break; }
                 }
-                if (slot[r] < 0) { ok = false; break; }
+                if (slot[r] < 0 && r < first_missing) first_missing = r;
             }
         }
-        if (ok && nf > 0) {
-            if ((e = first_diag_slot.upload(slot)) != hipSuccess) return e;
-            n_first = nf;
+        if (S.n_rows > 0 && first_missing >= nf) {
+            if ((e = diag_slot.upload(slot)) != hipSuccess) return e;
+            if (S.color_slice_ptr.size() >= 3) n_first = nf;
+            if (first_missing == S.n_rows) n_all = S.n_rows;
         }
     }
     return hipSuccess;
@@ -234,6 +254,19 @@ extern "C" int smg_hierarchy_set_stream(smg_hierarchy* h, void* hip_stream)
     h->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream
     h->own_stream = false;
     h->user_stream = true;
+    return SMG_OK;
+}
+
+extern "C" int smg_hierarchy_set_smoother(smg_hierarchy* h, int smoother, double omega, int jacobi_max_rows)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    if (smoother != SMG_SMOOTH_GS && smoother != SMG_SMOOTH_JACOBI && smoother != SMG_SMOOTH_HYBRID)
+        return fail(SMG_ERR_INVALID, "smoother must be SMG_SMOOTH_GS, _JACOBI or _HYBRID");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_smoother called during a split-phase solve");
+    if (omega > 2.0 || omega != omega) return fail(SMG_ERR_INVALID, "omega must be in (0, 2]");
+    h->smoother = smoother;
+    if (omega > 0.0) h->omega = omega;
+    if (jacobi_max_rows >= 0) h->jacobi_max_rows = jacobi_max_rows;
     return SMG_OK;
 }
 
@@ -506,8 +539,8 @@ static int precompute_device(smg_hierarchy* h)
     drop_graphs(h);
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
-        Lv.b.release(); Lv.u.release(); Lv.r.release();
-        Lv.b32.release(); Lv.u32.release(); Lv.r32.release();
+        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release();
+        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release();
     }
     h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
     StageTimer tm;
@@ -518,11 +551,22 @@ static int precompute_device(smg_hierarchy* h)
         std::vector<std::function<void()>> tasks;
         std::vector<hipError_t> errs;
         errs.reserve((size_t)4 * L);
+        if (L == 1) {
+            // a single level goes straight to coarseSolve (src/mg_VCycle.cpp:28-33); the outer loop still needs A_0 for its residual
+            errs.push_back(hipSuccess);
+            hipError_t* eA = &errs.back();
+            tasks.push_back([&, eA] {
+                DeviceScope ds(h->device);
+                Sell S = build_sell(h->lv[0].A_int, nullptr, sellC, false);
+                *eA = h->lv[0].dA.upload(S);
+            });
+        }
         for (int lv = 0; lv < L; lv++) {
             if (lv < L - 1) {
                 errs.push_back(hipSuccess);
                 hipError_t* eA = &errs.back();
                 tasks.push_back([&, lv, eA] {
+                    DeviceScope ds(h->device);   // worker threads start on device 0
                     Sell S = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region);
                     *eA = h->lv[lv].dA.upload(S);
                 });
@@ -532,6 +576,7 @@ static int precompute_device(smg_hierarchy* h)
                 errs.push_back(hipSuccess);
                 hipError_t* eT = &errs.back();
                 tasks.push_back([&, lv, eT] {
+                    DeviceScope ds(h->device);
                     Level& Lw = h->lv[lv];
                     Csr AT = transpose(Lw.A_int);
                     Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
@@ -552,6 +597,7 @@ static int precompute_device(smg_hierarchy* h)
                 // launch for 33 MB of algorithmic bytes before)
                 static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
                 tasks.push_back([&, lv, eP] {
+                    DeviceScope ds(h->device);
                     const bool cut = tr_region && region && h->lv[lv - 1].ord.color_ptr.size() > 2;
                     Sell S = build_sell(h->lv[lv].P_int, cut ? &h->lv[lv - 1].ord.color_ptr : nullptr, sellC, cut);
                     *eP = h->lv[lv].dP.upload(S);
@@ -559,6 +605,7 @@ static int precompute_device(smg_hierarchy* h)
                 errs.push_back(hipSuccess);
                 hipError_t* eQ = &errs.back();
                 tasks.push_back([&, lv, eQ] {
+                    DeviceScope ds(h->device);
                     const bool cut = tr_region && region && lv < L - 1 && h->lv[lv].ord.color_ptr.size() > 2;
                     Sell S = build_sell(h->lv[lv].PT_int, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
                     *eQ = h->lv[lv].dPT.upload(S);
@@ -593,6 +640,8 @@ static int precompute_device(smg_hierarchy* h)
         const int nc = Lc.n;
         const int np = ((nc + 63) / 64) * 64;
         h->nc = nc; h->nc_pad = np;
+        if ((double)np * np * 8.0 > 96e9)
+            return fail(SMG_ERR_ALLOC, "coarsest level has %d unknowns: its dense inverse (%.0f GB) is out of range -- add levels", nc, (double)np * np * 8e-9);
         // dense image on the device: the few entries travel, not n^2 zeros
         std::vector<long long> pos(Lc.A.nnz());
         for (int i = 0; i < nc; i++)
@@ -670,6 +719,7 @@ static int build_recipes(smg_hierarchy* h)
         auto up = [](hipError_t& acc, hipError_t e) { if (acc == hipSuccess) acc = e; };
         for (int lv = 0; lv < L; lv++) {
             if (lv < L - 1) tasks.push_back([&, lv] {
+                DeviceScope ds(h->device);
                 // SELL slot -> caller CSR entry, for A and for A^T (the sweep always reads A^T in this mode: whether new
                 // values are bit-symmetric cannot be known in advance)
                 Level& Lv = h->lv[lv];
@@ -691,6 +741,7 @@ static int build_recipes(smg_hierarchy* h)
                 if (!Lv.gs_on_transpose) { up(er, Lv.dAT.upload(ST)); Lv.gs_on_transpose = true; }
             });
             tasks.push_back([&, lv] {
+                DeviceScope ds(h->device);
                 Level& Lv = h->lv[lv];
                 hipError_t& er = errs[2 * lv + 1];
                 up(er, Lv.d_Aval.upload(Lv.A.val));
@@ -789,6 +840,8 @@ extern "C" int smg_precompute_values_device(smg_hierarchy* h, const double* d_va
     if (!h->precomputed || h->device < 0) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: run a full smg_precompute with this sparsity first");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute_values_device called during a split-phase solve");
     if (!h->input_canonical) return fail(SMG_ERR_INVALID, "the matrix given to smg_precompute had unsorted or duplicate entries: entry indices are not stable");
+    if (h->n_levels < 2) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: single-level hierarchies take the full smg_precompute");
+    DeviceScope dsc(h->device);
     if (!h->recipes_built) { int rc = build_recipes(h); if (rc) return rc; }
     int rc = precompute_values_device(h, d_val);
     if (rc != SMG_OK) h->precomputed = false;
@@ -857,10 +910,10 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
     StageTimer tmv;
     if (const char* e = check_compressed(n, n, rowptr, col)) return fail(SMG_ERR_INVALID, "smg_precompute: %s", e);
     tmv.lap("precompute: input check");
-    if (h->n_levels < 2) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, src/mg_precompute.cpp:39)");
     const uint64_t key = precompute_key(h, n, rowptr, col, known, n_known);
     tmv.lap("precompute: pattern key");
-    if (h->precomputed && h->device >= 0 && key == h->pre_key && h->input_canonical && env_int("SMG_NO_FAST_PRECOMPUTE", 0) == 0) {
+    if (h->precomputed && h->device >= 0 && key == h->pre_key && h->input_canonical && h->n_levels > 1 && env_int("SMG_NO_FAST_PRECOMPUTE", 0) == 0) {
+        DeviceScope dsc(h->device);
         // same sparsity, same constraints, same prolongations: only the values changed
         int rc = SMG_OK;
         if (!h->recipes_built) rc = build_recipes(h);
@@ -883,6 +936,7 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
     if (rc != SMG_OK) return rc;
     rc = ensure_device(h);
     if (rc != SMG_OK) return rc;
+    DeviceScope dsc(h->device);
     rc = precompute_device(h);
     if (rc != SMG_OK) return rc;
     h->pre_key = key;
@@ -891,79 +945,38 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
 }
 
 // ------------------------------------------------------------------------------------------------ V-cycle
+static bool level_is_jacobi(const smg_hierarchy* h, int lv);
+
 static int ensure_work(smg_hierarchy* h, int k)
 {
-    if (k <= h->kcap) return SMG_OK;
-    drop_graphs(h);
     const int L = h->n_levels;
-    size_t maxblocks = 0;
-    for (int lv = 0; lv < L; lv++) {
+    if (k > h->kcap) {
+        drop_graphs(h);
+        size_t maxblocks = 0;
+        for (int lv = 0; lv < L; lv++) {
+            Level& Lv = h->lv[lv];
+            size_t rows = (lv == L - 1) ? (size_t)h->nc_pad : (size_t)Lv.n;
+            HIPCHK(Lv.b.alloc(rows * k));
+            HIPCHK(Lv.u.alloc(rows * k));
+            HIPCHK(hipMemsetAsync(Lv.b.p, 0, rows * k * sizeof(double), h->stream));
+            HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
+            Lv.t.release();
+            if (lv < L - 1 || L == 1) HIPCHK(Lv.r.alloc(rows * k));
+            if (lv < L - 1 || L == 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
+        }
+        HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
+        h->kcap = k;
+    }
+    // Jacobi-smoothed levels ping-pong between u and a second iterate
+    for (int lv = 0; lv < L - 1; lv++) {
         Level& Lv = h->lv[lv];
-        size_t rows = (lv == L - 1) ? (size_t)h->nc_pad : (size_t)Lv.n;
-        HIPCHK(Lv.b.alloc(rows * k));
-        HIPCHK(Lv.u.alloc(rows * k));
-        HIPCHK(hipMemsetAsync(Lv.b.p, 0, rows * k * sizeof(double), h->stream));
-        HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
-        if (lv < L - 1) HIPCHK(Lv.r.alloc(rows * k));
-        if (lv < L - 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
+        if (level_is_jacobi(h, lv) && Lv.t.n < (size_t)Lv.n * h->kcap) {
+            drop_graphs(h);
+            HIPCHK(Lv.t.alloc((size_t)Lv.n * h->kcap));
+            HIPCHK(hipMemsetAsync(Lv.t.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
+        }
     }
-    HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
-    h->kcap = k;
     return SMG_OK;
-}
-
-// `iters` forward Gauss-Seidel sweeps: one launch per colour (reference relax(), src/mg_VCycle.cpp:113-178)
-// first_done: the first colour of the first sweep was already produced by the restriction launch (FirstColour)
-static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
-{
-    Level& Lv = h->lv[lv];
-    ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
-    const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
-    const std::vector<int>& cs = G.color_slice_ptr;
-    for (int it = 0; it < iters; it++)
-        for (size_t c = (it == 0 && first_done) ? 1 : 0; c + 1 < cs.size(); c++)
-            HIPCHK(launch_sell(SELL_GS, G.view, cs[c], cs[c + 1], u, b, u, k, ctrl, nullptr, nullptr, h->stream));
-    return SMG_OK;
-}
-
-// reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
-static bool fuse_first_colour() { static const int on = env_int("SMG_FUSE_FIRST", 1); return on != 0; }
-
-static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
-{
-    const int L = h->n_levels;
-    Level& Lv = h->lv[lv];
-    if (lv == L - 1) {  // coarseSolve: u = u + solver.solve(B)  (:28-33, :199-200)
-        ProfGuard pg(h, "MG: coarse solve");
-        HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, ctrl, h->stream, h->d_sympart.p));
-        return SMG_OK;
-    }
-    Level& Lc = h->lv[lv + 1];
-    int rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, pre, ctrl, first_done);  // :36
-    if (rc) return rc;
-    {   // r = B - A u  (:40-42)
-        ProfGuard pg(h, "MG: residual");
-        HIPCHK(launch_sell(SELL_RESID, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, Lv.r.p, k, ctrl, nullptr, nullptr, h->stream));
-    }
-    // With uc = 0 the first colour launch of the coarse level's first pre-smoothing sweep computes (rc_i - 0) / a_ii: the
-    // restriction launch writes that into uc itself (bit for bit the same value) and the sweep starts at the second colour.
-    const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
-    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Gc.n_first > 0;
-    {   // rc = PT r  (:43-44, :80)
-        ProfGuard pg(h, "MG: restrict");
-        // rc = PT r (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
-        FirstColour fc;
-        if (fuse) { fc.diag_slot = Gc.first_diag_slot.p; fc.n_first = Gc.n_first; fc.val = Gc.view.val; }
-        HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, ctrl, nullptr, nullptr, h->stream, Lc.u.p,
-                           fuse ? &fc : nullptr));
-    }
-    rc = enqueue_vcycle(h, lv + 1, k, pre, post, ctrl, fuse);  // :48
-    if (rc) return rc;
-    {   // u = u + P uc  (:51-53, :91)
-        ProfGuard pg(h, "MG: prolong");
-        HIPCHK(launch_sell(SELL_ADD, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.u.p, k, ctrl, nullptr, nullptr, h->stream));
-    }
-    return enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, post, ctrl);  // :57
 }
 
 // ---- mixed precision: fp32 images of the operators and an fp32 V-cycle ------------------------------------------------
@@ -1006,58 +1019,178 @@ static int ensure_fp32(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.b32.p, 0, rows * k * sizeof(float), h->stream));
             HIPCHK(hipMemsetAsync(Lv.u32.p, 0, rows * k * sizeof(float), h->stream));
             if (lv < L - 1) HIPCHK(Lv.r32.alloc(rows * k));
+            Lv.t32.release();
         }
         h->kcap32 = k;
     }
+    for (int lv = 0; lv < L - 1; lv++) {
+        Level& Lv = h->lv[lv];
+        if (level_is_jacobi(h, lv) && Lv.t32.n < (size_t)Lv.n * h->kcap32) {
+            drop_graphs(h);
+            HIPCHK(Lv.t32.alloc((size_t)Lv.n * h->kcap32));
+            HIPCHK(hipMemsetAsync(Lv.t32.p, 0, (size_t)Lv.n * h->kcap32 * sizeof(float), h->stream));
+        }
+    }
     return SMG_OK;
 }
 
-static int enqueue_relax32(smg_hierarchy* h, int lv, const float* b, float* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
+// ---- the smoother of a level -------------------------------------------------------------------------------------------
+// SMG_SMOOTH_GS (default): the reference's relax().  SMG_SMOOTH_JACOBI / _HYBRID: damped Jacobi on all / on the small levels
+// (BASELINE.json north_star: "Gauss-Seidel/Jacobi smoothing"; one whole-matrix launch per sweep instead of one per colour).
+static bool level_is_jacobi(const smg_hierarchy* h, int lv)
+{
+    if (lv < 0 || lv >= h->n_levels - 1) return false;
+    if (h->smoother == SMG_SMOOTH_JACOBI) return true;
+    if (h->smoother == SMG_SMOOTH_HYBRID) return h->lv[lv].n <= h->jacobi_max_rows;
+    return false;
+}
+
+// one accessor set per arithmetic: fp64 (the reference's) and the fp32 images of the mixed-precision V-cycle
+template <typename T> struct Prec;
+template <> struct Prec<double> {
+    static double* b(Level& L) { return L.b.p; }
+    static double* u(Level& L) { return L.u.p; }
+    static double* r(Level& L) { return L.r.p; }
+    static double* t(Level& L) { return L.t.p; }
+    static const SellDev& A(Level& L) { return L.dA.view; }
+    static const SellDev& G(Level& L) { return L.gs_on_transpose ? L.dAT.view : L.dA.view; }   // what the smoother streams
+    static const SellDev& P(Level& L) { return L.dP.view; }
+    static const SellDev& PT(Level& L) { return L.dPT.view; }
+    static bool has_vals(const SellDev& V) { return V.val != nullptr; }
+    static hipError_t sell(SellMode m, const SellDev& V, int s0, int s1, const double* x, const double* bb, double* y, int k, const Ctrl* ctrl,
+                           hipStream_t st, double* zero_rows = nullptr, const FirstColour* first = nullptr, double omega = 1.0)
+    { return launch_sell(m, V, s0, s1, x, bb, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega); }
+    static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
+    { return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p); }
+};
+template <> struct Prec<float> {
+    static float* b(Level& L) { return L.b32.p; }
+    static float* u(Level& L) { return L.u32.p; }
+    static float* r(Level& L) { return L.r32.p; }
+    static float* t(Level& L) { return L.t32.p; }
+    static const SellDev& A(Level& L) { return L.dA32; }
+    static const SellDev& G(Level& L) { return L.gs_on_transpose ? L.dAT32 : L.dA32; }
+    static const SellDev& P(Level& L) { return L.dP32; }
+    static const SellDev& PT(Level& L) { return L.dPT32; }
+    static bool has_vals(const SellDev& V) { return V.valf != nullptr; }
+    static hipError_t sell(SellMode m, const SellDev& V, int s0, int s1, const float* x, const float* bb, float* y, int k, const Ctrl* ctrl,
+                           hipStream_t st, float* zero_rows = nullptr, const FirstColour* first = nullptr, double omega = 1.0)
+    { return launch_sell_f32(m, V, s0, s1, x, bb, y, k, ctrl, st, zero_rows, first, omega); }
+    static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
+    { return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p); }
+};
+
+// `iters` forward Gauss-Seidel sweeps in place: one launch per colour (reference relax(), src/mg_VCycle.cpp:113-178)
+// first_done: the first colour of the first sweep was already produced by the restriction launch (FirstColour)
+template <typename T>
+static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
 {
     Level& Lv = h->lv[lv];
-    ProfGuard pg(h, "MG: relaxation");
+    ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
     const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
-    const SellDev& V = Lv.gs_on_transpose ? Lv.dAT32 : Lv.dA32;
     const std::vector<int>& cs = G.color_slice_ptr;
     for (int it = 0; it < iters; it++)
         for (size_t c = (it == 0 && first_done) ? 1 : 0; c + 1 < cs.size(); c++)
-            HIPCHK(launch_sell_f32(SELL_GS, V, cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
+            HIPCHK(Prec<T>::sell(SELL_GS, Prec<T>::G(Lv), cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
     return SMG_OK;
 }
 
-// the same cycle as enqueue_vcycle, on the fp32 images and fp32 work vectors
-static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
+// `iters` damped-Jacobi sweeps, ping-pong between buf[0] and buf[1]: sweep s reads buf[*cur], writes the other, flips *cur.
+template <typename T>
+static int enqueue_jacobi(smg_hierarchy* h, int lv, const T* b, T* const buf[2], int* cur, int k, int iters, const Ctrl* ctrl)
+{
+    Level& Lv = h->lv[lv];
+    ProfGuard pg(h, "MG: relaxation");
+    const SellDev& G = Prec<T>::G(Lv);
+    for (int it = 0; it < iters; it++) {
+        HIPCHK(Prec<T>::sell(SELL_JACOBI, G, 0, G.n_slices, buf[*cur], b, buf[1 - *cur], k, ctrl, h->stream, nullptr, nullptr, h->omega));
+        *cur ^= 1;
+    }
+    return SMG_OK;
+}
+
+// reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
+static bool fuse_first_colour() { static const int on = env_int("SMG_FUSE_FIRST", 1); return on != 0; }
+
+// first_done: the restriction launch of the finer level already produced the first launch of this level's first pre-smoothing
+// sweep -- the first colour (Gauss-Seidel, in Lv.u) or the whole first sweep (Jacobi, in Lv.t).
+template <typename T>
+static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
 {
     const int L = h->n_levels;
     Level& Lv = h->lv[lv];
-    if (lv == L - 1) {
+    if (lv == L - 1) {  // coarseSolve: u = u + solver.solve(B)  (:28-33, :199-200)
         ProfGuard pg(h, "MG: coarse solve");
-        HIPCHK(launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, Lv.b32.p, Lv.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p));
+        HIPCHK(Prec<T>::coarse(h, Lv, k, ctrl));
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
-    int rc = enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, pre, ctrl, first_done);
+    const bool jac = level_is_jacobi(h, lv);
+    T* const buf[2] = {Prec<T>::u(Lv), Prec<T>::t(Lv)};   // Jacobi levels ping-pong; the level's result always ends in buf[0] = u
+    int cur = 0;
+    int rc;
+    if (jac) {
+        if (first_done) cur = 1;
+        rc = enqueue_jacobi<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, pre - (first_done ? 1 : 0), ctrl);            // :36
+    } else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first_done);                            // :36
     if (rc) return rc;
-    {
+    {   // r = B - A u  (:40-42)
         ProfGuard pg(h, "MG: residual");
-        HIPCHK(launch_sell_f32(SELL_RESID, Lv.dA32, 0, Lv.dA32.n_slices, Lv.u32.p, Lv.b32.p, Lv.r32.p, k, ctrl, h->stream));
+        HIPCHK(Prec<T>::sell(SELL_RESID, Prec<T>::A(Lv), 0, Prec<T>::A(Lv).n_slices, buf[cur], Prec<T>::b(Lv), Prec<T>::r(Lv), k, ctrl, h->stream));
     }
+    // With uc = 0 the first launch of the coarse level's first pre-smoothing sweep computes (rc_i - 0) / a_ii for the rows it covers
+    // (the first colour / with Jacobi all rows, damped): the restriction launch writes that itself, bit for bit the same value, and
+    // the sweep starts one launch later.
     const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
-    const SellDev& Vc = Lc.gs_on_transpose ? Lc.dAT32 : Lc.dA32;
-    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Gc.n_first > 0 && Vc.valf;
-    {
+    const bool jac_c = level_is_jacobi(h, lv + 1);
+    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
         FirstColour fc;
-        if (fuse) { fc.diag_slot = Gc.first_diag_slot.p; fc.n_first = Gc.n_first; fc.valf = Vc.valf; }
-        HIPCHK(launch_sell_f32(SELL_AX, Lc.dPT32, 0, Lc.dPT32.n_slices, Lv.r32.p, nullptr, Lc.b32.p, k, ctrl, h->stream, Lc.u32.p, fuse ? &fc : nullptr));
+        if (fuse) {
+            fc.diag_slot = Gc.diag_slot.p; fc.n_first = jac_c ? Gc.n_all : Gc.n_first;
+            fc.val = Prec<T>::G(Lc).val; fc.valf = Prec<T>::G(Lc).valf;
+            fc.jacobi = jac_c ? 1 : 0; fc.omega = h->omega;
+        }
+        // Jacobi + fuse: the first sweep's output buffer (t) receives the sweep, u = 0 is never read
+        T* init = (fuse && jac_c) ? Prec<T>::t(Lc) : Prec<T>::u(Lc);
+        HIPCHK(Prec<T>::sell(SELL_AX, Prec<T>::PT(Lc), 0, Prec<T>::PT(Lc).n_slices, Prec<T>::r(Lv), nullptr, Prec<T>::b(Lc), k, ctrl, h->stream, init,
+                             fuse ? &fc : nullptr));
     }
-    rc = enqueue_vcycle32(h, lv + 1, k, pre, post, ctrl, fuse);
+    rc = enqueue_vcycle_t<T>(h, lv + 1, k, pre, post, ctrl, fuse);  // :48
     if (rc) return rc;
-    {
+    {   // u = u + P uc  (:51-53, :91).  A Jacobi level with an odd number of post-smoothing sweeps to go adds out of place, so that
+        // the last sweep lands in u.
         ProfGuard pg(h, "MG: prolong");
-        HIPCHK(launch_sell_f32(SELL_ADD, Lc.dP32, 0, Lc.dP32.n_slices, Lc.u32.p, nullptr, Lv.u32.p, k, ctrl, h->stream));
+        int dst = cur;
+        if (jac && ((cur + post) & 1)) dst = 1 - cur;
+        HIPCHK(Prec<T>::sell(SELL_ADD, Prec<T>::P(Lc), 0, Prec<T>::P(Lc).n_slices, Prec<T>::u(Lc), buf[cur], buf[dst], k, ctrl, h->stream));
+        cur = dst;
     }
-    return enqueue_relax32(h, lv, Lv.b32.p, Lv.u32.p, k, post, ctrl);
+    if (jac) return enqueue_jacobi<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
+    return enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, post, ctrl);                    // :57
+}
+
+static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+{
+    return enqueue_vcycle_t<double>(h, lv, k, pre, post, ctrl);
+}
+static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+{
+    return enqueue_vcycle_t<float>(h, lv, k, pre, post, ctrl);
+}
+
+// relax() on caller-provided device vectors (pieces, raw interface): the result always ends in u
+static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl)
+{
+    if (!level_is_jacobi(h, lv)) return enqueue_gs<double>(h, lv, b, u, k, iters, ctrl);
+    Level& Lv = h->lv[lv];
+    double* const buf[2] = {u, Lv.t.p};
+    int cur = 0;
+    int rc = enqueue_jacobi<double>(h, lv, b, buf, &cur, k, iters, ctrl);
+    if (rc) return rc;
+    if (cur == 1) HIPCHK(hipMemcpyAsync(u, Lv.t.p, (size_t)Lv.n * k * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return SMG_OK;
 }
 
 // sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
@@ -1066,7 +1199,6 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
     Level& L0 = h->lv[0];
     ProfGuard pg(h, "MG: outer residual");
     int nb = 0;
-    if (h->n_levels == 1) return fail(SMG_ERR_INVALID, "single-level hierarchies are not supported (reference TODO, mg_precompute.cpp:39)");
     if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
         HIPCHK(launch_sell(SELL_RESID_BOTH, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     else
@@ -1131,7 +1263,8 @@ static int capture_split_graphs(smg_hierarchy* h, double* buf)
 
 static int ensure_graphs(smg_hierarchy* h)
 {
-    if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision) return SMG_OK;
+    if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision &&
+        h->g_smoother == h->smoother && h->g_omega == h->omega && h->g_jmax == h->jacobi_max_rows) return SMG_OK;
     drop_graphs(h);
     const int k = h->k;
     int rc = capture_graph(h, &h->g_iter, [&]() {
@@ -1143,10 +1276,12 @@ static int ensure_graphs(smg_hierarchy* h)
     rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
     if (rc) return rc;
     h->g_k = k; h->g_pre = h->pre; h->g_post = h->post; h->g_prec = h->precision;
+    h->g_smoother = h->smoother; h->g_omega = h->omega; h->g_jmax = h->jacobi_max_rows;
     return SMG_OK;
 }
 
-static bool graphs_usable(const smg_hierarchy* h) { return h->use_graph && !h->prof_on; }
+// hipStreamBeginCapture is not allowed on the legacy default stream (smg_hierarchy_set_stream(h, NULL)): eager launches there
+static bool graphs_usable(const smg_hierarchy* h) { return h->use_graph && !h->prof_on && h->stream != nullptr; }
 
 // one full outer iteration, single-GPU form
 static int enqueue_outer_iteration(smg_hierarchy* h)
@@ -1184,12 +1319,14 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
     if (opts) o = *opts;
     const int n = h->n_full;
     if (!RHS || !z0 || k < 1 || ld_rhs < n || ld_z0 < n) return fail(SMG_ERR_INVALID, "smg_solve: bad RHS/z0/k/ld");
-    if (o.max_iter < 0 || o.max_iter > SMG_MAX_HIS) return fail(SMG_ERR_INVALID, "max_iter must be in [0, %d]", SMG_MAX_HIS);
+    if (o.max_iter < 0) return fail(SMG_ERR_INVALID, "max_iter must be >= 0");
     if (h->has_known && (!known_val || ld_kv < (int)h->known.size())) return fail(SMG_ERR_INVALID, "known_val missing or ld_kv too small");
     h->tol = o.tol; h->max_iter = o.max_iter; h->pre = o.pre; h->post = o.post; h->verbosity = o.verbosity;
     h->check_every = std::max(1, o.check_every); h->use_graph = o.use_graph;
     if (o.precision != 0 && o.precision != 1) return fail(SMG_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
     h->precision = o.precision;
+    if ((rc = smg_hierarchy_set_smoother(h, o.smoother, o.omega, o.jacobi_max_rows))) return rc;
+    DeviceScope dsc(h->device);
     rc = ensure_work(h, k);
     if (rc) return rc;
     if (h->precision == 1 && (rc = ensure_fp32(h, k))) return rc;
@@ -1229,10 +1366,14 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
     } else {
         HIPCHK(launch_gather_in(L0.b.p, dR, h->d_map0.p, L0.n, k, ldR, h->stream));
     }
+    // the residual history lives in HBM, sized from max_iter (the reference's r_his grows with the loop, .cpp:112)
+    HIPCHK(h->d_rhis.ensure((size_t)std::max(h->max_iter, 1)));
     Ctrl zero;
     std::memset(&zero, 0, sizeof(zero));
     zero.tol = h->tol;
-    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, offsetof(Ctrl, r_his), hipMemcpyHostToDevice, h->stream));
+    zero.r_his = h->d_rhis.p;
+    zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
+    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // `zero` lives on this stack frame
     h->iters_enqueued = 0;
     h->in_solve = true;
@@ -1242,6 +1383,7 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
 extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_residual: no solve in progress");
+    DeviceScope dsc(h->device);
     double* buf = d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq;
     if (graphs_usable(h)) {
         int rc = ensure_graphs(h);
@@ -1258,6 +1400,7 @@ extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
 extern "C" int smg_solve_iter_cycle(smg_hierarchy* h, const double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle: no solve in progress");
+    DeviceScope dsc(h->device);
     double* buf = d_sumsq ? const_cast<double*>(d_sumsq) : &h->d_ctrl.p->sumsq;
     if (graphs_usable(h)) {
         int rc = ensure_graphs(h);
@@ -1284,6 +1427,7 @@ static int enqueue_cycle_speculative(smg_hierarchy* h)
 extern "C" int smg_solve_iter_cycle_speculative(smg_hierarchy* h)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_cycle_speculative: no solve in progress");
+    DeviceScope dsc(h->device);
     HIPCHK(h->d_zsave.ensure((size_t)h->lv[0].n * h->k));
     if (graphs_usable(h)) {
         int rc = ensure_graphs(h);
@@ -1301,6 +1445,7 @@ extern "C" int smg_solve_iter_cycle_speculative(smg_hierarchy* h)
 extern "C" int smg_solve_iter_commit(smg_hierarchy* h, const double* d_sumsq)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_iter_commit: no solve in progress");
+    DeviceScope dsc(h->device);
     Level& L0 = h->lv[0];
     HIPCHK(launch_decide_spec(h->d_ctrl.p, d_sumsq ? d_sumsq : &h->d_ctrl.p->sumsq, h->stream));
     HIPCHK(launch_restore_if_just_done(L0.u.p, h->d_zsave.p, (size_t)L0.n * h->k, h->d_ctrl.p, h->stream));
@@ -1310,6 +1455,7 @@ extern "C" int smg_solve_iter_commit(smg_hierarchy* h, const double* d_sumsq)
 extern "C" int smg_solve_poll(smg_hierarchy* h, int* done, int* n_his)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_poll: no solve in progress");
+    DeviceScope dsc(h->device);
     int hdr[4];
     HIPCHK(hipMemcpyAsync(hdr, h->d_ctrl.p, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1321,6 +1467,7 @@ extern "C" int smg_solve_poll(smg_hierarchy* h, int* done, int* n_his)
 extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace, double* r_his, int* n_his, int* converged)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_end: no solve in progress");
+    DeviceScope dsc(h->device);
     const int n = h->n_full, k = h->k;
     if (!z || ld_z < n) return fail(SMG_ERR_INVALID, "smg_solve_end: bad z / ld_z");
     Level& L0 = h->lv[0];
@@ -1339,16 +1486,19 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     static thread_local Ctrl hc;
     HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    const int cnt = std::max(0, std::min(hc.n_his, hc.his_cap));
+    static thread_local std::vector<double> his;
+    his.resize((size_t)std::max(cnt, 1));
+    if (cnt > 0) HIPCHK(hipMemcpy(his.data(), h->d_rhis.p, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
     h->in_solve = false;
     prof_collect(h);
-    const int cnt = std::min(hc.n_his, SMG_MAX_HIS);
-    if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = hc.r_his[i];
+    if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = his[i];
     if (n_his) *n_his = cnt;
-    const double last = cnt > 0 ? hc.r_his[cnt - 1] : HUGE_VAL;
+    const double last = cnt > 0 ? his[cnt - 1] : HUGE_VAL;
     if (converged) *converged = (last > h->tol) ? 0 : 1;  // :131-134 / :357-360
     if (h->verbosity > 0) {
-        for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, hc.r_his[i]);  // :111
-        if (cnt) std::printf("residual norm: %g\n", hc.r_his[cnt - 1]);                                    // :127
+        for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, his[i]);  // :111
+        if (cnt) std::printf("residual norm: %g\n", his[cnt - 1]);                                    // :127
     }
     if (hc.status != 0) return fail(SMG_ERR_NONFINITE, "non-finite residual at iteration %d", cnt - 1);
     return SMG_OK;
@@ -1383,6 +1533,7 @@ extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const 
 extern "C" int smg_raw_outer_iteration(smg_hierarchy* h, int n_iter)
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_raw_outer_iteration: call smg_solve_begin first");
+    DeviceScope dsc(h->device);
     for (int i = 0; i < n_iter; i++) {
         int rc = enqueue_outer_iteration(h);
         if (rc) return rc;
@@ -1396,6 +1547,7 @@ extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int po
 {
     int rc = piece_prolog(h, lv, k, "smg_bench_vcycle", false);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     if (reps < 1 || !us_per_cycle) return fail(SMG_ERR_INVALID, "smg_bench_vcycle: bad arguments");
     hipGraphExec_t g = nullptr;
     rc = capture_graph(h, &g, [&]() { return enqueue_vcycle(h, lv, k, pre, post, nullptr); });
@@ -1419,6 +1571,7 @@ extern "C" int smg_bench_relax(smg_hierarchy* h, int lv, int k, int sweeps, int 
 {
     int rc = piece_prolog(h, lv, k, "smg_bench_relax", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     if (reps < 1 || sweeps < 1 || !us_per_call) return fail(SMG_ERR_INVALID, "smg_bench_relax: bad arguments");
     Level& Lv = h->lv[lv];
     hipGraphExec_t g = nullptr;
@@ -1442,6 +1595,7 @@ extern "C" int smg_bench_relax(smg_hierarchy* h, int lv, int k, int sweeps, int 
 extern "C" int smg_synchronize(smg_hierarchy* h)
 {
     if (!h || h->device < 0) return fail(SMG_ERR_INVALID, "smg_synchronize: no device");
+    DeviceScope dsc(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
     return SMG_OK;
 }
@@ -1482,6 +1636,7 @@ static int piece_prolog(smg_hierarchy* h, int lv, int k, const char* who, bool n
     if (h->in_solve) return fail(SMG_ERR_INVALID, "%s: a split-phase solve is in progress", who);
     if (lv < 0 || lv >= h->n_levels || (need_coarser && lv >= h->n_levels - 1) || k < 1)
         return fail(SMG_ERR_INVALID, "%s: bad level %d or k %d", who, lv, k);
+    DeviceScope dsc(h->device);
     return ensure_work(h, k);
 }
 
@@ -1489,6 +1644,7 @@ extern "C" int smg_apply_A(smg_hierarchy* h, int lv, const double* u, int k, dou
 {
     int rc = piece_prolog(h, lv, k, "smg_apply_A", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
     HIPCHK(launch_sell(SELL_AX, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
@@ -1499,6 +1655,7 @@ extern "C" int smg_restrict(smg_hierarchy* h, int lv, const double* x, int k, do
 {
     int rc = piece_prolog(h, lv, k, "smg_restrict", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
     if ((rc = put_block(h, lv, x, k, Lv.r.p))) return rc;
     HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, nullptr, nullptr, nullptr, h->stream));
@@ -1509,6 +1666,7 @@ extern "C" int smg_prolong(smg_hierarchy* h, int lv, const double* x, int k, dou
 {
     int rc = piece_prolog(h, lv, k, "smg_prolong", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
     if ((rc = put_block(h, lv + 1, x, k, Lc.u.p))) return rc;
     HIPCHK(launch_sell(SELL_AX, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
@@ -1519,6 +1677,7 @@ extern "C" int smg_relax(smg_hierarchy* h, int lv, const double* B, int k, int i
 {
     int rc = piece_prolog(h, lv, k, "smg_relax", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
@@ -1531,6 +1690,7 @@ extern "C" int smg_coarse_solve(smg_hierarchy* h, const double* B, int k, double
     const int lv = h ? h->n_levels - 1 : 0;
     int rc = piece_prolog(h, lv, k, "smg_coarse_solve", false);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
@@ -1542,6 +1702,7 @@ extern "C" int smg_vcycle(smg_hierarchy* h, const double* B, int pre, int post, 
 {
     int rc = piece_prolog(h, lv, k, "smg_vcycle", false);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
@@ -1553,13 +1714,15 @@ extern "C" int smg_residual_norm(smg_hierarchy* h, int lv, const double* B, cons
 {
     int rc = piece_prolog(h, lv, k, "smg_residual_norm", true);
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
     int nb = 0;
     Ctrl zero;
     std::memset(&zero, 0, sizeof(zero));
-    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, offsetof(Ctrl, r_his), hipMemcpyHostToDevice, h->stream));
+    zero.r_his = h->d_rhis.p; zero.his_cap = (int)h->d_rhis.n;
+    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     HIPCHK(launch_sell(SELL_RESID_SS, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, nullptr, k, nullptr, h->d_partials.p, &nb, h->stream));
     HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
     double ss = 0.0;
@@ -1574,6 +1737,7 @@ extern "C" int smg_raw_spmv(smg_hierarchy* h, int lv, int mode, const double* x,
 {
     int rc = check_ready(h, "smg_raw_spmv");
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1 || (mode != SELL_AX && mode != SELL_RESID && mode != SELL_ADD))
         return fail(SMG_ERR_INVALID, "smg_raw_spmv: bad level/mode");
     Level& Lv = h->lv[lv];
@@ -1585,6 +1749,7 @@ extern "C" int smg_raw_spmv_f32(smg_hierarchy* h, int lv, const float* x, float*
 {
     int rc = check_ready(h, "smg_raw_spmv_f32");
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_spmv_f32: bad level");
     if ((rc = ensure_work(h, k))) return rc;
     if ((rc = ensure_fp32(h, k))) return rc;
@@ -1597,6 +1762,7 @@ extern "C" int smg_raw_relax(smg_hierarchy* h, int lv, const double* b, double* 
 {
     int rc = check_ready(h, "smg_raw_relax");
     if (rc) return rc;
+    DeviceScope dsc(h->device);
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_relax: bad level");
     return enqueue_relax(h, lv, b, u, k, iters, nullptr);
 }

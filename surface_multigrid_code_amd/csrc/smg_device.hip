@@ -47,7 +47,9 @@ static const int* never_done()
 
 
 // what a restriction launch leaves in the coarse level's u (see FirstColour in smg_device.hpp)
-template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; };
+// jacobi != 0: the coarse level is smoothed by damped Jacobi -- ALL its rows (n_first = n_rows) get what the first Jacobi sweep from
+// u = 0 leaves there, 0 + omega * (rc_i / a_ii - 0).  omega doubles as the damping factor of a SELL_JACOBI launch.
+template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; int jacobi; T omega; };
 
 // One wavefront per slice of 64 rows; lane l owns row row0 + l.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         // reads below from scalar into vector loads.)
         {
             size_t keep = (size_t)x ^ (size_t)A.slice_row ^ (size_t)A.slice_w ^ (size_t)b ^ (size_t)y ^ (size_t)done ^ (size_t)ld;
-            if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first;
+            if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first ^ (size_t)z.jacobi;
             asm("" : "+s"(keep));
             if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
         }
@@ -118,16 +120,16 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         const int rowb = row0 + lane;
         T acc[KB];
         T diag = (T)1;
-        T bv[KB];  // b (or y for SELL_ADD): requested now, consumed after the panel loop
+        T xi[KB];  // SELL_JACOBI: the row's own old value (it travels with the gathers: the diagonal entry's column)
+        T bv[KB];  // b (or the prolongation's input iterate for SELL_ADD): requested now, consumed after the panel loop
         const bool live = lane < nrow;
         T zd = (T)1;   // restriction with a fused first colour: the coarse diagonal, requested now
         if (MODE == SELL_AX && live && rowb < z.n_first) zd = z.gs_val[z.diag_slot[rowb]];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
-            acc[q] = (T)0;
+            acc[q] = (T)0; xi[q] = (T)0;
             if (MODE == SELL_AX) bv[q] = (T)0;
-            else if (MODE == SELL_ADD) bv[q] = live ? y[(size_t)rowb * ld + q] : (T)0;
-            else bv[q] = live ? b[(size_t)rowb * ld + q] : (T)0;
+            else bv[q] = live ? b[(size_t)rowb * ld + q] : (T)0;   // SELL_ADD: b is the iterate the correction is added to (== y in place)
         }
         // one batch of U panel columns: gather x for all of them, then accumulate in ascending column order
         auto consume = [&](const int (&c)[U], const T (&v)[U]) {
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                 if (c[t] >= 0) {
                     if (MODE == SELL_GS && c[t] == rowb) {
                         diag = v[t];
+                    } else if (MODE == SELL_JACOBI && c[t] == rowb) {
+                        diag = v[t];
+#pragma unroll
+                        for (int q = 0; q < KB; q++) xi[q] = xv[t][q];
                     } else {
 #pragma unroll
                         for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
@@ -185,10 +191,17 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
             const size_t o = (size_t)rowb * ld;
 #pragma unroll
             for (int q = 0; q < KB; q++) {
-                if (MODE == SELL_AX) { y[o + q] = acc[q]; if (z.u) z.u[o + q] = rowb < z.n_first ? acc[q] / zd : (T)0; }
+                if (MODE == SELL_AX) {
+                    y[o + q] = acc[q];
+                    if (z.u) {
+                        const T t = acc[q] / zd;
+                        z.u[o + q] = rowb < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+                    }
+                }
                 else if (MODE == SELL_RESID) y[o + q] = bv[q] - acc[q];
                 else if (MODE == SELL_ADD) y[o + q] = bv[q] + acc[q];
                 else if (MODE == SELL_GS) y[o + q] = (bv[q] - acc[q]) / diag;
+                else if (MODE == SELL_JACOBI) { const T t = (bv[q] - acc[q]) / diag; y[o + q] = xi[q] + z.omega * (t - xi[q]); }
                 else { const double t = (double)(bv[q] - acc[q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[q] - acc[q]; }
             }
         }
@@ -242,17 +255,16 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int w = A.slice_w[s];
         int rl[R];
-        T acc[R], diag[R], bv[R], zd[R];
+        T acc[R], diag[R], bv[R], zd[R], xi[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             rl[r] = sub * RW + r * G + g;   // row inside the slice
-            acc[r] = (T)0; diag[r] = (T)1;
+            acc[r] = (T)0; diag[r] = (T)1; xi[r] = (T)0;
             const bool live = rl[r] < nrow;
             zd[r] = (T)1;
             if (MODE == SELL_AX && live && row0 + rl[r] < z.n_first) zd[r] = z.gs_val[z.diag_slot[row0 + rl[r]]];
             const size_t o = (size_t)(row0 + rl[r]) * ld + c;
             if (MODE == SELL_AX) bv[r] = (T)0;
-            else if (MODE == SELL_ADD) bv[r] = live ? y[o] : (T)0;
             else bv[r] = live ? b[o] : (T)0;
         }
         const int* cp = A.col + (size_t)off0 * 64;
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                 for (int r = 0; r < R; r++) {
                     if (cc[t][r] >= 0) {
                         if (MODE == SELL_GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
+                        else if (MODE == SELL_JACOBI && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
                         else acc[r] += vv[t][r] * xv[t][r];
                     }
                 }
@@ -290,10 +303,17 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         for (int r = 0; r < R; r++) {
             if (rl[r] < nrow && !stop) {
                 const size_t o = (size_t)(row0 + rl[r]) * ld + c;
-                if (MODE == SELL_AX) { y[o] = acc[r]; if (z.u) z.u[o] = row0 + rl[r] < z.n_first ? acc[r] / zd[r] : (T)0; }
+                if (MODE == SELL_AX) {
+                    y[o] = acc[r];
+                    if (z.u) {
+                        const T t = acc[r] / zd[r];
+                        z.u[o] = row0 + rl[r] < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+                    }
+                }
                 else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
                 else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
                 else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
+                else if (MODE == SELL_JACOBI) { const T t = (bv[r] - acc[r]) / diag[r]; y[o] = xi[r] + z.omega * (t - xi[r]); }
                 else { const double t = (double)(bv[r] - acc[r]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o] = bv[r] - acc[r]; }
             }
         }
@@ -309,13 +329,15 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
 }
 
 template <typename T> static const T* host_vals(const SellDev& A);
-template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, const FirstColour* first)
+template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, const FirstColour* first, double omega)
 {
-    CoarseInit<T> z{zero_rows ? zero_rows + c0 : nullptr, nullptr, nullptr, 0};
+    CoarseInit<T> z{zero_rows ? zero_rows + c0 : nullptr, nullptr, nullptr, 0, 0, (T)omega};
     if (zero_rows && first && first->n_first > 0) {
         if constexpr (std::is_same<T, double>::value) z.gs_val = first->val; else z.gs_val = first->valf;
         z.diag_slot = first->diag_slot;
         z.n_first = (z.gs_val && z.diag_slot) ? first->n_first : 0;
+        z.jacobi = first->jacobi;
+        if (first->jacobi) z.omega = (T)first->omega;
     }
     return z;
 }
@@ -347,9 +369,11 @@ int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb();
 
 template <int MODE, typename T>
 static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, const T* x, const T* b, T* y,
-                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows, const FirstColour* first)
+                                   int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st, T* zero_rows, const FirstColour* first,
+                                   double omega)
 {
     int s_end = s_end_in;
+    if (MODE == SELL_ADD && !b) b = y;   // in place: the iterate the correction is added to is the output
     const int ns = s_end - s_begin;
     const int nb = sell_blocks(ns);
     const int* done = ctrl ? &ctrl->done : never_done();
@@ -369,7 +393,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             const T* bb = b ? b + c0 : nullptr;
             T* yy = y ? y + c0 : nullptr;
             double* pp = partials ? partials + poff : nullptr;
-            const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first);
+            const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first, omega);
             int wnb = 0;
             switch (kw) {
                 case 64: launch_wide_one<MODE, 64, T>(A, s_begin, s_end, use_order, xx, bb, yy, k, done, pp, zz, st, &wnb); break;
@@ -391,7 +415,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         const T* bb = b ? b + c0 : nullptr;
         T* yy = y ? y + c0 : nullptr;
         double* pp = partials ? partials + poff : nullptr;
-        const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first);
+        const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first, omega);
         poff += (size_t)nb;
         switch (kb) {
             case 1: {
@@ -426,18 +450,19 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
 template <typename T>
 static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, int s_end, const T* x, const T* b,
                                   T* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                                  T* zero_rows, const FirstColour* first)
+                                  T* zero_rows, const FirstColour* first, double omega)
 {
     switch (mode) {
-        case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
-        case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+        case SELL_JACOBI: return launch_sell_mode<SELL_JACOBI, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+        case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+        case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
         case SELL_RESID_SS:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_SS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
             else return hipErrorInvalidValue;
-        case SELL_ADD: return launch_sell_mode<SELL_ADD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
-        case SELL_GS: return launch_sell_mode<SELL_GS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+        case SELL_ADD: return launch_sell_mode<SELL_ADD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+        case SELL_GS: return launch_sell_mode<SELL_GS, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
         case SELL_RESID_BOTH:
-            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
             else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
@@ -445,17 +470,17 @@ static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, 
 
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                       double* zero_rows, const FirstColour* first)
+                       double* zero_rows, const FirstColour* first, double omega)
 {
-    return launch_sell_any<double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first);
+    return launch_sell_any<double>(mode, A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
 }
 
 // fp32 twin for the mixed-precision V-cycle (A.valf must be set; the norm modes are fp64-only)
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
-                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows, const FirstColour* first)
+                           float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows, const FirstColour* first, double omega)
 {
     if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
-    return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows, first);
+    return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega);
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control
@@ -480,7 +505,7 @@ __device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
     const double tol = ctrl->tol;
     const double r = sqrt(sumsq);
     const int i = ctrl->n_his;
-    if (i < SMG_MAX_HIS) ctrl->r_his[i] = r;
+    if (i < ctrl->his_cap) ctrl->r_his[i] = r;
     ctrl->n_his = i + 1;
     if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
     else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
@@ -492,8 +517,9 @@ __global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partia
     // a kernel that is nothing but latency: everything it will need -- the partial sums, the flag, the tolerance, the history
     // length -- is requested up front, in one round trip (same summation order as before)
     __shared__ double red[256];
-    const int done = ctrl->done, n_his = ctrl->n_his;
+    const int done = ctrl->done, n_his = ctrl->n_his, his_cap = ctrl->his_cap;
     const double tol = ctrl->tol;
+    double* const r_his = ctrl->r_his;
     double s = 0.0;
 #pragma unroll 8
     for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partia
     if (threadIdx.x == 0) {
         const double sumsq = red[0], r = sqrt(sumsq);
         ctrl->sumsq = sumsq;
-        if (n_his < SMG_MAX_HIS) ctrl->r_his[n_his] = r;
+        if (n_his < his_cap) r_his[n_his] = r;
         ctrl->n_his = n_his + 1;
         if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
         else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116

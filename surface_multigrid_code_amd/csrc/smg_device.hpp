@@ -10,8 +10,6 @@
 
 namespace smg {
 
-constexpr int SMG_MAX_HIS = 1024;  // capacity of the device-side residual history (>= max_iter)
-
 // Solve-loop control block, resident in HBM.  The outer loop of min_quad_with_fixed_mg_solve
 // (reference src/min_quad_with_fixed_mg.cpp:108-125) is enqueued without host round trips: the decide
 // kernel appends to r_his and raises `done`; every later kernel of the stream starts with `if (done) return`.
@@ -22,7 +20,9 @@ struct Ctrl {
     int just_done; // set by the speculative decide when this very decision ended the loop
     double sumsq;  // sum of squares of the last residual (all-reduced across ranks when column-sharded)
     double tol;    // absolute tolerance of the break test (kept here so captured graphs do not bake it in)
-    double r_his[SMG_MAX_HIS];
+    double* r_his; // residual history in HBM, his_cap entries (sized from max_iter at smg_solve_begin; read through this
+    int his_cap;   // pointer at run time, so captured graphs survive a re-allocation)
+    int pad_;
 };
 
 struct SellDev {
@@ -46,8 +46,11 @@ enum SellMode {
     SELL_ADD = 3,       // y = y + A x                   (mg_VCycle.cpp:51-53  u = u + P uc)
     SELL_GS = 4,        // y_i = (b_i - sum_{j != i} A_ij y_j) / A_ii on the given slice range (one colour)
     SELL_RESID_BOTH = 5,  // y = b - A x AND the partial sums of its squares (outer loop of the mixed-precision mode)
+    SELL_JACOBI = 6,    // y_i = x_i + omega * ((b_i - sum_{j != i} A_ij x_j) / A_ii - x_i): one damped-Jacobi sweep from x into y (x != y),
+                        // whole matrix in one launch (the "Jacobi" of BASELINE.json's north_star; same slot as SELL_GS, mg_VCycle.cpp:113-178)
 };
 
+// SELL_ADD: y = b + A x, where b is the iterate the correction is added to (b == nullptr: in place, b = y).
 // y/x/b: internal layout, ld = number of columns k.  Slices [s_begin, s_end).  `ctrl` may be null (no
 // early-exit test).  For SELL_RESID_SS, `partials` receives one double per launched block; the number of
 // blocks is returned through *n_blocks.
@@ -61,13 +64,15 @@ struct FirstColour {
     int n_first = 0;                  // rows of the first colour (they lead the colour-major numbering)
     const double* val = nullptr;      // the sweep's SELL values (A or A^T) ...
     const float* valf = nullptr;      // ... and their fp32 image
+    int jacobi = 0;                   // != 0: the coarse level is smoothed by damped Jacobi: n_first = all its rows, and they receive the
+    double omega = 1.0;               //        first sweep from u = 0:  0 + omega * (y_i / a_ii - 0)
 };
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
-                       double* zero_rows = nullptr, const FirstColour* first = nullptr);
+                       double* zero_rows = nullptr, const FirstColour* first = nullptr, double omega = 1.0);
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
                            float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows = nullptr,
-                           const FirstColour* first = nullptr);
+                           const FirstColour* first = nullptr, double omega = 1.0);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

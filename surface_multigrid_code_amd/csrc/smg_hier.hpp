@@ -46,8 +46,9 @@ struct SellBuf {  // device image of one SELL matrix
     DevBuf<double> val;
     SellDev view;
     std::vector<int> color_slice_ptr;
-    DevBuf<int> first_diag_slot;             // coloured square matrices: slot of a_ii for the rows of the first colour ...
-    int n_first = 0;                         // ... and their number (0: not available), see FirstColour in smg_device.hpp
+    DevBuf<int> diag_slot;                   // coloured square matrices: slot of a_ii in the value array, per row ...
+    int n_first = 0;                         // ... rows of the first colour (they lead the numbering; 0: not available) and
+    int n_all = 0;                           // ... all rows (0: some row has no stored diagonal), see FirstColour in smg_device.hpp
     long stored = 0, padded = 0, used = 0;   // CSR entries / allocated slots / slots the kernels read
     hipError_t upload(const Sell& S);
 };
@@ -83,6 +84,8 @@ struct Level {
     DevBuf<float> b32, u32, r32;
     // ---- work vectors, internal layout n x kcap ----
     DevBuf<double> b, u, r;
+    DevBuf<double> t;       // second iterate of a Jacobi-smoothed level (the sweeps ping-pong between u and t); allocated on demand
+    DevBuf<float> t32;
     int n = 0;
 };
 
@@ -127,6 +130,7 @@ struct smg_hierarchy {
     hipStream_t stream = nullptr;
     bool own_stream = false, user_stream = false;
     smg::DevBuf<smg::Ctrl> d_ctrl;
+    smg::DevBuf<double> d_rhis;     // residual history (Ctrl::r_his points here), at least max_iter entries
     smg::DevBuf<double> d_partials;
     int kcap = 0;
     // ---- solve state ----
@@ -134,6 +138,10 @@ struct smg_hierarchy {
     int k = 0;
     double tol = 1e-3;
     int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1, precision = 0;
+    // ---- smoother selection (smg_hierarchy_set_smoother / smg_solve_opts): 0 GS everywhere (reference), 1 Jacobi, 2 hybrid ----
+    int smoother = 0;
+    double omega = 0.8;
+    int jacobi_max_rows = 100000;
     int iters_enqueued = 0;
     smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
     smg::DevBuf<double> d_zsave;     // iterate saved by the speculative cycle
@@ -144,6 +152,8 @@ struct smg_hierarchy {
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
     double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
     int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
+    int g_smoother = 0, g_jmax = 0;   // the smoother selection the cached graphs were captured with
+    double g_omega = 0.0;
     // ---- profc mirror ----
     bool prof_on = false;
     std::vector<smg::ProfScope> scopes;

@@ -288,8 +288,10 @@ def test_error_paths(smg, oracle_mod):
     with pytest.raises(smg.SmgError):            # solve before precompute
         mg.solve(p["RHS"], p["z0"])
     mg.precompute(p["A"])
-    with pytest.raises(smg.SmgError):            # max_iter beyond the device-side history capacity
-        mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(max_iter=5000))
+    with pytest.raises(smg.SmgError):            # negative max_iter (any non-negative count is legal, tests/test_gpu_smoothers.py)
+        mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(max_iter=-1))
+    with pytest.raises(smg.SmgError):            # unknown smoother / damping out of range
+        mg.set_smoother(2, 2.5)
     with pytest.raises(smg.SmgError):            # matrix size does not match P_1
         mg.precompute(p["A"][:100, :100].tocsr())
     mg.precompute(p["A"])

@@ -124,3 +124,42 @@ def test_all_core_mode_of_the_oracle_is_the_same_arithmetic(oracle_mod):
     back = np.empty_like(seq[1]); back[perms[0]] = seq[1]
     ref = o.solve(p["RHS"], p["z0"], tol=1e-10, max_iter=30)
     assert np.linalg.norm(back - ref[1]) <= 1e-7 * np.linalg.norm(ref[1])
+
+
+def test_oracle_jacobi_matches_a_numpy_restatement(oracle_mod):
+    """orc_set_smoother(JACOBI): u <- u + omega ((b - (A - D) u) / d - u), all rows from the old iterate -- against dense-free numpy
+    (summation order differs: 1e-14), and a hybrid V-cycle still contracts."""
+    from problems import subdiv_problem
+    import scipy.sparse as sp
+    p = subdiv_problem(kind="mcf", k=2, n_sub=2)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"])
+    rng = np.random.default_rng(0)
+    for lv in range(orc.n_levels - 1):
+        A = orc.level_A(lv).tocsr()
+        d = A.diagonal()
+        R = A - sp.diags(d)
+        n = A.shape[0]
+        b, u = rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2))
+        for omega in (0.8, 1.0):
+            orc.set_smoother(lv, "jacobi", omega)
+            got = orc.relax(lv, b, u, 3)
+            ref = u.copy()
+            for _ in range(3):
+                t = (b - R @ ref) / d[:, None]
+                ref = ref + omega * (t - ref)
+            assert abs(got - ref).max() <= 1e-13 * abs(ref).max()
+            orc.set_smoother(lv, "gs")
+    assert np.array_equal(orc.relax(0, b0 := rng.uniform(-1, 1, (orc.rows(0), 1)), np.zeros((orc.rows(0), 1)), 1),
+                          orc.relax(0, b0, np.zeros((orc.rows(0), 1)), 1))
+    # hybrid: GS on level 0, Jacobi below
+    for lv in range(1, orc.n_levels - 1):
+        orc.set_smoother(lv, "jacobi", 0.8)
+    conv, z, rh = orc.solve(p["RHS"], p["z0"], tol=1e-9, max_iter=40)
+    assert conv and (np.diff(rh) < 0).all()
+    # all-core mode runs the same Jacobi arithmetic
+    colors = [np.array([0, orc.rows(lv)], dtype=np.int32) for lv in range(orc.n_levels - 1)]
+    orc.L.orc_enable_parallel(orc.h, 1, 4)
+    conv2, z2, rh2 = orc.solve(p["RHS"], p["z0"], tol=1e-9, max_iter=40)
+    orc.set_sequential()
+    assert len(rh2) == len(rh) and np.linalg.norm(z - z2) <= 1e-12 * np.linalg.norm(z)

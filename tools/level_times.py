@@ -9,7 +9,10 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mg, A, Mb, Vf, Ff, label, _ = B.build_workload(wl, smg, mesh)
 mg.precompute(A)
-print(label, "k =", k)
+sm = os.environ.get("SMG_TOOL_SMOOTHER", "gs")      # gs | jacobi | hybrid[:max_rows[:omega]]
+parts = sm.split(":")
+mg.set_smoother(parts[0], float(parts[2]) if len(parts) > 2 else 0.8, int(parts[1]) if len(parts) > 1 else 100000)
+print(label, "k =", k, "smoother", sm)
 prev = None
 ts = []
 for lv in range(mg.n_levels):
