@@ -138,6 +138,128 @@ def cpu_allcore(mg, A, rhs, budget_s=6.0):
             "ms_per_cycle": best[1], "r_his_head": best[3]}
 
 
+def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, smoother_kw, steps=200, warmup=20):
+    """BASELINE config C4: mean-curvature-flow system on ogre.obj (05_example_mean_curvature_flow/main.cpp:57-76), k = 64 right-hand
+    sides, column-sharded over the ranks: rank g owns columns [g k / N, (g+1) k / N), the hierarchy is
+    replicated, the only communication is the 8-byte all-reduce of the residual sum of squares per outer iteration.  STRONG scaling:
+    the 64 columns are the whole job at every N.  Returns the rank-0 record (None on the other ranks)."""
+    from surface_multigrid_code_amd.dist import GpuEngine, column_range, sharded_solve
+    K64, tol = 64, 5e-7                                              # main.cpp:60
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    t0 = time.time()
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)                       # main.cpp:48-50 (defaults of mg_precompute)
+    t_hier = time.time() - t0
+    n = V.shape[0]
+    L = mesh.cotmatrix(V, F)
+    Mb = mesh.massmatrix(V, F, "barycentric")                        # main.cpp:67
+    A = (Mb - 0.01 * L).tocsr()                                      # main.cpp:68
+    A.sort_indices()
+    mg.precompute(A)
+    mg.set_stream(stream.cuda_stream)
+    cols = [V[:, 0], V[:, 1], V[:, 2]] + [np.random.default_rng(100 + j).uniform(-1.0, 1.0, n) for j in range(K64 - 3)]
+    X = np.stack(cols, axis=1)                                       # n x 64
+    RHS = Mb @ X                                                     # main.cpp:69
+    Z0 = np.concatenate([V, np.zeros((n, K64 - 3))], axis=1)         # z0 = U for the coordinate columns (main.cpp:76)
+    lo, hi = column_range(K64, rank, world)
+    kl = hi - lo
+    rhs = torch.from_numpy(np.ascontiguousarray(RHS[:, lo:hi].T)).to(dev)     # (k_local, n): column-major n x k_local
+    z0 = torch.from_numpy(np.ascontiguousarray(Z0[:, lo:hi].T)).to(dev)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def allreduce(t):
+        if world == 1:
+            return
+        if stream_ar is not None:
+            stream_ar(t.data_ptr())
+        else:
+            dist.all_reduce(t)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # 1. the solve itself (tol 5e-7, the reference's setting): cycles, convergence, identical history on every rank
+    opts = smg.SolveOpts(tol=tol, max_iter=40, **smoother_kw)
+    eng = GpuEngine(mg, rhs, z0, None, opts)
+    sync_all()
+    tw = time.perf_counter()
+    conv, z, rh = sharded_solve(eng, 40, allreduce, check_every=1)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - tw
+    # 2. steady state: `steps` outer iterations of the 64-column block with tol = 0 (never converges)
+    HIS = max(steps + warmup, 1)
+    oo = smg.SolveOpts(tol=0.0, max_iter=HIS, **smoother_kw)
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=oo)
+
+    def block(m):
+        if world == 1:
+            mg.outer_iterations(m)
+            return
+        for _ in range(m):
+            mg.iter_residual(sumsq.data_ptr())
+            allreduce(sumsq)
+            mg.iter_cycle(sumsq.data_ptr())
+    block(warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    block(steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    zt = torch.empty_like(z0)
+    mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
+    # 3. the all-reduce alone, back to back on the solve stream
+    ar_us = None
+    if world > 1:
+        for _ in range(20):
+            allreduce(sumsq)
+        sync_all()
+        ta = time.perf_counter()
+        for _ in range(200):
+            allreduce(sumsq)
+        torch.cuda.synchronize()
+        ar_us = 1e6 * (time.perf_counter() - ta) / 200
+        t = torch.tensor([dt, ar_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ar_us = float(t[0].item()), float(t[1].item())
+        # every rank must have seen the same residual history
+        h = torch.zeros(64, dtype=torch.float64, device=dev)
+        h[: min(len(rh), 64)] = torch.from_numpy(np.asarray(rh[:64])).to(dev)
+        hmin, hmax = h.clone(), h.clone()
+        dist.all_reduce(hmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(hmin, hmax))
+    else:
+        same = True
+    ref_gs = None
+    if world == 1 and smoother_kw["smoother"] != "gs":    # the reference's smoother on the same job, for the time-to-tolerance comparison
+        g_kw = dict(smoother_kw, smoother="gs")
+        cg, zg, rg = sharded_solve(GpuEngine(mg, rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, **g_kw)), 40, allreduce)
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, **g_kw))
+        mg.outer_iterations(warmup)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        mg.outer_iterations(steps)
+        torch.cuda.synchronize()
+        msg = 1e3 * (time.perf_counter() - tg) / steps
+        mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
+        ref_gs = {"ms_per_step": msg, "cycles": len(rg) - 1, "converged": bool(cg), "time_to_tol_ms": msg * (len(rg) - 1)}
+    if rank != 0:
+        return None
+    ms = 1e3 * dt / steps
+    return {"workload": "C4: ogre.obj (19985 verts), M_bary+0.01(-L), k = 64 RHS columns (U + 61 synthetic M g_j), mg_precompute hierarchy",
+            "levels": [mg.rows(l) for l in range(mg.n_levels)], "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],
+            "k": K64, "columns_per_gpu": kl, "n_gpus": world, "scaling": "strong", "smoother": smoother_kw["smoother"],
+            "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms, "column_cycles_per_s": K64 * 1e3 / ms,
+            "allreduce_us": ar_us, "allreduce": (("RCCL on the solve stream, %d ranks (ncclCommCount)" % stream_ar.n_ranks()) if stream_ar is not None else "torch.distributed") if world > 1 else None,
+            "solve": {"tol": tol, "converged": bool(conv), "cycles": len(rh) - 1, "wall_ms": 1e3 * wall, "same_history_on_all_ranks": same,
+                      "r_his_head": [float(v) for v in rh[:4]], "final_residual": float(rh[-1])},
+            "time_to_tol_ms": ms * (len(rh) - 1), "reference_gs": ref_gs,
+            "hierarchy_build_s": t_hier}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +267,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4 (ogre.obj, k = 64, column-sharded) leg")
     ap.add_argument("--spmv-reps", type=int, default=500)
     ap.add_argument("--smoother", default="hybrid", choices=["gs", "jacobi", "hybrid"],
                     help="gs (default): the reference's Gauss-Seidel on every level; hybrid: GS on the big levels, damped Jacobi on "
@@ -199,29 +322,14 @@ def main():
     z = torch.empty(n, dtype=torch.float64, device=dev)
     sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    # multi-GPU: the 8-byte all-reduce runs on the solve's stream through RCCL directly (dist.StreamAllReduce); torch's collective
-    # is the fallback when that cannot be set up (SMG_BENCH_TORCH_ALLREDUCE=1 forces it)
+    # multi-GPU: the 8-byte all-reduce runs on the solve's stream through RCCL directly (dist.StreamAllReduce: named enum constants,
+    # version check, symmetric bootstrap and a known-answer reduction before it is trusted); torch's collective is the fallback when
+    # that cannot be set up (SMG_BENCH_TORCH_ALLREDUCE=1 forces it)
     stream_ar = None
     if (world > 1 or force_split) and os.environ.get("SMG_BENCH_TORCH_ALLREDUCE", "0") != "1" and os.environ.get("SMG_BENCH_BACKEND", "nccl") == "nccl":
         from surface_multigrid_code_amd.dist import StreamAllReduce
-
-        def all_agree(flag):
-            t = torch.tensor([1 if flag else 0], device=dev)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return int(t.item()) == 1
-
         sar = StreamAllReduce(rank, world, stream.cuda_stream, device=dev)
-        good = all_agree(sar.ready) and all_agree(sar.connect())
-        if good:   # known answer before it is trusted: sum over ranks of (rank + 1)
-            probe = torch.tensor([rank + 1.0], dtype=torch.float64, device=dev)
-            torch.cuda.synchronize()
-            sar(probe.data_ptr())
-            stream.synchronize()
-            good = all_agree(float(probe.item()) == world * (world + 1) / 2.0)
-            if not good:
-                sar.err = "known-answer all-reduce gave %r" % float(probe.item())
-        if good:
+        if sar.connect():       # collective: every rank gets the same verdict
             stream_ar = sar
         elif rank == 0:
             print("bench: direct RCCL all-reduce unavailable (%s), using torch.distributed" % sar.err, file=sys.stderr)
@@ -420,6 +528,16 @@ def main():
                 out["cpu_allcore"] = cpu_allcore(mg, A, rhs_h)
             except Exception as e:  # the comparator is informational: never lose the bench line over it
                 out["cpu_allcore"] = {"error": str(e)}
+    # ---- BASELINE config C4: k = 64 columns sharded over the ranks (strong scaling; N = 1 is the curve's first point)
+    if not args.no_c4:
+        try:
+            c4 = c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, sm_kw)
+        except Exception as e:   # never lose the bench line over the secondary measurement
+            c4 = {"error": repr(e)}
+            if world > 1:
+                raise
+        if rank == 0:
+            out["c4_k64_sharded"] = c4
     # tear the process group down BEFORE the line is printed: RCCL may write to stdout when a communicator is created or
     # destroyed, and the JSON must be the last line
     if world > 1 or force_split:

@@ -16,6 +16,44 @@ def column_range(k, rank, world):
     return lo, hi
 
 
+class EmptyEngine:
+    """A rank that owns no column (k < world size): it contributes 0 to the reduction and follows the others' decision, so that
+    every rank still takes part in every all-reduce."""
+
+    def __init__(self, tol, device=None):
+        import torch
+        self.tol = tol
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+        self.done, self.r_his = False, []
+
+    def begin(self):
+        pass
+
+    def residual_sumsq(self):
+        self.sumsq.zero_()
+        return self.sumsq
+
+    def cycle(self, sumsq):
+        if self.done:
+            return
+        r = float(sumsq.item()) ** 0.5
+        self.r_his.append(r)
+        if r < self.tol or r != r:
+            self.done = True
+
+    def cycle_speculative(self):
+        pass
+
+    commit = cycle
+
+    def poll(self):
+        return self.done, len(self.r_his)
+
+    def end(self):
+        last = self.r_his[-1] if self.r_his else float("inf")
+        return not (last > self.tol), None, np.array(self.r_his)
+
+
 class GpuEngine:
     """libsmg engine: everything stays in HBM; `sumsq` is a 1-element float64 CUDA tensor."""
 
@@ -102,14 +140,27 @@ def sharded_solve(engine, max_iter, all_reduce, check_every=1):
     return engine.end()
 
 
+# rccl.h (ROCm 7.2, NCCL API 2.27): the enum values of the two constants ncclAllReduce is called with.  They have been stable
+# since NCCL 2.0; `StreamAllReduce` refuses libraries older than that and proves the whole binding (struct layout, enum values,
+# stream) with a known-answer reduction before it reports `ok`.
+NCCL_UNIQUE_ID_BYTES = 128     # rccl.h:40
+NCCL_SUM = 0                   # ncclRedOp_t::ncclSum, rccl.h:448
+NCCL_FLOAT64 = 8               # ncclDataType_t::ncclFloat64 / ncclDouble, rccl.h:467
+NCCL_MIN_VERSION = 20000       # 2.0.0 in ncclGetVersion's encoding of that era (>= 2.9: major * 10000 + minor * 100 + patch)
+
+
 class StreamAllReduce:
     """Sum-all-reduce of a small fp64 device buffer ON THE CALLER'S STREAM, through RCCL directly (ctypes on the librccl.so
     that torch loaded).  torch.distributed.all_reduce always runs on the process group's own stream: the two cross-stream
     hand-overs around an 8-byte reduction cost more than the reduction (about 20 us of stream time per outer iteration of
-    the column-sharded solve).  Two steps, so that a rank that cannot load the library never leaves the others waiting in a
-    collective: the constructor only loads and binds (`ready`), `connect()` -- to be called by all ranks or none --
-    bootstraps the communicator over the existing torch process group (the unique id travels by broadcast_object_list)
-    and sets `ok`.  Callers fall back to torch's collective when either flag stays False."""
+    the column-sharded solve).
+
+    Two steps.  The constructor only loads and binds (`ready`).  `connect()` is a COLLECTIVE over the torch process group --
+    every rank calls it, whatever its own `ready` says -- and every rank leaves it with the same verdict: the unique id (or an
+    error sentinel) is broadcast from rank 0, each step is followed by an agreement (all-reduce MIN of a success flag), and
+    before `ok` is set the communicator has to pass a known-answer reduction.  The bootstrap uses its own gloo group, so that a
+    failure cannot leave a collective pending on the caller's group.  Callers fall back to torch's collective when it
+    returns False."""
 
     def __init__(self, rank, world, stream_ptr, device=None):
         import ctypes as C
@@ -119,6 +170,8 @@ class StreamAllReduce:
         self.rank, self.world = rank, world
         self.stream = C.c_void_p(stream_ptr)
         self.err = ""
+        self.version = 0
+        self.comm = None
         try:
             import torch
             path = None
@@ -132,61 +185,127 @@ class StreamAllReduce:
             L = C.CDLL(path)
 
             class UniqueId(C.Structure):
-                _fields_ = [("internal", C.c_char * 128)]
+                _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
 
+            L.ncclGetVersion.argtypes = [C.POINTER(C.c_int)]
             L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
             L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
             L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             L.ncclCommDestroy.argtypes = [C.c_void_p]
+            L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            v = C.c_int(0)
+            if L.ncclGetVersion(C.byref(v)) != 0 or v.value < NCCL_MIN_VERSION:
+                raise RuntimeError("unsupported RCCL/NCCL version %d" % v.value)
+            self.version = v.value
             self.L, self.UniqueId, self.C = L, UniqueId, C
             self.ready = True
         except Exception as e:   # pragma: no cover - depends on the installation
             self.err = repr(e)
 
+    # -- agreement helpers (bootstrap group, CPU tensors)
+    def _agree(self, group, flag):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item()) == 1
+
     def connect(self, timeout_s=120.0):
-        """Collective.  Runs on a helper thread with a deadline: should the bootstrap hang, the caller gets False after
-        `timeout_s` (and must not use this object), instead of the whole job hanging."""
+        """Collective (all ranks).  Returns the common verdict.  The RCCL calls run on a helper thread with a deadline: should the
+        bootstrap hang on this rank, the rank gives up after `timeout_s`, and the final agreement turns that into False everywhere."""
         import threading
-        done = threading.Event()
+        import torch.distributed as dist
+        group = None
+        if self.world > 1:
+            import datetime
+            group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=2 * timeout_s + 60))
+        finished = threading.Event()
+        verdict = [False]
 
         def work():
-            self._connect()
-            done.set()
+            verdict[0] = self._connect(group)
+            finished.set()
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        if not done.wait(timeout_s):
+        if not finished.wait(timeout_s):
             self.err = "RCCL bootstrap timed out after %.0f s" % timeout_s
-            self.ok = False
             self._abandoned = True
+            verdict[0] = False
+            # the helper thread may still sit in a bootstrap-group collective: the final agreement must not share the group with it
+            self.ok = False
             return False
+        try:
+            self.ok = self._agree(group, bool(verdict[0])) and bool(verdict[0])
+        except Exception as e:   # a rank gave up on its deadline and never reached the agreement
+            self.err = self.err or repr(e)
+            self.ok = False
+        if not self.ok and self.comm is not None:
+            try:
+                self.L.ncclCommDestroy(self.comm)
+            except Exception:
+                pass
+            self.comm = None
         return self.ok
 
-    def _connect(self):
-        C = self.C
+    def _connect(self, group):
+        import torch
+        import torch.distributed as dist
+        C = getattr(self, "C", None)
         try:
+            if not self._agree(group, self.ready):
+                self.err = self.err or "another rank could not load RCCL"
+                return False
             if self.device is not None:   # the current device is per thread
-                import torch
                 torch.cuda.set_device(self.device)
+            # 1. the unique id travels from rank 0; an error there travels instead of it
             uid = self.UniqueId()
-            if self.rank == 0 and self.L.ncclGetUniqueId(C.byref(uid)) != 0:
-                raise RuntimeError("ncclGetUniqueId failed")
+            box = [None]
+            if self.rank == 0:
+                rc = self.L.ncclGetUniqueId(C.byref(uid))
+                box[0] = C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES) if rc == 0 else ("error", rc)
             if self.world > 1:
-                import torch.distributed as dist
-                box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                C.memmove(C.addressof(uid), box[0], 128)
+                dist.broadcast_object_list(box, src=0, group=group)
+            if not isinstance(box[0], (bytes, bytearray)):
+                self.err = "ncclGetUniqueId failed on rank 0: %r" % (box[0],)
+                return False
+            C.memmove(C.addressof(uid), box[0], NCCL_UNIQUE_ID_BYTES)
+            # 2. communicator (itself a collective inside RCCL: every rank got a valid id, so every rank calls it)
             comm = C.c_void_p()
-            if self.L.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank) != 0:
-                raise RuntimeError("ncclCommInitRank failed")
-            self.comm = comm
-            self.ok = not getattr(self, "_abandoned", False)
+            rc = self.L.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+            good = rc == 0
+            if good:
+                self.comm = comm
+                cnt = C.c_int(0)
+                good = self.L.ncclCommCount(comm, C.byref(cnt)) == 0 and cnt.value == self.world
+            if not self._agree(group, good):
+                self.err = self.err or "ncclCommInitRank failed on some rank (rc=%d here)" % rc
+                return False
+            # 3. known answer: sum over ranks of (rank + 1, 1) -- proves datatype / op constants, count and stream handling
+            dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+            probe = torch.tensor([self.rank + 1.0, 1.0], dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            rc = self.L.ncclAllReduce(probe.data_ptr(), probe.data_ptr(), 2, NCCL_FLOAT64, NCCL_SUM, self.comm, self.stream)
+            torch.cuda.synchronize()
+            got = probe.tolist()
+            good = rc == 0 and got == [self.world * (self.world + 1) / 2.0, float(self.world)]
+            if not self._agree(group, good):
+                self.err = self.err or "known-answer all-reduce gave %r (rc=%d)" % (got, rc)
+                return False
+            return not getattr(self, "_abandoned", False)
         except Exception as e:   # pragma: no cover
             self.err = repr(e)
+            return False
+
+    def n_ranks(self):
+        """ranks of the RCCL communicator (ncclCommCount)"""
+        cnt = self.C.c_int(0)
+        return cnt.value if self.ok and self.L.ncclCommCount(self.comm, self.C.byref(cnt)) == 0 else 0
 
     def __call__(self, ptr, count=1):
         """in-place sum of `count` doubles at device pointer `ptr`, enqueued on the stream given at construction"""
-        rc = self.L.ncclAllReduce(ptr, ptr, count, 8, 0, self.comm, self.stream)   # ncclFloat64 = 8, ncclSum = 0
+        rc = self.L.ncclAllReduce(ptr, ptr, count, NCCL_FLOAT64, NCCL_SUM, self.comm, self.stream)
         if rc != 0:
             raise RuntimeError("ncclAllReduce failed: %d" % rc)
 
@@ -194,3 +313,4 @@ class StreamAllReduce:
         if self.ok:
             self.L.ncclCommDestroy(self.comm)
             self.ok = False
+            self.comm = None

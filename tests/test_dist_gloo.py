@@ -85,6 +85,15 @@ def _worker(rank, world, port, q):
     zfull = np.concatenate([t.numpy() for t in zs], axis=1)
     ok = (conv == conv_ref and len(rh) == len(rh_ref) and np.allclose(rh, rh_ref, rtol=1e-12, atol=0)
           and np.array_equal(zfull, z_ref))
+    # fewer columns than ranks: the rank without a column contributes 0 and follows the others' decision
+    from surface_multigrid_code_amd.dist import EmptyEngine
+    lo1, hi1 = column_range(1, rank, world)
+    e1 = OracleEngine(orc, p["RHS"][:, :1], p["z0"][:, :1], tol) if hi1 > lo1 else EmptyEngine(tol)
+    c1, z1, rh1 = sharded_solve(e1, 20, lambda t: dist.all_reduce(t))
+    c1r, z1r, rh1r = orc.solve(p["RHS"][:, :1], p["z0"][:, :1], tol=tol, max_iter=20)
+    ok = ok and c1 == c1r and len(rh1) == len(rh1r) and np.allclose(rh1, rh1r, rtol=1e-12, atol=0)
+    if hi1 > lo1:
+        ok = ok and np.array_equal(z1, z1r)
     q.put((rank, bool(ok), len(rh), float(rh[-1])))
     dist.barrier()
     dist.destroy_process_group()

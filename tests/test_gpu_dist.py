@@ -1,0 +1,109 @@
+"""GPU (-m gpu): the column-sharded solve driven by TWO processes (gloo rendezvous, both ranks on GPU 0 -- RCCL refuses ranks that
+share a device, the driver runs the real 8-GPU RCCL job): surface_multigrid_code_amd.dist.GpuEngine + sharded_solve and its
+latency-hiding form against the fused k-column smg_solve.
+
+Per column the sparse kernels and the dense coarse solve (k_dense_gemv_add for 2 <= k < 16) do the same arithmetic whatever the
+number of columns in the block, so the sharded iterate is BIT-IDENTICAL to the fused one; only the residual norm is summed in
+another order (per-rank partial sums, then the all-reduce): r_his agrees to 1e-12 relative."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, q, smoother):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        import surface_multigrid_code_amd as smg
+        from surface_multigrid_code_amd.dist import EmptyEngine, GpuEngine, column_range, sharded_solve, sharded_solve_overlapped
+        from problems import subdiv_problem
+        k, tol = 6, 5e-7
+        p = subdiv_problem(kind="mcf", k=k, n_sub=2)
+        mg = smg.Hierarchy.from_prolongs(p["Ps"])
+        mg.precompute(p["A"])
+        n = mg.rows(0)
+        stream = torch.cuda.Stream(device=dev)
+        kw = dict(smoother=smoother, jacobi_max_rows=mg.rows(1))
+        with torch.cuda.stream(stream):
+            mg.set_stream(stream.cuda_stream)
+            lo, hi = column_range(k, rank, world)
+            rhs = torch.from_numpy(np.ascontiguousarray(p["RHS"][:, lo:hi].T)).to(dev)
+            z0 = torch.from_numpy(np.ascontiguousarray(p["z0"][:, lo:hi].T)).to(dev)
+
+            def allreduce(t):
+                dist.all_reduce(t)          # gloo on a CUDA tensor: ordered with the current (= the solve's) stream
+
+            outs = []
+            for form in ("plain", "speculative", "eager"):
+                opts = smg.SolveOpts(tol=tol, max_iter=30, use_graph=0 if form == "eager" else 1, **kw)
+                eng = GpuEngine(mg, rhs, z0, None, opts)
+                if form == "speculative":
+                    conv, z, rh = sharded_solve_overlapped(eng, 30, lambda t: dist.all_reduce(t, async_op=True), check_every=3)
+                else:
+                    conv, z, rh = sharded_solve(eng, 30, allreduce, check_every=2 if form == "plain" else 1)
+                stream.synchronize()
+                outs.append((conv, z.cpu().numpy().T.copy(), np.asarray(rh)))
+            # a rank without columns (k < world) still takes part in every reduction: k = 1 on two ranks
+            lo1, hi1 = column_range(1, rank, world)
+            if hi1 > lo1:
+                r1 = torch.from_numpy(np.ascontiguousarray(p["RHS"][:, :1].T)).to(dev)
+                s1 = torch.from_numpy(np.ascontiguousarray(p["z0"][:, :1].T)).to(dev)
+                e1 = GpuEngine(mg, r1, s1, None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
+            else:
+                e1 = EmptyEngine(tol, dev)
+            c1, z1, rh1 = sharded_solve(e1, 30, allreduce)
+            stream.synchronize()
+            # the fused k-column solve (rank 0's reference for everything)
+            conv_f, z_f, rh_f = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
+            conv_1, z_1, rh_1 = mg.solve(p["RHS"][:, :1], p["z0"][:, :1], None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
+        ok = True
+        msg = ""
+        for form, (conv, z, rh) in zip(("plain", "speculative", "eager"), outs):
+            good = (conv == conv_f and len(rh) == len(rh_f) and np.allclose(rh, rh_f, rtol=1e-12, atol=0)
+                    and np.array_equal(z, z_f[:, lo:hi]))
+            if not good:
+                ok = False
+                msg += "%s: conv %s/%s its %d/%d zdiff %.3e; " % (form, conv, conv_f, len(rh), len(rh_f),
+                                                                  abs(z - z_f[:, lo:hi]).max() if z.shape == z_f[:, lo:hi].shape else -1)
+        if not (np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])):
+            ok = False
+            msg += "the three forms of the loop disagree; "
+        if not (c1 == conv_1 and len(rh1) == len(rh_1) and np.allclose(rh1, rh_1, rtol=1e-12, atol=0)):
+            ok = False
+            msg += "k=1 on two ranks: %s its %d/%d; " % (c1, len(rh1), len(rh_1))
+        q.put((rank, ok, msg, len(outs[0][2]), float(outs[0][2][-1])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:   # surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, False, "exception: " + traceback.format_exc()[-1500:], 0, 0.0))
+
+
+@pytest.mark.parametrize("smoother", ["gs", "hybrid"])
+def test_two_ranks_drive_the_gpu_engine(smg_mod, smoother):
+    assert smg_mod._lib.load().smg_device_count() > 0, "GPU tests need a HIP device (no CPU fallback exists)"
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, smoother)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=120)
+    assert all(r[1] for r in res), res
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4]      # identical history on both ranks
