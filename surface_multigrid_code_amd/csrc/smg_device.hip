@@ -692,6 +692,65 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
         for (int q = 0; q < CT; q++) u[(size_t)row * ld + tc * CT + q] = u[(size_t)row * ld + tc * CT + q] + acc[q];
 }
 
+// k >= 16 columns, fp64: the same product on the fp64 matrix cores.  One workgroup per 16 x 16 tile of u (grid: row blocks x
+// column blocks: 4 x the workgroups of the LDS-tiled kernel above, whose n / 16 workgroups left two thirds of the CUs idle and made the
+// coarse solve 40 % of a 64-column cycle on ogre.obj: 113 -> 9 us), the four waves of a workgroup each walk a quarter of the inner index
+// in steps of 4 (v_mfma_f64_16x16x4_f64), their partial tiles are summed through LDS in a fixed order (deterministic).  The inverse is
+// symmetric (k_mirror_lower), so the A operand A[i][j] is read as Ainv[j][i]: 16 consecutive doubles per j -- both operands are
+// 128-byte segments, no staging.  Loads run DEPTH steps ahead of the products (at most one workgroup per CU: occupancy hides nothing).
+// The coarse solve is compared with LDL^T to 1e-11, not bit for bit: the fused multiply-adds of the matrix cores are fine here.
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+template <int KC>
+__global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restrict__ Ainv, int n, int lda, const double* __restrict__ b,
+                                                         double* u, int ld, const int* done)
+{
+    const int stop = load_flag(done);
+    constexpr int CB = KC / 16, DEPTH = 12;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rb = blockIdx.x / CB, cb = blockIdx.x % CB;
+    const int row0 = rb * 16, col0 = cb * 16;
+    const int lc = lane & 15, lr = lane >> 4;
+    const int per = lda / 16;                 // MFMA steps per wave (lda % 64 == 0)
+    const int s0 = per * w;
+    const double* pa = Ainv + (size_t)(4 * s0 + lr) * lda + row0 + lc;
+    const double* pb = b + (size_t)(4 * s0 + lr) * ld + col0 + lc;
+    const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ld;
+    v4f64_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[DEPTH], bv[DEPTH];
+#pragma unroll
+    for (int t = 0; t < DEPTH; t++) {
+        av[t] = t < per ? pa[t * sa] : 0.0;
+        bv[t] = t < per ? pb[t * sb] : 0.0;
+    }
+    for (int s = 0; s < per; s += DEPTH) {
+        double an[DEPTH], bn[DEPTH];
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++) {
+            const int q = s + DEPTH + t;
+            an[t] = q < per ? pa[q * sa] : 0.0;
+            bn[t] = q < per ? pb[q * sb] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);   // zero operands past the end
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++) { av[t] = an[t]; bv[t] = bn[t]; }
+    }
+    __shared__ double red[4][4][64];
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[w][r][lane] = acc[r];
+    __syncthreads();
+    if (w == 0 && !stop) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = row0 + lr + 4 * r;      // C/D layout: register r of lane -> row (lane >> 4) + 4 r, column lane & 15
+            if (row < n) {
+                const size_t o = (size_t)row * ld + col0 + lc;
+                u[o] = u[o] + ((red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]));
+            }
+        }
+    }
+}
+
 // ---- k = 1, symmetric: the inverse of an SPD matrix is symmetric, so one column's product needs only the lower triangle of
 // tiles -- half the bytes of the (bandwidth-bound) coarse solve.  Tile (I, J), I >= J, yields A_IJ b_J (a share of y_I) and, off the
 // diagonal, A_IJ^T b_I (a share of y_J); the 64-row shares are summed per row in ascending block order by a second small launch:
@@ -767,6 +826,18 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
         int kc = 64;
         while (kc > k - c0) kc >>= 1;
         const int tb = (n + 15) / 16;
+        static const int use_mfma = getenv("SMG_COARSE_MFMA") ? atoi(getenv("SMG_COARSE_MFMA")) : 1;   // A/B knob
+        if constexpr (std::is_same<T, double>::value) {
+            if (use_mfma && lda % 64 == 0) {
+                switch (kc) {
+                    case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+                    case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+                    default: hipLaunchKernelGGL((k_dense_gemm_mfma<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+                }
+                c0 += kc;
+                continue;
+            }
+        }
         switch (kc) {
             case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
             case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;

@@ -95,11 +95,14 @@ def test_colouring_is_valid_and_sell_matches_csr(smg, oracle_mod):
             assert st["padded"] / st["stored"] < 1.10, "SELL padding above 10%"
 
 
-def test_coarse_solve_matches_ldlt(smg, oracle_mod):
+@pytest.mark.parametrize("k", [1, 2, 7, 16, 40, 64, 91])
+def test_coarse_solve_matches_ldlt(smg, oracle_mod, k):
+    """k = 1: lower triangle of the symmetric inverse; 2..15: one wave per row; >= 16: 16 x 16 tiles on the fp64 matrix cores
+    (blocks of 64 / 32 / 16 columns, remainders through the narrow kernels: 40 = 32 + 4 + 4, 91 = 64 + 16 + 4 + 4 + 3)."""
     p, mg, orc = build(smg, oracle_mod, kind="poisson", k=2, n_sub=2)
     rng = np.random.default_rng(5)
     nc = mg.rows(mg.n_levels - 1)
-    B, u = rng.uniform(-1, 1, (nc, 2)), rng.uniform(-1, 1, (nc, 2))
+    B, u = rng.uniform(-1, 1, (nc, k)), rng.uniform(-1, 1, (nc, k))
     got, ref = mg.coarse_solve(B, u), orc.coarse_solve(B, u)
     assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
 

@@ -12,7 +12,10 @@ mg = smg.mg_precompute(V, F, 0.25, 500, 1)
 A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
 mg.precompute(A)
 print("ogre.obj: levels", [mg.rows(l) for l in range(mg.n_levels)], "colours", [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)])
-for k in (1, 2, 3, 4, 8, 64):
+sm = os.environ.get("SMG_TOOL_SMOOTHER", "gs").split(":")
+mg.set_smoother(sm[0], float(sm[2]) if len(sm) > 2 else 0.8, int(sm[1]) if len(sm) > 1 else 100000)
+print("smoother", sm)
+for k in (1, 2, 3, 4, 8, 16, 32, 64):
     us = mg.bench_vcycle(0, k, 2, 2, 200)
     print("k = %2d: %.1f us per V(2,2) cycle (%.2f us per column)" % (k, us, us / k))
 o = OracleMG([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]); o.precompute(A)
