@@ -67,5 +67,54 @@ def build(force=False, verbose=True):
     return LIB
 
 
+# ---- sanitizer lane ("-fsanitize=address,undefined CPU test config") ------------------------------------------
+# The five host translation units -- decimator, colouring / ordering, sparse algebra, mesh numerics, the C ABI: the pointer-heavy
+# code -- compiled by g++ with AddressSanitizer + UndefinedBehaviorSanitizer; the device file keeps its normal hipcc object (device
+# code cannot carry host sanitizer instrumentation).  Result: lib/libsmg_asan.so, loaded through SMG_LIB by tests/test_sanitized_host.py
+# with LD_PRELOAD=libasan (python itself is not instrumented).
+ASAN_LIB = os.path.join(LIBDIR, "libsmg_asan.so")
+ASAN_FLAGS = ["-std=c++17", "-O1", "-g", "-fPIC", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
+              "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-w"]
+
+
+def build_sanitized(verbose=False):
+    build(verbose=verbose)                                   # the device object comes from the regular build
+    objdir = os.path.join(LIBDIR, "obj_asan")
+    os.makedirs(objdir, exist_ok=True)
+    host = [s for s in SOURCES if s.endswith(".cpp")]
+    objs, procs = [os.path.join(LIBDIR, "obj", "smg_device.o")], []
+    newest_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    for s in host:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr, os.path.getmtime(os.path.abspath(__file__))):
+            continue
+        cmd = ["g++"] + ASAN_FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("sanitized build failed: " + " ".join(cmd))
+    if procs or not os.path.exists(ASAN_LIB) or os.path.getmtime(ASAN_LIB) < os.path.getmtime(objs[0]):
+        cmd = ["g++", "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", ASAN_LIB] + objs + ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return ASAN_LIB
+
+
+def sanitizer_env(base=None):
+    """Environment for a python child that loads libsmg_asan.so."""
+    env = dict(base if base is not None else os.environ)
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    env["LD_PRELOAD"] = asan + ":" + ubsan
+    env["ASAN_OPTIONS"] = "detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0:detect_odr_violation=0"
+    env["UBSAN_OPTIONS"] = "halt_on_error=1:print_stacktrace=1"
+    env["SMG_LIB"] = ASAN_LIB
+    return env
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

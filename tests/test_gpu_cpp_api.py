@@ -100,3 +100,20 @@ def test_cpp_closed_mesh_with_pins_example(smg_mod, oracle_mod):
     assert abs(float(m.group(3)) - float((z * z).sum())) <= 1e-9 * float((z * z).sum())
     unk = np.setdiff1d(np.arange(n), b)
     assert np.linalg.norm((B - A @ z[:, 0])[unk]) < 1e-10 and abs(z[b, 0]).max() == 0.0
+
+
+def test_eigen_adapter_runs_through_the_reference_signatures(smg_mod):
+    """examples/smg_eigen_adapter.cpp (the reference's Eigen signatures on libsmg) built against tests/mock_eigen -- a
+    stand-in with the Eigen members the adapter touches, NOT Eigen -- and driven like 03_mg_solver/main.cpp:38-75 by
+    examples/adapter_check.cpp: precompute fills data.n/known/unknown/LHS/Auk and writes mg[l].A/A_diag/P/PT back, solve converges
+    to the true residual, mg_VCycle / A() work on a coarser level, the no-constraint overloads re-precompute on the same mg."""
+    exe = os.path.join(ROOT, "examples", "adapter_check")
+    srcs = [os.path.join(ROOT, "examples", f) for f in ("adapter_check.cpp", "smg_eigen_adapter.cpp")]
+    lib = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", "-DSMG_ADAPTER_MOCK", "-I" + os.path.join(ROOT, "tests", "mock_eigen"),
+                               "-I" + os.path.join(ROOT, "include")] + srcs + ["-L" + lib, "-lsmg", "-Wl,-rpath," + lib, "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny.smgm")], env=env, text=True, capture_output=True)
+    assert out.returncode == 0 and "ADAPTER_CHECK OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    assert "MG iteration: 0, residual:" in out.stdout and "residual norm:" in out.stdout      # the reference's prints (.cpp:111,127)

@@ -1,0 +1,38 @@
+"""CPU: the AddressSanitizer + UndefinedBehaviorSanitizer lane for the host C++ ("Race detection / sanitizers").
+Builds lib/libsmg_asan.so (surface_multigrid_code_amd/build.py: the five host translation units through g++ -fsanitize=address,undefined,
+the device object unchanged) and runs, in a child python with libasan preloaded and SMG_LIB pointing at it,
+  * the host-logic and ABI tests (precompute slices / Galerkin products / orderings / decimator invariants / malformed inputs / save+load),
+  * tools/fuzz_host.py: random meshes through all three decimators and the host half of the precompute.
+Any sanitizer report fails the test."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout):
+    from surface_multigrid_code_amd import build as smg_build
+    smg_build.build_sanitized()
+    env = smg_build.sanitizer_env()
+    env["SMG_HOST_THREADS"] = "4"
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert r.returncode == 0, out[-4000:]
+    return out
+
+
+def test_sanitized_library_is_the_one_loaded():
+    out = _run(["-c", "import surface_multigrid_code_amd as s; from surface_multigrid_code_amd import _lib; print('LIB', _lib.LIB_PATH, _lib.load().smg_version())"], 300)
+    assert "libsmg_asan.so 200" in out
+
+
+def test_host_logic_and_abi_under_asan_ubsan():
+    out = _run(["-m", "pytest", "tests/test_host_logic.py", "tests/test_abi.py", "-x", "-q", "-p", "no:cacheprovider"], 1500)
+    assert " passed" in out and " failed" not in out
+
+
+def test_host_fuzz_under_asan_ubsan():
+    out = _run(["tools/fuzz_host.py", "10", "0"], 1500)
+    assert "FUZZ_HOST OK" in out
