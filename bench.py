@@ -319,11 +319,13 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the out-of-cache roofline leg (C5, 4.19 M vertices)")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (ogre.obj, k = 64, column-sharded) leg")
     ap.add_argument("--spmv-reps", type=int, default=500)
-    ap.add_argument("--smoother", default="hybrid", choices=["gs", "jacobi", "hybrid"],
-                    help="gs (default): the reference's Gauss-Seidel on every level; hybrid: GS on the big levels, damped Jacobi on "
-                         "those with <= --jacobi-max-rows unknowns; jacobi: Jacobi everywhere")
+    ap.add_argument("--smoother", default="hybrid_chebyshev", choices=["gs", "jacobi", "hybrid", "chebyshev", "hybrid_chebyshev"],
+                    help="gs: the reference's Gauss-Seidel on every level (the library's default); hybrid_chebyshev (the benchmark's "
+                         "default): GS on the levels with more than --jacobi-max-rows unknowns, Chebyshev-accelerated Jacobi (degree 3) "
+                         "below -- as many cycles as GS everywhere, a third of the launches on the latency-bound levels; hybrid: damped "
+                         "Jacobi instead (cheaper per cycle, but 30-70 %% more cycles on anisotropic meshes); jacobi / chebyshev: everywhere")
     ap.add_argument("--omega", type=float, default=0.8)
-    ap.add_argument("--jacobi-max-rows", type=int, default=100000)
+    ap.add_argument("--jacobi-max-rows", type=int, default=300000)
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
                     help="f64 (default): the reference arithmetic; mixed: fp32 V-cycle inside the fp64 outer loop")
     args = ap.parse_args()
@@ -481,8 +483,8 @@ def main():
                 ms = ea.elapsed_time(eb) / 300
             cyc = len(rh_) - 1
             return {"smoother": kw["smoother"], "omega": kw.get("omega"), "jacobi_max_rows": kw.get("jacobi_max_rows"),
-                    "jacobi_levels": [l for l in range(mg.n_levels - 1) if kw["smoother"] == "jacobi" or
-                                      (kw["smoother"] == "hybrid" and mg.rows(l) <= kw["jacobi_max_rows"])],
+                    "jacobi_levels": [l for l in range(mg.n_levels - 1) if kw["smoother"] in ("jacobi", "chebyshev") or
+                                      (kw["smoother"].startswith("hybrid") and mg.rows(l) <= kw["jacobi_max_rows"])],
                     "converged": bool(cv), "cycles_to_tol": cyc, "tol": 1e-10, "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms,
                     "time_to_tol_ms": cyc * ms, "solve_wall_ms": wall, "final_residual": float(rh_[-1]) if len(rh_) else None}
         smoothers = None
@@ -490,6 +492,8 @@ def main():
             smoothers = {"timed": smoother_line(sm_kw, ms_step)}
             if args.smoother != "gs":
                 smoothers["reference_gs"] = smoother_line(dict(smoother="gs", omega=args.omega, jacobi_max_rows=args.jacobi_max_rows))
+            if args.smoother != "hybrid":
+                smoothers["hybrid_damped_jacobi"] = smoother_line(dict(smoother="hybrid", omega=args.omega, jacobi_max_rows=100000))
             mg.set_smoother("gs")   # the kernel-level measurements below are of the reference smoother
         # ---- roofline of the fine-level SpMV kernel (k_sell<SELL_AX,1> on A_0), HIP events on the launch stream
         x = torch.from_numpy(rng.uniform(-1.0, 1.0, n)).to(dev)
@@ -548,7 +552,9 @@ def main():
                        "rhs_columns_per_gpu": 1,
                        "cycle": {"gs": "V(2,2), multi-colour Gauss-Seidel on every level (the reference's relax()), dense coarsest solve",
                                  "hybrid": "V(2,2), multi-colour Gauss-Seidel on levels > %d rows, damped Jacobi (omega %.2f) below, dense coarsest solve" % (args.jacobi_max_rows, args.omega),
-                                 "jacobi": "V(2,2), damped Jacobi (omega %.2f) on every level, dense coarsest solve" % args.omega}[args.smoother],
+                                 "jacobi": "V(2,2), damped Jacobi (omega %.2f) on every level, dense coarsest solve" % args.omega,
+                                 "chebyshev": "V(2,2), Chebyshev-Jacobi (degree 3) on every level, dense coarsest solve",
+                                 "hybrid_chebyshev": "V(2,2), multi-colour Gauss-Seidel on levels > %d rows, Chebyshev-Jacobi (degree 3) below, dense coarsest solve" % args.jacobi_max_rows}[args.smoother],
                        "smoother": args.smoother,
                        "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU",
                        "allreduce": ("RCCL on the solve stream (dist.StreamAllReduce)" if stream_ar is not None else "torch.distributed") if (world > 1 or force_split) else None},

@@ -50,8 +50,15 @@ enum { SMG_DEC_QSLIM = 0, SMG_DEC_MIDPOINT = 1, SMG_DEC_VERTEX_REMOVAL = 2 };
  *   GS      forward Gauss-Seidel on every level: the reference's sweep on the colour-major numbering (default)
  *   JACOBI  damped Jacobi on every level:  u_i <- u_i + omega * ((b_i - sum_{j != i} A(j,i) u_j) / A_diag_i - u_i), all rows from the old u
  *   HYBRID  Gauss-Seidel on the levels with more than `jacobi_max_rows` unknowns (bandwidth-bound: a sweep costs its bytes),
- *           Jacobi on the smaller ones (launch-latency-bound: a sweep costs its launches) */
-enum { SMG_SMOOTH_GS = 0, SMG_SMOOTH_JACOBI = 1, SMG_SMOOTH_HYBRID = 2 };
+ *           Jacobi on the smaller ones (launch-latency-bound: a sweep costs its launches)
+ *   CHEBYSHEV / HYBRID_CHEBYSHEV  the same two layouts with Chebyshev-accelerated Jacobi instead of damped Jacobi: relax(iters) is ONE
+ *           polynomial of degree iters + 1 in D^-1 A (so V(2,2) smooths with degree 3: three whole-matrix launches where two Gauss-Seidel
+ *           sweeps take two launches per colour), optimal on [cheby_fraction * lam, lam] with lam the Gershgorin bound
+ *           max_i sum_j |A(j,i)| / A_diag_i.  Step s of the three-term recurrence (theta, delta = centre / half width of that interval,
+ *           sigma = theta / delta, rho_0 = 1 / sigma):   r_i = (b_i - sum_{j != i} A(j,i) u_j) / A_diag_i - u_i,
+ *           s = 0: d = r / theta;  s >= 1: rho_s = 1 / (2 sigma - rho_{s-1}), d = rho_s rho_{s-1} d + (2 rho_s / delta) r;   u += d.
+ *           Measured: as many cycles as Gauss-Seidel everywhere where damped Jacobi needs 30-70 % more (anisotropic torus, C5). */
+enum { SMG_SMOOTH_GS = 0, SMG_SMOOTH_JACOBI = 1, SMG_SMOOTH_HYBRID = 2, SMG_SMOOTH_CHEBYSHEV = 3, SMG_SMOOTH_HYBRID_CHEBYSHEV = 4 };
 
 typedef struct smg_hierarchy smg_hierarchy;
 
@@ -70,7 +77,8 @@ typedef struct {
                           ~2/3 of the bytes (BASELINE config 5: fp32 vs fp64) */
     int smoother;      /* SMG_SMOOTH_GS (default, the reference) / SMG_SMOOTH_JACOBI / SMG_SMOOTH_HYBRID */
     double omega;      /* Jacobi damping factor (default 0.8) */
-    int jacobi_max_rows; /* HYBRID: levels with at most this many unknowns are smoothed by Jacobi (default 100000) */
+    int jacobi_max_rows; /* HYBRID*: levels with at most this many unknowns are smoothed by (Chebyshev-)Jacobi (default 100000) */
+    double cheby_fraction; /* lower end of the Chebyshev interval as a fraction of the Gershgorin bound (default 0.1) */
 } smg_solve_opts;
 void smg_solve_opts_default(smg_solve_opts *o);
 
@@ -88,6 +96,9 @@ int smg_hierarchy_set_stream(smg_hierarchy *h, void *hip_stream);
 /* Smoother used by smg_vcycle / smg_relax and the raw / bench entry points (which take no smg_solve_opts); smg_solve* set the same
  * state from their opts.  omega <= 0 keeps the current value, jacobi_max_rows < 0 likewise. */
 int smg_hierarchy_set_smoother(smg_hierarchy *h, int smoother, double omega, int jacobi_max_rows);
+int smg_hierarchy_set_chebyshev(smg_hierarchy *h, double cheby_fraction);     /* (0, 1); <= 0 keeps the current value */
+/* the Gershgorin bound the Chebyshev smoother of level lv uses (0 before smg_precompute / on the coarsest level) */
+double smg_level_spectral_bound(const smg_hierarchy *h, int lv);
 /* mg[lv].P_full = mg[lv].P = P; mg[lv].PT = P^T  (what mg_precompute stores per level, src/mg_precompute.cpp:71-77).
  * P is #V_{lv-1} x #V_lv for lv = 1 .. n_levels-1 (the operator lives on the COARSER level, mg_VCycle.cpp:80,:91). */
 int smg_level_set_prolong(smg_hierarchy *h, int lv, int n_fine, int n_coarse, const int *rowptr, const int *col,

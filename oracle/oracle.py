@@ -66,6 +66,8 @@ def lib():
     L.orc_set_parallel.argtypes = [vp, C.c_int, C.c_int, ip]
     L.orc_enable_parallel.argtypes = [vp, C.c_int, C.c_int]
     L.orc_set_smoother.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+    L.orc_spectral_bound.argtypes = [vp, C.c_int]
+    L.orc_spectral_bound.restype = C.c_double
     L.orc_csc_times_dense.argtypes = [C.POINTER(_Csc), dp, C.c_int, C.c_int, dp, C.c_int]
     _lib = L
     return L
@@ -154,8 +156,12 @@ class OracleMG:
         return self.L.orc_enable_parallel(self.h, 1, int(threads))
 
     # -- smoother per level (extension: damped Jacobi, see smg_oracle.h)
+    def spectral_bound(self, lv):
+        return self.L.orc_spectral_bound(self.h, lv)
+
     def set_smoother(self, lv, kind="gs", omega=1.0):
-        rc = self.L.orc_set_smoother(self.h, lv, {"gs": 0, "jacobi": 1}[kind], float(omega))
+        """kind "gs" / "jacobi" (omega = damping) / "chebyshev" (omega = interval fraction), see smg_oracle.h"""
+        rc = self.L.orc_set_smoother(self.h, lv, {"gs": 0, "jacobi": 1, "chebyshev": 2}[kind], float(omega))
         if rc != 0:
             raise RuntimeError("orc_set_smoother failed rc=%d" % rc)
 

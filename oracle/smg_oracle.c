@@ -578,9 +578,65 @@ static void relax_jacobi(orc_mg *mg, int lv, const double *B, int k, int iters, 
     free(tmp);
 }
 
+/* Gershgorin bound of the spectrum of D^-1 A (extension, see smg_oracle.h) */
+double orc_spectral_bound(const orc_mg *mg, int lv)
+{
+    const orc_csc *A = &mg->lv[lv].A;
+    const double *diag = mg->lv[lv].A_diag;
+    double lam = 0.0;
+    for (int i = 0; i < A->n_cols; i++) {
+        double sum = 0.0;
+        for (int p = A->colptr[i]; p < A->colptr[i + 1]; p++) sum += fabs(A->val[p]);
+        if (diag[i] > 0.0) { double r = sum / diag[i]; if (r > lam) lam = r; }
+    }
+    return lam;
+}
+
+/* Chebyshev-accelerated Jacobi (extension, see smg_oracle.h): one polynomial of degree iters + 1 */
+static void relax_chebyshev(orc_mg *mg, int lv, const double *B, int k, int iters, double *u, double frac)
+{
+    if (iters <= 0) return;
+    const orc_csc *A = &mg->lv[lv].A;
+    const double *diag = mg->lv[lv].A_diag;
+    int n = A->n_rows;
+    const double lam = orc_spectral_bound(mg, lv);
+    const double lmax = lam, lmin = lam * frac;
+    const double theta = (lmax + lmin) / 2.0, delta = (lmax - lmin) / 2.0;
+    const double sigma = theta / delta;
+    double *tmp = (double *)xmalloc((size_t)n * sizeof(double));
+    double *d = (double *)xcalloc((size_t)n, sizeof(double));
+    for (int ri = 0; ri < k; ri++) {
+        double *uc = u + (size_t)ri * (size_t)n;
+        const double *bc = B + (size_t)ri * (size_t)n;
+        double rho = 1.0 / sigma;
+        for (int s = 0; s <= iters; s++) {
+            double c1 = 0.0, c2 = 1.0 / theta;
+            if (s > 0) {
+                const double rho_new = 1.0 / (2.0 * sigma - rho);
+                c1 = rho_new * rho;
+                c2 = 2.0 * rho_new / delta;
+                rho = rho_new;
+            }
+#pragma omp parallel for schedule(static) if (mg->par && n > ORC_PAR_MIN_ROWS)
+            for (int colIdx = 0; colIdx < n; colIdx++) {
+                double sum = 0;
+                for (int p = A->colptr[colIdx]; p < A->colptr[colIdx + 1]; p++)
+                    if (A->rowidx[p] != colIdx) sum += A->val[p] * uc[A->rowidx[p]];
+                double t = (bc[colIdx] - sum) / diag[colIdx];
+                double r = t - uc[colIdx];
+                double dn = (s == 0) ? c2 * r : c1 * d[colIdx] + c2 * r;
+                d[colIdx] = dn;
+                tmp[colIdx] = uc[colIdx] + dn;
+            }
+            memcpy(uc, tmp, (size_t)n * sizeof(double));
+        }
+    }
+    free(tmp); free(d);
+}
+
 int orc_set_smoother(orc_mg *mg, int lv, int kind, double omega)
 {
-    if (!mg || lv < 0 || lv >= mg->n_levels || (kind != ORC_SMOOTH_GS && kind != ORC_SMOOTH_JACOBI)) return -1;
+    if (!mg || lv < 0 || lv >= mg->n_levels || (kind != ORC_SMOOTH_GS && kind != ORC_SMOOTH_JACOBI && kind != ORC_SMOOTH_CHEBY)) return -1;
     if (!mg->smoother) {
         mg->smoother = (int *)xcalloc((size_t)mg->n_levels, sizeof(int));
         mg->omega = (double *)xcalloc((size_t)mg->n_levels, sizeof(double));
@@ -596,8 +652,9 @@ void orc_relax(orc_mg *mg, int lv, const double *B, int k, int iters, double *u)
     const orc_csc *A = &mg->lv[lv].A;
     const double *diag = mg->lv[lv].A_diag;
     int n = A->n_rows;
-    if (mg->smoother && mg->smoother[lv] == ORC_SMOOTH_JACOBI) {
-        relax_jacobi(mg, lv, B, k, iters, u, mg->omega[lv]);
+    if (mg->smoother && mg->smoother[lv] != ORC_SMOOTH_GS) {
+        if (mg->smoother[lv] == ORC_SMOOTH_JACOBI) relax_jacobi(mg, lv, B, k, iters, u, mg->omega[lv]);
+        else relax_chebyshev(mg, lv, B, k, iters, u, mg->omega[lv]);
         mg->t_relax += now_s() - t0; mg->c_relax++;
         return;
     }

@@ -119,8 +119,16 @@ void orc_coarse_solve(orc_mg *mg, int lv, const double *B, int k, double *u);   
  *     t = (B[i] - s) / A_diag[i]
  *     u_new[i] = u_old[i] + omega * (t - u_old[i])
  * kind: ORC_SMOOTH_GS (default on every level) or ORC_SMOOTH_JACOBI.  orc_relax() dispatches on the level's setting. */
-enum { ORC_SMOOTH_GS = 0, ORC_SMOOTH_JACOBI = 1 };
+enum { ORC_SMOOTH_GS = 0, ORC_SMOOTH_JACOBI = 1, ORC_SMOOTH_CHEBY = 2 };
 int orc_set_smoother(orc_mg *mg, int lv, int kind, double omega);
+/* ORC_SMOOTH_CHEBY (extension, same slot): Chebyshev-accelerated Jacobi; `omega` is the interval fraction.  relax(iters) applies ONE
+ * polynomial of degree iters + 1 in D^-1 A, optimal on [fraction * lam, lam], lam = orc_spectral_bound(lv):
+ *   theta = (lam + fraction lam) / 2, delta = (lam - fraction lam) / 2, sigma = theta / delta, rho = 1 / sigma
+ *   step s:  r_i = (B[i] - sum_{j != i, ascending j} A(j,i) u[j]) / A_diag[i] - u[i]          (all rows from the old u)
+ *            s = 0: d = (1 / theta) r;   s >= 1: rho' = 1 / (2 sigma - rho), d = (rho' rho) d + (2 rho' / delta) r, rho = rho'
+ *            u_new = u + d
+ * lam = max_i (sum_j |A(j,i)|, ascending j) / A_diag[i]: the Gershgorin bound of the spectrum of D^-1 A. */
+double orc_spectral_bound(const orc_mg *mg, int lv);
 
 /* ---- introspection for tests ---- */
 int orc_level_rows(const orc_mg *mg, int lv);

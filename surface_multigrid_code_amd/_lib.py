@@ -11,7 +11,7 @@ SMG_HOST, SMG_DEVICE = 0, 1
 class SolveOptsC(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("pre", C.c_int), ("post", C.c_int),
                 ("verbosity", C.c_int), ("check_every", C.c_int), ("use_graph", C.c_int), ("precision", C.c_int),
-                ("smoother", C.c_int), ("omega", C.c_double), ("jacobi_max_rows", C.c_int)]
+                ("smoother", C.c_int), ("omega", C.c_double), ("jacobi_max_rows", C.c_int), ("cheby_fraction", C.c_double)]
 
 
 _lib = None
@@ -37,6 +37,8 @@ def load():
         "smg_hierarchy_levels": (i, [vp]),
         "smg_hierarchy_set_stream": (i, [vp, vp]),
         "smg_hierarchy_set_smoother": (i, [vp, i, d, i]),
+        "smg_hierarchy_set_chebyshev": (i, [vp, d]),
+        "smg_level_spectral_bound": (d, [vp, i]),
         "smg_level_set_prolong": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_prolong_csc": (i, [vp, i, i, i, ip, ip, dp]),
         "smg_level_set_mesh": (i, [vp, i, dp, i, ip, i]),

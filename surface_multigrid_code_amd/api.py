@@ -52,19 +52,20 @@ def _colmajor(X):
     return np.asfortranarray(X)
 
 
-SMOOTHERS = {"gs": 0, "jacobi": 1, "hybrid": 2, 0: 0, 1: 1, 2: 2}
+SMOOTHERS = {"gs": 0, "jacobi": 1, "hybrid": 2, "chebyshev": 3, "hybrid_chebyshev": 4, 0: 0, 1: 1, 2: 2, 3: 3, 4: 4}
 
 
 class SolveOpts:
     """tol / maxIter / pre / post with the reference's defaults (src/min_quad_with_fixed_mg.cpp:63,77,102-103)."""
 
     def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1, precision="f64",
-                 smoother="gs", omega=0.8, jacobi_max_rows=100000):
+                 smoother="gs", omega=0.8, jacobi_max_rows=100000, cheby_fraction=0.1):
         """smoother: "gs" (the reference's relax(), default) / "jacobi" (damped Jacobi on every level) / "hybrid" (Gauss-Seidel on
-        the levels with more than `jacobi_max_rows` unknowns, Jacobi below)."""
+        the levels with more than `jacobi_max_rows` unknowns, Jacobi below) / "chebyshev", "hybrid_chebyshev" (the same layouts with
+        Chebyshev-accelerated Jacobi: one polynomial of degree iters + 1 per relax(iters), include/smg.h)."""
         prec = {"f64": 0, "fp64": 0, 0: 0, "mixed": 1, 1: 1}[precision]
         self.c = SolveOptsC(tol, max_iter, pre, post, verbosity, check_every, use_graph, prec, SMOOTHERS[smoother], omega,
-                            jacobi_max_rows)
+                            jacobi_max_rows, cheby_fraction)
 
 
 class Hierarchy:
@@ -103,9 +104,14 @@ class Hierarchy:
         """Use the given HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); None / 0 = the default stream."""
         _chk(self.L.smg_hierarchy_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "smg_hierarchy_set_stream")
 
-    def set_smoother(self, smoother="gs", omega=0.0, jacobi_max_rows=-1):
+    def set_smoother(self, smoother="gs", omega=0.0, jacobi_max_rows=-1, cheby_fraction=0.0):
         """Smoother of vcycle()/relax() and the raw entry points (solve() takes it from its SolveOpts)."""
         _chk(self.L.smg_hierarchy_set_smoother(self.h, SMOOTHERS[smoother], omega, jacobi_max_rows), "smg_hierarchy_set_smoother")
+        _chk(self.L.smg_hierarchy_set_chebyshev(self.h, cheby_fraction), "smg_hierarchy_set_chebyshev")
+
+    def spectral_bound(self, lv):
+        """Gershgorin bound of D^-1 A on level lv (what the Chebyshev-Jacobi smoother uses)."""
+        return self.L.smg_level_spectral_bound(self.h, lv)
 
     def save(self, path):
         _chk(self.L.smg_hierarchy_save(self.h, path.encode()), "smg_hierarchy_save")

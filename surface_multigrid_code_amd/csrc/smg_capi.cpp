@@ -67,6 +67,7 @@ extern "C" void smg_solve_opts_default(smg_solve_opts* o)
     o->smoother = SMG_SMOOTH_GS;   // the reference's relax()
     o->omega = 0.8;
     o->jacobi_max_rows = 100000;
+    o->cheby_fraction = 0.1;
 }
 
 // ------------------------------------------------------------------------------------------------ device plumbing
@@ -260,14 +261,28 @@ extern "C" int smg_hierarchy_set_stream(smg_hierarchy* h, void* hip_stream)
 extern "C" int smg_hierarchy_set_smoother(smg_hierarchy* h, int smoother, double omega, int jacobi_max_rows)
 {
     if (!h) return fail(SMG_ERR_INVALID, "null handle");
-    if (smoother != SMG_SMOOTH_GS && smoother != SMG_SMOOTH_JACOBI && smoother != SMG_SMOOTH_HYBRID)
-        return fail(SMG_ERR_INVALID, "smoother must be SMG_SMOOTH_GS, _JACOBI or _HYBRID");
+    if (smoother < SMG_SMOOTH_GS || smoother > SMG_SMOOTH_HYBRID_CHEBYSHEV)
+        return fail(SMG_ERR_INVALID, "smoother must be one of SMG_SMOOTH_GS, _JACOBI, _HYBRID, _CHEBYSHEV, _HYBRID_CHEBYSHEV");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_smoother called during a split-phase solve");
     if (omega > 2.0 || omega != omega) return fail(SMG_ERR_INVALID, "omega must be in (0, 2]");
     h->smoother = smoother;
     if (omega > 0.0) h->omega = omega;
     if (jacobi_max_rows >= 0) h->jacobi_max_rows = jacobi_max_rows;
     return SMG_OK;
+}
+
+extern "C" int smg_hierarchy_set_chebyshev(smg_hierarchy* h, double cheby_fraction)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_chebyshev called during a split-phase solve");
+    if (cheby_fraction >= 1.0 || cheby_fraction != cheby_fraction) return fail(SMG_ERR_INVALID, "cheby_fraction must be in (0, 1)");
+    if (cheby_fraction > 0.0) h->cheby_fraction = cheby_fraction;
+    return SMG_OK;
+}
+extern "C" double smg_level_spectral_bound(const smg_hierarchy* h, int lv)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return 0.0;
+    return h->lv[lv].lam;
 }
 
 // CSR/CSC array sanity: monotone pointers, indices in range.  Returns an error string or nullptr.
@@ -529,6 +544,28 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     return SMG_OK;
 }
 
+// Gershgorin bound of D^-1 A per smoothed level (what the Chebyshev-Jacobi smoother is built on), from the SELL image the smoother
+// streams, i.e. in the device numbering's summation order -- the same value the oracle computes on the level matrix in that numbering.
+static int spectral_bounds(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    if (L < 2) return SMG_OK;
+    HIPCHK(h->d_lam.ensure((size_t)L));
+    for (int lv = 0; lv < L - 1; lv++) {
+        Level& Lv = h->lv[lv];
+        HIPCHK(launch_gershgorin(Lv.gs_on_transpose ? Lv.dAT.view : Lv.dA.view, h->d_lam.p + lv, h->stream));
+    }
+    std::vector<double> lam((size_t)L, 0.0);
+    HIPCHK(hipMemcpyAsync(lam.data(), h->d_lam.p, (size_t)(L - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int lv = 0; lv < L - 1; lv++) {
+        if (!(lam[lv] > 0.0) || !std::isfinite(lam[lv])) return fail(SMG_ERR_INVALID, "level %d: no positive diagonal to scale by", lv);
+        if (lam[lv] != h->lv[lv].lam) drop_graphs(h);   // the coefficients are kernel arguments of the captured launches
+        h->lv[lv].lam = lam[lv];
+    }
+    return SMG_OK;
+}
+
 // Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
 static int precompute_device(smg_hierarchy* h)
 {
@@ -539,8 +576,8 @@ static int precompute_device(smg_hierarchy* h)
     drop_graphs(h);
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
-        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release();
-        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release();
+        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release(); Lv.d.release();
+        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release(); Lv.d32.release();
     }
     h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
     StageTimer tm;
@@ -659,7 +696,7 @@ static int precompute_device(smg_hierarchy* h)
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     tm.lap("device: coarse dense inverse");
-    return SMG_OK;
+    return spectral_bounds(h);
 }
 
 // ---- value-only re-precompute --------------------------------------------------------
@@ -815,7 +852,7 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
     }
     h->host_stale = true;
     h->f32_valid = false;   // the fp32 copies are re-made from the new values when a mixed solve asks for them
-    return SMG_OK;
+    return spectral_bounds(h);
 }
 
 // bring the host copies (mg[l].A, A_diag, Auk, A_int) up to date after a device-side re-precompute
@@ -945,6 +982,8 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
 }
 
 // ------------------------------------------------------------------------------------------------ V-cycle
+enum { LV_GS = 0, LV_JACOBI = 1, LV_CHEBY = 2 };
+static int level_kind(const smg_hierarchy* h, int lv);
 static bool level_is_jacobi(const smg_hierarchy* h, int lv);
 
 static int ensure_work(smg_hierarchy* h, int k)
@@ -960,7 +999,7 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(Lv.u.alloc(rows * k));
             HIPCHK(hipMemsetAsync(Lv.b.p, 0, rows * k * sizeof(double), h->stream));
             HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
-            Lv.t.release();
+            Lv.t.release(); Lv.d.release();
             if (lv < L - 1 || L == 1) HIPCHK(Lv.r.alloc(rows * k));
             if (lv < L - 1 || L == 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
         }
@@ -974,6 +1013,11 @@ static int ensure_work(smg_hierarchy* h, int k)
             drop_graphs(h);
             HIPCHK(Lv.t.alloc((size_t)Lv.n * h->kcap));
             HIPCHK(hipMemsetAsync(Lv.t.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
+        }
+        if (level_kind(h, lv) == LV_CHEBY && Lv.d.n < (size_t)Lv.n * h->kcap) {
+            drop_graphs(h);
+            HIPCHK(Lv.d.alloc((size_t)Lv.n * h->kcap));
+            HIPCHK(hipMemsetAsync(Lv.d.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
         }
     }
     return SMG_OK;
@@ -1019,7 +1063,7 @@ static int ensure_fp32(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.b32.p, 0, rows * k * sizeof(float), h->stream));
             HIPCHK(hipMemsetAsync(Lv.u32.p, 0, rows * k * sizeof(float), h->stream));
             if (lv < L - 1) HIPCHK(Lv.r32.alloc(rows * k));
-            Lv.t32.release();
+            Lv.t32.release(); Lv.d32.release();
         }
         h->kcap32 = k;
     }
@@ -1030,6 +1074,11 @@ static int ensure_fp32(smg_hierarchy* h, int k)
             HIPCHK(Lv.t32.alloc((size_t)Lv.n * h->kcap32));
             HIPCHK(hipMemsetAsync(Lv.t32.p, 0, (size_t)Lv.n * h->kcap32 * sizeof(float), h->stream));
         }
+        if (level_kind(h, lv) == LV_CHEBY && Lv.d32.n < (size_t)Lv.n * h->kcap32) {
+            drop_graphs(h);
+            HIPCHK(Lv.d32.alloc((size_t)Lv.n * h->kcap32));
+            HIPCHK(hipMemsetAsync(Lv.d32.p, 0, (size_t)Lv.n * h->kcap32 * sizeof(float), h->stream));
+        }
     }
     return SMG_OK;
 }
@@ -1037,12 +1086,38 @@ static int ensure_fp32(smg_hierarchy* h, int k)
 // ---- the smoother of a level -------------------------------------------------------------------------------------------
 // SMG_SMOOTH_GS (default): the reference's relax().  SMG_SMOOTH_JACOBI / _HYBRID: damped Jacobi on all / on the small levels
 // (BASELINE.json north_star: "Gauss-Seidel/Jacobi smoothing"; one whole-matrix launch per sweep instead of one per colour).
-static bool level_is_jacobi(const smg_hierarchy* h, int lv)
+static int level_kind(const smg_hierarchy* h, int lv)
 {
-    if (lv < 0 || lv >= h->n_levels - 1) return false;
-    if (h->smoother == SMG_SMOOTH_JACOBI) return true;
-    if (h->smoother == SMG_SMOOTH_HYBRID) return h->lv[lv].n <= h->jacobi_max_rows;
-    return false;
+    if (lv < 0 || lv >= h->n_levels - 1) return LV_GS;
+    switch (h->smoother) {
+        case SMG_SMOOTH_JACOBI: return LV_JACOBI;
+        case SMG_SMOOTH_HYBRID: return h->lv[lv].n <= h->jacobi_max_rows ? LV_JACOBI : LV_GS;
+        case SMG_SMOOTH_CHEBYSHEV: return LV_CHEBY;
+        case SMG_SMOOTH_HYBRID_CHEBYSHEV: return h->lv[lv].n <= h->jacobi_max_rows ? LV_CHEBY : LV_GS;
+    }
+    return LV_GS;
+}
+static bool level_is_jacobi(const smg_hierarchy* h, int lv) { return level_kind(h, lv) != LV_GS; }   // needs the second iterate buffer
+
+// Coefficients of the Chebyshev-Jacobi recurrence (include/smg.h, SMG_SMOOTH_CHEBYSHEV): step s computes d = c1 d + c2 r, u += d.
+// The same statements, in the same order, as oracle/smg_oracle.c: cheby_coefs() -- both are compiled without FMA contraction.
+struct ChebyCoef { double c1, c2; };
+static void cheby_coefs(double lam, double frac, int degree, std::vector<ChebyCoef>& out)
+{
+    out.resize((size_t)std::max(degree, 0));
+    const double lmax = lam, lmin = lam * frac;
+    const double theta = (lmax + lmin) / 2.0, delta = (lmax - lmin) / 2.0;
+    const double sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    for (int s = 0; s < degree; s++) {
+        if (s == 0) { out[s].c1 = 0.0; out[s].c2 = 1.0 / theta; }
+        else {
+            const double rho_new = 1.0 / (2.0 * sigma - rho);
+            out[s].c1 = rho_new * rho;
+            out[s].c2 = 2.0 * rho_new / delta;
+            rho = rho_new;
+        }
+    }
 }
 
 // one accessor set per arithmetic: fp64 (the reference's) and the fp32 images of the mixed-precision V-cycle
@@ -1052,6 +1127,8 @@ template <> struct Prec<double> {
     static double* u(Level& L) { return L.u.p; }
     static double* r(Level& L) { return L.r.p; }
     static double* t(Level& L) { return L.t.p; }
+    static double* d(Level& L) { return L.d.p; }
+    static void set_d(FirstColour& fc, Level& L) { fc.d = L.d.p; }
     static const SellDev& A(Level& L) { return L.dA.view; }
     static const SellDev& G(Level& L) { return L.gs_on_transpose ? L.dAT.view : L.dA.view; }   // what the smoother streams
     static const SellDev& P(Level& L) { return L.dP.view; }
@@ -1068,6 +1145,8 @@ template <> struct Prec<float> {
     static float* u(Level& L) { return L.u32.p; }
     static float* r(Level& L) { return L.r32.p; }
     static float* t(Level& L) { return L.t32.p; }
+    static float* d(Level& L) { return L.d32.p; }
+    static void set_d(FirstColour& fc, Level& L) { fc.df = L.d32.p; }
     static const SellDev& A(Level& L) { return L.dA32; }
     static const SellDev& G(Level& L) { return L.gs_on_transpose ? L.dAT32 : L.dA32; }
     static const SellDev& P(Level& L) { return L.dP32; }
@@ -1109,6 +1188,27 @@ static int enqueue_jacobi(smg_hierarchy* h, int lv, const T* b, T* const buf[2],
     return SMG_OK;
 }
 
+// relax(iters) on a Chebyshev-Jacobi level: ONE polynomial of degree iters + 1, i.e. iters + 1 whole-matrix launches ping-ponging like
+// the Jacobi sweeps; first_done: step 0 was produced by the restriction launch.
+template <typename T>
+static int enqueue_cheby(smg_hierarchy* h, int lv, const T* b, T* const buf[2], int* cur, int k, int iters, const Ctrl* ctrl, bool first_done = false)
+{
+    if (iters <= 0) return SMG_OK;
+    Level& Lv = h->lv[lv];
+    ProfGuard pg(h, "MG: relaxation");
+    const SellDev& G = Prec<T>::G(Lv);
+    std::vector<ChebyCoef> cf;
+    cheby_coefs(Lv.lam, h->cheby_fraction, iters + 1, cf);
+    for (int s = first_done ? 1 : 0; s <= iters; s++) {
+        FirstColour fc;
+        Prec<T>::set_d(fc, Lv);
+        fc.c1 = cf[s].c1;
+        HIPCHK(Prec<T>::sell(SELL_CHEBY, G, 0, G.n_slices, buf[*cur], b, buf[1 - *cur], k, ctrl, h->stream, nullptr, &fc, cf[s].c2));
+        *cur ^= 1;
+    }
+    return SMG_OK;
+}
+
 // reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
 static bool fuse_first_colour() { static const int on = env_int("SMG_FUSE_FIRST", 1); return on != 0; }
 
@@ -1125,13 +1225,17 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         return SMG_OK;
     }
     Level& Lc = h->lv[lv + 1];
-    const bool jac = level_is_jacobi(h, lv);
-    T* const buf[2] = {Prec<T>::u(Lv), Prec<T>::t(Lv)};   // Jacobi levels ping-pong; the level's result always ends in buf[0] = u
+    const int kind = level_kind(h, lv);
+    const bool jac = kind != LV_GS;
+    T* const buf[2] = {Prec<T>::u(Lv), Prec<T>::t(Lv)};   // Jacobi-type levels ping-pong; the level's result always ends in buf[0] = u
     int cur = 0;
     int rc;
-    if (jac) {
+    if (kind == LV_JACOBI) {
         if (first_done) cur = 1;
         rc = enqueue_jacobi<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, pre - (first_done ? 1 : 0), ctrl);            // :36
+    } else if (kind == LV_CHEBY) {
+        if (first_done) cur = 1;
+        rc = enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, pre, ctrl, first_done);                         // :36
     } else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first_done);                            // :36
     if (rc) return rc;
     {   // r = B - A u  (:40-42)
@@ -1142,7 +1246,8 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     // (the first colour / with Jacobi all rows, damped): the restriction launch writes that itself, bit for bit the same value, and
     // the sweep starts one launch later.
     const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
-    const bool jac_c = level_is_jacobi(h, lv + 1);
+    const int kind_c = level_kind(h, lv + 1);
+    const bool jac_c = kind_c != LV_GS;
     const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
     {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
@@ -1150,7 +1255,13 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         if (fuse) {
             fc.diag_slot = Gc.diag_slot.p; fc.n_first = jac_c ? Gc.n_all : Gc.n_first;
             fc.val = Prec<T>::G(Lc).val; fc.valf = Prec<T>::G(Lc).valf;
-            fc.jacobi = jac_c ? 1 : 0; fc.omega = h->omega;
+            fc.jacobi = kind_c == LV_CHEBY ? 2 : (jac_c ? 1 : 0); fc.omega = h->omega;
+            if (kind_c == LV_CHEBY) {   // step 0 of the coarse level's polynomial: d = (rc_i / a_ii - 0) / theta, uc = 0 + d
+                std::vector<ChebyCoef> cf;
+                cheby_coefs(Lc.lam, h->cheby_fraction, 1, cf);
+                fc.omega = cf[0].c2;
+                Prec<T>::set_d(fc, Lc);
+            }
         }
         // Jacobi + fuse: the first sweep's output buffer (t) receives the sweep, u = 0 is never read
         T* init = (fuse && jac_c) ? Prec<T>::t(Lc) : Prec<T>::u(Lc);
@@ -1163,10 +1274,12 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         // the last sweep lands in u.
         ProfGuard pg(h, "MG: prolong");
         int dst = cur;
-        if (jac && ((cur + post) & 1)) dst = 1 - cur;
+        const int flips = kind == LV_CHEBY ? (post > 0 ? post + 1 : 0) : post;   // buffer switches of the post-smoothing
+        if (jac && ((cur + flips) & 1)) dst = 1 - cur;
         HIPCHK(Prec<T>::sell(SELL_ADD, Prec<T>::P(Lc), 0, Prec<T>::P(Lc).n_slices, Prec<T>::u(Lc), buf[cur], buf[dst], k, ctrl, h->stream));
         cur = dst;
     }
+    if (kind == LV_CHEBY) return enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
     if (jac) return enqueue_jacobi<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
     return enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, post, ctrl);                    // :57
 }
@@ -1187,7 +1300,8 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
     Level& Lv = h->lv[lv];
     double* const buf[2] = {u, Lv.t.p};
     int cur = 0;
-    int rc = enqueue_jacobi<double>(h, lv, b, buf, &cur, k, iters, ctrl);
+    int rc = level_kind(h, lv) == LV_CHEBY ? enqueue_cheby<double>(h, lv, b, buf, &cur, k, iters, ctrl)
+                                           : enqueue_jacobi<double>(h, lv, b, buf, &cur, k, iters, ctrl);
     if (rc) return rc;
     if (cur == 1) HIPCHK(hipMemcpyAsync(u, Lv.t.p, (size_t)Lv.n * k * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return SMG_OK;
@@ -1264,7 +1378,7 @@ static int capture_split_graphs(smg_hierarchy* h, double* buf)
 static int ensure_graphs(smg_hierarchy* h)
 {
     if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision &&
-        h->g_smoother == h->smoother && h->g_omega == h->omega && h->g_jmax == h->jacobi_max_rows) return SMG_OK;
+        h->g_smoother == h->smoother && h->g_omega == h->omega && h->g_jmax == h->jacobi_max_rows && h->g_frac == h->cheby_fraction) return SMG_OK;
     drop_graphs(h);
     const int k = h->k;
     int rc = capture_graph(h, &h->g_iter, [&]() {
@@ -1276,7 +1390,7 @@ static int ensure_graphs(smg_hierarchy* h)
     rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
     if (rc) return rc;
     h->g_k = k; h->g_pre = h->pre; h->g_post = h->post; h->g_prec = h->precision;
-    h->g_smoother = h->smoother; h->g_omega = h->omega; h->g_jmax = h->jacobi_max_rows;
+    h->g_smoother = h->smoother; h->g_omega = h->omega; h->g_jmax = h->jacobi_max_rows; h->g_frac = h->cheby_fraction;
     return SMG_OK;
 }
 
@@ -1326,6 +1440,7 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
     if (o.precision != 0 && o.precision != 1) return fail(SMG_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
     h->precision = o.precision;
     if ((rc = smg_hierarchy_set_smoother(h, o.smoother, o.omega, o.jacobi_max_rows))) return rc;
+    if ((rc = smg_hierarchy_set_chebyshev(h, o.cheby_fraction))) return rc;
     DeviceScope dsc(h->device);
     rc = ensure_work(h, k);
     if (rc) return rc;

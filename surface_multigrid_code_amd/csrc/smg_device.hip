@@ -49,7 +49,11 @@ static const int* never_done()
 // what a restriction launch leaves in the coarse level's u (see FirstColour in smg_device.hpp)
 // jacobi != 0: the coarse level is smoothed by damped Jacobi -- ALL its rows (n_first = n_rows) get what the first Jacobi sweep from
 // u = 0 leaves there, 0 + omega * (rc_i / a_ii - 0).  omega doubles as the damping factor of a SELL_JACOBI launch.
-template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; int jacobi; T omega; };
+// jacobi == 2: the coarse level is smoothed by Chebyshev-accelerated Jacobi: its first step from u = 0 is d = omega * (rc_i / a_ii - 0),
+// u = 0 + d (omega = that step's coefficient), written to u and d.
+// SELL_CHEBY launches use d (the step's update vector, own row in / out), c1 (coefficient of the old update; 0 on the first step: d is
+// not read then) and omega (coefficient of the scaled residual).
+template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; int jacobi; T omega; T* d; T c1; };
 
 // One wavefront per slice of 64 rows; lane l owns row row0 + l.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         // reads below from scalar into vector loads.)
         {
             size_t keep = (size_t)x ^ (size_t)A.slice_row ^ (size_t)A.slice_w ^ (size_t)b ^ (size_t)y ^ (size_t)done ^ (size_t)ld;
-            if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first ^ (size_t)z.jacobi;
+            if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first ^ (size_t)z.jacobi ^ (size_t)z.d;
+            if (MODE == SELL_CHEBY) keep ^= (size_t)z.d;
             asm("" : "+s"(keep));
             if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
         }
@@ -120,16 +125,18 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         const int rowb = row0 + lane;
         T acc[KB];
         T diag = (T)1;
-        T xi[KB];  // SELL_JACOBI: the row's own old value (it travels with the gathers: the diagonal entry's column)
+        T xi[KB];  // SELL_JACOBI / SELL_CHEBY: the row's own old value (it travels with the gathers: the diagonal entry's column)
+        T dold[KB];  // SELL_CHEBY: the row's previous update
         T bv[KB];  // b (or the prolongation's input iterate for SELL_ADD): requested now, consumed after the panel loop
         const bool live = lane < nrow;
         T zd = (T)1;   // restriction with a fused first colour: the coarse diagonal, requested now
         if (MODE == SELL_AX && live && rowb < z.n_first) zd = z.gs_val[z.diag_slot[rowb]];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
-            acc[q] = (T)0; xi[q] = (T)0;
+            acc[q] = (T)0; xi[q] = (T)0; dold[q] = (T)0;
             if (MODE == SELL_AX) bv[q] = (T)0;
             else bv[q] = live ? b[(size_t)rowb * ld + q] : (T)0;   // SELL_ADD: b is the iterate the correction is added to (== y in place)
+            if (MODE == SELL_CHEBY && live && z.c1 != (T)0) dold[q] = z.d[(size_t)rowb * ld + q];
         }
         // one batch of U panel columns: gather x for all of them, then accumulate in ascending column order
         auto consume = [&](const int (&c)[U], const T (&v)[U]) {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                 if (c[t] >= 0) {
                     if (MODE == SELL_GS && c[t] == rowb) {
                         diag = v[t];
-                    } else if (MODE == SELL_JACOBI && c[t] == rowb) {
+                    } else if ((MODE == SELL_JACOBI || MODE == SELL_CHEBY) && c[t] == rowb) {
                         diag = v[t];
 #pragma unroll
                         for (int q = 0; q < KB; q++) xi[q] = xv[t][q];
@@ -195,13 +202,21 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                     y[o + q] = acc[q];
                     if (z.u) {
                         const T t = acc[q] / zd;
-                        z.u[o + q] = rowb < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+                        if (z.jacobi == 2) { const T dn = z.omega * (t - (T)0); z.u[o + q] = (T)0 + dn; z.d[o + q] = dn; }
+                        else z.u[o + q] = rowb < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
                     }
                 }
                 else if (MODE == SELL_RESID) y[o + q] = bv[q] - acc[q];
                 else if (MODE == SELL_ADD) y[o + q] = bv[q] + acc[q];
                 else if (MODE == SELL_GS) y[o + q] = (bv[q] - acc[q]) / diag;
                 else if (MODE == SELL_JACOBI) { const T t = (bv[q] - acc[q]) / diag; y[o + q] = xi[q] + z.omega * (t - xi[q]); }
+                else if (MODE == SELL_CHEBY) {
+                    const T t = (bv[q] - acc[q]) / diag;
+                    const T r = t - xi[q];
+                    const T dn = z.c1 != (T)0 ? z.c1 * dold[q] + z.omega * r : z.omega * r;
+                    y[o + q] = xi[q] + dn;
+                    z.d[o + q] = dn;
+                }
                 else { const double t = (double)(bv[q] - acc[q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[q] - acc[q]; }
             }
         }
@@ -255,17 +270,18 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int w = A.slice_w[s];
         int rl[R];
-        T acc[R], diag[R], bv[R], zd[R], xi[R];
+        T acc[R], diag[R], bv[R], zd[R], xi[R], dold[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             rl[r] = sub * RW + r * G + g;   // row inside the slice
-            acc[r] = (T)0; diag[r] = (T)1; xi[r] = (T)0;
+            acc[r] = (T)0; diag[r] = (T)1; xi[r] = (T)0; dold[r] = (T)0;
             const bool live = rl[r] < nrow;
             zd[r] = (T)1;
             if (MODE == SELL_AX && live && row0 + rl[r] < z.n_first) zd[r] = z.gs_val[z.diag_slot[row0 + rl[r]]];
             const size_t o = (size_t)(row0 + rl[r]) * ld + c;
             if (MODE == SELL_AX) bv[r] = (T)0;
             else bv[r] = live ? b[o] : (T)0;
+            if (MODE == SELL_CHEBY && live && z.c1 != (T)0) dold[r] = z.d[o];
         }
         const int* cp = A.col + (size_t)off0 * 64;
         const T* vp = a_val + (size_t)off0 * 64;
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                 for (int r = 0; r < R; r++) {
                     if (cc[t][r] >= 0) {
                         if (MODE == SELL_GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
-                        else if (MODE == SELL_JACOBI && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
+                        else if ((MODE == SELL_JACOBI || MODE == SELL_CHEBY) && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
                         else acc[r] += vv[t][r] * xv[t][r];
                     }
                 }
@@ -307,13 +323,21 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                     y[o] = acc[r];
                     if (z.u) {
                         const T t = acc[r] / zd[r];
-                        z.u[o] = row0 + rl[r] < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+                        if (z.jacobi == 2) { const T dn = z.omega * (t - (T)0); z.u[o] = (T)0 + dn; z.d[o] = dn; }
+                        else z.u[o] = row0 + rl[r] < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
                     }
                 }
                 else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
                 else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
                 else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
                 else if (MODE == SELL_JACOBI) { const T t = (bv[r] - acc[r]) / diag[r]; y[o] = xi[r] + z.omega * (t - xi[r]); }
+                else if (MODE == SELL_CHEBY) {
+                    const T t = (bv[r] - acc[r]) / diag[r];
+                    const T rr = t - xi[r];
+                    const T dn = z.c1 != (T)0 ? z.c1 * dold[r] + z.omega * rr : z.omega * rr;
+                    y[o] = xi[r] + dn;
+                    z.d[o] = dn;
+                }
                 else { const double t = (double)(bv[r] - acc[r]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o] = bv[r] - acc[r]; }
             }
         }
@@ -331,7 +355,11 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
 template <typename T> static const T* host_vals(const SellDev& A);
 template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, const FirstColour* first, double omega)
 {
-    CoarseInit<T> z{zero_rows ? zero_rows + c0 : nullptr, nullptr, nullptr, 0, 0, (T)omega};
+    CoarseInit<T> z{zero_rows ? zero_rows + c0 : nullptr, nullptr, nullptr, 0, 0, (T)omega, nullptr, (T)0};
+    if (first) {   // Chebyshev step / fused first Chebyshev step: the update vector and the old update's coefficient
+        if constexpr (std::is_same<T, double>::value) z.d = first->d ? first->d + c0 : nullptr; else z.d = first->df ? first->df + c0 : nullptr;
+        z.c1 = (T)first->c1;
+    }
     if (zero_rows && first && first->n_first > 0) {
         if constexpr (std::is_same<T, double>::value) z.gs_val = first->val; else z.gs_val = first->valf;
         z.diag_slot = first->diag_slot;
@@ -454,6 +482,7 @@ static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, 
 {
     switch (mode) {
         case SELL_JACOBI: return launch_sell_mode<SELL_JACOBI, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+        case SELL_CHEBY: return launch_sell_mode<SELL_CHEBY, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
         case SELL_AX: return launch_sell_mode<SELL_AX, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
         case SELL_RESID: return launch_sell_mode<SELL_RESID, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
         case SELL_RESID_SS:
@@ -481,6 +510,38 @@ hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_e
 {
     if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
     return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega);
+}
+
+// ---- Gershgorin bound of D^-1 A for the Chebyshev-Jacobi smoother: max over rows of (sum_j |a_ij|) / a_ii, the row sums accumulated in
+// ascending column order (the order of the SELL panel), the maximum over rows through an integer atomic on the bit pattern (the values
+// are positive: order-preserving, and a maximum does not depend on the order it is taken in: deterministic).  *out must be 0 on entry.
+__global__ __launch_bounds__(256) void k_gershgorin(const int* a_col, const double* a_val, const int* a_slice_row, const int* a_slice_off, const int* a_slice_w,
+                                                    int stride, int n_slices, unsigned long long* out)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double ratio = 0.0;
+    if (s < n_slices) {
+        const int row0 = a_slice_row[s], nrow = a_slice_row[s + 1] - row0, w = a_slice_w[s];
+        const size_t off = (size_t)(stride ? s * stride : a_slice_off[s]) * 64 + lane;
+        double sum = 0.0, diag = 0.0;
+        for (int j = 0; j < w; j++) {
+            const int c = a_col[off + (size_t)j * 64];
+            const double v = a_val[off + (size_t)j * 64];
+            if (c >= 0) { sum += fabs(v); if (c == row0 + lane) diag = v; }
+        }
+        if (lane < nrow && diag > 0.0) ratio = sum / diag;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ratio = fmax(ratio, __shfl_down(ratio, o, 64));
+    if (lane == 0 && ratio > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(ratio));
+}
+hipError_t launch_gershgorin(const SellDev& A, double* out, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess || A.n_slices <= 0) return e;
+    hipLaunchKernelGGL(k_gershgorin, dim3((A.n_slices + 3) / 4), dim3(256), 0, st, A.col, A.val, A.slice_row, A.slice_off, A.slice_w, A.stride, A.n_slices,
+                       (unsigned long long*)out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------- solve-loop control

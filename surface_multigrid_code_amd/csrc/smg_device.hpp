@@ -48,6 +48,8 @@ enum SellMode {
     SELL_RESID_BOTH = 5,  // y = b - A x AND the partial sums of its squares (outer loop of the mixed-precision mode)
     SELL_JACOBI = 6,    // y_i = x_i + omega * ((b_i - sum_{j != i} A_ij x_j) / A_ii - x_i): one damped-Jacobi sweep from x into y (x != y),
                         // whole matrix in one launch (the "Jacobi" of BASELINE.json's north_star; same slot as SELL_GS, mg_VCycle.cpp:113-178)
+    SELL_CHEBY = 7,     // one step of Chebyshev-accelerated Jacobi from x into y (x != y):  r_i = (b_i - sum_{j != i} A_ij x_j) / A_ii - x_i,
+                        // d_i = c1 d_i + c2 r_i (first step, c1 == 0: d_i = c2 r_i, d not read),  y_i = x_i + d_i
 };
 
 // SELL_ADD: y = b + A x, where b is the iterate the correction is added to (b == nullptr: in place, b = y).
@@ -64,8 +66,12 @@ struct FirstColour {
     int n_first = 0;                  // rows of the first colour (they lead the colour-major numbering)
     const double* val = nullptr;      // the sweep's SELL values (A or A^T) ...
     const float* valf = nullptr;      // ... and their fp32 image
-    int jacobi = 0;                   // != 0: the coarse level is smoothed by damped Jacobi: n_first = all its rows, and they receive the
-    double omega = 1.0;               //        first sweep from u = 0:  0 + omega * (y_i / a_ii - 0)
+    int jacobi = 0;                   // 1: the coarse level is smoothed by damped Jacobi: n_first = all its rows, and they receive the
+    double omega = 1.0;               //    first sweep from u = 0:  0 + omega * (y_i / a_ii - 0).  2: Chebyshev-Jacobi: d_i = omega * (y_i /
+                                      //    a_ii - 0), u_i = 0 + d_i, both written (d / df below)
+    double* d = nullptr;              // SELL_CHEBY launches and jacobi == 2: the update vector (n x k, internal layout) ...
+    float* df = nullptr;              // ... its fp32 twin
+    double c1 = 0.0;                  // SELL_CHEBY: coefficient of the old update (0 = first step, d is not read); `omega` is c2
 };
 hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, const double* x, const double* b,
                        double* y, int k, const Ctrl* ctrl, double* partials, int* n_blocks, hipStream_t st,
@@ -73,6 +79,8 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
                            float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows = nullptr,
                            const FirstColour* first = nullptr, double omega = 1.0);
+// *out (device double) = max_i (sum_j |a_ij|) / a_ii over the rows of A: the Gershgorin bound of the spectrum of D^-1 A
+hipError_t launch_gershgorin(const SellDev& A, double* out, hipStream_t st);
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

@@ -86,6 +86,9 @@ struct Level {
     DevBuf<double> b, u, r;
     DevBuf<double> t;       // second iterate of a Jacobi-smoothed level (the sweeps ping-pong between u and t); allocated on demand
     DevBuf<float> t32;
+    DevBuf<double> d;       // update vector of a Chebyshev-Jacobi-smoothed level; allocated on demand
+    DevBuf<float> d32;
+    double lam = 0.0;       // Gershgorin bound of the spectrum of D^-1 A (D^-1 A^T where the smoother streams A^T), device numbering
     int n = 0;
 };
 
@@ -142,6 +145,8 @@ struct smg_hierarchy {
     int smoother = 0;
     double omega = 0.8;
     int jacobi_max_rows = 100000;
+    double cheby_fraction = 0.1;   // Chebyshev-Jacobi: the polynomial damps the eigenvalues of D^-1 A in [fraction * lam, lam]
+    smg::DevBuf<double> d_lam;     // scratch for launch_gershgorin
     int iters_enqueued = 0;
     smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
     smg::DevBuf<double> d_zsave;     // iterate saved by the speculative cycle
@@ -153,7 +158,7 @@ struct smg_hierarchy {
     double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
     int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
     int g_smoother = 0, g_jmax = 0;   // the smoother selection the cached graphs were captured with
-    double g_omega = 0.0;
+    double g_omega = 0.0, g_frac = 0.0;
     // ---- profc mirror ----
     bool prof_on = false;
     std::vector<smg::ProfScope> scopes;

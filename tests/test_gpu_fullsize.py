@@ -99,3 +99,113 @@ def test_c5_four_million_vertices_fp64_and_mixed(smg_mod):
         conv, z, rh = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10 * np.linalg.norm(rhs), max_iter=60, precision=prec))
         assert conv and (np.diff(rh) < 0).all(), (prec, rh)
         assert np.linalg.norm(rhs - A @ z[:, 0]) <= 2e-10 * np.linalg.norm(rhs)
+
+
+# ----------------------------------------------------------------------------------------------- oracle at full size, all-core mode
+def _oracle_in_device_numbering(oracle_mod, mg, A, known=None, threads=32):
+    """The oracle on the system renumbered colour-major with the GPU path's own numbering (level by level): the reference's
+    lexicographic sweep on it IS the multi-colour sweep the GPU runs, so GPU and oracle iterate identically up to the coarse solve
+    (dense inverse vs LDL^T, 1e-11) and summation order of the norms -- and the colour blocks can be swept by all host cores without
+    changing a bit (oracle all-core mode), which brings 1 M / 4 M-vertex solves into test time."""
+    import scipy.sparse as sp
+    L = mg.n_levels
+    perms = [mg.perm(l) for l in range(L)]
+    Ps = [sp.csr_matrix(mg.matrix(l, "P"))[perms[l - 1]][:, perms[l]].tocsc() for l in range(1, L)]
+    A0 = sp.csr_matrix(mg.matrix(0, "A"))[perms[0]][:, perms[0]].tocsr()      # LHS = A(unknown, unknown), device numbering
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A0)
+    orc.set_parallel([mg.colors(l) for l in range(L - 1)], threads)
+    return orc, perms[0]
+
+
+def test_c3_poisson_with_346_pins_full_size_against_oracle(c3, oracle_mod):
+    """C3's second system: Poisson -L with 346 pinned vertices on the 1 011 330-vertex mesh, z0 uniform(-1,1),
+    tol 1e-10 -- GPU against the oracle in the device numbering, iteration for iteration."""
+    smg, mg0, A_mcf, Mb, Vf = c3
+    mesh = smg.mesh
+    V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg, Vf2, Ff = smg.mg_precompute_subdiv(V, F, 3, ratio=0.25, nVCoarsest=1000, n_extra_levels=1)
+    n = Vf2.shape[0]
+    A = (-mesh.cotmatrix(Vf2, Ff)).tocsr()
+    A.sort_indices()
+    known = np.sort(np.random.default_rng(0).choice(n, 346, replace=False)).astype(np.int32)
+    mg.precompute(A, known)
+    assert mg.rows(0) == n - 346
+    B = mesh.massmatrix(Vf2, Ff, "voronoi") @ np.ones(n)
+    B[known] = 0.0
+    z0 = np.random.default_rng(1).uniform(-1, 1, n)
+    kv = np.zeros(346)
+    conv, z, rh = mg.solve(B, z0, kv, smg.SolveOpts(tol=1e-10, max_iter=60))
+    assert conv and np.array_equal(z[known, 0], kv)
+    unk = mg.unknown()
+    true = np.linalg.norm((B - A @ z[:, 0])[unk])
+    assert true < 1.5e-10
+    # the same reduced system through the oracle (device numbering, all-core): identical iteration
+    orc, perm0 = _oracle_in_device_numbering(oracle_mod, mg, A, known)
+    rhs_u = (B - A[:, known] @ kv)[unk][perm0]
+    conv2, z2, rh2 = orc.solve(rhs_u, z0[unk][perm0], tol=1e-10, max_iter=60)
+    assert conv2 and len(rh2) == len(rh)
+    np.testing.assert_allclose(rh, rh2, rtol=1e-6)
+    assert np.linalg.norm(z[unk, 0][perm0] - z2[:, 0]) <= 1e-9 * np.linalg.norm(z2)
+
+
+def test_c5_solve_against_oracle_all_core(smg_mod, oracle_mod):
+    """BASELINE config C5 (4 194 304 vertices, 6 levels): the fp64 solve against the oracle in the device numbering (all-core mode:
+    seconds instead of minutes), iteration for iteration; the mixed-precision solve lands on the same solution."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    import bench as B
+    mg, A, Mb, Vf, Ff, label, _ = B.build_workload("C5", smg, mesh)
+    n = A.shape[0]
+    assert n == 4194304 and mg.n_levels == 6
+    mg.precompute(A)
+    rhs = Mb @ np.random.default_rng(100).uniform(-1, 1, n)
+    z0 = np.zeros(n)
+    tol = 1e-9 * np.linalg.norm(rhs)
+    conv, z, rh = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40))
+    assert conv
+    orc, perm0 = _oracle_in_device_numbering(oracle_mod, mg, A)
+    conv2, z2, rh2 = orc.solve(rhs[perm0], z0[perm0], tol=tol, max_iter=40)
+    assert conv2 and len(rh2) == len(rh)
+    np.testing.assert_allclose(rh, rh2, rtol=1e-6)
+    assert np.linalg.norm(z[perm0, 0] - z2[:, 0]) <= 1e-9 * np.linalg.norm(z2)
+    conv3, z3, rh3 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, precision="mixed"))
+    assert conv3 and np.linalg.norm(z3 - z) <= 1e-7 * np.linalg.norm(z)
+    # hybrid smoother at this size: the oracle with the same per-level choice (Jacobi is numbering-independent, GS runs in the
+    # device numbering) tracks it too
+    thr = 100000
+    for lv in range(mg.n_levels - 1):
+        orc.set_smoother(lv, "jacobi" if mg.rows(lv) <= thr else "gs", 0.8)
+    conv4, z4, rh4 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, smoother="hybrid", jacobi_max_rows=thr))
+    conv5, z5, rh5 = orc.solve(rhs[perm0], z0[perm0], tol=tol, max_iter=40)
+    assert conv4 and conv5 and len(rh4) == len(rh5), (conv4, conv5, rh4, rh5)
+    np.testing.assert_allclose(rh4, rh5, rtol=1e-6)
+
+
+def test_03_mg_solver_on_ogre_with_its_boundary_loop(smg_mod, oracle_mod):
+    """What 03_mg_solver/main.cpp:29-75 actually runs: ogre.obj, A = -cotmatrix, the (longest) boundary loop pinned to 0,
+    B = M_voronoi 1, z0 = 0, defaults tol 1e-3 / maxIter 20 -- and the same at tol 1e-10 -- against the oracle (lexicographic GS)."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    from oracle import mesh_np as M
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    n = V.shape[0]
+    assert n == 19985
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)                                   # main.cpp:35-39
+    A = (-mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    b = mesh.boundary_loop(F)
+    assert len(b) == 112 and np.array_equal(np.sort(b), np.sort(M.boundary_loop(F)))   # SURVEY App. A item 14
+    Bv = mesh.massmatrix(V, F, "voronoi") @ np.ones(n)
+    Bv[b] = 0.0
+    mg.precompute(A, b)
+    assert mg.rows(0) == 19873
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A, b)
+    for tol, mx in ((1e-3, 20), (1e-10, 60)):
+        conv, z, rh = mg.solve(Bv, np.zeros(n), np.zeros(len(b)), smg.SolveOpts(tol=tol, max_iter=mx))
+        conv2, z2, rh2 = orc.solve(Bv, np.zeros(n), np.zeros((len(b), 1)), tol=tol, max_iter=mx)
+        assert conv and conv2 and abs(len(rh) - len(rh2)) <= 2 and abs(rh[0] - rh2[0]) <= 1e-12 * rh2[0]
+        assert np.linalg.norm(z - z2) <= (1e-8 if tol <= 1e-9 else 1e-3) * np.linalg.norm(z2)
+        assert np.array_equal(z[b, 0], np.zeros(len(b)))

@@ -163,3 +163,61 @@ def test_oracle_jacobi_matches_a_numpy_restatement(oracle_mod):
     conv2, z2, rh2 = orc.solve(p["RHS"], p["z0"], tol=1e-9, max_iter=40)
     orc.set_sequential()
     assert len(rh2) == len(rh) and np.linalg.norm(z - z2) <= 1e-12 * np.linalg.norm(z)
+
+
+def test_oracle_chebyshev_matches_a_numpy_restatement(oracle_mod):
+    """orc_set_smoother(CHEBY): relax(iters) = one Chebyshev-Jacobi polynomial of degree iters + 1 on [fraction lam, lam], lam the
+    Gershgorin bound -- against the textbook three-term recurrence in numpy; and its optimality property: on the target interval the
+    polynomial is bounded by 1 / T_deg(sigma)."""
+    from problems import subdiv_problem
+    import scipy.sparse as sp
+    p = subdiv_problem(kind="poisson", k=2, n_sub=2)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], p["known"])
+    rng = np.random.default_rng(1)
+    for lv in range(orc.n_levels - 1):
+        A = orc.level_A(lv).tocsr()
+        d = A.diagonal()
+        n = A.shape[0]
+        lam = float((abs(A).sum(axis=0).A1 / d).max())
+        assert abs(orc.spectral_bound(lv) - lam) <= 1e-14 * lam
+        b, u = rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2))
+        for frac, iters in ((0.1, 2), (0.3, 1), (0.1, 4)):
+            orc.set_smoother(lv, "chebyshev", frac)
+            got = orc.relax(lv, b, u, iters)
+            lmin = lam * frac
+            theta, delta = (lam + lmin) / 2, (lam - lmin) / 2
+            sigma = theta / delta
+            rho = 1 / sigma
+            x = u.copy()
+            r = (b - A @ x) / d[:, None]
+            dd = r / theta
+            x = x + dd
+            for _ in range(iters):
+                rho_new = 1 / (2 * sigma - rho)
+                r = (b - A @ x) / d[:, None]
+                dd = rho_new * rho * dd + (2 * rho_new / delta) * r
+                x = x + dd
+                rho = rho_new
+            assert abs(got - x).max() <= 1e-12 * abs(x).max()
+            orc.set_smoother(lv, "gs")
+    # error propagation of the degree-3 polynomial on eigenvectors of D^-1 A inside the interval: |p(lambda)| <= 1 / T_3(sigma)
+    p = subdiv_problem(mesh="torus", kind="mcf", k=1, n_sub=1)
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"])
+    lv = 0
+    A = orc.level_A(lv).toarray()
+    d = np.diag(A)
+    w, Vv = np.linalg.eig(A / d[:, None])
+    w = w.real
+    lam, frac = orc.spectral_bound(lv), 0.1
+    sigma = (1 + frac) / (1 - frac)
+    bound = 1.0 / (4 * sigma ** 3 - 3 * sigma)
+    orc.set_smoother(lv, "chebyshev", frac)
+    for idx in np.argsort(w)[[-1, -len(w) // 4, -len(w) // 2]]:
+        if w[idx] < frac * lam:
+            continue
+        e = Vv[:, idx].real[:, None].copy()
+        out = orc.relax(lv, np.zeros_like(e), e, 2)         # b = 0: the iterate IS the error
+        assert np.linalg.norm(out) <= (bound + 1e-9) * np.linalg.norm(e) * 1.0001
+    orc.set_smoother(lv, "gs")

@@ -11,7 +11,7 @@ mg, A, Mb, Vf, Ff, label, _ = B.build_workload(wl, smg, mesh)
 mg.precompute(A)
 sm = os.environ.get("SMG_TOOL_SMOOTHER", "gs")      # gs | jacobi | hybrid[:max_rows[:omega]]
 parts = sm.split(":")
-mg.set_smoother(parts[0], float(parts[2]) if len(parts) > 2 else 0.8, int(parts[1]) if len(parts) > 1 else 100000)
+mg.set_smoother(parts[0], float(parts[2]) if len(parts) > 2 else 0.8, int(parts[1]) if len(parts) > 1 else 100000)   # gs | jacobi | hybrid | chebyshev | hybrid_chebyshev
 print(label, "k =", k, "smoother", sm)
 prev = None
 ts = []

@@ -13,9 +13,15 @@ from oracle.oracle import OracleMG
 
 n_sub = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 kind = sys.argv[2] if len(sys.argv) > 2 else "mcf"
-V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
-V = mesh.normalize_unit_area(V, F)
-mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, n_sub, ratio=0.25, nVCoarsest=1000, n_extra_levels=1)
+if len(sys.argv) > 3 and sys.argv[3] == "torus":
+    import bench as B
+    V, F = mesh.torus(64, 64)
+    mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, n_sub, n_extra_levels=0)
+    Vf = mesh.normalize_unit_area(B._onto_torus(Vf), Ff)
+else:
+    V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, n_sub, ratio=0.25, nVCoarsest=1000, n_extra_levels=1)
 L = mesh.cotmatrix(Vf, Ff)
 n = Vf.shape[0]
 rng = np.random.default_rng(100)
@@ -54,5 +60,9 @@ for w in (0.6, 0.7, 0.8, 0.9):
     run("Jacobi w=%.1f on levels >= 1" % w, {lv: ("jacobi", w) for lv in range(1, nl - 1)})
 for w in (0.7, 0.8):
     run("Jacobi w=%.1f on levels >= 2" % w, {lv: ("jacobi", w) for lv in range(2, nl - 1)})
-for w in (0.7, 0.8):
+for w in (0.7,):
     run("Jacobi w=%.1f everywhere" % w, {lv: ("jacobi", w) for lv in range(0, nl - 1)})
+for w in (0.8, 0.9, 1.0):
+    run("Jacobi w=%.1f on the last smoothed level only" % w, {nl - 2: ("jacobi", w)})
+    if nl >= 4:
+        run("Jacobi w=%.1f on the last two smoothed levels" % w, {nl - 2: ("jacobi", w), nl - 3: ("jacobi", w)})
