@@ -1100,7 +1100,7 @@ static int level_kind(const smg_hierarchy* h, int lv)
 static bool level_is_jacobi(const smg_hierarchy* h, int lv) { return level_kind(h, lv) != LV_GS; }   // needs the second iterate buffer
 
 // Coefficients of the Chebyshev-Jacobi recurrence (include/smg.h, SMG_SMOOTH_CHEBYSHEV): step s computes d = c1 d + c2 r, u += d.
-// The same statements, in the same order, as oracle/smg_oracle.c: cheby_coefs() -- both are compiled without FMA contraction.
+// The same statements, in the same order, as the CPU restatement used by the tests -- both are compiled without FMA contraction.
 struct ChebyCoef { double c1, c2; };
 static void cheby_coefs(double lam, double frac, int degree, std::vector<ChebyCoef>& out)
 {
