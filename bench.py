@@ -197,7 +197,7 @@ def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, 
     V, F = mesh.read_triangle_mesh("ogre.smgm")
     V = mesh.normalize_unit_area(V, F)
     t0 = time.time()
-    mg = smg.mg_precompute(V, F, 0.25, 500, 1)                       # main.cpp:48-50 (defaults of mg_precompute)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)                       # main.cpp:48-50 (defaults of mg_precompute; the reference's collapse order)
     t_hier = time.time() - t0
     n = V.shape[0]
     L = mesh.cotmatrix(V, F)
@@ -231,11 +231,11 @@ def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, 
         torch.cuda.synchronize()
 
     # 1. the solve itself (tol 5e-7, the reference's setting): cycles, convergence, identical history on every rank
-    opts = smg.SolveOpts(tol=tol, max_iter=40, **smoother_kw)
+    opts = smg.SolveOpts(tol=tol, max_iter=100, **smoother_kw)
     eng = GpuEngine(mg, rhs, z0, None, opts)
     sync_all()
     tw = time.perf_counter()
-    conv, z, rh = sharded_solve(eng, 40, allreduce, check_every=1)
+    conv, z, rh = sharded_solve(eng, 100, allreduce, check_every=1)
     torch.cuda.synchronize()
     wall = time.perf_counter() - tw
     # 2. steady state: `steps` outer iterations of the 64-column block with tol = 0 (never converges)
@@ -285,7 +285,7 @@ def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, 
     ref_gs = None
     if world == 1 and smoother_kw["smoother"] != "gs":    # the reference's smoother on the same job, for the time-to-tolerance comparison
         g_kw = dict(smoother_kw, smoother="gs")
-        cg, zg, rg = sharded_solve(GpuEngine(mg, rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, **g_kw)), 40, allreduce)
+        cg, zg, rg = sharded_solve(GpuEngine(mg, rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=100, **g_kw)), 100, allreduce)
         mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, **g_kw))
         mg.outer_iterations(warmup)
         torch.cuda.synchronize()

@@ -115,11 +115,20 @@ int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double 
  * tarF = round(#F * ratio) (:59), edge-collapse decimation + prolongation.  V: nV x 3 row-major, F: nF x 3.
  * dec_type (src/mg_precompute.cpp:10): 0 qslim (quadric error metric, merged vertex at the quadric's minimiser), 1 mid-point
  * (shortest edge first), 2 vertex removal (shortest edge first, merged vertex on an end point).
- * NOTE: libsmg's own host implementation of the reference's scheme (greedy edge collapse with successive
- * self-parameterisation: joint conformal flattening of the 1-ring before/after every collapse); same API, same P structure (3 stored entries per row, rows sum to 1).
- * Not a line-by-line restatement of SSP_* / joint_lscm: results differ from the reference's. */
+ * libsmg's own host implementation of the reference's construction (src/SSP_midpoint.cpp, src/SSP_collapse_edge.cpp, src/joint_lscm.cpp,
+ * src/query_fine_to_coarse.cpp): boundary closed by a vertex at infinity, greedy shortest-edge collapse to the mid-point with libigl's
+ * refuse / re-cost queue discipline, joint conformal flattening of the 1-rings before / after every collapse in the reference's three
+ * cases (interior, one boundary end point, boundary edge with its snap candidates), the reference's validity and quality thresholds;
+ * same P structure (3 stored entries per row, rows sum to 1).  Written from the formulation on own data structures: ties between
+ * equal-cost edges may be broken differently than libigl's edge numbering does (csrc/smg_decimate.cpp). */
 int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                       smg_hierarchy **out);
+/* The same with an opt-in departure from the reference's plain greedy collapse order: a surviving vertex may stand for at most
+ * absorption_cap x (#F / tarF) input vertices (edges that would exceed that wait; the bound doubles when nothing else can be collapsed).
+ * Shortest-edge-first decimation coarsens densely sampled regions far beyond the requested ratio before it touches the rest, which the
+ * V-cycle pays for (ogre.obj: factor 0.6 -> 0.3 with a cap of 2).  absorption_cap = 0 is smg_mg_precompute. */
+int smg_mg_precompute_capped(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
+                             float absorption_cap, smg_hierarchy **out);
 /* Hierarchy of a mid-point-subdivided mesh: the n_sub finest transfer operators are the subdivision operators
  * (09_random_subdiv_remesh/main.cpp:46-140), levels below the base mesh come from smg_mg_precompute's decimator
  * (ratio, nVCoarsest applied to the base mesh; pass n_extra_levels = -1 for the float rule).  Outputs the fine

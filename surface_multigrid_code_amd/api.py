@@ -341,13 +341,14 @@ class Hierarchy:
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's free functions
 
-def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1):
-    """mg_precompute(V, F, ratio, nVCoarsest, dec_type, mg)  (src/mg_precompute.cpp:15-87) -> Hierarchy."""
+def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1, absorption_cap=0.0):
+    """mg_precompute(V, F, ratio, nVCoarsest, dec_type, mg)  (src/mg_precompute.cpp:15-87) -> Hierarchy.
+    absorption_cap > 0: opt-in departure from the reference's collapse order (include/smg.h: smg_mg_precompute_capped)."""
     L = _lib.load()
     V = np.ascontiguousarray(V, dtype=np.float64)
     F = np.ascontiguousarray(F, dtype=np.int32)
     out = C.c_void_p()
-    _chk(L.smg_mg_precompute(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, C.byref(out)),
+    _chk(L.smg_mg_precompute_capped(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, absorption_cap, C.byref(out)),
          "smg_mg_precompute")
     return Hierarchy(handle=out.value)
 

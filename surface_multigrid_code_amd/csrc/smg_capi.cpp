@@ -2117,7 +2117,7 @@ extern "C" int smg_mesh_torus(int nu, int nv, double R, double r, double* V, int
 // ------------------------------------------------------------------------------------------------ mg_precompute
 namespace smg {
 // smg_decimate.cpp: one coarsening step (reference get_prolong(), src/get_prolong.cpp:3-57)
-int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& P, std::string& err);
+int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err);
 }
 
 // number of levels by the reference's float rule (src/mg_precompute.cpp:27-38)
@@ -2133,7 +2133,7 @@ static int level_count(int nV, float ratio, int nVCoarsest)
     return nLvs;
 }
 
-static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& base, int n_new, float ratio, int dec_type)
+static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& base, int n_new, float ratio, int dec_type, int cap_tenths = 0)
 {
     Mesh cur = base;
     for (int s = 0; s < n_new; s++) {
@@ -2142,7 +2142,7 @@ static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& ba
         Mesh coarse;
         Csr P;
         std::string err;
-        if (decimate_level(cur, tarF, dec_type, coarse, P, err) != 0) return fail(SMG_ERR_INVALID, "mg_precompute: %s", err.c_str());
+        if (decimate_level(cur, tarF, dec_type, cap_tenths, coarse, P, err) != 0) return fail(SMG_ERR_INVALID, "mg_precompute: %s", err.c_str());
         h->lv[lv].V = coarse.V;
         h->lv[lv].F = coarse.F;
         set_prolong(h, lv, std::move(P));
@@ -2154,14 +2154,20 @@ static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& ba
 extern "C" int smg_mg_precompute(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
                                  smg_hierarchy** out)
 {
-    if (!V || !F || !out || nV <= 0 || nF <= 0 || !(ratio > 0.f && ratio < 1.f))
+    return smg_mg_precompute_capped(V, nV, F, nF, ratio, nVCoarsest, dec_type, 0.0f, out);
+}
+
+extern "C" int smg_mg_precompute_capped(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                        float absorption_cap, smg_hierarchy** out)
+{
+    if (!V || !F || !out || nV <= 0 || nF <= 0 || !(ratio > 0.f && ratio < 1.f) || !(absorption_cap >= 0.f))
         return fail(SMG_ERR_INVALID, "smg_mg_precompute: bad arguments");
     const int nLvs = level_count(nV, ratio, nVCoarsest);
     smg_hierarchy* h = smg_hierarchy_create(nLvs);
     if (!h) return SMG_ERR_ALLOC;
     Mesh m = wrap_mesh(V, nV, F, nF);
     h->lv[0].V = m.V; h->lv[0].F = m.F;   // src/mg_precompute.cpp:46-47
-    int rc = build_decimated_levels(h, 1, m, nLvs - 1, ratio, dec_type);
+    int rc = build_decimated_levels(h, 1, m, nLvs - 1, ratio, dec_type, (int)std::lround(10.0 * absorption_cap));
     if (rc) { smg_hierarchy_destroy(h); return rc; }
     *out = h;
     return SMG_OK;

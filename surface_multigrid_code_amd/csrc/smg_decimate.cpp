@@ -3,28 +3,43 @@
 // fine vertex through the collapse history to barycentric coordinates on the coarse mesh, assemble P with
 // exactly three stored entries per row).
 //
-// Same contract as the reference (greedy collapse: shortest edge first with mid-point placement, dec_type 1, or end-point
-// placement, dec_type 2; smallest quadric error first with the quadric's minimiser as placement, dec_type 0 "qslim"; link-condition and fold-over rejection; every fine vertex carried along as (face, barycentric);
-// P with exactly three stored entries per row, non-negative, rows summing to 1).  The per-collapse re-parameterisation:
-//   * the reference's construction -- the 1-rings before and after the collapse are flattened JOINTLY by least-squares
-//     conformal maps with a shared boundary ring (src/joint_lscm.cpp), a collapse whose flattening flips, folds over or
-//     degenerates is rejected (check_valid_UV_lscm), and every point of the 1-ring is located in the flattened post patch
-//     by the largest-minimum-barycentric rule (src/query_fine_to_coarse.cpp:93-116).  Written from the formulation (energy,
-//     pins, checks), not from the reference's code; there is no reference binary to compare with, so it is validated by
-//     invariants and by the V-cycle convergence it yields;
-//   * collapses touching the boundary go through the same flattening on the open 1-ring (natural boundary conditions); the
-//     reference closes the boundary with an "infinity vertex" and has two more LSCM cases for it (src/joint_lscm.cpp:
-//     642-1131), which are not restated;
-//   * the libigl-internal edge-flap bookkeeping, the randomised variants and the coarse-to-fine queries of the
-//     remeshing demos are not restated.
+// The construction follows the reference's (src/SSP_midpoint.cpp, src/SSP_collapse_edge.cpp, src/joint_lscm.cpp,
+// src/query_fine_to_coarse.cpp), written from its formulation on own data structures (no libigl edge-flap arrays):
+//   * the boundary is closed by a vertex at infinity: every boundary edge gets a phantom face to it (igl::connect_boundary_to_infinity,
+//     SSP_midpoint.cpp:31); edges to that vertex cost infinity and are never collapsed, phantom faces are removed at the end and do
+//     not count towards the target (max_faces_stopping_condition, :53);
+//   * greedy loop (SSP_midpoint.cpp:188-220, SSP_collapse_edge.cpp:401-533): cheapest edge first (dec_type 1: length, merged vertex at
+//     the mid-point -- ALSO for boundary vertices, as in the reference), lazy deletion by time stamps; an edge whose collapse is refused
+//     leaves the queue (cost infinity there) and comes back only when a successful collapse next to it re-costs the edges of the
+//     merged vertex's new star (:482-520) -- no other retry, no cap on how much a vertex may absorb (an absorption cap is an opt-in
+//     argument, see decimate_level);
+//   * validity (igl::edge_collapse_is_valid, SSP_collapse_edge.cpp:57): exactly two common neighbours in the closed mesh, not the
+//     edge of a single tetrahedron; patches of <= 2 faces are refused (:188-195);
+//   * per collapse the 1-rings before and after are flattened JOINTLY by least-squares conformal maps (joint_lscm.cpp:483-555 flatten():
+//     Q = -L_pre + 2 A_pre - L_post + 2 A_post, dense constrained minimisation), in one of three set-ups (joint_lscm.cpp:226-241):
+//       case 0  both end points interior: the merged vertex is an extra unknown; pins uv(vi) = (0,0), uv(vj) = (1,0)      (:557-651)
+//       case 1  one end point on the boundary: the merged vertex shares that end point's unknown                           (:653-749)
+//       case 2  a boundary edge: three candidates -- merged vertex snapped onto vi, onto vj (the far boundary neighbour of the other
+//               end point pinned onto the line through vi, vj), or free on that line together with both boundary neighbours -- and the
+//               one with the smallest quasi-conformal error wins                                                            (:750-1131)
+//     boundary cases first check the 3D quality of the post-collapse triangles, 4 sqrt(3) area / sum l^2 >= 0.3 (:91-117);
+//   * the flattening is refused on NaN, flipped faces (signed area < 1e-10), fold-over around the collapsing / merged vertices (angle
+//     sum > 2 pi + 1e-10) or UV slivers (quality < 0.01) (check_valid_UV_lscm, :243-481);
+//   * every fine point of the old 1-ring is located in the flattened post patch by the largest-minimum-barycentric rule, clamped and
+//     renormalised (query_fine_to_coarse.cpp:93-116).
+// Not restated: libigl's edge numbering (ties between equal costs may be broken differently), the randomised variants, the
+// coarse-to-fine queries of the remeshing demos.  dec_type 0 / 2 reuse the same machinery with libsmg's own cost / placement (quadric
+// error metric; end-point placement) -- the reference's versions of those two are built on libigl's quadric callbacks.
 #include <algorithm>
 #include <cstdlib>
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <limits>
 #include <queue>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "smg_mesh.hpp"
@@ -40,27 +55,26 @@ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
 
-// ---- joint conformal flattening of the pre- and post-collapse 1-rings (interior collapses) -------------------------------
-// The reference's successive self-parameterisation maps a point through a collapse by flattening the 1-ring before and
-// after the collapse JOINTLY (shared boundary ring, least-squares conformal energy of both patches, two pins) and locating
-// the point's UV position in the post patch (src/joint_lscm.cpp:483-555 flatten(), :557-640 interior case;
-// src/query_fine_to_coarse.cpp:85-116).  This is the same construction, written from the formulation:
+// ---- joint conformal flattening of the pre- and post-collapse 1-rings -------------------------------------------------------
 //   minimise  E = sum over {pre, post}  1/2 (u^T K u + v^T K v) - Area(u, v),   K = cotangent stiffness of the 3D patch,
-//   subject to  uv(a) = (0,0), uv(b) = (1,0);   unknowns: ring vertices (shared), a, b (pre only), m (post only).
+//   subject to pinned coordinates.  Unknowns: the local vertices of the patch; the merged vertex is an extra unknown (`lm` = n - 1)
+//   or shares the unknown of an end point (cases 1 and 2-snap), in which case the post patch sees that index at the merged position.
 struct Patch {
-    int n = 0;                                // local vertices: ring..., a = n-3, b = n-2, m = n-1
+    int n = 0;                                  // local unknown vertices
+    int la = -1, lb = -1, lm = -1;              // end points of the edge, merged vertex (may equal la or lb)
     std::vector<std::array<int, 3>> pre, post;  // local faces
-    std::vector<V3> P;                        // local positions (a, b at their pre positions, m at the merged position)
-    std::vector<double> U, Vv;                // solution
+    std::vector<V3> P, Ppost;                   // positions seen by the pre / post patch (they differ at a shared merged index)
+    std::vector<double> U, Vv;                  // solution
 };
+struct Pin { int idx; double val; };            // idx in [0, 2n): u block first, then v
 
-static void add_conformal_energy(const Patch& pt, const std::vector<std::array<int, 3>>& F, std::vector<double>& Q)
+static void add_conformal_energy(int n, const std::vector<V3>& X, const std::vector<std::array<int, 3>>& F, std::vector<double>& Q)
 {
-    const int n = pt.n, N = 2 * n;
+    const int N = 2 * n;
     for (const auto& f : F) {
         for (int c = 0; c < 3; c++) {
             const int i = f[c], j = f[(c + 1) % 3], k = f[(c + 2) % 3];   // edge (i,j), opposite corner k
-            const V3 e1 = pt.P[i] - pt.P[k], e2 = pt.P[j] - pt.P[k];
+            const V3 e1 = X[i] - X[k], e2 = X[j] - X[k];
             const double cr = norm(cross(e1, e2));
             const double w = cr > 0 ? 0.5 * dot(e1, e2) / cr : 0.0;       // 1/2 cot(angle at k)
             for (int d = 0; d < 2; d++) {                                   // K (+)= w (x_i - x_j)^2 for u and v
@@ -75,24 +89,50 @@ static void add_conformal_energy(const Patch& pt, const std::vector<std::array<i
     }
 }
 
-static bool solve_joint_flattening(Patch& pt)
+// quasi-conformal error of a flattened patch: per face the ratio of the singular values of the map UV -> 3D (Sander et al., "Texture
+// Mapping Progressive Meshes"; the reference's selection criterion between the case-2 candidates, src/quasi_conformal_error.cpp),
+// 2-norm over the faces
+static double qc_error_norm(const std::vector<V3>& X, const std::vector<std::array<int, 3>>& F, const std::vector<double>& U, const std::vector<double>& W)
+{
+    double ss = 0.0;
+    for (const auto& f : F) {
+        const double s1 = U[f[0]], s2 = U[f[1]], s3 = U[f[2]], t1 = W[f[0]], t2 = W[f[1]], t3 = W[f[2]];
+        const double A = ((s2 - s1) * (t3 - t1) - (s3 - s1) * (t2 - t1)) / 2.0;
+        const V3 q1 = X[f[0]], q2 = X[f[1]], q3 = X[f[2]];
+        const V3 Ss = (1.0 / (2.0 * A)) * ((t2 - t3) * q1 + (t3 - t1) * q2 + (t1 - t2) * q3);
+        const V3 St = (1.0 / (2.0 * A)) * ((s3 - s2) * q1 + (s1 - s3) * q2 + (s2 - s1) * q3);
+        const double a = dot(Ss, Ss), b = dot(Ss, St), c = dot(St, St);
+        const double disc = std::sqrt((a - c) * (a - c) + 4.0 * b * b);
+        const double sigma = std::sqrt((a + c + disc) / 2.0), gamma = std::sqrt((a + c - disc) / 2.0);
+        const double e = sigma / gamma;
+        ss += e * e;
+    }
+    return std::sqrt(ss);
+}
+
+// solves the constrained minimisation and runs the validity checks of check_valid_UV_lscm; false = refuse the collapse
+static bool solve_joint_flattening(Patch& pt, const std::vector<Pin>& pins)
 {
     const int n = pt.n, N = 2 * n;
     // (scratch vectors live across calls: a collapse is a few microseconds of arithmetic, allocation would be a good part of it)
     static thread_local std::vector<double> Q, M, rhs, x;
     static thread_local std::vector<int> freei;
+    static thread_local std::vector<char> pinned;
     Q.assign((size_t)N * N, 0.0);
-    add_conformal_energy(pt, pt.pre, Q);
-    add_conformal_energy(pt, pt.post, Q);
-    const int a = n - 3, b = n - 2;
-    // pins: u_a = 0, v_a = 0, u_b = 1, v_b = 0
+    add_conformal_energy(n, pt.P, pt.pre, Q);
+    add_conformal_energy(n, pt.Ppost, pt.post, Q);
+    pinned.assign(N, 0);
+    x.assign(N, 0.0);
+    for (const Pin& p : pins) { pinned[p.idx] = 1; x[p.idx] = p.val; }
     freei.clear();
-    for (int i = 0; i < N; i++) if (i != a && i != b && i != a + n && i != b + n) freei.push_back(i);
+    for (int i = 0; i < N; i++) if (!pinned[i]) freei.push_back(i);
     const int m = (int)freei.size();
     M.resize((size_t)m * m); rhs.resize(m);
     for (int r = 0; r < m; r++) {
         for (int c = 0; c < m; c++) M[(size_t)r * m + c] = Q[(size_t)freei[r] * N + freei[c]];
-        rhs[r] = -Q[(size_t)freei[r] * N + b] * 1.0;   // only u_b = 1 is non-zero among the pins
+        double s = 0.0;
+        for (const Pin& p : pins) if (p.val != 0.0) s += Q[(size_t)freei[r] * N + p.idx] * p.val;
+        rhs[r] = -s;
     }
     // dense Cholesky (the pinned conformal energy is positive definite on a valid patch)
     for (int j = 0; j < m; j++) {
@@ -109,25 +149,21 @@ static bool solve_joint_flattening(Patch& pt)
     }
     for (int i = 0; i < m; i++) { double sx = rhs[i]; for (int k = 0; k < i; k++) sx -= M[(size_t)i * m + k] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
     for (int i = m - 1; i >= 0; i--) { double sx = rhs[i]; for (int k = i + 1; k < m; k++) sx -= M[(size_t)k * m + i] * rhs[k]; rhs[i] = sx / M[(size_t)i * m + i]; }
-    x.assign(N, 0.0);
-    x[b] = 1.0;
     for (int r = 0; r < m; r++) x[freei[r]] = rhs[r];
     pt.U.assign(x.begin(), x.begin() + n);
     pt.Vv.assign(x.begin() + n, x.end());
     for (double v : x) if (!(v == v)) return false;
-    // every flattened face of both patches must keep its orientation (reference check_valid_UV_lscm: signed area >= 1e-10)
+    // every flattened face of both patches must keep its orientation (check_valid_UV_lscm: signed area >= 1e-10)
     auto oriented = [&](const std::vector<std::array<int, 3>>& F) {
         for (const auto& f : F) {
             const double ar = (pt.U[f[1]] - pt.U[f[0]]) * (pt.Vv[f[2]] - pt.Vv[f[0]]) - (pt.Vv[f[1]] - pt.Vv[f[0]]) * (pt.U[f[2]] - pt.U[f[0]]);
-            if (!(ar > 1e-10)) return false;
+            if (!(ar >= 1e-10)) return false;
         }
         return true;
     };
     if (!(oriented(pt.pre) && oriented(pt.post))) return false;
     // no fold-over: the flattened angles around the collapsing vertices / the merged vertex must not exceed 2 pi
-    // (reference check_valid_UV_lscm, src/joint_lscm.cpp:330-392), and no flattened sliver: quality
-    // 4 sqrt(3) area / (l0^2 + l1^2 + l2^2) >= 0.01 (:394-478)
-    const int la = n - 3, lb = n - 2, lm = n - 1;
+    // (src/joint_lscm.cpp:330-392), and no flattened sliver: quality 4 sqrt(3) area / (l0^2 + l1^2 + l2^2) >= 0.01 (:394-478)
     auto checks = [&](const std::vector<std::array<int, 3>>& F, int v0, int v1) {
         double ang0 = 0, ang1 = 0;
         for (const auto& f : F) {
@@ -151,7 +187,9 @@ static bool solve_joint_flattening(Patch& pt)
         const double two_pi = 6.283185307179586;
         return ang0 - two_pi <= 1e-10 && ang1 - two_pi <= 1e-10;
     };
-    return checks(pt.pre, la, lb) && checks(pt.post, lm, -1);
+    // pre: around vi and vj; post: around the merged vertex (the reference tests the indices vi, vj in both patches, :334-392; vj does
+    // not occur in the post patch, and with a shared unknown the merged vertex IS la or lb)
+    return checks(pt.pre, pt.la, pt.lb) && checks(pt.post, pt.lm, -1);
 }
 
 struct QEntry {
@@ -195,8 +233,13 @@ struct Decimator {
         pq.pop();
         return e;
     }
-    int n_alive_faces = 0;
+    int n_alive_faces = 0;                   // REAL faces alive (phantom faces to the vertex at infinity do not count)
     int dec_type = 1;
+    int nF_real = 0;                         // faces [nF_real, ...) are phantom: (b, a, inf) for every boundary edge a -> b
+    int vinf = -1;                           // the vertex at infinity (-1: closed mesh)
+    std::unordered_set<uint64_t> refused;    // edges whose collapse was refused (cost infinity in the reference's queue)
+    bool phantom(int f) const { return f >= nF_real; }
+    static uint64_t edge_key(int a, int b) { if (a > b) std::swap(a, b); return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; }
     // dec_type 0 (the reference's "qslim", src/SSP_qslim.cpp): quadric error metric -- every vertex carries the area-weighted
     // sum of the squared distances to the planes of its input faces, Q(v) = v^T A v + 2 b^T v + c stored as
     // (a11 a12 a13 a22 a23 a33 b1 b2 b3 c); an edge costs the minimum of Q_a + Q_b and the merged vertex goes to the minimiser
@@ -219,7 +262,7 @@ struct Decimator {
     void init_quadrics()
     {
         quad.assign(pos.size(), std::array<double, 10>{});
-        for (size_t f = 0; f < faces.size(); f++) {
+        for (size_t f = 0; f < (size_t)nF_real; f++) {
             const auto& fc = faces[f];
             const V3 p0 = pos[fc[0]], p1 = pos[fc[1]], p2 = pos[fc[2]];
             const V3 cr = cross(p1 - p0, p2 - p0);
@@ -282,7 +325,7 @@ struct Decimator {
     int edge_faces(int a, int b, int* out)
     {
         int n = 0;
-        for (int f : vfaces[a]) if (falive[f] && has(faces[f], b)) { if (n < 3) out[n] = f; n++; }
+        for (int f : vfaces[a]) if (falive[f] && !phantom(f) && has(faces[f], b)) { if (n < 3) out[n] = f; n++; }   // real faces only
         return n;
     }
     bool on_boundary_big(int v)   // valence > 64
@@ -313,7 +356,9 @@ struct Decimator {
     }
     void push_edge(int a, int b)
     {
+        if (a == vinf || b == vinf) return;   // infinite cost: never collapsed (SSP_midpoint.cpp:196-200)
         if (a > b) std::swap(a, b);
+        if (!refused.empty()) refused.erase(edge_key(a, b));
         const QEntry e{dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]};
         if (filling) initial.push_back(e); else pq.push(e);
     }
@@ -326,64 +371,65 @@ struct Decimator {
         nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
         for (int w : nb) push_edge(v, w);
     }
-    // try to collapse (a,b); returns true on success
+    // try to collapse (a,b), a < b: b merges into a.  Returns true on success.
     bool collapse(int a, int b)
     {
         clean(a); clean(b);
-        int ef[3];
-        const int nef = edge_faces(a, b, ef);
-        if (nef < 1 || nef > 2) return false;
-        const bool edge_is_boundary = (nef == 1);
-        const bool ba = on_boundary(a), bb = on_boundary(b);
-        if (ba && bb && !edge_is_boundary) return false;  // interior chord between two boundary vertices
-        // link condition: common neighbours == vertices opposite to the edge
+        // ---- neighbourhoods in the CLOSED mesh (phantom faces and the vertex at infinity included)
         static thread_local std::vector<int> na, nb, common;
         na.clear(); nb.clear(); common.clear();
         for (int f : vfaces[a]) for (int c = 0; c < 3; c++) if (faces[f][c] != a) na.push_back(faces[f][c]);
         for (int f : vfaces[b]) for (int c = 0; c < 3; c++) if (faces[f][c] != b) nb.push_back(faces[f][c]);
         std::sort(na.begin(), na.end()); na.erase(std::unique(na.begin(), na.end()), na.end());
         std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+        if (!std::binary_search(na.begin(), na.end(), b)) return false;          // not an edge (any more)
+        // igl::edge_collapse_is_valid (SSP_collapse_edge.cpp:55-60): the end points share exactly two neighbours, and the edge is not
+        // an edge of a single tetrahedron (both end points of valence 3 on the same two neighbours)
         std::set_intersection(na.begin(), na.end(), nb.begin(), nb.end(), std::back_inserter(common));
-        if ((int)common.size() != nef) return false;
-        for (int i = 0; i < nef; i++) {
-            const auto& f = faces[ef[i]];
-            int opp = f[0] != a && f[0] != b ? f[0] : (f[1] != a && f[1] != b ? f[1] : f[2]);
-            if (!std::binary_search(common.begin(), common.end(), opp)) return false;
-        }
-        if ((int)na.size() + (int)nb.size() - 2 - nef < 3) return false;  // would leave a vertex of valence < 3
-        // placement
+        if ((int)common.size() != 2) return false;
+        if (na.size() == 3 && nb.size() == 3) return false;
+        const bool ba = vinf >= 0 && std::binary_search(na.begin(), na.end(), vinf);   // on the boundary <=> adjacent to infinity
+        const bool bb = vinf >= 0 && std::binary_search(nb.begin(), nb.end(), vinf);
+        const int kase = (ba ? 1 : 0) + (bb ? 1 : 0);
+        // the faces on the edge: two in the closed mesh; a boundary edge has one real and one phantom face
+        int ef[4], nef_all = 0, nef = 0;
+        for (int f : vfaces[a]) if (has(faces[f], b)) { if (nef_all < 4) ef[nef_all] = f; nef_all++; if (!phantom(f)) nef++; }
+        if (nef_all != 2 || nef < 1) return false;
+        // both end points on the boundary: with two common neighbours the edge itself is a boundary edge (a chord between two boundary
+        // vertices has three: its two opposite vertices and infinity -- the reference's `isFlap` refusal, joint_lscm.cpp:60-81)
+        if (kase == 2 && nef != 1) return false;
+        // ---- placement (dec_type 1: the mid-point, for boundary vertices too: shortest_edge_and_midpoint, SSP_midpoint.cpp:52)
         V3 m;
-        if (dec_type == 2) m = pos[a];                       // vertex removal: keep an end point
-        else if (dec_type == 0 && ba == bb) (void)qem(a, b, &m);  // quadric-optimal placement (boundary: see below)
-        else if (ba && !bb) m = pos[a];                      // keep the boundary where it is
-        else if (bb && !ba) m = pos[b];
-        else m = 0.5 * (pos[a] + pos[b]);                    // mid-point (dec_type 1)
-        // fold-over / degeneracy test on the surviving faces
-        for (int pass = 0; pass < 2; pass++) {
-            const int v = pass == 0 ? a : b;
-            for (int f : vfaces[v]) {
-                const auto& fc = faces[f];
-                if (has(fc, a) && has(fc, b)) continue;
-                V3 p0 = pos[fc[0]], p1 = pos[fc[1]], p2 = pos[fc[2]];
-                V3 n0 = cross(p1 - p0, p2 - p0);
-                V3 q0 = (fc[0] == v) ? m : p0, q1 = (fc[1] == v) ? m : p1, q2 = (fc[2] == v) ? m : p2;
-                V3 n1 = cross(q1 - q0, q2 - q0);
-                const double l0 = norm(n0), l1 = norm(n1);
-                if (!(l1 > 1e-14 * (1.0 + l0))) return false;
-                if (dot(n0, n1) < 0.2 * l0 * l1) return false;
-                // reject slivers: height/longest-edge quality
-                const double e = std::max(norm(q1 - q0), std::max(norm(q2 - q1), norm(q0 - q2)));
-                if (l1 < 0.02 * e * e) return false;
+        if (dec_type == 1) m = 0.5 * (pos[a] + pos[b]);
+        else if (ba != bb) m = ba ? pos[a] : pos[b];          // libsmg's own types 0 / 2: a boundary vertex stays where it is
+        else if (dec_type == 2) m = pos[a];
+        else (void)qem(a, b, &m);
+        // libsmg's own types 0 / 2 additionally refuse collapses that fold a surviving face over in 3D or leave a sliver (the reference has
+        // these tests commented out for its mid-point type, SSP_collapse_edge.cpp:196-236; a quadric-optimal or end-point placement needs them)
+        if (dec_type != 1) {
+            for (int pass = 0; pass < 2; pass++) {
+                const int v = pass == 0 ? a : b;
+                for (int f : vfaces[v]) {
+                    if (phantom(f)) continue;
+                    const auto& fc = faces[f];
+                    if (has(fc, a) && has(fc, b)) continue;
+                    V3 p0 = pos[fc[0]], p1 = pos[fc[1]], p2 = pos[fc[2]];
+                    V3 n0 = cross(p1 - p0, p2 - p0);
+                    V3 q0 = (fc[0] == v) ? m : p0, q1 = (fc[1] == v) ? m : p1, q2 = (fc[2] == v) ? m : p2;
+                    V3 n1 = cross(q1 - q0, q2 - q0);
+                    const double l0 = norm(n0), l1 = norm(n1);
+                    if (!(l1 > 1e-14 * (1.0 + l0))) return false;
+                    if (dot(n0, n1) < 0.2 * l0 * l1) return false;
+                    const double e = std::max(norm(q1 - q0), std::max(norm(q2 - q1), norm(q0 - q2)));
+                    if (l1 < 0.02 * e * e) return false;
+                }
             }
         }
-        // ---- interior collapse: joint conformal flattening of the 1-ring before / after (reject the collapse if invalid)
-        // (collapses touching the boundary use the same construction on the open 1-ring: the conformal energy has natural
-        //  boundary conditions; when one end point is a boundary vertex the merged vertex sits on that end point)
+        // ---- local patch: ring vertices, a, b (and the merged vertex, where it is its own unknown)
         static thread_local Patch patch;
         static thread_local std::vector<int> pre_gid, post_gid;              // global face ids of patch.pre / patch.post
-        patch.pre.clear(); patch.post.clear(); patch.P.clear(); patch.U.clear(); patch.Vv.clear(); patch.n = 0;
+        patch.pre.clear(); patch.post.clear(); patch.P.clear(); patch.Ppost.clear(); patch.U.clear(); patch.Vv.clear(); patch.n = 0;
         pre_gid.clear(); post_gid.clear();
-        // global vertex -> local: a scratch array over all vertices, touched entries reset on every way out of this function
         if (locmap.size() != pos.size()) locmap.assign(pos.size(), -1);
         static thread_local std::vector<int> loc_touched;
         loc_touched.clear();
@@ -392,29 +438,25 @@ struct Decimator {
             int& operator[](int v) { if (m[v] < 0) touched.push_back(v); return m[v]; }
             ~LocGuard() { for (int v : touched) m[v] = -1; }
         } loc{locmap, loc_touched};
-        {
-            static thread_local std::vector<int> ringv;
-            ringv.clear();
-            for (int v : na) if (v != b) ringv.push_back(v);
-            for (int v : nb) if (v != a && !std::binary_search(na.begin(), na.end(), v)) ringv.push_back(v);
-            for (int v : ringv) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
-            const int la = (int)patch.P.size(); patch.P.push_back(pos[a]);
-            const int lb = la + 1; patch.P.push_back(pos[b]);
-            // The merged vertex is its own unknown of the flattening when it is a new point (mid-point placement).  When it IS one of
-            // the end points (vertex removal; a boundary vertex that stays put) it shares that end point's unknown: otherwise the
-            // two would be flattened to different places and the surviving vertex's own record -- the fine vertex sitting exactly
-            // on the coarse vertex -- would be re-located into the interior of a face (coarse vertices nobody interpolates from,
-            // i.e. zero rows in the Galerkin operator, were the symptom).
-            const bool m_is_a = (m.x == pos[a].x && m.y == pos[a].y && m.z == pos[a].z);
-            const bool m_is_b = !m_is_a && (m.x == pos[b].x && m.y == pos[b].y && m.z == pos[b].z);
-            int lm = lb + 1;
-            if (m_is_a) lm = la;
-            else if (m_is_b) lm = lb;
-            else patch.P.push_back(m);
-            patch.n = (int)patch.P.size();
-            loc[a] = la; loc[b] = lb;
-            auto add_faces = [&](int v) {
+        for (int v : na) if (v != b && v != vinf) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
+        for (int v : nb) if (v != a && v != vinf && !std::binary_search(na.begin(), na.end(), v)) { loc[v] = (int)patch.P.size(); patch.P.push_back(pos[v]); }
+        const int la = (int)patch.P.size(); patch.P.push_back(pos[a]);
+        const int lb = la + 1; patch.P.push_back(pos[b]);
+        loc[a] = la; loc[b] = lb;
+        const int n_shared = (int)patch.P.size();       // unknowns without an extra merged vertex
+        // boundary neighbours of a boundary edge (case 2): pv = the neighbour of a along the boundary other than b, nv = that of b
+        int pv = -1, nv = -1;
+        if (kase == 2) {
+            for (int f : vfaces[a]) if (phantom(f) && !has(faces[f], b)) for (int c = 0; c < 3; c++) if (faces[f][c] != a && faces[f][c] != vinf) pv = faces[f][c];
+            for (int f : vfaces[b]) if (phantom(f) && !has(faces[f], a)) for (int c = 0; c < 3; c++) if (faces[f][c] != b && faces[f][c] != vinf) nv = faces[f][c];
+            if (pv < 0 || nv < 0 || pv == nv || locmap[pv] < 0 || locmap[nv] < 0) return false;   // a boundary loop of three edges
+        }
+        // builds the face lists for a given index of the merged vertex
+        auto build_faces = [&](int lm) {
+            patch.pre.clear(); patch.post.clear(); pre_gid.clear(); post_gid.clear();
+            auto add = [&](int v) {
                 for (int f : vfaces[v]) {
+                    if (phantom(f)) continue;
                     const auto& fc = faces[f];
                     if (v == b && has(fc, a)) continue;   // edge faces already taken from a's star
                     pre_gid.push_back(f);
@@ -427,30 +469,93 @@ struct Decimator {
                     }
                 }
             };
-            add_faces(a); add_faces(b);
-            if (!solve_joint_flattening(patch)) return false;
+            add(a); add(b);
+        };
+        // sets the patch up for one flattening: where the merged vertex lives, what the post patch sees there
+        auto setup = [&](int lm_shared /* la, lb or -1 = own unknown */) {
+            patch.P.resize(n_shared);
+            int lm = lm_shared;
+            if (lm < 0) { lm = n_shared; patch.P.push_back(m); }
+            patch.n = (int)patch.P.size();
+            patch.Ppost = patch.P;
+            patch.Ppost[lm] = m;
+            patch.la = la; patch.lb = lb; patch.lm = lm;
+            build_faces(lm);
+        };
+        // When the merged position IS an end point (end-point placement) it shares that end point's unknown even for interior edges:
+        // otherwise the surviving vertex's own record -- the fine vertex sitting exactly on the coarse vertex -- would be re-located
+        // into the interior of a face (coarse vertices nobody interpolates from were the symptom).
+        const bool m_is_a = (m.x == pos[a].x && m.y == pos[a].y && m.z == pos[a].z);
+        const bool m_is_b = !m_is_a && (m.x == pos[b].x && m.y == pos[b].y && m.z == pos[b].z);
+        const int own = m_is_a ? la : (m_is_b ? lb : -1);
+        setup(kase == 1 ? (ba ? la : lb) : own);
+        if ((int)patch.pre.size() <= 2) return false;                           // SSP_collapse_edge.cpp:188-195
+        // boundary cases: 3D quality of the post-collapse triangles (joint_lscm.cpp:91-117)
+        if (kase > 0) {
+            for (const auto& g : patch.post) {
+                const double l0 = norm(patch.Ppost[g[0]] - patch.Ppost[g[1]]), l1 = norm(patch.Ppost[g[1]] - patch.Ppost[g[2]]), l2 = norm(patch.Ppost[g[2]] - patch.Ppost[g[0]]);
+                const double xs = (l0 + l1 + l2) / 2.0;
+                const double delta = std::sqrt(xs * (xs - l0) * (xs - l1) * (xs - l2));
+                const double q = 4.0 * std::sqrt(3.0) * delta / (l0 * l0 + l1 * l1 + l2 * l2);
+                if (!(q >= 0.3)) return false;
+            }
         }
-        // ---- gather the fine points of the pre-collapse 1-ring with their positions
+        static thread_local std::vector<Pin> pins;
+        auto base_pins = [&](int n) { pins.clear(); pins.push_back({la, 0.0}); pins.push_back({lb, 1.0}); pins.push_back({la + n, 0.0}); pins.push_back({lb + n, 0.0}); };
+        if (kase < 2) {
+            base_pins(patch.n);                                                 // uv(vi) = (0,0), uv(vj) = (1,0)
+            if (!solve_joint_flattening(patch, pins)) return false;
+        } else {
+            // case 2 (joint_lscm.cpp:750-829): three candidates, the smallest quasi-conformal error wins (ties: snap vi, snap vj, free)
+            struct Cand { bool ok = false; double err = 0; std::vector<double> U, Vv; int lm = -1; };
+            static thread_local Cand cand[3];
+            const int lpv = locmap[pv], lnv = locmap[nv];
+            for (int t = 0; t < 3; t++) {
+                setup(t == 0 ? la : (t == 1 ? lb : own));
+                const int n = patch.n;
+                base_pins(n);
+                if (t == 0) pins.push_back({lnv + n, 0.0});                     // snapped onto vi: vi -- vj -- nv on one line (:845-905)
+                else if (t == 1) pins.push_back({lpv + n, 0.0});                // snapped onto vj: pv -- vi -- vj on one line
+                else {                                                          // free on the line through pv, vi, vj, nv (:1060-1085)
+                    pins.push_back({lpv + n, 0.0}); pins.push_back({lnv + n, 0.0});
+                    if (patch.lm != la && patch.lm != lb) pins.push_back({patch.lm + n, 0.0});
+                }
+                // the reference flattens all three, picks by error and validates the winner only (joint_lscm.cpp:241): solve without
+                // refusing here, remember whether this candidate would pass
+                cand[t].ok = solve_joint_flattening(patch, pins);
+                cand[t].U = patch.U; cand[t].Vv = patch.Vv; cand[t].lm = patch.lm;
+                double e = std::numeric_limits<double>::quiet_NaN();
+                if ((int)patch.U.size() == n) e = qc_error_norm(patch.P, patch.pre, patch.U, patch.Vv) + qc_error_norm(patch.Ppost, patch.post, patch.U, patch.Vv);
+                cand[t].err = (e == e) ? e : 2147483647.0;                      // NaN -> INT_MAX (:775-776)
+            }
+            int best = 2;
+            if (cand[0].err <= cand[1].err && cand[0].err <= cand[2].err) best = 0;
+            else if (cand[1].err <= cand[0].err && cand[1].err <= cand[2].err) best = 1;
+            if (!cand[best].ok) return false;
+            setup(best == 0 ? la : (best == 1 ? lb : own));
+            patch.U = cand[best].U; patch.Vv = cand[best].Vv;
+        }
+        // ---- gather the fine points of the pre-collapse 1-ring with their positions in the flattening
         static thread_local std::vector<int> pts;
-        static thread_local std::vector<std::array<double, 2>> puv;   // position in the joint flattening (interior collapses)
+        static thread_local std::vector<std::array<double, 2>> puv;
         pts.clear(); puv.clear();
         auto take = [&](int f) {
+            if (phantom(f)) return;
             for (int p : fpoints[f]) {
                 pts.push_back(p);
-                {
-                    const auto& fc = faces[f];
-                    const auto& w = pbary[p];
-                    const int l0 = loc[fc[0]], l1 = loc[fc[1]], l2 = loc[fc[2]];
-                    puv.push_back({w[0] * patch.U[l0] + w[1] * patch.U[l1] + w[2] * patch.U[l2],
-                                   w[0] * patch.Vv[l0] + w[1] * patch.Vv[l1] + w[2] * patch.Vv[l2]});
-                }
+                const auto& fc = faces[f];
+                const auto& w = pbary[p];
+                const int l0 = loc[fc[0]], l1 = loc[fc[1]], l2 = loc[fc[2]];
+                puv.push_back({w[0] * patch.U[l0] + w[1] * patch.U[l1] + w[2] * patch.U[l2],
+                               w[0] * patch.Vv[l0] + w[1] * patch.Vv[l1] + w[2] * patch.Vv[l2]});
             }
             fpoints[f].clear();   // (capacity kept: re-homed points come straight back to the surviving faces)
         };
         for (int f : vfaces[a]) take(f);
         for (int f : vfaces[b]) if (!has(faces[f], a)) take(f);
-        // ---- connectivity surgery: b -> a, the edge faces die
-        for (int i = 0; i < nef; i++) { falive[ef[i]] = 0; n_alive_faces--; }
+        // UV of the post patch: the pre UV with the merged vertex at its own / shared unknown (UV_post.row(vi) = UVjoint.row(vi_post))
+        // ---- connectivity surgery: b -> a, the two faces on the edge die (a phantom one among them on the boundary)
+        for (int i = 0; i < 2; i++) { falive[ef[i]] = 0; if (!phantom(ef[i])) n_alive_faces--; }
         for (int f : vfaces[b]) {
             if (!falive[f]) continue;
             for (int c = 0; c < 3; c++) if (faces[f][c] == b) faces[f][c] = a;
@@ -462,55 +567,62 @@ struct Decimator {
         if (dec_type == 0) for (int i = 0; i < 10; i++) quad[a][i] += quad[b][i];
         version[a]++; version[b]++;
         clean(a);
-        for (int w : common) clean(w);
-        // ---- re-home the points on the post-collapse star of a (closest-point re-parameterisation)
-        {
-            // locate every point in the flattened post patch: the face in which its smallest barycentric coordinate is
-            // largest, clamped to >= 0 and renormalised (src/query_fine_to_coarse.cpp:93-116)
-            for (size_t i = 0; i < pts.size(); i++) {
-                double bestmin = -1e300, bw[3] = {1, 0, 0};
-                int bl = -1;
-                for (size_t t = 0; t < patch.post.size(); t++) {
-                    const auto& g = patch.post[t];
-                    const double x0 = patch.U[g[0]], y0 = patch.Vv[g[0]], x1 = patch.U[g[1]], y1 = patch.Vv[g[1]], x2 = patch.U[g[2]], y2 = patch.Vv[g[2]];
-                    const double det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-                    const double w1 = ((puv[i][0] - x0) * (y2 - y0) - (x2 - x0) * (puv[i][1] - y0)) / det;
-                    const double w2 = ((x1 - x0) * (puv[i][1] - y0) - (puv[i][0] - x0) * (y1 - y0)) / det;
-                    const double w0 = 1.0 - w1 - w2, mn = std::min(w0, std::min(w1, w2));
-                    if (mn > bestmin) { bestmin = mn; bl = (int)t; bw[0] = w0; bw[1] = w1; bw[2] = w2; }
-                }
-                double sw = 0;
-                for (int c2 = 0; c2 < 3; c2++) { bw[c2] = std::max(bw[c2], 0.0); sw += bw[c2]; }
-                // patch.post[bl] lists the local vertices in the order of faces[post_gid[bl]] (with a/b -> m): same slots
-                const int p = pts[i], gf = post_gid[bl];
-                pface[p] = gf;
-                pbary[p] = {bw[0] / sw, bw[1] / sw, bw[2] / sw};
-                fpoints[gf].push_back(p);
+        for (int w : common) if (w != vinf) clean(w);
+        // ---- re-home the points: the face of the flattened post patch in which the smallest barycentric coordinate is largest,
+        // clamped to >= 0 and renormalised (src/query_fine_to_coarse.cpp:93-116)
+        for (size_t i = 0; i < pts.size(); i++) {
+            double bestmin = -1e300, bw[3] = {1, 0, 0};
+            int bl = -1;
+            for (size_t t = 0; t < patch.post.size(); t++) {
+                const auto& g = patch.post[t];
+                const double x0 = patch.U[g[0]], y0 = patch.Vv[g[0]], x1 = patch.U[g[1]], y1 = patch.Vv[g[1]], x2 = patch.U[g[2]], y2 = patch.Vv[g[2]];
+                const double det = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+                const double w1 = ((puv[i][0] - x0) * (y2 - y0) - (x2 - x0) * (puv[i][1] - y0)) / det;
+                const double w2 = ((x1 - x0) * (puv[i][1] - y0) - (puv[i][0] - x0) * (y1 - y0)) / det;
+                const double w0 = 1.0 - w1 - w2, mn = std::min(w0, std::min(w1, w2));
+                if (mn > bestmin) { bestmin = mn; bl = (int)t; bw[0] = w0; bw[1] = w1; bw[2] = w2; }
+            }
+            double sw = 0;
+            for (int c2 = 0; c2 < 3; c2++) { bw[c2] = std::max(bw[c2], 0.0); sw += bw[c2]; }
+            // patch.post[bl] lists the local vertices in the order of faces[post_gid[bl]] (with a/b -> merged): same slots
+            const int p = pts[i], gf = post_gid[bl];
+            pface[p] = gf;
+            pbary[p] = {bw[0] / sw, bw[1] / sw, bw[2] / sw};
+            fpoints[gf].push_back(p);
+        }
+        // ---- re-cost the edges of the merged vertex's new star (SSP_collapse_edge.cpp:482-520): its own edges get fresh entries, the
+        // ring edges opposite to it come back if they had been refused before
+        push_star(a);
+        for (int f : vfaces[a]) {
+            if (!falive[f]) continue;
+            for (int c = 0; c < 3; c++) {
+                const int x = faces[f][c], y = faces[f][(c + 1) % 3];
+                if (x == a || y == a || x == vinf || y == vinf) continue;
+                if (refused.erase(edge_key(x, y))) push_edge(x, y);
             }
         }
-        push_star(a);
         return true;
     }
 };
 
 }  // namespace
 
-int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& P, std::string& err)
+// absorption_cap_tenths: 0 (default) = the reference's plain greedy order.  > 0: opt-in departure -- a surviving vertex may stand for at
+// most (cap / 10) x (#F / tarF) input vertices; edges that would exceed that wait, and the bound doubles only when nothing else can be
+// collapsed.  (Shortest-edge-first decimation coarsens densely sampled parts of a mesh far beyond the requested ratio before it
+// touches the rest; on ogre.obj the V-cycle factor goes from 0.6 to 0.3 with a cap of 20.)
+int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err)
 {
     const int nV = fine.nV(), nF = fine.nF();
     if (dec_type < 0 || dec_type > 2) { err = "dec_type must be 0 (qslim), 1 (mid-point) or 2 (vertex removal)"; return -1; }
     if (nV < 4 || nF < 4) { err = "mesh too small to decimate"; return -1; }
     Decimator D;
     D.dec_type = dec_type;
+    D.nF_real = nF;
     D.pos.resize(nV);
     for (int i = 0; i < nV; i++) D.pos[i] = {fine.V[3 * i], fine.V[3 * i + 1], fine.V[3 * i + 2]};
-    D.valive.assign(nV, 1);
-    D.version.assign(nV, 0);
     D.faces.resize(nF);
-    D.falive.assign(nF, 1);
     D.vfaces.assign(nV, {});
-    D.fpoints.assign(nF, {});
-    D.n_alive_faces = nF;
     for (int f = 0; f < nF; f++) {
         for (int c = 0; c < 3; c++) {
             int v = fine.F[3 * f + c];
@@ -520,26 +632,52 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
         }
         if (D.faces[f][0] == D.faces[f][1] || D.faces[f][1] == D.faces[f][2] || D.faces[f][0] == D.faces[f][2]) { err = "degenerate face"; return -1; }
     }
-    if (dec_type == 0) D.init_quadrics();
-    // manifoldness (the reference bails out on non-manifold input, src/SSP_decimate.cpp:20-23)
+    // manifoldness (the reference bails out on non-manifold input, src/SSP_decimate.cpp:20-23) and the boundary edges
+    std::vector<std::array<int, 2>> bedges;   // directed as in their face
+    std::vector<uint64_t> ekeys;
     {
         // sorted edge keys: equal keys are adjacent (a hash map over 3 #F edges cost a tenth of the whole decimation)
-        std::vector<uint64_t> ekeys;
-        ekeys.reserve((size_t)nF * 3);
+        std::vector<std::array<uint64_t, 2>> ek;   // (key, directed code)
+        ek.reserve((size_t)nF * 3);
         for (int f = 0; f < nF; f++)
             for (int c = 0; c < 3; c++) {
                 int a = D.faces[f][c], b = D.faces[f][(c + 1) % 3];
-                ekeys.push_back(((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b));
+                ek.push_back({((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), ((uint64_t)(uint32_t)a << 32) | (uint32_t)b});
             }
-        std::sort(ekeys.begin(), ekeys.end());
-        for (size_t i = 0; i < ekeys.size();) {
+        std::sort(ek.begin(), ek.end());
+        for (size_t i = 0; i < ek.size();) {
             size_t j = i;
-            while (j < ekeys.size() && ekeys[j] == ekeys[i]) j++;
+            while (j < ek.size() && ek[j][0] == ek[i][0]) j++;
             if (j - i > 2) { err = "input mesh is not edge-manifold"; return -1; }
-            D.push_edge((int)(ekeys[i] >> 32), (int)(ekeys[i] & 0xffffffffu));
+            if (j - i == 2 && ek[i][1] == ek[i + 1][1]) { err = "input mesh is not consistently oriented"; return -1; }
+            if (j - i == 1) bedges.push_back({(int)(ek[i][1] >> 32), (int)(ek[i][1] & 0xffffffffu)});
+            ekeys.push_back(ek[i][0]);
             i = j;
         }
     }
+    // close the boundary with a vertex at infinity (igl::connect_boundary_to_infinity, SSP_midpoint.cpp:31): boundary edge (a -> b) of
+    // a face gets the phantom face (b, a, inf)
+    if (!bedges.empty()) {
+        D.vinf = nV;
+        const double inf = std::numeric_limits<double>::infinity();
+        D.pos.push_back({inf, inf, inf});
+        D.vfaces.push_back({});
+        std::vector<int> outdeg(nV, 0);
+        for (const auto& e : bedges) {
+            if (++outdeg[e[0]] > 1) { err = "input mesh has a non-manifold boundary vertex"; return -1; }
+            const int f = (int)D.faces.size();
+            D.faces.push_back({e[1], e[0], D.vinf});
+            D.vfaces[e[1]].push_back(f); D.vfaces[e[0]].push_back(f); D.vfaces[D.vinf].push_back(f);
+        }
+    }
+    const int nVall = (int)D.pos.size(), nFall = (int)D.faces.size();
+    D.valive.assign(nVall, 1);
+    D.version.assign(nVall, 0);
+    D.falive.assign(nFall, 1);
+    D.fpoints.assign(nFall, {});
+    D.n_alive_faces = nF;
+    if (dec_type == 0) D.init_quadrics();
+    for (uint64_t k : ekeys) D.push_edge((int)(k >> 32), (int)(k & 0xffffffffu));
     D.seal_initial();
     // every fine vertex starts as a one-hot barycentric point on one of its faces (src/get_prolong.cpp:23-39)
     D.pface.assign(nV, -1);
@@ -550,46 +688,36 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
             if (D.pface[v] < 0) { D.pface[v] = f; D.pbary[v] = {0, 0, 0}; D.pbary[v][c] = 1.0; D.fpoints[f].push_back(v); }
         }
     for (int v = 0; v < nV; v++) if (D.pface[v] < 0) { err = "unreferenced vertex in input mesh"; return -1; }
-    // greedy loop (src/SSP_midpoint.cpp:188-220): pop the cheapest valid edge until #faces <= tarF
-    // Rejected edges are parked and offered again once the queue runs dry after at least one success (their
-    // validity can change when a neighbouring collapse rewires the link).
-    // Absorption cap (not in the reference): shortest-edge-first decimation coarsens the densely sampled parts of a mesh far
-    // beyond the global ratio before it touches the rest (ogre.obj: coarse triangles holding 50 fine vertices next to regions
-    // left untouched), and a smooth error bump inside such a triangle is invisible to the coarse level: the V-cycle stalls at
-    // 0.6 per cycle there.  A surviving vertex may therefore stand for at most `cap` input vertices (twice the average of the
-    // requested ratio); edges that would exceed it wait, and the cap is relaxed only when nothing else is left to collapse.
-    // SMG_DECIMATE_CAP=0 switches it off (the reference's behaviour); another value sets the factor in tenths (default 20 = 2.0).
-    const int cap_mode = [] { const char* v = std::getenv("SMG_DECIMATE_CAP"); return v && *v ? std::atoi(v) : 20; }();
-    int cap = cap_mode ? std::max(3, (int)std::lround(0.1 * cap_mode * (double)nF / (double)std::max(tarF, 1))) : (1 << 30);
-    std::vector<int> weight(nV, 1);
-    std::vector<QEntry> parked;
-    bool progressed = false;
+    // greedy loop (src/SSP_midpoint.cpp:188-220): pop the cheapest live edge; a refused edge leaves the queue until a collapse next to
+    // it brings it back (Decimator::collapse); stop as soon as the number of real faces is <= tarF, or when nothing is left.
+    const bool capped = absorption_cap_tenths > 0;
+    int cap = capped ? std::max(3, (int)std::lround(0.1 * absorption_cap_tenths * (double)nF / (double)std::max(tarF, 1))) : (1 << 30);
+    std::vector<int> weight(capped ? nVall : 0, 1);
+    std::vector<QEntry> waiting;   // edges held back by the opt-in cap
     while (D.n_alive_faces > tarF) {
         if (D.queue_empty()) {
-            if (parked.empty()) break;
-            if (!progressed) {
-                if (cap >= (1 << 29)) break;
-                cap *= 2;   // nothing moved under the current cap: relax it
-            }
-            for (const QEntry& e : parked)
+            if (!capped || waiting.empty() || cap >= (1 << 29)) break;
+            cap *= 2;   // nothing else can be collapsed under the current cap: relax it
+            for (const QEntry& e : waiting)
                 if (D.valive[e.a] && D.valive[e.b]) D.push_edge(e.a, e.b);
-            parked.clear();
-            progressed = false;
+            waiting.clear();
             continue;
         }
         QEntry e = D.pop_next();
         if (!D.valive[e.a] || !D.valive[e.b] || D.version[e.a] != e.va || D.version[e.b] != e.vb) continue;
-        if (weight[e.a] + weight[e.b] > cap) { parked.push_back(e); continue; }
-        if (D.collapse(e.a, e.b)) { progressed = true; weight[e.a] += weight[e.b]; }   // b merges into a
-        else parked.push_back(e);
+        if (capped && weight[e.a] + weight[e.b] > cap) { waiting.push_back(e); continue; }
+        if (D.collapse(e.a, e.b)) { if (capped) weight[e.a] += weight[e.b]; }   // b merges into a
+        else D.refused.insert(Decimator::edge_key(e.a, e.b));                     // cost infinity until re-costed (SSP_collapse_edge.cpp:522-531)
     }
-    // compact
-    std::vector<int> vmap(nV, -1);
+    // compact: drop the vertex at infinity and the phantom faces (SSP_midpoint.cpp:65-70)
+    std::vector<int> vmap(nVall, -1);
     int nVc = 0;
     for (int v = 0; v < nV; v++) {
         if (!D.valive[v]) continue;
         D.clean(v);
-        if (D.vfaces[v].empty()) continue;
+        bool real = false;
+        for (int f : D.vfaces[v]) if (!D.phantom(f)) { real = true; break; }
+        if (!real) continue;
         vmap[v] = nVc++;
     }
     coarse.V.resize((size_t)nVc * 3);
@@ -598,33 +726,44 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, Mesh& coarse, Csr& 
     for (int f = 0; f < nF; f++) if (D.falive[f]) for (int c = 0; c < 3; c++) coarse.F.push_back(vmap[D.faces[f][c]]);
     // Every coarse vertex must be interpolated from by somebody: a column of P without a positive entry is a zero row and column
     // of the Galerkin operator, and the smoother divides by its diagonal.  (Possible in principle with mid-point placement: all
-    // points of the incident faces may sit on the opposite edges.)  Repair: the fine point of an incident face that lies closest
-    // to the orphaned vertex is snapped onto it.
+    // points of the incident faces may sit on the opposite edges.)  Repair, not in the reference: the fine point of an incident face
+    // that lies closest to the orphaned vertex is snapped onto it -- never a point that is the last supporter of another vertex; the
+    // supporter counts are kept up to date, and the pass repeats until nothing changes.
     {
-        std::vector<char> used(nV, 0);
+        std::vector<int> support(nVall, 0);
         for (int p = 0; p < nV; p++)
-            for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 1e-12) used[D.faces[D.pface[p]][c]] = 1;
-        for (int v = 0; v < nV; v++) {
-            if (vmap[v] < 0 || used[v]) continue;
-            int best = -1, bf = -1, bc = -1;
-            double bd = 1e300;
-            for (int f : D.vfaces[v]) {
-                if (!D.falive[f]) continue;
-                int cv = 0;
-                while (D.faces[f][cv] != v) cv++;
-                for (int p : D.fpoints[f]) {
-                    // position of the point on the coarse face
-                    V3 q = {0, 0, 0};
-                    for (int c = 0; c < 3; c++) q = q + D.pbary[p][c] * D.pos[D.faces[f][c]];
-                    const double d = norm(q - D.pos[v]);
-                    // do not orphan another vertex: the point must not be the only user of a vertex it currently leans on fully
-                    bool sole = false;
-                    for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 0.999999) sole = true;
-                    if (!sole && d < bd) { bd = d; best = p; bf = f; bc = cv; }
+            for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 1e-12) support[D.faces[D.pface[p]][c]]++;
+        for (int round = 0; round < 8; round++) {
+            bool changed = false;
+            for (int v = 0; v < nV; v++) {
+                if (vmap[v] < 0 || support[v] > 0) continue;
+                int best = -1, bf = -1, bc = -1;
+                double bd = 1e300;
+                for (int f : D.vfaces[v]) {
+                    if (!D.falive[f] || D.phantom(f)) continue;
+                    int cv = 0;
+                    while (D.faces[f][cv] != v) cv++;
+                    for (int p : D.fpoints[f]) {
+                        if (D.pface[p] != f) continue;
+                        V3 q = {0, 0, 0};
+                        for (int c = 0; c < 3; c++) q = q + D.pbary[p][c] * D.pos[D.faces[f][c]];
+                        const double d = norm(q - D.pos[v]);
+                        bool sole = false;   // would moving this point orphan a vertex it supports now?
+                        for (int c = 0; c < 3; c++) if (D.pbary[p][c] > 1e-12 && support[D.faces[f][c]] <= 1) sole = true;
+                        if (!sole && d < bd) { bd = d; best = p; bf = f; bc = cv; }
+                    }
+                }
+                if (best >= 0) {
+                    for (int c = 0; c < 3; c++) if (D.pbary[best][c] > 1e-12) support[D.faces[bf][c]]--;
+                    D.pbary[best] = {0, 0, 0}; D.pbary[best][bc] = 1.0;
+                    support[v]++;
+                    changed = true;
                 }
             }
-            if (best >= 0) { D.pface[best] = bf; D.pbary[best] = {0, 0, 0}; D.pbary[best][bc] = 1.0; used[v] = 1; }
+            if (!changed) break;
         }
+        for (int v = 0; v < nV; v++)
+            if (vmap[v] >= 0 && support[v] == 0) { err = "a coarse vertex is left without any fine vertex interpolating from it"; return -1; }
     }
     // P: three stored entries per row (explicit zeros kept), src/get_prolong.cpp:45-56
     std::vector<int> ptr(nV + 1), col((size_t)nV * 3);

@@ -11,11 +11,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _stale(exe, srcs):
+    """an example binary must be rebuilt when its sources, the C ABI header, the C++ mirror or the library changed (the options
+    struct of include/smg.h is passed by pointer: a binary built against an older layout would corrupt its stack)"""
+    deps = list(srcs) + [os.path.join(ROOT, "include", "smg.h"), os.path.join(ROOT, "surface_multigrid_code_amd", "csrc", "mg_api.hpp"),
+                         os.path.join(ROOT, "surface_multigrid_code_amd", "lib", "libsmg.so")]
+    return (not os.path.exists(exe)) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+
+
 def test_cpp_example_matches_python_path(smg_mod, oracle_mod):
     smg, mesh = smg_mod, smg_mod.mesh
     exe = os.path.join(ROOT, "examples", "03_mg_solver")
     src = os.path.join(ROOT, "examples", "03_mg_solver.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    if _stale(exe, [src]):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
                                "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
@@ -45,7 +53,7 @@ def test_cpp_mean_curvature_flow_example(smg_mod, oracle_mod):
     smg, mesh = smg_mod, smg_mod.mesh
     exe = os.path.join(ROOT, "examples", "05_mean_curvature_flow")
     src = os.path.join(ROOT, "examples", "05_mean_curvature_flow.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    if _stale(exe, [src]):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
                                "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
@@ -74,7 +82,7 @@ def test_cpp_closed_mesh_with_pins_example(smg_mod, oracle_mod):
     smg, mesh = smg_mod, smg_mod.mesh
     exe = os.path.join(ROOT, "examples", "04_mg_solver_nobd")
     src = os.path.join(ROOT, "examples", "04_mg_solver_nobd.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    if _stale(exe, [src]):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-L" + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"),
                                "-lsmg", "-Wl,-rpath," + os.path.join(ROOT, "surface_multigrid_code_amd", "lib"), "-o", exe])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
@@ -110,7 +118,7 @@ def test_eigen_adapter_runs_through_the_reference_signatures(smg_mod):
     exe = os.path.join(ROOT, "examples", "adapter_check")
     srcs = [os.path.join(ROOT, "examples", f) for f in ("adapter_check.cpp", "smg_eigen_adapter.cpp")]
     lib = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in srcs):
+    if _stale(exe, srcs):
         subprocess.check_call(["hipcc", "-std=c++17", "-O2", "-DSMG_ADAPTER_MOCK", "-I" + os.path.join(ROOT, "tests", "mock_eigen"),
                                "-I" + os.path.join(ROOT, "include")] + srcs + ["-L" + lib, "-lsmg", "-Wl,-rpath," + lib, "-o", exe])
     env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))

@@ -171,15 +171,23 @@ def test_c5_solve_against_oracle_all_core(smg_mod, oracle_mod):
     assert np.linalg.norm(z[perm0, 0] - z2[:, 0]) <= 1e-9 * np.linalg.norm(z2)
     conv3, z3, rh3 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, precision="mixed"))
     assert conv3 and np.linalg.norm(z3 - z) <= 1e-7 * np.linalg.norm(z)
-    # hybrid smoother at this size: the oracle with the same per-level choice (Jacobi is numbering-independent, GS runs in the
-    # device numbering) tracks it too
+    # hybrid smoothers at this size: the oracle with the same per-level choice (Jacobi-type sweeps are numbering-independent, GS runs in
+    # the device numbering) tracks them iteration for iteration.  Chebyshev-Jacobi below 300 k rows needs no more cycles than
+    # Gauss-Seidel everywhere; damped Jacobi on this anisotropic mesh needs ~45 % more (which is why it is not the benchmark's default).
+    thr = 300000
+    for lv in range(mg.n_levels - 1):
+        orc.set_smoother(lv, "chebyshev" if mg.rows(lv) <= thr else "gs", 0.1)
+    conv4, z4, rh4 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, smoother="hybrid_chebyshev", jacobi_max_rows=thr))
+    conv5, z5, rh5 = orc.solve(rhs[perm0], z0[perm0], tol=tol, max_iter=40)
+    assert conv4 and conv5 and len(rh4) == len(rh5) and len(rh4) <= len(rh) + 1, (len(rh), len(rh4), len(rh5))
+    np.testing.assert_allclose(rh4, rh5, rtol=1e-6)
     thr = 100000
     for lv in range(mg.n_levels - 1):
         orc.set_smoother(lv, "jacobi" if mg.rows(lv) <= thr else "gs", 0.8)
-    conv4, z4, rh4 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40, smoother="hybrid", jacobi_max_rows=thr))
-    conv5, z5, rh5 = orc.solve(rhs[perm0], z0[perm0], tol=tol, max_iter=40)
-    assert conv4 and conv5 and len(rh4) == len(rh5), (conv4, conv5, rh4, rh5)
-    np.testing.assert_allclose(rh4, rh5, rtol=1e-6)
+    conv6, z6, rh6 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=80, smoother="hybrid", jacobi_max_rows=thr))
+    conv7, z7, rh7 = orc.solve(rhs[perm0], z0[perm0], tol=tol, max_iter=80)
+    assert conv6 and conv7 and len(rh6) == len(rh7) and len(rh6) > len(rh)
+    np.testing.assert_allclose(rh6, rh7, rtol=1e-6)
 
 
 def test_03_mg_solver_on_ogre_with_its_boundary_loop(smg_mod, oracle_mod):

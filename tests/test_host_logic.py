@@ -250,10 +250,12 @@ def test_malformed_inputs_are_rejected(smg_mod):
     assert abs(mgA.matrix(0, "A") - A).max() == 0
 
 
-def test_weak_kat_bunny_500_faces(smg_mod):
+def test_kat_bunny_500_faces(smg_mod):
     """The only decimation output the reference checks in: 08_subdiv_remesh/output_s0.obj = bunny.obj decimated by
-    mid-point collapse to tarF = 500 -> 261 V / 499 F.  libigl-version dependent on the reference
-    side and a different implementation here, so only the counts are compared (Euler: V = 1 + (F + #boundary edges) / 2)."""
+    mid-point collapse to tarF = 500 -> 261 V / 499 F.  With the reference's construction (boundary closed by a
+    vertex at infinity, mid-point placement also on the boundary, libigl's refuse / re-cost queue discipline, the three flattening
+    cases and their thresholds) the counts are reproduced exactly.  By Euler's formula V = 1 + (F + #boundary edges) / 2, so 261 fixes
+    the number of boundary collapses as well: 21 boundary edges remain of 149."""
     import ctypes as C
     smg, mesh = smg_mod, smg_mod.mesh
     V, F = mesh.read_triangle_mesh("bunny.smgm")
@@ -262,19 +264,28 @@ def test_weak_kat_bunny_500_faces(smg_mod):
     assert mg.n_levels == 2
     nV, nF = C.c_int(), C.c_int()
     smg._lib.load().smg_level_get_mesh(mg.h, 1, C.byref(nV), C.byref(nF), None, None)
-    assert nF.value == 499 and abs(nV.value - 261) <= 3
+    assert nF.value == 499 and nV.value == 261
     assert mg.matrix(1, "P_full").shape == (9353, nV.value)
+    Vc = np.zeros((nV.value, 3)); Fc = np.zeros((nF.value, 3), np.int32)
+    smg._lib.load().smg_level_get_mesh(mg.h, 1, None, None, Vc.ctypes.data_as(C.POINTER(C.c_double)), Fc.ctypes.data_as(C.POINTER(C.c_int)))
+    assert len(mesh.boundary_loop(Fc)) == 21
+    # the opt-in absorption cap is a different collapse order: it is not what the known answer is about
+    mgc = smg.mg_precompute(V, F, ratio, 200, 1, absorption_cap=2.0)
+    smg._lib.load().smg_level_get_mesh(mgc.h, 1, C.byref(nV), C.byref(nF), None, None)
+    assert nF.value in (499, 500)
 
 
-@pytest.mark.parametrize("mesh_name,bound,dec_type", [("bunny.smgm", 0.12, 1), ("ogre.smgm", 0.36, 1), ("bunny_15K_init.smgm", 0.12, 1),
-                                                      ("bunny.smgm", 0.35, 0), ("bunny.smgm", 0.3, 2)])
-def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, bound, dec_type):
-    """no reference binary to compare the hierarchy builder with, so it is judged by what it is for --
-    the V-cycle convergence factor of the reference algorithm (CPU oracle) on its hierarchy, expected <~ 0.3 (ogre.obj, strongly
-    non-uniform sampling, needs the absorption cap of the decimator for that: 0.62 without)."""
+@pytest.mark.parametrize("mesh_name,bound,dec_type,cap", [("bunny.smgm", 0.12, 1, 0.0), ("bunny_15K_init.smgm", 0.2, 1, 0.0), ("ogre_sim.smgm", 0.2, 1, 0.0),
+                                                          ("ogre.smgm", 0.75, 1, 0.0), ("ogre.smgm", 0.36, 1, 2.0), ("bunny_15K_init.smgm", 0.12, 1, 2.0),
+                                                          ("bunny.smgm", 0.35, 0, 0.0), ("bunny.smgm", 0.3, 2, 0.0)])
+def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, bound, dec_type, cap):
+    """the hierarchy builder is judged by what it is for -- the V-cycle convergence factor of the reference
+    algorithm (CPU oracle) on its hierarchy, expected <~ 0.3.  The reference's plain greedy order (cap 0, the default) delivers that on
+    evenly sampled meshes; on ogre.obj (strongly non-uniform sampling) shortest-edge-first coarsens the dense regions far beyond the
+    ratio and the factor is 0.6-0.7 -- a property of the construction, which the opt-in absorption cap repairs (0.3)."""
     V, F = M.read_smgm(mesh_name)
     V = M.normalize_unit_area(V, F)
-    mg = smg_mod.mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=dec_type)
+    mg = smg_mod.mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=dec_type, absorption_cap=cap)
     Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
     sizes = [Ps[0].shape[0]] + [P.shape[1] for P in Ps]
     assert all(0.2 < sizes[i + 1] / sizes[i] < 0.3 for i in range(len(sizes) - 1))
