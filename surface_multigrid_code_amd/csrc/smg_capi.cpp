@@ -45,6 +45,16 @@ static int fail(int code, const char* fmt, ...)
         if (e__ != hipSuccess) return fail(SMG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+// Nothing may throw across the C ABI: the entry points that allocate host memory run their bodies through this guard.
+template <typename Fn>
+static int guarded(const char* who, Fn&& body)
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) { return fail(SMG_ERR_ALLOC, "%s: out of host memory", who); }
+    catch (const std::exception& e) { return fail(SMG_ERR_INVALID, "%s: %s", who, e.what()); }
+    catch (...) { return fail(SMG_ERR_INVALID, "%s: unknown exception", who); }
+}
+
 extern "C" const char* smg_last_error(void) { return g_err.c_str(); }
 extern "C" int smg_version(void) { return SMG_VERSION; }
 extern "C" int smg_device_count(void)
@@ -306,7 +316,7 @@ static int set_prolong(smg_hierarchy* h, int lv, Csr&& P)
     return SMG_OK;
 }
 
-extern "C" int smg_level_set_prolong(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* rowptr,
+static int smg_level_set_prolong_impl(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* rowptr,
                                      const int* col, const double* val)
 {
     if (!h || lv < 1 || lv >= h->n_levels || !rowptr || n_fine < 0 || n_coarse < 0)
@@ -315,7 +325,13 @@ extern "C" int smg_level_set_prolong(smg_hierarchy* h, int lv, int n_fine, int n
     return set_prolong(h, lv, csr_from_arrays(n_fine, n_coarse, rowptr, col, val));
 }
 
-extern "C" int smg_level_set_prolong_csc(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* colptr,
+extern "C" int smg_level_set_prolong(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* rowptr,
+                                     const int* col, const double* val)
+{
+    return guarded("smg_level_set_prolong", [&]() { return smg_level_set_prolong_impl(h, lv, n_fine, n_coarse, rowptr, col, val); });
+}
+
+static int smg_level_set_prolong_csc_impl(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* colptr,
                                          const int* rowidx, const double* val)
 {
     if (!h || lv < 1 || lv >= h->n_levels || !colptr || n_fine < 0 || n_coarse < 0)
@@ -324,12 +340,23 @@ extern "C" int smg_level_set_prolong_csc(smg_hierarchy* h, int lv, int n_fine, i
     return set_prolong(h, lv, csr_from_csc_arrays(n_fine, n_coarse, colptr, rowidx, val));
 }
 
-extern "C" int smg_level_set_mesh(smg_hierarchy* h, int lv, const double* V, int nV, const int* F, int nF)
+extern "C" int smg_level_set_prolong_csc(smg_hierarchy* h, int lv, int n_fine, int n_coarse, const int* colptr,
+                                         const int* rowidx, const double* val)
+{
+    return guarded("smg_level_set_prolong_csc", [&]() { return smg_level_set_prolong_csc_impl(h, lv, n_fine, n_coarse, colptr, rowidx, val); });
+}
+
+static int smg_level_set_mesh_impl(smg_hierarchy* h, int lv, const double* V, int nV, const int* F, int nF)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_set_mesh: bad level");
     h->lv[lv].V.assign(V, V + (size_t)nV * 3);
     h->lv[lv].F.assign(F, F + (size_t)nF * 3);
     return SMG_OK;
+}
+
+extern "C" int smg_level_set_mesh(smg_hierarchy* h, int lv, const double* V, int nV, const int* F, int nF)
+{
+    return guarded("smg_level_set_mesh", [&]() { return smg_level_set_mesh_impl(h, lv, V, nV, F, nF); });
 }
 
 extern "C" int smg_level_get_mesh(const smg_hierarchy* h, int lv, int* nV, int* nF, double* V, int* F)
@@ -892,7 +919,7 @@ struct smg_assembler {
     smg::DevBuf<double> Qc, Qm, Md;
 };
 
-extern "C" int smg_assembler_create(const int* F, int nF, int nV, smg_assembler** out)
+static int smg_assembler_create_impl(const int* F, int nF, int nV, smg_assembler** out)
 {
     if (!F || nF <= 0 || nV <= 0 || !out) return fail(SMG_ERR_INVALID, "smg_assembler_create: bad arguments");
     int ndev = 0;
@@ -917,6 +944,11 @@ extern "C" int smg_assembler_create(const int* F, int nF, int nV, smg_assembler*
     *out = a;
     return SMG_OK;
 }
+
+extern "C" int smg_assembler_create(const int* F, int nF, int nV, smg_assembler** out)
+{
+    return guarded("smg_assembler_create", [&]() { return smg_assembler_create_impl(F, nF, nV, out); });
+}
 extern "C" void smg_assembler_destroy(smg_assembler* a) { delete a; }
 extern "C" int smg_assembler_pattern(const smg_assembler* a, int* nnz, int* rowptr, int* col)
 {
@@ -937,7 +969,7 @@ extern "C" int smg_assemble(smg_assembler* a, const double* d_V, int voronoi, do
     return SMG_OK;
 }
 
-extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
+static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
                               const int* known, int n_known)
 {
     if (!h || n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_precompute: bad arguments");
@@ -979,6 +1011,12 @@ extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const 
     h->pre_key = key;
     h->precomputed = true;
     return SMG_OK;
+}
+
+extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
+                              const int* known, int n_known)
+{
+    return guarded("smg_precompute", [&]() { return smg_precompute_impl(h, n, rowptr, col, val, known, n_known); });
 }
 
 // ------------------------------------------------------------------------------------------------ V-cycle
@@ -1423,7 +1461,7 @@ static int check_ready(const smg_hierarchy* h, const char* who)
     return SMG_OK;
 }
 
-extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
+static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
                                const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts)
 {
     int rc = check_ready(h, "smg_solve_begin");
@@ -1493,6 +1531,12 @@ extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, 
     h->iters_enqueued = 0;
     h->in_solve = true;
     return SMG_OK;
+}
+
+extern "C" int smg_solve_begin(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
+                               const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts)
+{
+    return guarded("smg_solve_begin", [&]() { return smg_solve_begin_impl(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts); });
 }
 
 extern "C" int smg_solve_iter_residual(smg_hierarchy* h, double* d_sumsq)
@@ -2032,7 +2076,7 @@ static Mesh wrap_mesh(const double* V, int nV, const int* F, int nF)
     return m;
 }
 
-extern "C" int smg_mesh_read(const char* path, double** V, int* nV, int** F, int* nF)
+static int smg_mesh_read_impl(const char* path, double** V, int* nV, int** F, int* nF)
 {
     if (!path || !V || !nV || !F || !nF) return fail(SMG_ERR_INVALID, "smg_mesh_read: bad arguments");
     Mesh m;
@@ -2045,6 +2089,11 @@ extern "C" int smg_mesh_read(const char* path, double** V, int* nV, int** F, int
     std::memcpy(*F, m.F.data(), m.F.size() * sizeof(int));
     return SMG_OK;
 }
+
+extern "C" int smg_mesh_read(const char* path, double** V, int* nV, int** F, int* nF)
+{
+    return guarded("smg_mesh_read", [&]() { return smg_mesh_read_impl(path, V, nV, F, nF); });
+}
 extern "C" void smg_free(void* p) { std::free(p); }
 
 extern "C" int smg_mesh_normalize_unit_area(double* V, int nV, const int* F, int nF)
@@ -2056,7 +2105,7 @@ extern "C" int smg_mesh_normalize_unit_area(double* V, int nV, const int* F, int
     return SMG_OK;
 }
 
-extern "C" int smg_mesh_cotmatrix(const double* V, int nV, const int* F, int nF, int* nnz, int* rowptr, int* col, double* val)
+static int smg_mesh_cotmatrix_impl(const double* V, int nV, const int* F, int nF, int* nnz, int* rowptr, int* col, double* val)
 {
     if (!V || !F) return fail(SMG_ERR_INVALID, "smg_mesh_cotmatrix: bad arguments");
     static thread_local Csr cache;
@@ -2071,6 +2120,11 @@ extern "C" int smg_mesh_cotmatrix(const double* V, int nV, const int* F, int nF,
         cache = Csr(); cacheV = nullptr;
     }
     return SMG_OK;
+}
+
+extern "C" int smg_mesh_cotmatrix(const double* V, int nV, const int* F, int nF, int* nnz, int* rowptr, int* col, double* val)
+{
+    return guarded("smg_mesh_cotmatrix", [&]() { return smg_mesh_cotmatrix_impl(V, nV, F, nF, nnz, rowptr, col, val); });
 }
 
 extern "C" int smg_mesh_massmatrix(const double* V, int nV, const int* F, int nF, int voronoi, double* diag)
@@ -2091,7 +2145,7 @@ extern "C" int smg_mesh_boundary_loop(const int* F, int nF, int nV, int* loop, i
     return SMG_OK;
 }
 
-extern "C" int smg_mesh_midpoint_upsample(int nV, const int* F, int nF, int* nE, int* S_rowptr, int* S_col, double* S_val, int* NF)
+static int smg_mesh_midpoint_upsample_impl(int nV, const int* F, int nF, int* nE, int* S_rowptr, int* S_col, double* S_val, int* NF)
 {
     if (!F) return fail(SMG_ERR_INVALID, "smg_mesh_midpoint_upsample: bad arguments");
     std::vector<int> Fv(F, F + (size_t)nF * 3), NFv;
@@ -2103,6 +2157,11 @@ extern "C" int smg_mesh_midpoint_upsample(int nV, const int* F, int nF, int* nE,
     if (S_val) std::copy(S.val.begin(), S.val.end(), S_val);
     if (NF) std::copy(NFv.begin(), NFv.end(), NF);
     return SMG_OK;
+}
+
+extern "C" int smg_mesh_midpoint_upsample(int nV, const int* F, int nF, int* nE, int* S_rowptr, int* S_col, double* S_val, int* NF)
+{
+    return guarded("smg_mesh_midpoint_upsample", [&]() { return smg_mesh_midpoint_upsample_impl(nV, F, nF, nE, S_rowptr, S_col, S_val, NF); });
 }
 
 extern "C" int smg_mesh_torus(int nu, int nv, double R, double r, double* V, int* F)
@@ -2157,7 +2216,7 @@ extern "C" int smg_mg_precompute(const double* V, int nV, const int* F, int nF, 
     return smg_mg_precompute_capped(V, nV, F, nF, ratio, nVCoarsest, dec_type, 0.0f, out);
 }
 
-extern "C" int smg_mg_precompute_capped(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+static int smg_mg_precompute_capped_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
                                         float absorption_cap, smg_hierarchy** out)
 {
     if (!V || !F || !out || nV <= 0 || nF <= 0 || !(ratio > 0.f && ratio < 1.f) || !(absorption_cap >= 0.f))
@@ -2173,7 +2232,13 @@ extern "C" int smg_mg_precompute_capped(const double* V, int nV, const int* F, i
     return SMG_OK;
 }
 
-extern "C" int smg_mg_precompute_block(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+extern "C" int smg_mg_precompute_capped(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                        float absorption_cap, smg_hierarchy** out)
+{
+    return guarded("smg_mg_precompute_capped", [&]() { return smg_mg_precompute_capped_impl(V, nV, F, nF, ratio, nVCoarsest, dec_type, absorption_cap, out); });
+}
+
+static int smg_mg_precompute_block_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
                                        smg_hierarchy** out)
 {
     int rc = smg_mg_precompute(V, nV, F, nF, ratio, nVCoarsest, dec_type, out);
@@ -2195,6 +2260,12 @@ extern "C" int smg_mg_precompute_block(const double* V, int nV, const int* F, in
         set_prolong(h, lv, std::move(B));
     }
     return SMG_OK;
+}
+
+extern "C" int smg_mg_precompute_block(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                       smg_hierarchy** out)
+{
+    return guarded("smg_mg_precompute_block", [&]() { return smg_mg_precompute_block_impl(V, nV, F, nF, ratio, nVCoarsest, dec_type, out); });
 }
 
 extern "C" int smg_hierarchy_save(const smg_hierarchy* h, const char* path)
@@ -2221,43 +2292,57 @@ extern "C" int smg_hierarchy_save(const smg_hierarchy* h, const char* path)
     return ok ? SMG_OK : fail(SMG_ERR_IO, "short write to '%s'", path);
 }
 
-extern "C" int smg_hierarchy_load(const char* path, smg_hierarchy** out)
+static int smg_hierarchy_load_impl(const char* path, smg_hierarchy** out)
 {
     if (!path || !out) return fail(SMG_ERR_INVALID, "smg_hierarchy_load: bad arguments");
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(SMG_ERR_IO, "cannot open '%s'", path);
+    // every count read from the file is checked against what the file can still hold before anything is allocated from it
+    long fsize = 0;
+    if (std::fseek(f, 0, SEEK_END) == 0) { fsize = std::ftell(f); std::rewind(f); }
+    auto room = [&](double bytes) { const long at = std::ftell(f); return at >= 0 && bytes >= 0 && (double)at + bytes <= (double)fsize; };
     char magic[4];
     uint32_t ver = 0;
     int32_t L = 0;
     bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "SMGH", 4) == 0 && std::fread(&ver, 4, 1, f) == 1 && ver == 1 &&
               std::fread(&L, 4, 1, f) == 1 && L >= 1 && L < 64;
     smg_hierarchy* h = ok ? smg_hierarchy_create(L) : nullptr;
+    const char* why = "not a hierarchy file";
+    int prev_cols = -1;
     for (int lv = 0; lv < L && ok && h; lv++) {
         int32_t nV = 0, nF = 0;
-        ok = std::fread(&nV, 4, 1, f) == 1 && std::fread(&nF, 4, 1, f) == 1 && nV >= 0 && nF >= 0;
-        if (!ok) break;
+        ok = std::fread(&nV, 4, 1, f) == 1 && std::fread(&nF, 4, 1, f) == 1 && nV >= 0 && nF >= 0 && room(24.0 * nV + 12.0 * nF);
+        if (!ok) { why = "truncated or corrupt mesh block"; break; }
         h->lv[lv].V.resize((size_t)nV * 3); h->lv[lv].F.resize((size_t)nF * 3);
         ok = std::fread(h->lv[lv].V.data(), 8, h->lv[lv].V.size(), f) == h->lv[lv].V.size() &&
              std::fread(h->lv[lv].F.data(), 4, h->lv[lv].F.size(), f) == h->lv[lv].F.size();
+        for (size_t i = 0; ok && i < h->lv[lv].F.size(); i++) if (h->lv[lv].F[i] < 0 || h->lv[lv].F[i] >= nV) { ok = false; why = "face index out of range"; }
         if (lv >= 1 && ok) {
             int32_t hdr[3];
-            ok = std::fread(hdr, 4, 3, f) == 3 && hdr[0] >= 0 && hdr[1] >= 0 && hdr[2] >= 0;
-            if (!ok) break;
+            ok = std::fread(hdr, 4, 3, f) == 3 && hdr[0] >= 0 && hdr[1] >= 0 && hdr[2] >= 0 && room(4.0 * (hdr[0] + 1.0) + 12.0 * hdr[2]);
+            if (!ok) { why = "truncated or corrupt prolongation block"; break; }
             Csr P;
             P.nr = hdr[0]; P.nc = hdr[1];
             P.ptr.resize((size_t)P.nr + 1); P.col.resize(hdr[2]); P.val.resize(hdr[2]);
             ok = std::fread(P.ptr.data(), 4, P.ptr.size(), f) == P.ptr.size() && std::fread(P.col.data(), 4, P.col.size(), f) == P.col.size() &&
                  std::fread(P.val.data(), 8, P.val.size(), f) == P.val.size() && P.ptr.back() == hdr[2];
-            if (ok) set_prolong(h, lv, std::move(P));
+            if (ok) if (const char* e = check_compressed(P.nr, P.nc, P.ptr.data(), P.col.data())) { ok = false; why = e; }
+            if (ok && prev_cols >= 0 && P.nr != prev_cols) { ok = false; why = "prolongation sizes of consecutive levels do not chain"; }
+            if (ok) { prev_cols = P.nc; set_prolong(h, lv, std::move(P)); }
         }
     }
     std::fclose(f);
-    if (!ok || !h) { if (h) smg_hierarchy_destroy(h); return fail(SMG_ERR_IO, "'%s' is not a valid hierarchy file", path); }
+    if (!ok || !h) { if (h) smg_hierarchy_destroy(h); return fail(SMG_ERR_IO, "'%s' is not a valid hierarchy file (%s)", path, why); }
     *out = h;
     return SMG_OK;
 }
 
-extern "C" int smg_mg_precompute_subdiv(const double* V, int nV, const int* F, int nF, int n_sub, float ratio, int nVCoarsest,
+extern "C" int smg_hierarchy_load(const char* path, smg_hierarchy** out)
+{
+    return guarded("smg_hierarchy_load", [&]() { return smg_hierarchy_load_impl(path, out); });
+}
+
+static int smg_mg_precompute_subdiv_impl(const double* V, int nV, const int* F, int nF, int n_sub, float ratio, int nVCoarsest,
                                         int n_extra_levels, smg_hierarchy** out, double* V_out, int* F_out)
 {
     if (!V || !F || !out || nV <= 0 || nF <= 0 || n_sub < 0) return fail(SMG_ERR_INVALID, "smg_mg_precompute_subdiv: bad arguments");
@@ -2277,4 +2362,10 @@ extern "C" int smg_mg_precompute_subdiv(const double* V, int nV, const int* F, i
     if (F_out) std::copy(fine.F.begin(), fine.F.end(), F_out);
     *out = h;
     return SMG_OK;
+}
+
+extern "C" int smg_mg_precompute_subdiv(const double* V, int nV, const int* F, int nF, int n_sub, float ratio, int nVCoarsest,
+                                        int n_extra_levels, smg_hierarchy** out, double* V_out, int* F_out)
+{
+    return guarded("smg_mg_precompute_subdiv", [&]() { return smg_mg_precompute_subdiv_impl(V, nV, F, nF, n_sub, ratio, nVCoarsest, n_extra_levels, out, V_out, F_out); });
 }

@@ -107,3 +107,33 @@ def test_two_ranks_drive_the_gpu_engine(smg_mod, smoother):
         pr.join(timeout=120)
     assert all(r[1] for r in res), res
     assert res[0][3] == res[1][3] and res[0][4] == res[1][4]      # identical history on both ranks
+
+
+def test_handle_lives_on_the_device_that_was_current_at_precompute(smg_mod):
+    """One process, two GPUs: a handle precomputed with device 1 current keeps everything (including what the precompute's worker
+    threads upload -- a std::thread starts on device 0) on device 1 and can be driven while another device is current; results are
+    those of a device-0 handle, bit for bit.  Needs >= 2 visible GPUs (skipped on the single-GPU box)."""
+    import torch
+    if smg_mod._lib.load().smg_device_count() < 2 or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    sys.path.insert(0, HERE)
+    from problems import subdiv_problem
+    smg = smg_mod
+    p = subdiv_problem(kind="poisson", k=2, n_sub=2)
+    o = smg.SolveOpts(tol=1e-9, max_iter=40)
+    torch.cuda.set_device(0)
+    mg0 = smg.Hierarchy.from_prolongs(p["Ps"]); mg0.precompute(p["A"], p["known"])
+    ref = mg0.solve(p["RHS"], p["z0"], p["known_val"], o)
+    torch.cuda.set_device(1)
+    mg1 = smg.Hierarchy.from_prolongs(p["Ps"]); mg1.precompute(p["A"], p["known"])
+    a = mg1.solve(p["RHS"], p["z0"], p["known_val"], o)
+    torch.cuda.set_device(0)                                   # the caller moves on; the handle stays on device 1
+    b = mg1.solve(p["RHS"], p["z0"], p["known_val"], o)
+    mg1.precompute(p["A"], p["known"])                         # value-only re-precompute path, still from device 0's thread state
+    c = mg1.solve(p["RHS"], p["z0"], p["known_val"], o)
+    assert torch.cuda.current_device() == 0
+    for r in (a, b, c):
+        assert r[0] and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
+    free0 = torch.cuda.mem_get_info(0)[0]
+    del mg1
+    assert torch.cuda.mem_get_info(0)[0] <= free0 + (64 << 20)   # nothing of mg1 had been living on device 0

@@ -198,6 +198,29 @@ def test_hierarchy_save_load_roundtrip_and_block_variant(smg_mod, tmp_path):
         assert np.array_equal(a.data, b.data)
     with pytest.raises(smg.SmgError):
         smg.Hierarchy.load(str(tmp_path / "missing.smgh"))
+    # truncated / corrupt files are refused with SMG_ERR_IO, not read out of bounds: cut the file, poison a column index, a row
+    # pointer, a count
+    raw = open(path, "rb").read()
+    import struct
+    bad_files = {"cut": raw[: len(raw) // 2], "short": raw[:11]}
+    nV0, nF0 = struct.unpack_from("<ii", raw, 12)
+    off1 = 12 + 8 + 24 * nV0 + 12 * nF0                       # level 1: i32 nV, nF, V, F, then the P header
+    nV1, nF1 = struct.unpack_from("<ii", raw, off1)
+    offP = off1 + 8 + 24 * nV1 + 12 * nF1
+    nr, nc, nnz = struct.unpack_from("<iii", raw, offP)
+    assert nr == V.shape[0] and nnz == 3 * nr
+    col_at = offP + 12 + 4 * (nr + 1)
+    b = bytearray(raw); struct.pack_into("<i", b, col_at + 40, nc + 5); bad_files["col"] = bytes(b)
+    b = bytearray(raw); struct.pack_into("<i", b, offP + 12 + 4 * 7, 2 ** 30); bad_files["ptr"] = bytes(b)
+    b = bytearray(raw); struct.pack_into("<i", b, offP + 8, 2 ** 31 - 1); bad_files["nnz"] = bytes(b)
+    b = bytearray(raw); struct.pack_into("<i", b, 12, 2 ** 31 - 1); bad_files["nV"] = bytes(b)
+    b = bytearray(raw); struct.pack_into("<i", b, 12 + 8 + 24 * nV0 + 4, nV0 + 3); bad_files["face"] = bytes(b)
+    for name, data in bad_files.items():
+        bp = str(tmp_path / ("bad_%s.smgh" % name))
+        open(bp, "wb").write(data)
+        with pytest.raises(smg.SmgError) as e:
+            smg.Hierarchy.load(bp)
+        assert e.value.code == -6, (name, e.value)
     # block variant: P (x) I_3 with DOF index 3*vertex + d (src/get_prolong.cpp:104-114)
     mb = smg.mg_precompute_block(V, F, 0.25, 100, 1)
     for l in range(1, mg.n_levels):
