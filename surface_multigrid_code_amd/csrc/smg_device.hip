@@ -449,7 +449,11 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
             case 1: {
                 // the usual widths get kernels with the look-ahead count fixed at compile time (no branch per panel column)
                 const int w0 = A.stride > 0 ? (A.w_lo < 8 ? A.w_lo : 8) : -1;
-                static const int pitch_max = getenv("SMG_PITCH_SPEC_MAX") ? atoi(getenv("SMG_PITCH_SPEC_MAX")) : 32;
+                // whole-pitch look-ahead: colour sweeps of <= 32 workgroups, and the whole-matrix launches (Jacobi / Chebyshev sweeps,
+                // residual, transfer) of a level that small, <= 64 workgroups (C3 level 3: 37.3 -> 34.1 us per visit; colour sweeps of 62
+                // workgroups lose with it)
+                static const int pitch_env = getenv("SMG_PITCH_SPEC_MAX") ? atoi(getenv("SMG_PITCH_SPEC_MAX")) : -1;
+                const int pitch_max = pitch_env >= 0 ? pitch_env : (MODE == SELL_GS ? 32 : 64);
                 if (nb <= pitch_max && A.stride == 12 && w0 >= 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 12>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
