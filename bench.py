@@ -584,6 +584,10 @@ def main():
             "profc": {k: {"count": v[0], "ms_total": v[1]} for k, v in prof.items()},
             "residual_history_head": [float(v) for v in r_his[:6]],
             "setup_s": {"mesh_hierarchy_host": t_host, "precompute": t_pre},
+            # memory budget: everything libsmg holds in HBM for this workload (operators in SELL incl. the fixed panel pitch, A^T images of the
+            # Galerkin levels, dense coarse inverse, work vectors, graphs' buffers) against the algorithmic size of the hierarchy
+            "device_bytes": {"libsmg_live": int(smg._lib.load().smg_device_bytes_live()), "hierarchy_algorithmic": int(sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels))),
+                             "hbm_capacity": 288 * 10 ** 9},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(mg, A, rhs_h)

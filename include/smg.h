@@ -85,6 +85,8 @@ void smg_solve_opts_default(smg_solve_opts *o);
 int smg_version(void);
 const char *smg_last_error(void);
 int smg_device_count(void);
+/* device memory currently held by all libsmg handles / assemblers of this process, in bytes (memory budget reporting) */
+long long smg_device_bytes_live(void);
 
 /* ---- std::vector<mg_data> (src/mg_data.h:11-27) ---------------------------------------------------------------- */
 /* mg.reserve(nLvs) */

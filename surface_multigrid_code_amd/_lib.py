@@ -31,6 +31,7 @@ def load():
         "smg_version": (i, []),
         "smg_last_error": (C.c_char_p, []),
         "smg_device_count": (i, []),
+        "smg_device_bytes_live": (C.c_longlong, []),
         "smg_solve_opts_default": (None, [C.POINTER(SolveOptsC)]),
         "smg_hierarchy_create": (vp, [i]),
         "smg_hierarchy_destroy": (None, [vp]),

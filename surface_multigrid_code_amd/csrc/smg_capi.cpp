@@ -57,6 +57,7 @@ static int guarded(const char* who, Fn&& body)
 
 extern "C" const char* smg_last_error(void) { return g_err.c_str(); }
 extern "C" int smg_version(void) { return SMG_VERSION; }
+extern "C" long long smg_device_bytes_live(void) { return (long long)smg::devbuf_live_bytes().load(); }
 extern "C" int smg_device_count(void)
 {
     int n = 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -12,6 +13,9 @@
 #include "smg_sparse.hpp"
 
 namespace smg {
+
+// bytes of device memory currently held by all DevBufs of the process (smg_device_bytes_live(): memory budget reporting)
+inline std::atomic<long long>& devbuf_live_bytes() { static std::atomic<long long> v{0}; return v; }
 
 template <typename T>
 struct DevBuf {
@@ -23,13 +27,13 @@ struct DevBuf {
     DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) { (void)hipFree(p); devbuf_live_bytes() -= (long long)(n * sizeof(T)); } p = nullptr; n = 0; }
     hipError_t alloc(size_t count)
     {
         release();
         if (count == 0) return hipSuccess;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-        if (e == hipSuccess) n = count; else p = nullptr;
+        if (e == hipSuccess) { n = count; devbuf_live_bytes() += (long long)(count * sizeof(T)); } else p = nullptr;
         return e;
     }
     hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
