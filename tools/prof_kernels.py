@@ -16,6 +16,7 @@ ap.add_argument("--workload", default="C3")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--cycles", type=int, default=10)
 ap.add_argument("--smoother", default="gs")
+ap.add_argument("--jacobi-max-rows", type=int, default=300000)
 ap.add_argument("--k", type=int, default=1, help="right-hand-side columns of the cycle part (C4k64: 64)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -40,7 +41,7 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 k = a.k
 bk = torch.from_numpy(np.ascontiguousarray((Mb @ rng.uniform(-1, 1, (n, k))).T)).to(dev); uk = torch.zeros_like(bk); z = torch.empty_like(bk)
-mg.solve_begin(bk.data_ptr(), n, uk.data_ptr(), n, k, opts=smg.SolveOpts(tol=0.0, max_iter=a.cycles, smoother=a.smoother))
+mg.solve_begin(bk.data_ptr(), n, uk.data_ptr(), n, k, opts=smg.SolveOpts(tol=0.0, max_iter=a.cycles, smoother=a.smoother, jacobi_max_rows=a.jacobi_max_rows))
 mg.outer_iterations(a.cycles)
 mg.solve_end(z.data_ptr(), n, max_iter=a.cycles)
 print("done", label)

@@ -8,10 +8,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. kernel trace + stats of the very command the driver runs (C3 main loop, smoother comparison, C5 and C4 legs)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 200 --warmup 20 --no-cpu > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err
 python tools/rocpd_stats.py $OUT/trace/bench_results.db $OUT/${TAG}_bench_kernel_stats.csv > /dev/null
-# 2. one outer iteration of the timed configuration (hybrid smoother), kernel by kernel; and of the wide (k = 64) kernels of C4
-rocprofv3 --kernel-trace -d $OUT/tl -o t -- python tools/prof_kernels.py --reps 5 --cycles 12 --smoother hybrid > $OUT/tl.log 2>&1
-python tools/rocpd_timeline.py $OUT/tl/t_results.db > $OUT/${TAG}_vcycle_timeline_hybrid.txt
-rocprofv3 --kernel-trace --stats -d $OUT/c4 -o t -- python tools/prof_kernels.py --workload C4k64 --reps 5 --cycles 30 --smoother hybrid > $OUT/c4.log 2>&1
+# 2. one outer iteration of the timed configuration (GS above 300 k rows, Chebyshev-Jacobi below), kernel by kernel -- and of the
+#    reference's Gauss-Seidel everywhere; and of the wide (k = 64) kernels of C4
+rocprofv3 --kernel-trace -d $OUT/tl -o t -- python tools/prof_kernels.py --reps 5 --cycles 12 --smoother hybrid_chebyshev > $OUT/tl.log 2>&1
+python tools/rocpd_timeline.py $OUT/tl/t_results.db > $OUT/${TAG}_vcycle_timeline_hybrid_chebyshev.txt
+rocprofv3 --kernel-trace -d $OUT/tlg -o t -- python tools/prof_kernels.py --reps 5 --cycles 12 --smoother gs > $OUT/tlg.log 2>&1
+python tools/rocpd_timeline.py $OUT/tlg/t_results.db > $OUT/${TAG}_vcycle_timeline_gs.txt
+rocprofv3 --kernel-trace --stats -d $OUT/c4 -o t -- python tools/prof_kernels.py --workload C4k64 --reps 5 --cycles 30 --smoother hybrid_chebyshev > $OUT/c4.log 2>&1
 python tools/rocpd_stats.py $OUT/c4/t_results.db $OUT/${TAG}_c4_k64_kernel_stats.csv > /dev/null
 python tools/rocpd_timeline.py $OUT/c4/t_results.db > $OUT/${TAG}_c4_k64_timeline.txt
 # 3. PMC passes (counters only, each in its own run), fine-level kernels isolated by grid size: C3 (in cache) and C5 (beyond it)
@@ -26,5 +29,5 @@ done
 rocprofv3 --kernel-trace --stats -d $OUT/c5t -o t -- python tools/prof_kernels.py --workload C5 --reps 50 --cycles 5 > $OUT/c5t.log 2>&1
 python tools/rocpd_stats.py $OUT/c5t/t_results.db $OUT/${TAG}_c5_kernel_stats.csv > /dev/null
 python tools/make_traffic.py $OUT/${TAG}_pmc_summary_C3.json $OUT/${TAG}_pmc_summary_C5.json $TAG > $OUT/traffic.json
-rm -rf $OUT/trace $OUT/tl $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5  # keep the summaries only (the dbs are large)
+rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5  # keep the summaries only (the dbs are large)
 ls -la $OUT

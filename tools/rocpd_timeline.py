@@ -5,10 +5,12 @@ import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 rows = list(cur.execute("select s.display_name, d.start, d.end, d.grid_size_x from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id order by d.start"))
-# find the last k_ss_finalize_decide (start of the final iteration's tail) -> take the window between the two last ones
+# windows between consecutive k_ss_finalize_decide launches = outer iterations; of the last ten, show the one with the smallest span
+# (the profiler stalls the queue now and then: an iteration with a 100 us hole in it says nothing about the kernels)
 idx = [i for i, r in enumerate(rows) if "finalize_decide" in r[0]]
 if len(idx) >= 3:
-    a, b = idx[-3], idx[-2]
+    cands = [(rows[idx[j + 1]][1] - rows[idx[j]][1], idx[j], idx[j + 1]) for j in range(max(0, len(idx) - 11), len(idx) - 1)]
+    _, a, b = min(cands)
     win = rows[a:b]
 else:
     win = rows[-N:]
