@@ -15,6 +15,7 @@ int main(int argc, char* argv[])
 {
     const char* path = argc > 1 ? argv[1] : "tests/golden/meshes/bunny_15K_init.smgm";
     const int n_pins = argc > 2 ? std::atoi(argv[2]) : 346;
+    const bool fast_cycle = argc > 3 && std::atoi(argv[3]) != 0;   // opt into libsmg's hybrid Gauss-Seidel / Chebyshev-Jacobi cycle
 
     double* Vp = nullptr; int* Fp = nullptr; int nV = 0, nF = 0;
     if (smg_mesh_read(path, &Vp, &nV, &Fp, &nF) != SMG_OK) { std::fprintf(stderr, "%s\n", smg_last_error()); return 1; }
@@ -52,6 +53,7 @@ int main(int argc, char* argv[])
 
     min_quad_with_fixed_mg_data solverData;
     smgCoarseSolver coarseSolver;
+    if (fast_cycle) { coarseSolver.opts.smoother = SMG_SMOOTH_HYBRID_CHEBYSHEV; coarseSolver.opts.jacobi_max_rows = 300000; }
     min_quad_with_fixed_mg_precompute(A, b, solverData, mg, coarseSolver);
 
     std::vector<double> rHis;

@@ -59,6 +59,11 @@ struct mg_data {  // reference src/mg_data.h:11-19
 
 struct smgCoarseSolver {  // stands in for Eigen::SimplicialLDLT<Eigen::SparseMatrix<double>>
     std::shared_ptr<smg_hierarchy> h;
+    // what the reference hard-codes in its solve (pre = post = 2, Gauss-Seidel) -- and the one place to opt into libsmg's extensions,
+    // e.g.  coarseSolver.opts.smoother = SMG_SMOOTH_HYBRID_CHEBYSHEV; coarseSolver.opts.jacobi_max_rows = 300000;
+    // tol / max_iter are overwritten by the solve overloads' arguments.
+    smg_solve_opts opts;
+    smgCoarseSolver() { smg_solve_opts_default(&opts); }
 };
 
 struct min_quad_with_fixed_mg_data {  // reference src/min_quad_with_fixed_mg.h:22-29
@@ -186,8 +191,7 @@ namespace smg_detail {
 inline bool solve_impl(const smgDense& RHS, const smgDense* known_val, const smgDense& z0, const smgCoarseSolver& solver,
                        double tolerance, int maxIter, smgDense& z, std::vector<double>& r_his)
 {
-    smg_solve_opts o;
-    smg_solve_opts_default(&o);
+    smg_solve_opts o = solver.opts;
     o.tol = tolerance; o.max_iter = maxIter;
     z.resize(z0.rows, z0.cols);
     r_his.assign((size_t)(maxIter > 0 ? maxIter : 1), 0.0);
@@ -243,5 +247,7 @@ inline bool min_quad_with_fixed_mg_solve(const min_quad_with_fixed_mg_data& d, c
 inline void mg_VCycle(const smgCoarseSolver& solver, const smgDense& B, const int& preRelaxIter, const int& postRelaxIter,
                       const int lv, smgDense& u, std::vector<mg_data>&)
 {
+    smg_detail::check(smg_hierarchy_set_smoother(solver.h.get(), solver.opts.smoother, solver.opts.omega, solver.opts.jacobi_max_rows), "smg_hierarchy_set_smoother");
+    smg_detail::check(smg_hierarchy_set_chebyshev(solver.h.get(), solver.opts.cheby_fraction), "smg_hierarchy_set_chebyshev");
     smg_detail::check(smg_vcycle(solver.h.get(), B.data.data(), preRelaxIter, postRelaxIter, lv, u.data.data(), B.cols), "mg_VCycle");
 }

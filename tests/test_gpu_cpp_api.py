@@ -108,6 +108,13 @@ def test_cpp_closed_mesh_with_pins_example(smg_mod, oracle_mod):
     assert abs(float(m.group(3)) - float((z * z).sum())) <= 1e-9 * float((z * z).sum())
     unk = np.setdiff1d(np.arange(n), b)
     assert np.linalg.norm((B - A @ z[:, 0])[unk]) < 1e-10 and abs(z[b, 0]).max() == 0.0
+    # the C++ mirror's opt-in (smgCoarseSolver::opts): the hybrid Gauss-Seidel / Chebyshev-Jacobi cycle lands on the same solution
+    out2 = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny_15K_init.smgm"), "346", "1"], env=env, text=True)
+    m2 = re.search(r"converged: (\d)  iterations: (\d+)  \|z\|\^2: ([0-9.eE+-]+)  unknowns: (\d+)", out2)
+    conv2, z2, rh2 = mg.solve(B, z0, np.zeros(len(b)), smg.SolveOpts(tol=1e-10, max_iter=20, smoother="hybrid_chebyshev", jacobi_max_rows=300000))
+    assert m2 and m2.group(1) == "1" and conv2 and len(rh2) == int(m2.group(2))
+    assert abs(float(m2.group(3)) - float((z2 * z2).sum())) <= 1e-9 * float((z2 * z2).sum())
+    assert abs(float(m2.group(3)) - float(m.group(3))) <= 1e-8 * float(m.group(3))
 
 
 def test_eigen_adapter_runs_through_the_reference_signatures(smg_mod):
