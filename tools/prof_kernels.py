@@ -24,7 +24,7 @@ if a.workload == "C4k64":      # BASELINE config C4: ogre.obj, mean-curvature-fl
     V, F = mesh.read_triangle_mesh("ogre.smgm"); V = mesh.normalize_unit_area(V, F)
     mg = smg.mg_precompute(V, F, 0.25, 500, 1)
     Mb = mesh.massmatrix(V, F, "barycentric"); A = (Mb - 0.01 * mesh.cotmatrix(V, F)).tocsr(); A.sort_indices()
-    label = "C4: ogre.obj k = 64"; a.k = 64
+    label = "C4: ogre.obj k = %d" % (a.k if a.k > 1 else 64); a.k = a.k if a.k > 1 else 64
 else:
     mg, A, Mb, Vf, Ff, label, _ = B.build_workload(a.workload, smg, mesh)
 mg.precompute(A)
