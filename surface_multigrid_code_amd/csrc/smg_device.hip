@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_tile(const T* __restrict__ A
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
 template <int KC>
 __global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restrict__ Ainv, int n, int lda, const double* __restrict__ b,
-                                                         double* u, int ld, const int* done)
+                                                         double* u, int ld, const int* done, int kvalid)
 {
     const int stop = load_flag(done);
     constexpr int CB = KC / 16, DEPTH = 12;
@@ -778,14 +778,15 @@ __global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restric
     const int per = lda / 16;                 // MFMA steps per wave (lda % 64 == 0)
     const int s0 = per * w;
     const double* pa = Ainv + (size_t)(4 * s0 + lr) * lda + row0 + lc;
-    const double* pb = b + (size_t)(4 * s0 + lr) * ld + col0 + lc;
+    const bool colok = col0 + lc < kvalid;    // a block of 8..15 columns runs as a 16-column tile with the excess lanes idle
+    const double* pb = b + (size_t)(4 * s0 + lr) * ld + col0 + (colok ? lc : 0);
     const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ld;
     v4f64_t acc = {0.0, 0.0, 0.0, 0.0};
     double av[DEPTH], bv[DEPTH];
 #pragma unroll
     for (int t = 0; t < DEPTH; t++) {
         av[t] = t < per ? pa[t * sa] : 0.0;
-        bv[t] = t < per ? pb[t * sb] : 0.0;
+        bv[t] = (t < per && colok) ? pb[t * sb] : 0.0;
     }
     for (int s = 0; s < per; s += DEPTH) {
         double an[DEPTH], bn[DEPTH];
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restric
         for (int t = 0; t < DEPTH; t++) {
             const int q = s + DEPTH + t;
             an[t] = q < per ? pa[q * sa] : 0.0;
-            bn[t] = q < per ? pb[q * sb] : 0.0;
+            bn[t] = (q < per && colok) ? pb[q * sb] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < DEPTH; t++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc, 0, 0, 0);   // zero operands past the end
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restric
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = row0 + lr + 4 * r;      // C/D layout: register r of lane -> row (lane >> 4) + 4 r, column lane & 15
-            if (row < n) {
+            if (row < n && colok) {
                 const size_t o = (size_t)row * ld + col0 + lc;
                 u[o] = u[o] + ((red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]));
             }
@@ -887,19 +888,22 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
         return hipGetLastError();
     }
     int c0 = 0;
-    while (k - c0 >= 16) {
+    static const int use_mfma8 = getenv("SMG_COARSE_MFMA") ? atoi(getenv("SMG_COARSE_MFMA")) : 1;
+    const int mfma_min = (std::is_same<T, double>::value && use_mfma8 && lda % 64 == 0) ? 8 : 16;   // 8..15 columns: one padded 16-column tile
+    while (k - c0 >= mfma_min) {
         int kc = 64;
-        while (kc > k - c0) kc >>= 1;
+        while (kc > k - c0 && kc > 16) kc >>= 1;
+        const int kv = kc < k - c0 ? kc : k - c0;   // valid columns of this block (< kc only for the padded 16-column tile)
         const int tb = (n + 15) / 16;
         static const int use_mfma = getenv("SMG_COARSE_MFMA") ? atoi(getenv("SMG_COARSE_MFMA")) : 1;   // A/B knob
         if constexpr (std::is_same<T, double>::value) {
             if (use_mfma && lda % 64 == 0) {
                 switch (kc) {
-                    case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-                    case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-                    default: hipLaunchKernelGGL((k_dense_gemm_mfma<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+                    case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
+                    case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
+                    default: hipLaunchKernelGGL((k_dense_gemm_mfma<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
                 }
-                c0 += kc;
+                c0 += kv;
                 continue;
             }
         }

@@ -2,7 +2,7 @@
 share a device, the driver runs the real 8-GPU RCCL job): surface_multigrid_code_amd.dist.GpuEngine + sharded_solve and its
 latency-hiding form against the fused k-column smg_solve.
 
-Per column the sparse kernels and the dense coarse solve (k_dense_gemv_add for 2 <= k < 16) do the same arithmetic whatever the
+Per column the sparse kernels and the dense coarse solve (k_dense_gemv_add for 2 <= k < 8) do the same arithmetic whatever the
 number of columns in the block, so the sharded iterate is BIT-IDENTICAL to the fused one; only the residual norm is summed in
 another order (per-rank partial sums, then the all-reduce): r_his agrees to 1e-12 relative."""
 import os

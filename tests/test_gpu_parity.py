@@ -95,10 +95,10 @@ def test_colouring_is_valid_and_sell_matches_csr(smg, oracle_mod):
             assert st["padded"] / st["stored"] < 1.10, "SELL padding above 10%"
 
 
-@pytest.mark.parametrize("k", [1, 2, 7, 16, 40, 64, 91])
+@pytest.mark.parametrize("k", [1, 2, 7, 8, 12, 16, 40, 64, 91])
 def test_coarse_solve_matches_ldlt(smg, oracle_mod, k):
-    """k = 1: lower triangle of the symmetric inverse; 2..15: one wave per row; >= 16: 16 x 16 tiles on the fp64 matrix cores
-    (blocks of 64 / 32 / 16 columns, remainders through the narrow kernels: 40 = 32 + 4 + 4, 91 = 64 + 16 + 4 + 4 + 3)."""
+    """k = 1: lower triangle of the symmetric inverse; 2..7: one wave per row; >= 8: 16 x 16 tiles on the fp64 matrix cores (blocks of
+    64 / 32 / 16 columns, a block of 8..15 columns as a 16-column tile with idle lanes: 12, 40 = 32 + 8, 91 = 64 + 16 + 11)."""
     p, mg, orc = build(smg, oracle_mod, kind="poisson", k=2, n_sub=2)
     rng = np.random.default_rng(5)
     nc = mg.rows(mg.n_levels - 1)
