@@ -21,15 +21,17 @@ rhs_h = Mb @ rng.uniform(-1, 1, n)
 rhs = torch.from_numpy(rhs_h).to(dev); z0 = torch.zeros(n, dtype=torch.float64, device=dev); z = torch.empty_like(z0)
 out = {"workload": label, "n_verts": n, "nnz": int(A.nnz), "levels": mg.n_levels, "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
        "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)], "setup_s": t_setup}
+sm = dict(smoother=os.environ.get("SMG_TOOL_SMOOTHER", "gs"), jacobi_max_rows=300000)
+out["smoother"] = sm["smoother"]
 for prec in ("f64", "mixed"):
     # attainable residual: run 40 cycles with tol 0
-    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=40, precision=prec))
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=40, precision=prec, **sm))
     mg.outer_iterations(40)
     conv, rh = mg.solve_end(z.data_ptr(), n, max_iter=40)
     true_res = float(np.linalg.norm(rhs_h - A @ z.cpu().numpy()))
     # throughput
     K = 300
-    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=K + 20, precision=prec))
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=K + 20, precision=prec, **sm))
     mg.outer_iterations(20); torch.cuda.synchronize()
     t = time.perf_counter(); mg.outer_iterations(K); torch.cuda.synchronize(); dt = time.perf_counter() - t
     mg.solve_end(z.data_ptr(), n, max_iter=K + 20)
