@@ -290,9 +290,14 @@ extern "C" int smg_hierarchy_set_chebyshev(smg_hierarchy* h, double cheby_fracti
     if (cheby_fraction > 0.0) h->cheby_fraction = cheby_fraction;
     return SMG_OK;
 }
+static int spectral_bounds(smg_hierarchy* h);
 extern "C" double smg_level_spectral_bound(const smg_hierarchy* h, int lv)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return 0.0;
+    if (!h->lam_valid && h->precomputed && h->device >= 0) {
+        DeviceScope dsc(h->device);
+        if (spectral_bounds(const_cast<smg_hierarchy*>(h)) != SMG_OK) return 0.0;
+    }
     return h->lv[lv].lam;
 }
 
@@ -591,7 +596,17 @@ static int spectral_bounds(smg_hierarchy* h)
         if (lam[lv] != h->lv[lv].lam) drop_graphs(h);   // the coefficients are kernel arguments of the captured launches
         h->lv[lv].lam = lam[lv];
     }
+    h->lam_valid = true;
     return SMG_OK;
+}
+static int level_kind(const smg_hierarchy* h, int lv);
+// lazily: only handles that smooth with Chebyshev-Jacobi pay the four small launches and the read-back
+static int ensure_spectral_bounds(smg_hierarchy* h)
+{
+    if (h->lam_valid) return SMG_OK;
+    bool need = false;
+    for (int lv = 0; lv < h->n_levels - 1; lv++) if (level_kind(h, lv) == 2 /* LV_CHEBY */) need = true;
+    return need ? spectral_bounds(h) : SMG_OK;
 }
 
 // Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
@@ -724,7 +739,8 @@ static int precompute_device(smg_hierarchy* h)
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     tm.lap("device: coarse dense inverse");
-    return spectral_bounds(h);
+    h->lam_valid = false;   // the Gershgorin bounds are computed when a Chebyshev smoother first asks for them (ensure_spectral_bounds)
+    return SMG_OK;
 }
 
 // ---- value-only re-precompute --------------------------------------------------------
@@ -880,7 +896,8 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
     }
     h->host_stale = true;
     h->f32_valid = false;   // the fp32 copies are re-made from the new values when a mixed solve asks for them
-    return spectral_bounds(h);
+    h->lam_valid = false;
+    return SMG_OK;
 }
 
 // bring the host copies (mg[l].A, A_diag, Auk, A_int) up to date after a device-side re-precompute
@@ -1059,7 +1076,7 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.d.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
         }
     }
-    return SMG_OK;
+    return ensure_spectral_bounds(h);
 }
 
 // ---- mixed precision: fp32 images of the operators and an fp32 V-cycle ------------------------------------------------
@@ -1924,6 +1941,7 @@ extern "C" int smg_raw_relax(smg_hierarchy* h, int lv, const double* b, double* 
     if (rc) return rc;
     DeviceScope dsc(h->device);
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_relax: bad level");
+    if ((rc = ensure_work(h, k))) return rc;   // second iterate / update vector / spectral bound of a Jacobi-type level
     return enqueue_relax(h, lv, b, u, k, iters, nullptr);
 }
 

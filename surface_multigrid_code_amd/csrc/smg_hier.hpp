@@ -151,6 +151,7 @@ struct smg_hierarchy {
     int jacobi_max_rows = 100000;
     double cheby_fraction = 0.1;   // Chebyshev-Jacobi: the polynomial damps the eigenvalues of D^-1 A in [fraction * lam, lam]
     smg::DevBuf<double> d_lam;     // scratch for launch_gershgorin
+    bool lam_valid = false;        // Level::lam belongs to the current matrix values
     int iters_enqueued = 0;
     smg::DevBuf<double> d_stage_rhs, d_stage_z, d_stage_kv, d_tmp_cm;
     smg::DevBuf<double> d_zsave;     // iterate saved by the speculative cycle

@@ -46,7 +46,7 @@ with torch.cuda.stream(st):
             mg.precompute_values_device(lhs.data_ptr())
         if step >= 2: t = lap("value-only precompute", t)
         z = torch.empty_like(z0)
-        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 3, opts=smg.SolveOpts(tol=tol, max_iter=20))
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 3, opts=smg.SolveOpts(tol=tol, max_iter=20, smoother=os.environ.get("SMG_TOOL_SMOOTHER", "gs"), jacobi_max_rows=300000))
         for _ in range(10):                          # enqueue two iterations, look at the device-side flag, stop when it is up
             mg.outer_iterations(2)
             if mg.poll()[0]:
