@@ -221,3 +221,63 @@ def test_oracle_chebyshev_matches_a_numpy_restatement(oracle_mod):
         out = orc.relax(lv, np.zeros_like(e), e, 2)         # b = 0: the iterate IS the error
         assert np.linalg.norm(out) <= (bound + 1e-9) * np.linalg.norm(e) * 1.0001
     orc.set_smoother(lv, "gs")
+
+
+def test_mesh_operators_against_closed_form_answers(smg_mod):
+    """Caller-side numerics (igl::cotmatrix, igl::massmatrix, igl::boundary_loop, normalize_unit_area) are third-party semantics that
+    neither the product's host C++ (csrc/smg_mesh.cpp) nor the checker (oracle/mesh_np.py) can be compared with libigl here; both are held
+    against configurations whose answers are known in closed form -- independent of either implementation:
+      * unit squares split along one diagonal: edges along the axes get 1/2 (cot 45 + cot 45) = 1, diagonals (opposite two right angles)
+        0; an interior vertex has Voronoi = barycentric area h^2; cotmatrix is negative semi-definite with zero row sums;
+      * equilateral triangles: every interior edge 1/2 (cot 60 + cot 60) = 1/sqrt(3); interior Voronoi area = sqrt(3)/2 h^2;
+      * one obtuse triangle: mixed-Voronoi areas A/2 at the obtuse corner, A/4 at the others; barycentric A/3 each;
+      * the boundary loop of the square grid is its perimeter, and normalize_unit_area leaves total area 1, centroid x = y = 0, min z = 0."""
+    from oracle import mesh_np as M
+    mesh = smg_mod.mesh
+    n, h = 7, 0.25
+    xs, ys = np.meshgrid(np.arange(n) * h, np.arange(n) * h, indexing="ij")
+    V = np.stack([xs.ravel(), ys.ravel(), 0 * xs.ravel()], axis=1)
+    idx = lambda i, j: i * n + j
+    F = np.array([(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)) for i in range(n - 1) for j in range(n - 1)] +
+                 [(idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(n - 1) for j in range(n - 1)], dtype=np.int32)
+    for name, cot, mass, bl in (("product", mesh.cotmatrix, mesh.massmatrix, mesh.boundary_loop), ("checker", M.cotmatrix, M.massmatrix, M.boundary_loop)):
+        L = cot(V, F).tocsr()
+        c = idx(3, 3)
+        assert abs(L[c, idx(4, 3)] - 1.0) < 1e-14 and abs(L[c, idx(3, 4)] - 1.0) < 1e-14, name      # axis edges
+        assert abs(L[c, idx(4, 4)]) < 1e-14 and L[c, idx(4, 2)] == 0.0, name                           # the diagonal / no edge
+        assert abs(L[c, c] + 4.0) < 1e-14 and abs(L.sum(axis=1)).max() < 1e-13, name                   # -sum of the off-diagonals
+        assert abs(L - L.T).max() < 1e-15, name
+        for kind in ("voronoi", "barycentric"):
+            d = mass(V, F, kind).diagonal()
+            assert abs(d[c] - h * h) < 1e-15 and abs(d.sum() - ((n - 1) * h) ** 2) < 1e-13, (name, kind)
+        b = np.asarray(bl(F))
+        on = {idx(i, j) for i in range(n) for j in range(n) if i in (0, n - 1) or j in (0, n - 1)}
+        assert set(b.tolist()) == on and len(b) == 4 * (n - 1), name
+    # equilateral grid
+    m = 6
+    P = np.array([[i + 0.5 * j, j * np.sqrt(3) / 2, 0.0] for i in range(m) for j in range(m)]) * h
+    idq = lambda i, j: i * m + j
+    Fq = np.array([(idq(i, j), idq(i + 1, j), idq(i, j + 1)) for i in range(m - 1) for j in range(m - 1)] +
+                  [(idq(i + 1, j), idq(i + 1, j + 1), idq(i, j + 1)) for i in range(m - 1) for j in range(m - 1)], dtype=np.int32)
+    for name, cot, mass in (("product", mesh.cotmatrix, mesh.massmatrix), ("checker", M.cotmatrix, M.massmatrix)):
+        L = cot(P, Fq).tocsr()
+        c = idq(2, 2)
+        nb = [idq(3, 2), idq(2, 3), idq(1, 3), idq(1, 2), idq(2, 1), idq(3, 1)]
+        assert all(abs(L[c, j] - 1 / np.sqrt(3)) < 1e-14 for j in nb) and abs(L[c, c] + 6 / np.sqrt(3)) < 1e-13, name
+        assert abs(mass(P, Fq, "voronoi").diagonal()[c] - np.sqrt(3) / 2 * h * h) < 1e-15, name
+        assert abs(mass(P, Fq, "barycentric").diagonal()[c] - np.sqrt(3) / 2 * h * h) < 1e-15, name
+    # one obtuse triangle (angle at vertex 0 > 90 degrees), plus a far-away second triangle so that the mesh has 4+ entries per call
+    T = np.array([[0.0, 0.0, 0.0], [2.0, 0.3, 0.0], [-1.5, 0.4, 0.0]])
+    Ft = np.array([[0, 1, 2]], dtype=np.int32)
+    area = 0.5 * abs(np.cross(T[1] - T[0], T[2] - T[0])[2])
+    for name, mass in (("product", mesh.massmatrix), ("checker", M.massmatrix)):
+        dv = mass(T, Ft, "voronoi").diagonal()
+        assert np.allclose(dv, [area / 2, area / 4, area / 4], rtol=1e-14), (name, dv)
+        assert np.allclose(mass(T, Ft, "barycentric").diagonal(), area / 3, rtol=1e-14), name
+    # normalize_unit_area (src/normalize_unit_area.cpp:13-24): total area 1, x / y centred, lowest point on z = 0
+    rng = np.random.default_rng(0)
+    W = V + 0.05 * rng.uniform(-1, 1, V.shape) + np.array([3.0, -2.0, 5.0])
+    for name, norm, mass in (("product", mesh.normalize_unit_area, mesh.massmatrix), ("checker", M.normalize_unit_area, M.massmatrix)):
+        U = norm(W, F)
+        assert abs(mass(U, F, "barycentric").diagonal().sum() - 1.0) < 1e-13, name
+        assert abs(U[:, 0].mean()) < 1e-13 and abs(U[:, 1].mean()) < 1e-13 and abs(U[:, 2].min()) < 1e-13, name
