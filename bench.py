@@ -460,8 +460,8 @@ def main():
         ms_step = 1e3 * dt / K
         vcyc_bytes = mg.vcycle_bytes(1, 2, 2)
         # ---- smoother comparison: the reference's Gauss-Seidel everywhere vs the timed configuration.  What counts is the time
-        # to the tolerance: cycles needed to 1e-10 (the drop-in solve on resident vectors, device-side break test, host polling
-        # every iteration) x the steady-state time of an outer iteration.
+        # to the tolerance: cycles needed to 1e-10 (the drop-in solve on resident vectors, device-side break test, adaptive host
+        # polling) x the steady-state time of an outer iteration.
         def smoother_line(kw, ms_known=None):
             o = smg.SolveOpts(tol=1e-10, max_iter=100, pre=2, post=2, precision=args.precision, **kw)
             mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)       # warm (graph capture)

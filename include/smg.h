@@ -69,7 +69,9 @@ typedef struct {
     int max_iter;
     int pre, post;
     int verbosity;     /* 0 silent; 1 prints "MG iteration: i, residual: r" lines like the reference (:111) */
-    int check_every;   /* host polls the device-side convergence flag every this many iterations (>=1) */
+    int check_every;   /* smg_solve looks at the device-side convergence flag every this many iterations; 0 (default): adaptive -- the
+                          number of cycles still needed is extrapolated from the last two residuals, and all but the last of them are
+                          enqueued before the next look.  Results do not depend on it (the break test runs on the device). */
     int use_graph;     /* 1: replay one captured hipGraph per outer iteration; 0: eager launches */
     int precision;     /* 0 (default): everything fp64, the reference arithmetic.  1: mixed -- the outer iterate and the
                           residual (hence r_his and the stopping test) stay fp64, the V-cycle runs on fp32 copies of the
@@ -191,7 +193,9 @@ int smg_solve(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *kno
 
 /* Split-phase form of the same loop for column-sharded multi-GPU runs: the caller owns
  * the all-reduce of the residual sum of squares between the two halves of an iteration.
- *   begin:     gathers RHS/z0 (device, column-major) into the handle, resets the control block;
+ *   begin:     gathers RHS/z0 (column-major) into the handle, resets the control block.  SMG_DEVICE: the gathers are ENQUEUED on the
+ *              handle's stream and the call returns (stream-ordered, like every other entry point of the split-phase API: do not
+ *              overwrite RHS / z0 from another stream before that work has run); SMG_HOST: the host blocks are consumed on return;
  *   residual:  *d_sumsq (device double) = sum over the local columns of |RHS_u - A_0 z_u|^2   (.cpp:110/:332);
  *   cycle:     r = sqrt(*d_sumsq) -> r_his, break test, then one V-cycle (skipped on the device once done);
  *   end:       scatters z, copies r_his back, reports convergence.

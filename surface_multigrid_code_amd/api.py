@@ -58,7 +58,7 @@ SMOOTHERS = {"gs": 0, "jacobi": 1, "hybrid": 2, "chebyshev": 3, "hybrid_chebyshe
 class SolveOpts:
     """tol / maxIter / pre / post with the reference's defaults (src/min_quad_with_fixed_mg.cpp:63,77,102-103)."""
 
-    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=1, use_graph=1, precision="f64",
+    def __init__(self, tol=1e-3, max_iter=20, pre=2, post=2, verbosity=0, check_every=0, use_graph=1, precision="f64",
                  smoother="gs", omega=0.8, jacobi_max_rows=100000, cheby_fraction=0.1):
         """smoother: "gs" (the reference's relax(), default) / "jacobi" (damped Jacobi on every level) / "hybrid" (Gauss-Seidel on
         the levels with more than `jacobi_max_rows` unknowns, Jacobi below) / "chebyshev", "hybrid_chebyshev" (the same layouts with

@@ -72,7 +72,7 @@ extern "C" void smg_solve_opts_default(smg_solve_opts* o)
     o->pre = 2;          // :102, :324
     o->post = 2;         // :103, :325
     o->verbosity = 0;
-    o->check_every = 1;
+    o->check_every = 0;   // adaptive polling (see smg_solve)
     o->use_graph = 1;
     o->precision = 0;
     o->smoother = SMG_SMOOTH_GS;   // the reference's relax()
@@ -1492,7 +1492,7 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     if (o.max_iter < 0) return fail(SMG_ERR_INVALID, "max_iter must be >= 0");
     if (h->has_known && (!known_val || ld_kv < (int)h->known.size())) return fail(SMG_ERR_INVALID, "known_val missing or ld_kv too small");
     h->tol = o.tol; h->max_iter = o.max_iter; h->pre = o.pre; h->post = o.post; h->verbosity = o.verbosity;
-    h->check_every = std::max(1, o.check_every); h->use_graph = o.use_graph;
+    h->check_every = std::max(0, o.check_every); h->use_graph = o.use_graph;
     if (o.precision != 0 && o.precision != 1) return fail(SMG_ERR_INVALID, "precision must be 0 (fp64) or 1 (mixed)");
     h->precision = o.precision;
     if ((rc = smg_hierarchy_set_smoother(h, o.smoother, o.omega, o.jacobi_max_rows))) return rc;
@@ -1539,13 +1539,13 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     }
     // the residual history lives in HBM, sized from max_iter (the reference's r_his grows with the loop, .cpp:112)
     HIPCHK(h->d_rhis.ensure((size_t)std::max(h->max_iter, 1)));
-    Ctrl zero;
+    Ctrl& zero = h->host_ctrl;   // lives in the handle: the asynchronous copy may read it after this call returns
     std::memset(&zero, 0, sizeof(zero));
     zero.tol = h->tol;
     zero.r_his = h->d_rhis.p;
     zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // `zero` lives on this stack frame
+    if (memspace == SMG_HOST) HIPCHK(hipStreamSynchronize(h->stream));  // the caller's host blocks may change after this call
     h->iters_enqueued = 0;
     h->in_solve = true;
     return SMG_OK;
@@ -1661,12 +1661,14 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     if (memspace == SMG_HOST)
         HIPCHK(hipMemcpy2DAsync(z, (size_t)ld_z * 8, dz, (size_t)n * 8, (size_t)n * 8, k, hipMemcpyDeviceToHost, h->stream));
     static thread_local Ctrl hc;
-    HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const int cnt = std::max(0, std::min(hc.n_his, hc.his_cap));
     static thread_local std::vector<double> his;
-    his.resize((size_t)std::max(cnt, 1));
-    if (cnt > 0) HIPCHK(hipMemcpy(his.data(), h->d_rhis.p, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+    // the history can hold at most one entry per enqueued iteration: fetched together with the control block, one synchronisation
+    const int cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(std::min(h->iters_enqueued, std::max(h->max_iter, 1)), 1));
+    his.resize((size_t)cap);
+    HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(his.data(), h->d_rhis.p, (size_t)cap * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int cnt = std::max(0, std::min(std::min(hc.n_his, hc.his_cap), cap));
     h->in_solve = false;
     prof_collect(h);
     if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = his[i];
@@ -1688,20 +1690,31 @@ extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const 
     int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
     if (rc) return rc;
     // for (iter < maxIter) { residual; push; if (residual < tol) break; V-cycle }   (:108-125 / :330-347)
-    // Enqueued `check_every` iterations at a time; the break happens on the device, the host only stops feeding.
+    // The break happens on the device; the host only decides how many iterations to enqueue before it looks at the flag again.
+    // check_every >= 1: that many.  check_every == 0 (default): adaptive -- from the two most recent residuals the host extrapolates
+    // how many more cycles the tolerance needs and enqueues all but the last of them before the next look (the results do not depend
+    // on this: an iteration enqueued after the break stores nothing).
     int it = 0;
+    int chunk_next = 1;
     while (it < h->max_iter) {
-        const int chunk = std::min(h->check_every, h->max_iter - it);
+        const int want = h->check_every > 0 ? h->check_every : chunk_next;
+        const int chunk = std::min(want, h->max_iter - it);
         for (int c = 0; c < chunk; c++) {
             rc = enqueue_outer_iteration(h);
             if (rc) { h->in_solve = false; return rc; }
         }
         it += chunk;
         if (it < h->max_iter) {
-            int done = 0;
-            rc = smg_solve_poll(h, &done, nullptr);
-            if (rc) { h->in_solve = false; return rc; }
-            if (done) break;
+            Ctrl hc;
+            hipError_t e = hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { h->in_solve = false; return fail(SMG_ERR_HIP, "smg_solve: %s", hipGetErrorString(e)); }
+            if (hc.done) break;
+            chunk_next = 1;
+            if (h->check_every == 0 && hc.n_his >= 2 && hc.r_last > 0.0 && hc.r_last < hc.r_prev && h->tol > 0.0 && hc.r_last > h->tol) {
+                const double need = std::ceil(std::log(h->tol / hc.r_last) / std::log(hc.r_last / hc.r_prev));   // more residuals until < tol
+                if (need > 2.0) chunk_next = (int)std::min(need - 1.0, 64.0);
+            }
         }
     }
     return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);

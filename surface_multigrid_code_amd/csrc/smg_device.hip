@@ -572,6 +572,7 @@ __device__ __forceinline__ void decide_body(Ctrl* ctrl, double sumsq)
     const int i = ctrl->n_his;
     if (i < ctrl->his_cap) ctrl->r_his[i] = r;
     ctrl->n_his = i + 1;
+    ctrl->r_prev = ctrl->r_last; ctrl->r_last = r;
     if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
     else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
 }
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(256) void k_ss_finalize_decide(const double* partia
         ctrl->sumsq = sumsq;
         if (n_his < his_cap) r_his[n_his] = r;
         ctrl->n_his = n_his + 1;
+        ctrl->r_prev = ctrl->r_last; ctrl->r_last = r;
         if (!(r == r) || r > 1.7e308) { ctrl->status = -1; ctrl->done = 1; }  // NaN / Inf
         else if (r < tol) ctrl->done = 1;                                       // min_quad_with_fixed_mg.cpp:113-116
     }

@@ -23,6 +23,7 @@ struct Ctrl {
     double* r_his; // residual history in HBM, his_cap entries (sized from max_iter at smg_solve_begin; read through this
     int his_cap;   // pointer at run time, so captured graphs survive a re-allocation)
     int pad_;
+    double r_last, r_prev;   // the two most recent residuals (what the host's adaptive polling extrapolates from)
 };
 
 struct SellDev {

@@ -137,6 +137,7 @@ struct smg_hierarchy {
     hipStream_t stream = nullptr;
     bool own_stream = false, user_stream = false;
     smg::DevBuf<smg::Ctrl> d_ctrl;
+    smg::Ctrl host_ctrl;            // staging of the control block smg_solve_begin uploads (must outlive the asynchronous copy)
     smg::DevBuf<double> d_rhis;     // residual history (Ctrl::r_his points here), at least max_iter entries
     smg::DevBuf<double> d_partials;
     int kcap = 0;

@@ -177,7 +177,7 @@ def test_outer_loop_bookkeeping_matches_reference(smg, oracle_mod):
     assert conv and len(rh) == 1 and np.array_equal(z, p["z0"])
     # the device-side break is independent of how often the host polls, and of graph replay vs eager launches
     ref = None
-    for check_every, use_graph in ((1, 1), (4, 1), (50, 1), (1, 0), (7, 0)):
+    for check_every, use_graph in ((1, 1), (0, 1), (4, 1), (50, 1), (1, 0), (0, 0), (7, 0)):      # 0: adaptive polling (the default)
         conv, z, rh = mg.solve(p["RHS"], p["z0"], None,
                                smg.SolveOpts(tol=1e-9, max_iter=50, check_every=check_every, use_graph=use_graph))
         assert conv

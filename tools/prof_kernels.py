@@ -17,14 +17,15 @@ ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--cycles", type=int, default=10)
 ap.add_argument("--smoother", default="gs")
 ap.add_argument("--jacobi-max-rows", type=int, default=300000)
-ap.add_argument("--k", type=int, default=1, help="right-hand-side columns of the cycle part (C4k64: 64)")
+ap.add_argument("--k", type=int, default=0, help="right-hand-side columns of the cycle part (default: 1, C4k64: 64)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 if a.workload == "C4k64":      # BASELINE config C4: ogre.obj, mean-curvature-flow system, 64 columns (k_sell_wide)
     V, F = mesh.read_triangle_mesh("ogre.smgm"); V = mesh.normalize_unit_area(V, F)
     mg = smg.mg_precompute(V, F, 0.25, 500, 1)
     Mb = mesh.massmatrix(V, F, "barycentric"); A = (Mb - 0.01 * mesh.cotmatrix(V, F)).tocsr(); A.sort_indices()
-    label = "C4: ogre.obj k = %d" % (a.k if a.k > 1 else 64); a.k = a.k if a.k > 1 else 64
+    a.k = a.k if a.k > 0 else 64
+    label = "C4: ogre.obj k = %d" % a.k
 else:
     mg, A, Mb, Vf, Ff, label, _ = B.build_workload(a.workload, smg, mesh)
 mg.precompute(A)
@@ -39,7 +40,7 @@ torch.cuda.synchronize()
 for _ in range(a.reps):
     mg.raw_relax(0, b.data_ptr(), u.data_ptr(), 1, 1)
 torch.cuda.synchronize()
-k = a.k
+k = a.k if a.k > 0 else 1
 bk = torch.from_numpy(np.ascontiguousarray((Mb @ rng.uniform(-1, 1, (n, k))).T)).to(dev); uk = torch.zeros_like(bk); z = torch.empty_like(bk)
 mg.solve_begin(bk.data_ptr(), n, uk.data_ptr(), n, k, opts=smg.SolveOpts(tol=0.0, max_iter=a.cycles, smoother=a.smoother, jacobi_max_rows=a.jacobi_max_rows))
 mg.outer_iterations(a.cycles)
