@@ -328,32 +328,6 @@ struct Decimator {
         for (int f : vfaces[a]) if (falive[f] && !phantom(f) && has(faces[f], b)) { if (n < 3) out[n] = f; n++; }   // real faces only
         return n;
     }
-    bool on_boundary_big(int v)   // valence > 64
-    {
-        std::unordered_map<int, int> cnt;
-        for (int f : vfaces[v]) if (falive[f]) for (int c = 0; c < 3; c++) if (faces[f][c] != v) cnt[faces[f][c]]++;
-        for (auto& kv : cnt) if (kv.second == 1) return true;
-        return false;
-    }
-    bool on_boundary(int v)
-    {
-        // v is a boundary vertex iff one of its edges has a single incident face
-        // (a one-ring holds a dozen vertices: a flat list beats a hash map, and this runs twice per attempted collapse)
-        int nbv[64], nbc[64], nn = 0;
-        for (int f : vfaces[v]) {
-            if (!falive[f]) continue;
-            for (int c = 0; c < 3; c++) {
-                const int w = faces[f][c];
-                if (w == v) continue;
-                int i = 0;
-                while (i < nn && nbv[i] != w) i++;
-                if (i == nn) { if (nn == 64) return on_boundary_big(v); nbv[nn] = w; nbc[nn] = 0; nn++; }
-                nbc[i]++;
-            }
-        }
-        for (int i = 0; i < nn; i++) if (nbc[i] == 1) return true;
-        return false;
-    }
     void push_edge(int a, int b)
     {
         if (a == vinf || b == vinf) return;   // infinite cost: never collapsed (SSP_midpoint.cpp:196-200)
