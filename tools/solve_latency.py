@@ -12,8 +12,9 @@ n = A.shape[0]
 rng = np.random.default_rng(3)
 rhs = np.asfortranarray((Mb @ rng.uniform(-1, 1, n))[:, None]); z0 = np.zeros_like(rhs)
 print(label)
-for ce in (1, 2, 4, 20):
-    o = smg.SolveOpts(tol=1e-10, max_iter=20, check_every=ce)
+sm = os.environ.get("SMG_TOOL_SMOOTHER", "gs")
+for ce in (0, 1, 2, 4, 20):     # 0: adaptive (the default)
+    o = smg.SolveOpts(tol=1e-10, max_iter=20, check_every=ce, smoother=sm, jacobi_max_rows=300000)
     mg.solve(rhs, z0, None, o)
     ts = []
     for _ in range(5):
