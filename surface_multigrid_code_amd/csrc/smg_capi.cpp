@@ -194,6 +194,20 @@ hipError_t SellBuf::upload(const Sell& S)
     return hipSuccess;
 }
 
+hipError_t SellBuf::upload_long(const std::vector<int>& rows, const std::vector<int>& ptr, const std::vector<int>& col, const std::vector<double>& val)
+{
+    hipError_t e;
+    view.long_n = 0; view.long_row = view.long_ptr = view.long_col = nullptr; view.long_val = nullptr; view.long_valf = nullptr;
+    long_valf.release();
+    if (rows.empty()) { long_row.release(); long_ptr.release(); long_col.release(); long_val.release(); return hipSuccess; }
+    if ((e = long_row.upload(rows)) != hipSuccess) return e;
+    if ((e = long_ptr.upload(ptr)) != hipSuccess) return e;
+    if ((e = long_col.upload(col)) != hipSuccess) return e;
+    if ((e = long_val.upload(val)) != hipSuccess) return e;
+    view.long_n = (int)rows.size(); view.long_row = long_row.p; view.long_ptr = long_ptr.p; view.long_col = long_col.p; view.long_val = long_val.p;
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------------ profc mirror
 static int prof_scope_id(smg_hierarchy* h, const char* name)
 {
@@ -687,8 +701,41 @@ static int precompute_device(smg_hierarchy* h)
                 tasks.push_back([&, lv, eQ] {
                     DeviceScope ds(h->device);
                     const bool cut = tr_region && region && lv < L - 1 && h->lv[lv].ord.color_ptr.size() > 2;
-                    Sell S = build_sell(h->lv[lv].PT_int, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                    // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
+                    // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
+                    // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
+                    static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+                    const Csr& M = h->lv[lv].PT_int;
+                    std::vector<int> lrow, lptr{0}, lcol;
+                    std::vector<double> lval;
+                    if (long_min > 0)
+                        for (int r = 0; r < M.nr; r++)
+                            if (M.ptr[r + 1] - M.ptr[r] >= long_min) {
+                                lrow.push_back(r);
+                                lcol.insert(lcol.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]);
+                                lval.insert(lval.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]);
+                                lptr.push_back((int)lcol.size());
+                            }
+                    if (lrow.empty()) {
+                        Sell S = build_sell(M, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                        *eQ = h->lv[lv].dPT.upload(S);
+                        if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
+                        return;
+                    }
+                    Csr Ms;     // M with the long rows emptied
+                    Ms.nr = M.nr; Ms.nc = M.nc; Ms.ptr.assign((size_t)M.nr + 1, 0);
+                    {
+                        size_t li = 0;
+                        for (int r = 0; r < M.nr; r++) {
+                            const bool is_long = li < lrow.size() && lrow[li] == r;
+                            if (is_long) li++;
+                            else { Ms.col.insert(Ms.col.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]); Ms.val.insert(Ms.val.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]); }
+                            Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
+                        }
+                    }
+                    Sell S = build_sell(Ms, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
                     *eQ = h->lv[lv].dPT.upload(S);
+                    if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
                 });
             }
         }
@@ -1086,6 +1133,11 @@ static int ensure_fp32(smg_hierarchy* h, int k)
     if (!h->f32_valid) {
         drop_graphs(h);
         auto mk = [&](SellBuf& src, DevBuf<float>& dst, SellDev& view) -> int {
+            if (src.view.long_n > 0) {     // the long rows' values, too
+                HIPCHK(src.long_valf.ensure(src.long_val.n));
+                HIPCHK(launch_cvt_f64_f32(src.long_valf.p, src.long_val.p, src.long_val.n, h->stream));
+                src.view.long_valf = src.long_valf.p;
+            }
             view = src.view;
             if (src.padded == 0) { view.valf = nullptr; return SMG_OK; }
             HIPCHK(dst.ensure((size_t)src.padded));

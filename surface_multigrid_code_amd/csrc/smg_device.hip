@@ -352,6 +352,90 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
     }
 }
 
+// ---- companion of SELL_AX for the long rows kept out of the panels (SellDev::long_*): one wave per (row, column).  The lanes form
+// the products of up to 64 entries at once (one round trip for the entries, one for the gathers, whatever the row's length); the sum
+// is then taken in ascending entry order by broadcasting the products one after the other -- the very sequence of additions the panel
+// kernel performs, starting from +0.
+template <typename T>
+__global__ __launch_bounds__(256) void k_long_ax(const int* rows, const int* ptr, const int* col, const T* val, int nl, const T* x, T* y, int ld, int k,
+                                                 const int* done, CoarseInit<T> z)
+{
+    const int stop = load_flag(done);
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)nl * k) return;
+    const int r = (int)(wid / k), c = (int)(wid % k);
+    const int row = rows[r], p0 = ptr[r], p1 = ptr[r + 1];
+    T zd = (T)1;
+    if (z.u && row < z.n_first) zd = z.gs_val[z.diag_slot[row]];
+    T acc = (T)0;
+    for (int base = p0; base < p1; base += 64) {
+        const int t = base + lane;
+        T prod = (T)0;
+        if (t < p1) prod = val[t] * x[(size_t)col[t] * ld + c];
+        const int n = (p1 - base) < 64 ? (p1 - base) : 64;
+        for (int i = 0; i < n; i++) acc += __shfl(prod, i, 64);
+    }
+    if (lane == 0 && !stop) {
+        const size_t o = (size_t)row * ld + c;
+        y[o] = acc;
+        if (z.u) {
+            const T t = acc / zd;
+            if (z.jacobi == 2) { const T dn = z.omega * (t - (T)0); z.u[o] = (T)0 + dn; z.d[o] = dn; }
+            else z.u[o] = row < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+        }
+    }
+}
+// the same for many columns (k >= 8): one wave per (row, block of 64 columns), lanes across the COLUMNS, so that every gather is one
+// contiguous segment of the row-major block; the entries are fetched 64 at a time and their gathers requested 32 at a time (independent
+// loads: the chain is a handful of round trips whatever the row's length), the additions run in entry order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_long_ax_cols(const int* rows, const int* ptr, const int* col, const T* val, int nl, const T* x, T* y, int ld, int k,
+                                                      const int* done, CoarseInit<T> z)
+{
+    const int stop = load_flag(done);
+    const int lane = threadIdx.x & 63;
+    const int cblocks = (k + 63) >> 6;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)nl * cblocks) return;
+    const int r = (int)(wid / cblocks), c = (int)(wid % cblocks) * 64 + lane;
+    const bool colok = c < k;
+    const int row = rows[r], p0 = ptr[r], p1 = ptr[r + 1];
+    T zd = (T)1;
+    if (z.u && row < z.n_first) zd = z.gs_val[z.diag_slot[row]];
+    T acc = (T)0;
+    constexpr int U = 32;
+    for (int base = p0; base < p1; base += 64) {
+        const int t = base + lane;
+        const int ce = t < p1 ? col[t] : 0;
+        const T ve = t < p1 ? val[t] : (T)0;
+        const int n = (p1 - base) < 64 ? (p1 - base) : 64;
+        for (int i0 = 0; i0 < n; i0 += U) {
+            T xv[U], vv[U];
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const int cc = __shfl(ce, (i0 + i) & 63, 64);
+                vv[i] = __shfl(ve, (i0 + i) & 63, 64);
+                xv[i] = (i0 + i < n && colok) ? x[(size_t)cc * ld + c] : (T)0;
+            }
+#pragma unroll
+            for (int i = 0; i < U; i++) if (i0 + i < n) acc += vv[i] * xv[i];
+        }
+    }
+    if (colok && !stop) {
+        const size_t o = (size_t)row * ld + c;
+        y[o] = acc;
+        if (z.u) {
+            const T t = acc / zd;
+            if (z.jacobi == 2) { const T dn = z.omega * (t - (T)0); z.u[o] = (T)0 + dn; z.d[o] = dn; }
+            else z.u[o] = row < z.n_first ? (z.jacobi ? (T)0 + z.omega * (t - (T)0) : t) : (T)0;
+        }
+    }
+}
+template <typename T> static const T* host_long_vals(const SellDev& A);
+template <> const double* host_long_vals<double>(const SellDev& A) { return A.long_val; }
+template <> const float* host_long_vals<float>(const SellDev& A) { return A.long_valf; }
+
 template <typename T> static const T* host_vals(const SellDev& A);
 template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, const FirstColour* first, double omega)
 {
@@ -473,6 +557,19 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
                 if (A.stride > 0 && A.w_lo == 7) hipLaunchKernelGGL((k_sell<MODE, 4, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else hipLaunchKernelGGL((k_sell<MODE, 4, T>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 break;
+        }
+    }
+    if (MODE == SELL_AX && A.long_n > 0 && s_begin == 0 && s_end_in == A.n_slices && host_long_vals<T>(A)) {
+        // the long rows of the matrix (their panel rows are empty: the launches above left zeros there), all k columns in one launch
+        const CoarseInit<T> zz = coarse_init<T>(zero_rows, 0, first, omega);
+        if (k >= 8) {
+            const long waves = (long)A.long_n * ((k + 63) / 64);
+            hipLaunchKernelGGL((k_long_ax_cols<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, A.long_row, A.long_ptr, A.long_col, host_long_vals<T>(A), A.long_n, x, y,
+                               k, k, done, zz);
+        } else {
+            const long waves = (long)A.long_n * k;
+            hipLaunchKernelGGL((k_long_ax<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, A.long_row, A.long_ptr, A.long_col, host_long_vals<T>(A), A.long_n, x, y, k, k,
+                               done, zz);
         }
     }
     if (n_blocks) *n_blocks = (int)poff;

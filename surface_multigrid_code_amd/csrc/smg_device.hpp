@@ -38,6 +38,16 @@ struct SellDev {
     const int* col = nullptr;
     const double* val = nullptr;
     const float* valf = nullptr;     // fp32 copy of val (same slots), only for the mixed-precision V-cycle
+    // Long rows taken out of the panels (restriction operators of decimated hierarchies: a coarse vertex of the reference's construction
+    // may gather from > 100 fine ones, and a panel row is one chain of dependent batches -- it set the launch's duration): in CSR,
+    // ascending column order, served by launch_sell(SELL_AX) through a companion launch of one wave per (row, column); the panels hold
+    // these rows empty.  Same products, same order of additions: bit-identical.
+    int long_n = 0;
+    const int* long_row = nullptr;   // long_n row numbers
+    const int* long_ptr = nullptr;   // long_n + 1
+    const int* long_col = nullptr;
+    const double* long_val = nullptr;
+    const float* long_valf = nullptr;
 };
 
 enum SellMode {

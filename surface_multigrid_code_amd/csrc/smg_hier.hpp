@@ -55,6 +55,11 @@ struct SellBuf {  // device image of one SELL matrix
     int n_all = 0;                           // ... all rows (0: some row has no stored diagonal), see FirstColour in smg_device.hpp
     long stored = 0, padded = 0, used = 0;   // CSR entries / allocated slots / slots the kernels read
     hipError_t upload(const Sell& S);
+    // long rows kept out of the panels (SellDev::long_*), see csrc/smg_device.hpp
+    DevBuf<int> long_row, long_ptr, long_col;
+    DevBuf<double> long_val;
+    DevBuf<float> long_valf;
+    hipError_t upload_long(const std::vector<int>& rows, const std::vector<int>& ptr, const std::vector<int>& col, const std::vector<double>& val);
 };
 
 // one element of std::vector<mg_data> (reference src/mg_data.h:11-27)

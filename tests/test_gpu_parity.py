@@ -749,3 +749,60 @@ def test_allreduce_on_the_solve_stream(smg):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_STREAM_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+_LONGROW_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import surface_multigrid_code_amd as smg
+from surface_multigrid_code_amd import mesh
+V, F = mesh.read_triangle_mesh("ogre.smgm"); V = mesh.normalize_unit_area(V, F)
+mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+A = (mesh.massmatrix(V, F, "barycentric") - 0.01 * mesh.cotmatrix(V, F)).tocsr(); A.sort_indices()
+mg.precompute(A)
+rng = np.random.default_rng(3)
+for k in (1, 3, 8, 64):
+    for sm in ("gs", "hybrid_chebyshev"):
+        B, u = rng.uniform(-1, 1, (V.shape[0], k)), rng.uniform(-1, 1, (V.shape[0], k))
+        mg.set_smoother(sm)
+        v = mg.vcycle(B, u)
+        conv, z, rh = mg.solve(B, u, None, smg.SolveOpts(tol=1e-9, max_iter=60, smoother=sm, precision="mixed" if k == 3 else "f64"))
+        print("case", k, sm, hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest(), hashlib.sha256(np.ascontiguousarray(z).tobytes()).hexdigest(), len(rh))
+"""
+
+
+def test_long_rows_of_decimated_restrictions_are_bit_exact(smg, oracle_mod):
+    """A coarse vertex of the reference's decimation may gather from > 100 fine ones (ogre.obj: a row of PT with 177 entries).  Such rows
+    leave the SELL panels and are served by k_long_ax (one wave per row and column: products in parallel, additions in the panel
+    kernel's order): restriction bit-exact against the oracle in the device numbering for k = 1..64, and whole cycles / solves
+    bit-identical to the build that keeps them in the panels (SMG_LONG_ROW_MIN=0)."""
+    import subprocess, sys
+    mesh = smg.mesh
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    A = (mesh.massmatrix(V, F, "barycentric") - 0.01 * mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    mg.precompute(A)
+    PT = mg.matrix(1, "PT", internal=True).tocsr()
+    assert np.diff(PT.indptr).max() >= 100                       # the situation this is about
+    rng = np.random.default_rng(4)
+    for lv in range(mg.n_levels - 1):
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        for k in (1, 2, 3, 5, 8, 27, 64):
+            x = rng.uniform(-1, 1, (mg.rows(lv), k))
+            assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm])), "restriction with long rows not bit-exact: level %d, k %d" % (lv, k)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env.update(SMG_LONG_ROW_MIN="0")
+        r = subprocess.run([sys.executable, "-c", _LONGROW_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("case")]
+        assert len(lines) == 8, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1]
