@@ -1106,13 +1106,16 @@ static int ensure_work(smg_hierarchy* h, int k)
             if (lv < L - 1 || L == 1) HIPCHK(Lv.r.alloc(rows * k));
             if (lv < L - 1 || L == 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
         }
+        // colour by colour (the level-0 head of an outer iteration, enqueue_residual_ss) every launch rounds its block count up on its own
+        maxblocks += (h->lv[0].dA.color_slice_ptr.size() + 1) * (size_t)((k + 3) / 4 + 8);
         HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
         h->kcap = k;
     }
     // Jacobi-smoothed levels ping-pong between u and a second iterate
     for (int lv = 0; lv < L - 1; lv++) {
         Level& Lv = h->lv[lv];
-        if (level_is_jacobi(h, lv) && Lv.t.n < (size_t)Lv.n * h->kcap) {
+        // (level 0 always: the first sweep of an outer iteration is written out of place, see enqueue_residual_ss)
+        if ((level_is_jacobi(h, lv) || lv == 0) && Lv.t.n < (size_t)Lv.n * h->kcap) {
             drop_graphs(h);
             HIPCHK(Lv.t.alloc((size_t)Lv.n * h->kcap));
             HIPCHK(hipMemsetAsync(Lv.t.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
@@ -1267,18 +1270,28 @@ template <> struct Prec<float> {
     { return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p); }
 };
 
+// what of a level's first pre-smoothing sweep exists when its V-cycle starts
+enum { FIRST_NONE = 0,
+       FIRST_LAUNCH = 1,   // its first launch, produced by the restriction launch of the finer level (FirstColour): the first colour
+                           // (Gauss-Seidel, in Lv.u) or the whole first sweep / step (Jacobi / Chebyshev, in Lv.t)
+       FIRST_SWEEP = 2 };  // level 0 inside an outer iteration: the whole first sweep / step, produced out of place into Lv.t by the
+                           // launches that also formed the outer residual (enqueue_head)
+
 // `iters` forward Gauss-Seidel sweeps in place: one launch per colour (reference relax(), src/mg_VCycle.cpp:113-178)
-// first_done: the first colour of the first sweep was already produced by the restriction launch (FirstColour)
+// first = FIRST_LAUNCH: the first colour of the first sweep is already in u.  FIRST_SWEEP: the whole first sweep is in `t`: the second
+// sweep goes from t back into u (out-of-place colour launches: same values), the rest run in place on u; needs iters >= 2.
 template <typename T>
-static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int iters, const Ctrl* ctrl, bool first_done = false)
+static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int iters, const Ctrl* ctrl, int first = FIRST_NONE, T* t = nullptr)
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
     const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
     const std::vector<int>& cs = G.color_slice_ptr;
-    for (int it = 0; it < iters; it++)
-        for (size_t c = (it == 0 && first_done) ? 1 : 0; c + 1 < cs.size(); c++)
-            HIPCHK(Prec<T>::sell(SELL_GS, Prec<T>::G(Lv), cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
+    for (int it = first == FIRST_SWEEP ? 1 : 0; it < iters; it++)
+        for (size_t c = (it == 0 && first == FIRST_LAUNCH) ? 1 : 0; c + 1 < cs.size(); c++) {
+            if (it == 1 && first == FIRST_SWEEP) HIPCHK(Prec<T>::sell(SELL_GS_OOP, Prec<T>::G(Lv), cs[c], cs[c + 1], t, b, u, k, ctrl, h->stream));
+            else HIPCHK(Prec<T>::sell(SELL_GS, Prec<T>::G(Lv), cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
+        }
     return SMG_OK;
 }
 
@@ -1320,11 +1333,11 @@ static int enqueue_cheby(smg_hierarchy* h, int lv, const T* b, T* const buf[2], 
 // reference mg_VCycle(), src/mg_VCycle.cpp:3-59.  B and u of level lv are Lv.b / Lv.u (level 0: RHS_u / z_u).
 static bool fuse_first_colour() { static const int on = env_int("SMG_FUSE_FIRST", 1); return on != 0; }
 
-// first_done: the restriction launch of the finer level already produced the first launch of this level's first pre-smoothing
-// sweep -- the first colour (Gauss-Seidel, in Lv.u) or the whole first sweep (Jacobi, in Lv.t).
+// first: what of this level's first pre-smoothing sweep already exists (FIRST_*).
 template <typename T>
-static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, bool first_done = false)
+static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, int first = FIRST_NONE)
 {
+    const bool first_done = first != FIRST_NONE;
     const int L = h->n_levels;
     Level& Lv = h->lv[lv];
     if (lv == L - 1) {  // coarseSolve: u = u + solver.solve(B)  (:28-33, :199-200)
@@ -1344,7 +1357,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     } else if (kind == LV_CHEBY) {
         if (first_done) cur = 1;
         rc = enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, pre, ctrl, first_done);                         // :36
-    } else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first_done);                            // :36
+    } else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first, buf[1]);                         // :36
     if (rc) return rc;
     {   // r = B - A u  (:40-42)
         ProfGuard pg(h, "MG: residual");
@@ -1376,7 +1389,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         HIPCHK(Prec<T>::sell(SELL_AX, Prec<T>::PT(Lc), 0, Prec<T>::PT(Lc).n_slices, Prec<T>::r(Lv), nullptr, Prec<T>::b(Lc), k, ctrl, h->stream, init,
                              fuse ? &fc : nullptr));
     }
-    rc = enqueue_vcycle_t<T>(h, lv + 1, k, pre, post, ctrl, fuse);  // :48
+    rc = enqueue_vcycle_t<T>(h, lv + 1, k, pre, post, ctrl, fuse ? FIRST_LAUNCH : FIRST_NONE);  // :48
     if (rc) return rc;
     {   // u = u + P uc  (:51-53, :91).  A Jacobi level with an odd number of post-smoothing sweeps to go adds out of place, so that
         // the last sweep lands in u.
@@ -1392,9 +1405,9 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     return enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, post, ctrl);                    // :57
 }
 
-static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
+static int enqueue_vcycle(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl, int first = FIRST_NONE)
 {
-    return enqueue_vcycle_t<double>(h, lv, k, pre, post, ctrl);
+    return enqueue_vcycle_t<double>(h, lv, k, pre, post, ctrl, first);
 }
 static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, const Ctrl* ctrl)
 {
@@ -1415,12 +1428,53 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
     return SMG_OK;
 }
 
+// The outer residual of iterate z (min_quad_with_fixed_mg.cpp:110) and the first pre-smoothing sweep of the V-cycle that follows
+// (mg_VCycle.cpp:36) stream the same matrix against the same z: when this returns true the sweep's launches form both -- the sweep's
+// result out of place in L0.t (z itself stays intact for the case that the break test stops the loop), the squared residual through a
+// second accumulator that repeats SELL_RESID_SS's additions (SELL_*_HEAD in smg_device.hpp) -- and the cycle starts with FIRST_SWEEP.
+// fp64 cycles only (the mixed mode's residual IS the right-hand side of its fp32 cycle); Gauss-Seidel needs a second sweep to come back
+// into u; a level 0 that smooths on A^T (non-symmetric storage) forms other sums than the residual.
+static bool head_fusable(smg_hierarchy* h)
+{
+    static const int on = env_int("SMG_FUSE_HEAD", 1);
+    if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on) return false;
+    Level& L0 = h->lv[0];
+    if (L0.gs_on_transpose) return false;
+    const int kind = level_kind(h, 0);
+    return kind == LV_GS ? h->pre >= 2 : h->pre >= 1;
+}
+
 // sum of squares of RHS_u - A_0 z_u into ctrl->sumsq  (min_quad_with_fixed_mg.cpp:110 / :332)
 static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false, double* sumsq_out = nullptr)
 {
     Level& L0 = h->lv[0];
-    ProfGuard pg(h, "MG: outer residual");
     int nb = 0;
+    if (head_fusable(h)) {
+        ProfGuard pg(h, "MG: relaxation");
+        const int kind = level_kind(h, 0);
+        const SellDev& G = L0.dA.view;
+        if (kind == LV_GS) {
+            const std::vector<int>& cs = L0.dA.color_slice_ptr;
+            for (size_t c = 0; c + 1 < cs.size(); c++) {
+                int nbc = 0;
+                HIPCHK(launch_sell(SELL_GS_HEAD, G, cs[c], cs[c + 1], L0.u.p, L0.b.p, L0.t.p, k, h->d_ctrl.p, h->d_partials.p + nb, &nbc, h->stream));
+                nb += nbc;
+            }
+        } else if (kind == LV_JACOBI) {
+            HIPCHK(launch_sell(SELL_JACOBI_HEAD, G, 0, G.n_slices, L0.u.p, L0.b.p, L0.t.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream, nullptr, nullptr, h->omega));
+        } else {
+            std::vector<ChebyCoef> cf;
+            cheby_coefs(L0.lam, h->cheby_fraction, h->pre + 1, cf);
+            FirstColour fc;
+            fc.d = L0.d.p;
+            fc.c1 = cf[0].c1;
+            HIPCHK(launch_sell(SELL_CHEBY_HEAD, G, 0, G.n_slices, L0.u.p, L0.b.p, L0.t.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream, nullptr, &fc, cf[0].c2));
+        }
+        if (fuse_decide) HIPCHK(launch_ss_finalize_decide(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
+        else HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream, sumsq_out));
+        return SMG_OK;
+    }
+    ProfGuard pg(h, "MG: outer residual");
     if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
         HIPCHK(launch_sell(SELL_RESID_BOTH, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     else
@@ -1445,7 +1499,7 @@ static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
             if (rc) return rc;
             HIPCHK(launch_add_correction(L0.u.p, L0.u32.p, cnt, h->d_ctrl.p, h->stream));
         } else {
-            int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p);
+            int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p, head_fusable(h) ? FIRST_SWEEP : FIRST_NONE);
             if (rc) return rc;
         }
     }

@@ -80,14 +80,15 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
     // n_blocks < 0 (small colour sweeps only): the launch has 8x the workgroups and only those that land on XCD 0 work, so the
     // values one colour launch writes are still in that XCD's L2 when the next launch gathers them -- a small level's launch chain
     // is pure latency, and this takes the trip to the Infinity Cache out of it (tools/micro/xcd_local.hip: 3.6 -> 2.85 us per launch)
+    constexpr bool GS = sell_is_gs(MODE), OOP = sell_is_oop(MODE), JAC = sell_is_jacobi(MODE), CHEB = sell_is_cheby(MODE), HEAD = sell_is_head(MODE);
     int bid;
-    if (MODE == SELL_GS && n_blocks < 0) { if (blockIdx.x & 7) return; bid = blockIdx.x >> 3; }
+    if (GS && n_blocks < 0) { if (blockIdx.x & 7) return; bid = blockIdx.x >> 3; }
     else bid = xcd_remap(blockIdx.x, n_blocks);
     const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * wpb + wave);
     double ss = 0.0;
     int stop = 0;
     if (ls < s_end) {
-        const int s = (MODE != SELL_GS && use_order) ? A.order[ls] : ls;   // colour sweeps never walk the region order
+        const int s = (!GS && use_order) ? A.order[ls] : ls;   // colour sweeps never walk the region order
         // Fixed-stride matrices: the panel address comes from s alone, and the first W0 columns (what most slices have; a
         // narrower slice holds padding there) are requested before the slice's table entries have arrived -- the table reads
         // leave the critical path.
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         {
             size_t keep = (size_t)x ^ (size_t)A.slice_row ^ (size_t)A.slice_w ^ (size_t)b ^ (size_t)y ^ (size_t)done ^ (size_t)ld;
             if (MODE == SELL_AX) keep ^= (size_t)z.u ^ (size_t)z.gs_val ^ (size_t)z.diag_slot ^ (size_t)z.n_first ^ (size_t)z.jacobi ^ (size_t)z.d;
-            if (MODE == SELL_CHEBY) keep ^= (size_t)z.d;
+            if (CHEB) keep ^= (size_t)z.d;
             asm("" : "+s"(keep));
             if (keep == 0x5a5a5a5a5a5a5a5bull) return;   // never: only there to consume `keep`
         }
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         const int nrow = A.slice_row[s + 1] - row0;
         const int w = A.slice_w[s];
         const int rowb = row0 + lane;
+        // out-of-place colour launch: rows below `split` (the first row of the launch = of the colour) already have this sweep's value in y
+        const int split = OOP ? A.slice_row[s_begin] : 0;
         T acc[KB];
+        T accr[KB];  // HEAD modes: sum over ALL stored entries of the row against the old iterate (the residual's own accumulator)
         T diag = (T)1;
         T xi[KB];  // SELL_JACOBI / SELL_CHEBY: the row's own old value (it travels with the gathers: the diagonal entry's column)
         T dold[KB];  // SELL_CHEBY: the row's previous update
@@ -133,18 +137,32 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         if (MODE == SELL_AX && live && rowb < z.n_first) zd = z.gs_val[z.diag_slot[rowb]];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
-            acc[q] = (T)0; xi[q] = (T)0; dold[q] = (T)0;
+            acc[q] = (T)0; accr[q] = (T)0; xi[q] = (T)0; dold[q] = (T)0;
             if (MODE == SELL_AX) bv[q] = (T)0;
             else bv[q] = live ? b[(size_t)rowb * ld + q] : (T)0;   // SELL_ADD: b is the iterate the correction is added to (== y in place)
-            if (MODE == SELL_CHEBY && live && z.c1 != (T)0) dold[q] = z.d[(size_t)rowb * ld + q];
+            if (CHEB && live && z.c1 != (T)0) dold[q] = z.d[(size_t)rowb * ld + q];
         }
         // one batch of U panel columns: gather x for all of them, then accumulate in ascending column order
         auto consume = [&](const int (&c)[U], const T (&v)[U]) {
             T xv[U][KB];
+            T xo[MODE == SELL_GS_HEAD ? U : 1][KB];   // SELL_GS_HEAD: the OLD iterate at every stored column (xv holds the sweep's operand)
 #pragma unroll
             for (int t = 0; t < U; t++) {
-                const bool use = (c[t] >= 0) && !(MODE == SELL_GS && c[t] == rowb);
-                if constexpr (KB == 1) {
+                const bool use = (c[t] >= 0) && !(GS && c[t] == rowb);
+                if constexpr (MODE == SELL_GS_HEAD) {
+                    // old value for every entry (diagonal included); the sweep's operand is y's value for the earlier colours
+#pragma unroll
+                    for (int q = 0; q < KB; q++) {
+                        xo[t][q] = c[t] >= 0 ? x[(size_t)c[t] * ld + q] : (T)0;
+                        xv[t][q] = (use && c[t] < split) ? y[(size_t)c[t] * ld + q] : xo[t][q];
+                    }
+                } else if constexpr (MODE == SELL_GS_OOP) {
+#pragma unroll
+                    for (int q = 0; q < KB; q++) {
+                        const T* src = c[t] < split ? (const T*)y : x;
+                        xv[t][q] = use ? src[(size_t)c[t] * ld + q] : (T)0;
+                    }
+                } else if constexpr (KB == 1) {
                     xv[t][0] = use ? x[(size_t)c[t] * ld] : (T)0;
                 } else {
                     // the KB columns of a neighbour are contiguous: one (KB = 2) or two wide loads instead of KB narrow ones -- the
@@ -170,9 +188,13 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
 #pragma unroll
             for (int t = 0; t < U; t++) {
                 if (c[t] >= 0) {
-                    if (MODE == SELL_GS && c[t] == rowb) {
+                    if (HEAD) {
+#pragma unroll
+                        for (int q = 0; q < KB; q++) accr[q] += v[t] * (MODE == SELL_GS_HEAD ? xo[t][q] : xv[t][q]);
+                    }
+                    if (GS && c[t] == rowb) {
                         diag = v[t];
-                    } else if ((MODE == SELL_JACOBI || MODE == SELL_CHEBY) && c[t] == rowb) {
+                    } else if ((JAC || CHEB) && c[t] == rowb) {
                         diag = v[t];
 #pragma unroll
                         for (int q = 0; q < KB; q++) xi[q] = xv[t][q];
@@ -208,9 +230,9 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                 }
                 else if (MODE == SELL_RESID) y[o + q] = bv[q] - acc[q];
                 else if (MODE == SELL_ADD) y[o + q] = bv[q] + acc[q];
-                else if (MODE == SELL_GS) y[o + q] = (bv[q] - acc[q]) / diag;
-                else if (MODE == SELL_JACOBI) { const T t = (bv[q] - acc[q]) / diag; y[o + q] = xi[q] + z.omega * (t - xi[q]); }
-                else if (MODE == SELL_CHEBY) {
+                else if (GS) y[o + q] = (bv[q] - acc[q]) / diag;
+                else if (JAC) { const T t = (bv[q] - acc[q]) / diag; y[o + q] = xi[q] + z.omega * (t - xi[q]); }
+                else if (CHEB) {
                     const T t = (bv[q] - acc[q]) / diag;
                     const T r = t - xi[q];
                     const T dn = z.c1 != (T)0 ? z.c1 * dold[q] + z.omega * r : z.omega * r;
@@ -218,10 +240,11 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                     z.d[o + q] = dn;
                 }
                 else { const double t = (double)(bv[q] - acc[q]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o + q] = bv[q] - acc[q]; }
+                if (HEAD) { const double t = (double)(bv[q] - accr[q]); ss += t * t; }
             }
         }
     }
-    if (MODE == SELL_RESID_SS || MODE == SELL_RESID_BOTH) {
+    if (sell_has_ss(MODE)) {
         __shared__ double red[16];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
         if (threadIdx.x == 0 && !stop) {
             double t = 0.0;
             for (int i2 = 0; i2 < wpb; i2++) t += red[i2];
-            partials[blockIdx.x] = t;
+            partials[HEAD ? bid : (int)blockIdx.x] = t;   // (one-XCD colour launches: only every 8th workgroup works)
         }
     }
 }
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
 {
     struct { const int *slice_row, *slice_off, *slice_w, *order, *col; int stride; } A = {a_slice_row, a_slice_off, a_slice_w, a_order, a_col,
                                                                                         a_stride};
+    constexpr bool GS = sell_is_gs(MODE), OOP = sell_is_oop(MODE), JAC = sell_is_jacobi(MODE), CHEB = sell_is_cheby(MODE), HEAD = sell_is_head(MODE);
     const int stop = load_flag(done);
     constexpr int G = 64 / KW;        // rows in flight per wave-instruction
     constexpr int R = 2;              // rows per lane
@@ -269,19 +293,20 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         const int nrow = A.slice_row[s + 1] - row0;
         const int off0 = A.stride ? s * A.stride : A.slice_off[s];
         const int w = A.slice_w[s];
+        const int split = OOP ? A.slice_row[s_begin] : 0;   // see k_sell
         int rl[R];
-        T acc[R], diag[R], bv[R], zd[R], xi[R], dold[R];
+        T acc[R], accr[R], diag[R], bv[R], zd[R], xi[R], dold[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             rl[r] = sub * RW + r * G + g;   // row inside the slice
-            acc[r] = (T)0; diag[r] = (T)1; xi[r] = (T)0; dold[r] = (T)0;
+            acc[r] = (T)0; accr[r] = (T)0; diag[r] = (T)1; xi[r] = (T)0; dold[r] = (T)0;
             const bool live = rl[r] < nrow;
             zd[r] = (T)1;
             if (MODE == SELL_AX && live && row0 + rl[r] < z.n_first) zd[r] = z.gs_val[z.diag_slot[row0 + rl[r]]];
             const size_t o = (size_t)(row0 + rl[r]) * ld + c;
             if (MODE == SELL_AX) bv[r] = (T)0;
             else bv[r] = live ? b[o] : (T)0;
-            if (MODE == SELL_CHEBY && live && z.c1 != (T)0) dold[r] = z.d[o];
+            if (CHEB && live && z.c1 != (T)0) dold[r] = z.d[o];
         }
         const int* cp = A.col + (size_t)off0 * 64;
         const T* vp = a_val + (size_t)off0 * 64;
@@ -289,6 +314,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         for (int j0 = 0; j0 < w; j0 += U) {
             int cc[U][R];
             T vv[U][R], xv[U][R];
+            T xo[MODE == SELL_GS_HEAD ? U : 1][R];
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
@@ -301,16 +327,23 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const bool use = (cc[t][r] >= 0) && !(MODE == SELL_GS && cc[t][r] == row0 + rl[r]);
-                    xv[t][r] = use ? x[(size_t)cc[t][r] * ld + c] : (T)0;
+                    const bool use = (cc[t][r] >= 0) && !(GS && cc[t][r] == row0 + rl[r]);
+                    if constexpr (MODE == SELL_GS_HEAD) {
+                        xo[t][r] = cc[t][r] >= 0 ? x[(size_t)cc[t][r] * ld + c] : (T)0;
+                        xv[t][r] = (use && cc[t][r] < split) ? y[(size_t)cc[t][r] * ld + c] : xo[t][r];
+                    } else if constexpr (MODE == SELL_GS_OOP) {
+                        const T* src = cc[t][r] < split ? (const T*)y : x;
+                        xv[t][r] = use ? src[(size_t)cc[t][r] * ld + c] : (T)0;
+                    } else xv[t][r] = use ? x[(size_t)cc[t][r] * ld + c] : (T)0;
                 }
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (cc[t][r] >= 0) {
-                        if (MODE == SELL_GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
-                        else if ((MODE == SELL_JACOBI || MODE == SELL_CHEBY) && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
+                        if (HEAD) accr[r] += vv[t][r] * (MODE == SELL_GS_HEAD ? xo[t][r] : xv[t][r]);
+                        if (GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
+                        else if ((JAC || CHEB) && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
                         else acc[r] += vv[t][r] * xv[t][r];
                     }
                 }
@@ -329,9 +362,9 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                 }
                 else if (MODE == SELL_RESID) y[o] = bv[r] - acc[r];
                 else if (MODE == SELL_ADD) y[o] = bv[r] + acc[r];
-                else if (MODE == SELL_GS) y[o] = (bv[r] - acc[r]) / diag[r];
-                else if (MODE == SELL_JACOBI) { const T t = (bv[r] - acc[r]) / diag[r]; y[o] = xi[r] + z.omega * (t - xi[r]); }
-                else if (MODE == SELL_CHEBY) {
+                else if (GS) y[o] = (bv[r] - acc[r]) / diag[r];
+                else if (JAC) { const T t = (bv[r] - acc[r]) / diag[r]; y[o] = xi[r] + z.omega * (t - xi[r]); }
+                else if (CHEB) {
                     const T t = (bv[r] - acc[r]) / diag[r];
                     const T rr = t - xi[r];
                     const T dn = z.c1 != (T)0 ? z.c1 * dold[r] + z.omega * rr : z.omega * rr;
@@ -339,10 +372,11 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                     z.d[o] = dn;
                 }
                 else { const double t = (double)(bv[r] - acc[r]); ss += t * t; if (MODE == SELL_RESID_BOTH) y[o] = bv[r] - acc[r]; }
+                if (HEAD) { const double t = (double)(bv[r] - accr[r]); ss += t * t; }
             }
         }
     }
-    if (MODE == SELL_RESID_SS || MODE == SELL_RESID_BOTH) {
+    if (sell_has_ss(MODE)) {
         __shared__ double red[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
@@ -519,7 +553,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
     }
     // small colour sweeps run on one XCD (see k_sell): grid 8 nb, n_blocks passed negated
     static const int one_xcd_max = getenv("SMG_ONE_XCD_MAX") ? atoi(getenv("SMG_ONE_XCD_MAX")) : 32;
-    const bool one_xcd = MODE == SELL_GS && nb <= one_xcd_max;
+    const bool one_xcd = sell_is_gs(MODE) && nb <= one_xcd_max;
     const int grid = one_xcd ? nb * 8 : nb, nbarg = one_xcd ? -nb : nb;
     for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
@@ -537,7 +571,7 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
                 // residual, transfer) of a level that small, <= 64 workgroups (C3 level 3: 37.3 -> 34.1 us per visit; colour sweeps of 62
                 // workgroups lose with it)
                 static const int pitch_env = getenv("SMG_PITCH_SPEC_MAX") ? atoi(getenv("SMG_PITCH_SPEC_MAX")) : -1;
-                const int pitch_max = pitch_env >= 0 ? pitch_env : (MODE == SELL_GS ? 32 : 64);
+                const int pitch_max = pitch_env >= 0 ? pitch_env : (sell_is_gs(MODE) ? 32 : 64);
                 if (nb <= pitch_max && A.stride == 12 && w0 >= 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 12>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
@@ -594,6 +628,19 @@ static hipError_t launch_sell_any(SellMode mode, const SellDev& A, int s_begin, 
         case SELL_RESID_BOTH:
             if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_RESID_BOTH, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
             else return hipErrorInvalidValue;
+        // the level-0 head of an outer iteration: fp64 only (the mixed-precision mode keeps its own residual pass)
+        case SELL_GS_OOP:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_GS_OOP, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+            else return hipErrorInvalidValue;
+        case SELL_GS_HEAD:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_GS_HEAD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+            else return hipErrorInvalidValue;
+        case SELL_JACOBI_HEAD:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_JACOBI_HEAD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+            else return hipErrorInvalidValue;
+        case SELL_CHEBY_HEAD:
+            if constexpr (std::is_same<T, double>::value) return launch_sell_mode<SELL_CHEBY_HEAD, T>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, zero_rows, first, omega);
+            else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -609,7 +656,7 @@ hipError_t launch_sell(SellMode mode, const SellDev& A, int s_begin, int s_end, 
 hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_end, const float* x, const float* b,
                            float* y, int k, const Ctrl* ctrl, hipStream_t st, float* zero_rows, const FirstColour* first, double omega)
 {
-    if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH) return hipErrorInvalidValue;
+    if (!A.valf || mode == SELL_RESID_SS || mode == SELL_RESID_BOTH || mode >= SELL_GS_OOP) return hipErrorInvalidValue;
     return launch_sell_any<float>(mode, A, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega);
 }
 

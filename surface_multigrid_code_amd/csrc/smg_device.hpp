@@ -61,7 +61,24 @@ enum SellMode {
                         // whole matrix in one launch (the "Jacobi" of BASELINE.json's north_star; same slot as SELL_GS, mg_VCycle.cpp:113-178)
     SELL_CHEBY = 7,     // one step of Chebyshev-accelerated Jacobi from x into y (x != y):  r_i = (b_i - sum_{j != i} A_ij x_j) / A_ii - x_i,
                         // d_i = c1 d_i + c2 r_i (first step, c1 == 0: d_i = c2 r_i, d not read),  y_i = x_i + d_i
+    // ---- the outer loop's residual folded into the first smoothing launches of the V-cycle (level 0 only, fp64 only) ----
+    // The reference computes |RHS - A z| (min_quad_with_fixed_mg.cpp:110), tests it, and then starts the cycle with relax() on the same
+    // z: the first sweep streams the same matrix rows again.  These modes take the squared residual of the OLD iterate out of that
+    // sweep -- per row a second accumulator, b_i - sum_j A_ij x_j over ALL stored entries in slot order, bit for bit what SELL_RESID_SS
+    // forms -- and write the sweep's result OUT OF PLACE (y != x), so that the old iterate survives when the break test says stop.
+    SELL_GS_OOP = 8,      // one colour of a Gauss-Seidel sweep from x into y: neighbours in earlier colours (rows below the first row of
+                          // the launch's slice range: colour-major numbering) are read from y, the others from x.  Same values, same order
+                          // as the in-place launch.
+    SELL_GS_HEAD = 9,     // SELL_GS_OOP + partial sums of |b - A x|^2 over the rows of the colour
+    SELL_JACOBI_HEAD = 10,  // SELL_JACOBI + partial sums of |b - A x|^2
+    SELL_CHEBY_HEAD = 11,   // SELL_CHEBY + partial sums of |b - A x|^2
 };
+constexpr bool sell_is_gs(int m) { return m == SELL_GS || m == SELL_GS_OOP || m == SELL_GS_HEAD; }
+constexpr bool sell_is_oop(int m) { return m == SELL_GS_OOP || m == SELL_GS_HEAD; }
+constexpr bool sell_is_jacobi(int m) { return m == SELL_JACOBI || m == SELL_JACOBI_HEAD; }
+constexpr bool sell_is_cheby(int m) { return m == SELL_CHEBY || m == SELL_CHEBY_HEAD; }
+constexpr bool sell_is_head(int m) { return m == SELL_GS_HEAD || m == SELL_JACOBI_HEAD || m == SELL_CHEBY_HEAD; }
+constexpr bool sell_has_ss(int m) { return sell_is_head(m) || m == SELL_RESID_SS || m == SELL_RESID_BOTH; }
 
 // SELL_ADD: y = b + A x, where b is the iterate the correction is added to (b == nullptr: in place, b = y).
 // y/x/b: internal layout, ld = number of columns k.  Slices [s_begin, s_end).  `ctrl` may be null (no

@@ -260,6 +260,50 @@ def test_fused_first_jacobi_sweep_does_not_change_a_bit(smg):
     assert outs[0] == outs[1]
 
 
+_CHILD_HEAD = r"""
+import hashlib, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import surface_multigrid_code_amd as smg
+from problems import subdiv_problem
+for kind, k, sm, pre in (("mcf", 1, "gs", 2), ("poisson", 3, "gs", 2), ("mcf", 9, "gs", 3), ("mcf", 64, "gs", 2), ("poisson", 1, "jacobi", 1),
+                         ("mcf", 12, "jacobi", 2), ("mcf", 1, "chebyshev", 2), ("poisson", 17, "chebyshev", 1), ("mcf", 2, "hybrid_chebyshev", 2),
+                         ("poisson", 1, "hybrid", 2), ("mcf", 1, "gs", 1)):
+    p = subdiv_problem(kind=kind, k=k, n_sub=3)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.precompute(p["A"], p["known"])
+    thr = mg.rows(1)
+    conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-9, max_iter=80, pre=pre, smoother=sm, jacobi_max_rows=thr))
+    conv2, z2, rh2 = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-9, max_iter=80, pre=pre, smoother=sm, jacobi_max_rows=thr, use_graph=0))
+    assert np.array_equal(z, z2) and np.array_equal(rh, rh2)
+    print("case", kind, k, sm, int(conv), hashlib.sha256(np.ascontiguousarray(z).tobytes()).hexdigest(), " ".join(repr(float(x)) for x in rh))
+"""
+
+
+def test_outer_residual_folded_into_the_first_sweep_changes_nothing_but_rounding_of_the_norm(smg):
+    """SELL_*_HEAD (csrc/smg_device.hpp): the first pre-smoothing sweep of level 0 also forms the outer residual of the iterate it starts
+    from and leaves that iterate intact.  Against SMG_FUSE_HEAD=0 (separate residual launch, in-place sweeps): the solutions are
+    bit-identical (same sweeps, same break iteration), the residual history agrees to the rounding of the sum of squares (the per-row
+    residuals are the same bits; their squares are summed colour by colour instead of in launch order)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env.update(SMG_FUSE_HEAD="0")
+        r = subprocess.run([sys.executable, "-c", _CHILD_HEAD, root], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("case")]
+        assert len(lines) == 11, r.stdout
+        outs.append(lines)
+    for a, b in zip(*outs):
+        assert a[:6] == b[:6], (a[:6], b[:6])                      # same case, converged flag, solution bits
+        ra, rb = np.array([float(x) for x in a[6:]]), np.array([float(x) for x in b[6:]])
+        assert len(ra) == len(rb) and a[4] == "1"
+        np.testing.assert_allclose(ra, rb, rtol=1e-13)
+
+
 # ----------------------------------------------------------------------------------------------- boundary clean-ups
 def test_single_level_hierarchy_goes_straight_to_the_coarse_solve(smg, oracle_mod):
     """mg.size() == 1: mg_VCycle is coarseSolve only, u += LDLT.solve(B) (src/mg_VCycle.cpp:28-33) -- exact after one cycle from
