@@ -55,6 +55,30 @@ static const int* never_done()
 // not read then) and omega (coefficient of the scaled residual).
 template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag_slot; int n_first; int jacobi; T omega; T* d; T c1; };
 
+// The KB columns of a neighbour are contiguous: one (KB = 2, 4) or two (KB = 3) wide loads instead of KB narrow ones -- the gathers
+// are what a small-level launch waits for (element-aligned only: gfx950 global loads do not need more).  !use: zeros, no request.
+template <int KB, typename T>
+__device__ __forceinline__ void gather_kb(const T* px, bool use, T (&out)[KB])
+{
+    if constexpr (KB == 1) {
+        out[0] = use ? px[0] : (T)0;
+    } else if constexpr (KB == 3) {   // a 3-vector would be padded to 4 elements: the load would run past the row
+        typedef T V2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+        V2 g = {(T)0, (T)0};
+        T g2 = (T)0;
+        if (use) { g = *reinterpret_cast<const V2*>(px); g2 = px[2]; }
+        out[0] = g[0]; out[1] = g[1]; out[2] = g2;
+    } else {
+        typedef T VK __attribute__((ext_vector_type(KB), aligned(sizeof(T))));
+        VK g;
+#pragma unroll
+        for (int q = 0; q < KB; q++) g[q] = (T)0;
+        if (use) g = *reinterpret_cast<const VK*>(px);
+#pragma unroll
+        for (int q = 0; q < KB; q++) out[q] = g[q];
+    }
+}
+
 // One wavefront per slice of 64 rows; lane l owns row row0 + l.
 // T = double: the reference arithmetic.  T = float: the fp32 V-cycle of the mixed-precision mode (values, vectors and
 // accumulation in fp32; SELL_RESID_SS is never instantiated for it: the outer residual stays fp64).
@@ -150,39 +174,15 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
             for (int t = 0; t < U; t++) {
                 const bool use = (c[t] >= 0) && !(GS && c[t] == rowb);
                 if constexpr (MODE == SELL_GS_HEAD) {
-                    // old value for every entry (diagonal included); the sweep's operand is y's value for the earlier colours
-#pragma unroll
-                    for (int q = 0; q < KB; q++) {
-                        xo[t][q] = c[t] >= 0 ? x[(size_t)c[t] * ld + q] : (T)0;
-                        xv[t][q] = (use && c[t] < split) ? y[(size_t)c[t] * ld + q] : xo[t][q];
-                    }
+                    // old value for every entry (diagonal included) and, for the earlier colours, y's value: two independent requests --
+                    // the choice between them is made when they are consumed (written as one select here, the second load waited for
+                    // the first: seven dependent round trips per row)
+                    gather_kb<KB, T>(x + (size_t)c[t] * ld, c[t] >= 0, xo[t]);
+                    gather_kb<KB, T>((const T*)y + (size_t)c[t] * ld, use && c[t] < split, xv[t]);
                 } else if constexpr (MODE == SELL_GS_OOP) {
-#pragma unroll
-                    for (int q = 0; q < KB; q++) {
-                        const T* src = c[t] < split ? (const T*)y : x;
-                        xv[t][q] = use ? src[(size_t)c[t] * ld + q] : (T)0;
-                    }
-                } else if constexpr (KB == 1) {
-                    xv[t][0] = use ? x[(size_t)c[t] * ld] : (T)0;
+                    gather_kb<KB, T>((c[t] < split ? (const T*)y : x) + (size_t)c[t] * ld, use, xv[t]);
                 } else {
-                    // the KB columns of a neighbour are contiguous: one (KB = 2) or two wide loads instead of KB narrow ones -- the
-                    // gathers are what a small-level launch waits for (element-aligned only: gfx950 global loads do not need more)
-                    typedef T V2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
-                    const T* px = x + (size_t)c[t] * ld;
-                    if constexpr (KB == 3) {   // a 3-vector would be padded to 4 elements: the load would run past the row
-                        V2 g = {(T)0, (T)0};
-                        T g2 = (T)0;
-                        if (use) { g = *reinterpret_cast<const V2*>(px); g2 = px[2]; }
-                        xv[t][0] = g[0]; xv[t][1] = g[1]; xv[t][2] = g2;
-                    } else {
-                        typedef T VK __attribute__((ext_vector_type(KB), aligned(sizeof(T))));
-                        VK g;
-#pragma unroll
-                        for (int q = 0; q < KB; q++) g[q] = (T)0;
-                        if (use) g = *reinterpret_cast<const VK*>(px);
-#pragma unroll
-                        for (int q = 0; q < KB; q++) xv[t][q] = g[q];
-                    }
+                    gather_kb<KB, T>(x + (size_t)c[t] * ld, use, xv[t]);
                 }
             }
 #pragma unroll
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
                         for (int q = 0; q < KB; q++) xi[q] = xv[t][q];
                     } else {
 #pragma unroll
-                        for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
+                        for (int q = 0; q < KB; q++) acc[q] += v[t] * ((MODE == SELL_GS_HEAD && c[t] >= split) ? xo[t][q] : xv[t][q]);
                     }
                 }
             }
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                     const bool use = (cc[t][r] >= 0) && !(GS && cc[t][r] == row0 + rl[r]);
                     if constexpr (MODE == SELL_GS_HEAD) {
                         xo[t][r] = cc[t][r] >= 0 ? x[(size_t)cc[t][r] * ld + c] : (T)0;
-                        xv[t][r] = (use && cc[t][r] < split) ? y[(size_t)cc[t][r] * ld + c] : xo[t][r];
+                        xv[t][r] = (use && cc[t][r] < split) ? y[(size_t)cc[t][r] * ld + c] : (T)0;   // chosen when consumed, see k_sell
                     } else if constexpr (MODE == SELL_GS_OOP) {
                         const T* src = cc[t][r] < split ? (const T*)y : x;
                         xv[t][r] = use ? src[(size_t)cc[t][r] * ld + c] : (T)0;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
                         if (HEAD) accr[r] += vv[t][r] * (MODE == SELL_GS_HEAD ? xo[t][r] : xv[t][r]);
                         if (GS && cc[t][r] == row0 + rl[r]) diag[r] = vv[t][r];
                         else if ((JAC || CHEB) && cc[t][r] == row0 + rl[r]) { diag[r] = vv[t][r]; xi[r] = xv[t][r]; }
-                        else acc[r] += vv[t][r] * xv[t][r];
+                        else acc[r] += vv[t][r] * ((MODE == SELL_GS_HEAD && cc[t][r] >= split) ? xo[t][r] : xv[t][r]);
                     }
                 }
         }
