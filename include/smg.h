@@ -133,6 +133,17 @@ int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio
  * V-cycle pays for (ogre.obj: factor 0.6 -> 0.3 with a cap of 2).  absorption_cap = 0 is smg_mg_precompute. */
 int smg_mg_precompute_capped(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                              float absorption_cap, smg_hierarchy **out);
+/* The same, keeping the record of every collapse (the reference's decInfo / decIM outputs of SSP_decimate, src/SSP_decimate.h:10-22;
+ * host memory ~0.5 kB per collapse) when keep_log != 0: smg_query_coarse_to_fine needs it. */
+int smg_mg_precompute_logged(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
+                             float absorption_cap, int keep_log, smg_hierarchy **out);
+/* query_coarse_to_fine (src/query_coarse_to_fine.h; 08_subdiv_remesh/main.cpp:146): n points on the mesh of level lv (lv >= 1) --
+ * face[i] a face of mg[lv].F, bary[3i..3i+2] barycentric coordinates with respect to its corners -- are carried through the bijection
+ * of the successive self-parameterisation onto the mesh of level lv - 1 by undoing the collapses of that coarsening step, last to
+ * first: out_face[i] a face of mg[lv-1].F, out_bary[3i..] coordinates there (>= 0, sum 1).  The level must have been built by
+ * smg_mg_precompute_logged(keep_log = 1); SMG_ERR_INVALID otherwise.  Host only (no GPU involved). */
+int smg_query_coarse_to_fine(const smg_hierarchy *h, int lv, int n, const int *face, const double *bary, int *out_face,
+                             double *out_bary);
 /* Hierarchy of a mid-point-subdivided mesh: the n_sub finest transfer operators are the subdivision operators
  * (09_random_subdiv_remesh/main.cpp:46-140), levels below the base mesh come from smg_mg_precompute's decimator
  * (ratio, nVCoarsest applied to the base mesh; pass n_extra_levels = -1 for the float rule).  Outputs the fine

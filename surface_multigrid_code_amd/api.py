@@ -341,16 +341,29 @@ class Hierarchy:
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's free functions
 
-def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1, absorption_cap=0.0):
+def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1, absorption_cap=0.0, keep_log=False):
     """mg_precompute(V, F, ratio, nVCoarsest, dec_type, mg)  (src/mg_precompute.cpp:15-87) -> Hierarchy.
-    absorption_cap > 0: opt-in departure from the reference's collapse order (include/smg.h: smg_mg_precompute_capped)."""
+    absorption_cap > 0: opt-in departure from the reference's collapse order (include/smg.h: smg_mg_precompute_capped).
+    keep_log: keep the record of every collapse (the reference's decInfo), which query_coarse_to_fine needs."""
     L = _lib.load()
     V = np.ascontiguousarray(V, dtype=np.float64)
     F = np.ascontiguousarray(F, dtype=np.int32)
     out = C.c_void_p()
-    _chk(L.smg_mg_precompute_capped(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, absorption_cap, C.byref(out)),
-         "smg_mg_precompute")
+    _chk(L.smg_mg_precompute_logged(_dp(V), V.shape[0], _ip(F), F.shape[0], ratio, nVCoarsest, dec_type, absorption_cap, int(bool(keep_log)),
+                                    C.byref(out)), "smg_mg_precompute")
     return Hierarchy(handle=out.value)
+
+
+def query_coarse_to_fine(mg, lv, face, bary):
+    """query_coarse_to_fine (src/query_coarse_to_fine.cpp): points (face of level lv's mesh, barycentric coordinates) -> (face of level
+    lv - 1's mesh, barycentric coordinates) through the bijection of the decimation that built level lv (needs keep_log=True)."""
+    face = np.ascontiguousarray(face, dtype=np.int32)
+    bary = np.ascontiguousarray(bary, dtype=np.float64).reshape(-1, 3)
+    assert bary.shape[0] == face.shape[0]
+    of = np.zeros(face.shape[0], dtype=np.int32)
+    ob = np.zeros_like(bary)
+    _chk(mg.L.smg_query_coarse_to_fine(mg.h, int(lv), face.shape[0], _ip(face), _dp(bary), _ip(of), _dp(ob)), "smg_query_coarse_to_fine")
+    return of, ob
 
 
 def mg_precompute_block(V, F, ratio=0.25, nVCoarsest=500, dec_type=1):

@@ -2314,7 +2314,7 @@ extern "C" int smg_mesh_torus(int nu, int nv, double R, double r, double* V, int
 // ------------------------------------------------------------------------------------------------ mg_precompute
 namespace smg {
 // smg_decimate.cpp: one coarsening step (reference get_prolong(), src/get_prolong.cpp:3-57)
-int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err);
+int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err, DecimationLog* log);
 }
 
 // number of levels by the reference's float rule (src/mg_precompute.cpp:27-38)
@@ -2330,7 +2330,7 @@ static int level_count(int nV, float ratio, int nVCoarsest)
     return nLvs;
 }
 
-static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& base, int n_new, float ratio, int dec_type, int cap_tenths = 0)
+static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& base, int n_new, float ratio, int dec_type, int cap_tenths = 0, bool keep_log = false)
 {
     Mesh cur = base;
     for (int s = 0; s < n_new; s++) {
@@ -2339,7 +2339,9 @@ static int build_decimated_levels(smg_hierarchy* h, int first_lv, const Mesh& ba
         Mesh coarse;
         Csr P;
         std::string err;
-        if (decimate_level(cur, tarF, dec_type, cap_tenths, coarse, P, err) != 0) return fail(SMG_ERR_INVALID, "mg_precompute: %s", err.c_str());
+        std::shared_ptr<DecimationLog> log = keep_log ? std::make_shared<DecimationLog>() : nullptr;
+        if (decimate_level(cur, tarF, dec_type, cap_tenths, coarse, P, err, log.get()) != 0) return fail(SMG_ERR_INVALID, "mg_precompute: %s", err.c_str());
+        h->lv[lv].dec_log = log;
         h->lv[lv].V = coarse.V;
         h->lv[lv].F = coarse.F;
         set_prolong(h, lv, std::move(P));
@@ -2355,7 +2357,7 @@ extern "C" int smg_mg_precompute(const double* V, int nV, const int* F, int nF, 
 }
 
 static int smg_mg_precompute_capped_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
-                                        float absorption_cap, smg_hierarchy** out)
+                                        float absorption_cap, smg_hierarchy** out, bool keep_log = false)
 {
     if (!V || !F || !out || nV <= 0 || nF <= 0 || !(ratio > 0.f && ratio < 1.f) || !(absorption_cap >= 0.f))
         return fail(SMG_ERR_INVALID, "smg_mg_precompute: bad arguments");
@@ -2364,7 +2366,7 @@ static int smg_mg_precompute_capped_impl(const double* V, int nV, const int* F, 
     if (!h) return SMG_ERR_ALLOC;
     Mesh m = wrap_mesh(V, nV, F, nF);
     h->lv[0].V = m.V; h->lv[0].F = m.F;   // src/mg_precompute.cpp:46-47
-    int rc = build_decimated_levels(h, 1, m, nLvs - 1, ratio, dec_type, (int)std::lround(10.0 * absorption_cap));
+    int rc = build_decimated_levels(h, 1, m, nLvs - 1, ratio, dec_type, (int)std::lround(10.0 * absorption_cap), keep_log);
     if (rc) { smg_hierarchy_destroy(h); return rc; }
     *out = h;
     return SMG_OK;
@@ -2374,6 +2376,30 @@ extern "C" int smg_mg_precompute_capped(const double* V, int nV, const int* F, i
                                         float absorption_cap, smg_hierarchy** out)
 {
     return guarded("smg_mg_precompute_capped", [&]() { return smg_mg_precompute_capped_impl(V, nV, F, nF, ratio, nVCoarsest, dec_type, absorption_cap, out); });
+}
+
+extern "C" int smg_mg_precompute_logged(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
+                                        float absorption_cap, int keep_log, smg_hierarchy** out)
+{
+    return guarded("smg_mg_precompute_logged", [&]() { return smg_mg_precompute_capped_impl(V, nV, F, nF, ratio, nVCoarsest, dec_type, absorption_cap, out, keep_log != 0); });
+}
+
+extern "C" int smg_query_coarse_to_fine(const smg_hierarchy* h, int lv, int n, const int* face, const double* bary, int* out_face,
+                                        double* out_bary)
+{
+    return guarded("smg_query_coarse_to_fine", [&]() {
+        if (!h || lv < 1 || lv >= h->n_levels || n < 0 || (n > 0 && (!face || !bary || !out_face || !out_bary)))
+            return fail(SMG_ERR_INVALID, "smg_query_coarse_to_fine: bad arguments");
+        const Level& Lv = h->lv[lv];
+        if (!Lv.dec_log) return fail(SMG_ERR_INVALID, "smg_query_coarse_to_fine: level %d keeps no decimation log (smg_mg_precompute_logged)", lv);
+        const int nFc = (int)Lv.dec_log->coarse_face.size();
+        for (int i = 0; i < n; i++) {
+            if (face[i] < 0 || face[i] >= nFc) return fail(SMG_ERR_INVALID, "smg_query_coarse_to_fine: face %d out of range", face[i]);
+            for (int c = 0; c < 3; c++) if (!(bary[3 * i + c] == bary[3 * i + c])) return fail(SMG_ERR_INVALID, "smg_query_coarse_to_fine: NaN coordinate");
+        }
+        query_coarse_to_fine(*Lv.dec_log, n, face, bary, out_face, out_bary);
+        return (int)SMG_OK;
+    });
 }
 
 static int smg_mg_precompute_block_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,

@@ -31,6 +31,7 @@
 // coarse-to-fine queries of the remeshing demos.  dec_type 0 / 2 reuse the same machinery with libsmg's own cost / placement (quadric
 // error metric; end-point placement) -- the reference's versions of those two are built on libigl's quadric callbacks.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <array>
 #include <cmath>
@@ -204,6 +205,8 @@ struct QEntry {
 };
 
 struct Decimator {
+    DecimationLog* log = nullptr;            // optional: the record of every collapse (query_coarse_to_fine)
+    long refuse_reason[32] = {0};   // statistics (SMG_DEC_STATS=1): refusals by the `return` that issued them, in source order
     std::vector<V3> pos;
     std::vector<char> valive;
     std::vector<int> version;
@@ -356,22 +359,22 @@ struct Decimator {
         for (int f : vfaces[b]) for (int c = 0; c < 3; c++) if (faces[f][c] != b) nb.push_back(faces[f][c]);
         std::sort(na.begin(), na.end()); na.erase(std::unique(na.begin(), na.end()), na.end());
         std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
-        if (!std::binary_search(na.begin(), na.end(), b)) return false;          // not an edge (any more)
+        if (!std::binary_search(na.begin(), na.end(), b)) return (refuse_reason[1]++, false);          // not an edge (any more)
         // igl::edge_collapse_is_valid (SSP_collapse_edge.cpp:55-60): the end points share exactly two neighbours, and the edge is not
         // an edge of a single tetrahedron (both end points of valence 3 on the same two neighbours)
         std::set_intersection(na.begin(), na.end(), nb.begin(), nb.end(), std::back_inserter(common));
-        if ((int)common.size() != 2) return false;
-        if (na.size() == 3 && nb.size() == 3) return false;
+        if ((int)common.size() != 2) return (refuse_reason[2]++, false);
+        if (na.size() == 3 && nb.size() == 3) return (refuse_reason[3]++, false);
         const bool ba = vinf >= 0 && std::binary_search(na.begin(), na.end(), vinf);   // on the boundary <=> adjacent to infinity
         const bool bb = vinf >= 0 && std::binary_search(nb.begin(), nb.end(), vinf);
         const int kase = (ba ? 1 : 0) + (bb ? 1 : 0);
         // the faces on the edge: two in the closed mesh; a boundary edge has one real and one phantom face
         int ef[4], nef_all = 0, nef = 0;
         for (int f : vfaces[a]) if (has(faces[f], b)) { if (nef_all < 4) ef[nef_all] = f; nef_all++; if (!phantom(f)) nef++; }
-        if (nef_all != 2 || nef < 1) return false;
+        if (nef_all != 2 || nef < 1) return (refuse_reason[4]++, false);
         // both end points on the boundary: with two common neighbours the edge itself is a boundary edge (a chord between two boundary
         // vertices has three: its two opposite vertices and infinity -- the reference's `isFlap` refusal, joint_lscm.cpp:60-81)
-        if (kase == 2 && nef != 1) return false;
+        if (kase == 2 && nef != 1) return (refuse_reason[5]++, false);
         // ---- placement (dec_type 1: the mid-point, for boundary vertices too: shortest_edge_and_midpoint, SSP_midpoint.cpp:52)
         V3 m;
         if (dec_type == 1) m = 0.5 * (pos[a] + pos[b]);
@@ -392,10 +395,10 @@ struct Decimator {
                     V3 q0 = (fc[0] == v) ? m : p0, q1 = (fc[1] == v) ? m : p1, q2 = (fc[2] == v) ? m : p2;
                     V3 n1 = cross(q1 - q0, q2 - q0);
                     const double l0 = norm(n0), l1 = norm(n1);
-                    if (!(l1 > 1e-14 * (1.0 + l0))) return false;
-                    if (dot(n0, n1) < 0.2 * l0 * l1) return false;
+                    if (!(l1 > 1e-14 * (1.0 + l0))) return (refuse_reason[6]++, false);
+                    if (dot(n0, n1) < 0.2 * l0 * l1) return (refuse_reason[7]++, false);
                     const double e = std::max(norm(q1 - q0), std::max(norm(q2 - q1), norm(q0 - q2)));
-                    if (l1 < 0.02 * e * e) return false;
+                    if (l1 < 0.02 * e * e) return (refuse_reason[8]++, false);
                 }
             }
         }
@@ -423,7 +426,7 @@ struct Decimator {
         if (kase == 2) {
             for (int f : vfaces[a]) if (phantom(f) && !has(faces[f], b)) for (int c = 0; c < 3; c++) if (faces[f][c] != a && faces[f][c] != vinf) pv = faces[f][c];
             for (int f : vfaces[b]) if (phantom(f) && !has(faces[f], a)) for (int c = 0; c < 3; c++) if (faces[f][c] != b && faces[f][c] != vinf) nv = faces[f][c];
-            if (pv < 0 || nv < 0 || pv == nv || locmap[pv] < 0 || locmap[nv] < 0) return false;   // a boundary loop of three edges
+            if (pv < 0 || nv < 0 || pv == nv || locmap[pv] < 0 || locmap[nv] < 0) return (refuse_reason[9]++, false);   // a boundary loop of three edges
         }
         // builds the face lists for a given index of the merged vertex
         auto build_faces = [&](int lm) {
@@ -463,7 +466,7 @@ struct Decimator {
         const bool m_is_b = !m_is_a && (m.x == pos[b].x && m.y == pos[b].y && m.z == pos[b].z);
         const int own = m_is_a ? la : (m_is_b ? lb : -1);
         setup(kase == 1 ? (ba ? la : lb) : own);
-        if ((int)patch.pre.size() <= 2) return false;                           // SSP_collapse_edge.cpp:188-195
+        if ((int)patch.pre.size() <= 2) return (refuse_reason[10]++, false);                           // SSP_collapse_edge.cpp:188-195
         // boundary cases: 3D quality of the post-collapse triangles (joint_lscm.cpp:91-117)
         if (kase > 0) {
             for (const auto& g : patch.post) {
@@ -471,14 +474,14 @@ struct Decimator {
                 const double xs = (l0 + l1 + l2) / 2.0;
                 const double delta = std::sqrt(xs * (xs - l0) * (xs - l1) * (xs - l2));
                 const double q = 4.0 * std::sqrt(3.0) * delta / (l0 * l0 + l1 * l1 + l2 * l2);
-                if (!(q >= 0.3)) return false;
+                if (!(q >= 0.3)) return (refuse_reason[11]++, false);
             }
         }
         static thread_local std::vector<Pin> pins;
         auto base_pins = [&](int n) { pins.clear(); pins.push_back({la, 0.0}); pins.push_back({lb, 1.0}); pins.push_back({la + n, 0.0}); pins.push_back({lb + n, 0.0}); };
         if (kase < 2) {
             base_pins(patch.n);                                                 // uv(vi) = (0,0), uv(vj) = (1,0)
-            if (!solve_joint_flattening(patch, pins)) return false;
+            if (!solve_joint_flattening(patch, pins)) return (refuse_reason[12]++, false);
         } else {
             // case 2 (joint_lscm.cpp:750-829): three candidates, the smallest quasi-conformal error wins (ties: snap vi, snap vj, free)
             struct Cand { bool ok = false; double err = 0; std::vector<double> U, Vv; int lm = -1; };
@@ -505,9 +508,24 @@ struct Decimator {
             int best = 2;
             if (cand[0].err <= cand[1].err && cand[0].err <= cand[2].err) best = 0;
             else if (cand[1].err <= cand[0].err && cand[1].err <= cand[2].err) best = 1;
-            if (!cand[best].ok) return false;
+            if (!cand[best].ok) return (refuse_reason[13]++, false);
             setup(best == 0 ? la : (best == 1 ? lb : own));
             patch.U = cand[best].U; patch.Vv = cand[best].Vv;
+        }
+        if (log) {   // decInfo.push_back(data); decIM[FIdx_onering_pre(ii)].push_back(...)  (SSP_collapse_edge.cpp:452-459)
+            DecimationLog::Rec r;
+            r.first_face = (int)log->face_id.size(); r.n_faces = (int)pre_gid.size();
+            r.first_uv = (int)log->U.size(); r.n_loc = patch.n;
+            r.la = la; r.lb = lb; r.lm = patch.lm;
+            const int k = (int)log->rec.size();
+            for (size_t t = 0; t < pre_gid.size(); t++) {
+                log->face_id.push_back(pre_gid[t]);
+                log->tri.push_back(patch.pre[t]);
+                log->face_recs[pre_gid[t]].push_back(k);
+            }
+            log->U.insert(log->U.end(), patch.U.begin(), patch.U.begin() + patch.n);
+            log->V.insert(log->V.end(), patch.Vv.begin(), patch.Vv.begin() + patch.n);
+            log->rec.push_back(r);
         }
         // ---- gather the fine points of the pre-collapse 1-ring with their positions in the flattening
         static thread_local std::vector<int> pts;
@@ -585,13 +603,18 @@ struct Decimator {
 // most (cap / 10) x (#F / tarF) input vertices; edges that would exceed that wait, and the bound doubles only when nothing else can be
 // collapsed.  (Shortest-edge-first decimation coarsens densely sampled parts of a mesh far beyond the requested ratio before it
 // touches the rest; on ogre.obj the V-cycle factor goes from 0.6 to 0.3 with a cap of 20.)
-int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err)
+int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_tenths, Mesh& coarse, Csr& P, std::string& err, DecimationLog* log)
 {
     const int nV = fine.nV(), nF = fine.nF();
     if (dec_type < 0 || dec_type > 2) { err = "dec_type must be 0 (qslim), 1 (mid-point) or 2 (vertex removal)"; return -1; }
     if (nV < 4 || nF < 4) { err = "mesh too small to decimate"; return -1; }
     Decimator D;
     D.dec_type = dec_type;
+    if (log) {
+        *log = DecimationLog();
+        log->face_recs.assign((size_t)fine.nF(), {});
+        D.log = log;
+    }
     D.nF_real = nF;
     D.pos.resize(nV);
     for (int i = 0; i < nV; i++) D.pos[i] = {fine.V[3 * i], fine.V[3 * i + 1], fine.V[3 * i + 2]};
@@ -683,6 +706,11 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
         if (D.collapse(e.a, e.b)) { if (capped) weight[e.a] += weight[e.b]; }   // b merges into a
         else D.refused.insert(Decimator::edge_key(e.a, e.b));                     // cost infinity until re-costed (SSP_collapse_edge.cpp:522-531)
     }
+    if (std::getenv("SMG_DEC_STATS")) {
+        std::fprintf(stderr, "[smg decimate] faces %d -> %d; refusals by site:", nF, D.n_alive_faces);
+        for (int i = 0; i < 32; i++) if (D.refuse_reason[i]) std::fprintf(stderr, " #%d:%ld", i, D.refuse_reason[i]);
+        std::fprintf(stderr, "\n");
+    }
     // compact: drop the vertex at infinity and the phantom faces (SSP_midpoint.cpp:65-70)
     std::vector<int> vmap(nVall, -1);
     int nVc = 0;
@@ -698,6 +726,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
     for (int v = 0; v < nV; v++) if (vmap[v] >= 0) { coarse.V[3 * vmap[v]] = D.pos[v].x; coarse.V[3 * vmap[v] + 1] = D.pos[v].y; coarse.V[3 * vmap[v] + 2] = D.pos[v].z; }
     coarse.F.clear();
     for (int f = 0; f < nF; f++) if (D.falive[f]) for (int c = 0; c < 3; c++) coarse.F.push_back(vmap[D.faces[f][c]]);
+    if (log) for (int f = 0; f < nF; f++) if (D.falive[f]) log->coarse_face.push_back(f);
     // Every coarse vertex must be interpolated from by somebody: a column of P without a positive entry is a zero row and column
     // of the Galerkin operator, and the smoother divides by its diagonal.  (Possible in principle with mid-point placement: all
     // points of the incident faces may sit on the opposite edges.)  Repair, not in the reference: the fine point of an incident face
@@ -753,6 +782,62 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
     ptr[nV] = 3 * nV;
     P = csr_from_arrays(nV, nVc, ptr.data(), col.data(), val.data());
     return 0;
+}
+
+// The reference's query_coarse_to_fine (src/query_coarse_to_fine.cpp:41-140): for the face the point lives in, the latest collapse not
+// yet undone whose one-ring held that face; the point's position in that collapse's flattening from the POST one-ring (the face's
+// corners, end points standing at the merged vertex); its barycentric coordinates in every face of the PRE one-ring
+// (compute_barycentric.cpp: the dot-product form); the face where the smallest coordinate is largest wins (the first one on ties),
+// coordinates clamped to >= 0 and renormalised; on to that face's earlier collapses.
+void query_coarse_to_fine(const DecimationLog& L, int n, const int* face, const double* bary, int* out_face, double* out_bary)
+{
+    for (int q = 0; q < n; q++) {
+        int f = L.coarse_face[(size_t)face[q]];
+        double w[3] = {bary[3 * q], bary[3 * q + 1], bary[3 * q + 2]};
+        int upper = (int)L.rec.size();
+        while (true) {
+            const std::vector<int>& lst = L.face_recs[(size_t)f];
+            auto it = std::lower_bound(lst.begin(), lst.end(), upper);
+            if (it == lst.begin()) break;
+            const int k = *(--it);
+            upper = k;
+            const DecimationLog::Rec& R = L.rec[(size_t)k];
+            const int* fid = &L.face_id[(size_t)R.first_face];
+            const std::array<int, 3>* tri = &L.tri[(size_t)R.first_face];
+            const double* U = &L.U[(size_t)R.first_uv];
+            const double* V = &L.V[(size_t)R.first_uv];
+            int t0 = -1;
+            for (int t = 0; t < R.n_faces; t++) if (fid[t] == f) { t0 = t; break; }
+            if (t0 < 0) break;   // (cannot happen: the record lists the face)
+            double pu = 0.0, pv = 0.0;
+            for (int c = 0; c < 3; c++) {
+                int l = tri[t0][c];
+                if (l == R.la || l == R.lb) l = R.lm;   // UV_post: both end points are the merged vertex
+                pu += w[c] * U[l]; pv += w[c] * V[l];
+            }
+            double best = 1.0, bw[3] = {w[0], w[1], w[2]};
+            int bt = -1;
+            for (int t = 0; t < R.n_faces; t++) {
+                const double ax = U[tri[t][0]], ay = V[tri[t][0]];
+                const double v0x = U[tri[t][1]] - ax, v0y = V[tri[t][1]] - ay, v1x = U[tri[t][2]] - ax, v1y = V[tri[t][2]] - ay;
+                const double v2x = -ax + pu, v2y = -ay + pv;
+                const double d00 = v0x * v0x + v0y * v0y, d01 = v0x * v1x + v0y * v1y, d11 = v1x * v1x + v1y * v1y;
+                const double d20 = v2x * v0x + v2y * v0y, d21 = v2x * v1x + v2y * v1y;
+                const double denom = d00 * d11 - d01 * d01;
+                const double bv = (d11 * d20 - d01 * d21) / denom, bwt = (d00 * d21 - d01 * d20) / denom;
+                const double bu = 1.0 - (bv + bwt);
+                const double dist = -std::min(bu, std::min(bv, bwt));
+                if (dist < best) { best = dist; bt = t; bw[0] = bu; bw[1] = bv; bw[2] = bwt; }
+            }
+            if (bt < 0) break;   // every face is further than a whole triangle away (the reference leaves this case undefined)
+            double sw = 0.0;
+            for (int c = 0; c < 3; c++) { bw[c] = std::max(0.0, bw[c]); sw += bw[c]; }
+            for (int c = 0; c < 3; c++) w[c] = bw[c] / sw;
+            f = fid[bt];
+        }
+        out_face[q] = f;
+        out_bary[3 * q] = w[0]; out_bary[3 * q + 1] = w[1]; out_bary[3 * q + 2] = w[2];
+    }
 }
 
 }  // namespace smg

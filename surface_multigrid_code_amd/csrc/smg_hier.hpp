@@ -1,6 +1,7 @@
 // smg_hier.hpp -- the hierarchy handle behind the C ABI (include/smg.h): host mirror of the reference's
 // std::vector<mg_data> + min_quad_with_fixed_mg_data + coarse solver, plus their device images.
 #pragma once
+#include <memory>
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -9,6 +10,7 @@
 #include <vector>
 
 #include "smg_device.hpp"
+#include "smg_mesh.hpp"
 #include "smg_order.hpp"
 #include "smg_sparse.hpp"
 
@@ -68,6 +70,7 @@ struct Level {
     std::vector<double> V;  // mg_data::V (optional)
     std::vector<int> F;     // mg_data::F (optional)
     Csr P_full;             // mg_data::P_full
+    std::shared_ptr<DecimationLog> dec_log;   // collapses of the step that built this level (smg_mg_precompute_logged), else null
     Csr A;                  // mg_data::A   (unknown-only system matrix of the level)
     std::vector<double> A_diag;  // mg_data::A_diag
     Csr P, PT;              // mg_data::P / PT (unknown-only, maps level lv -> lv-1 / back)

@@ -4,6 +4,7 @@
 // 09_random_subdiv_remesh/main.cpp:46-140 used to generate the ~1M / ~4M-vertex benchmark meshes.
 // libigl is not part of the reference checkout (empty submodule): semantics follow SURVEY.md Appendix A.
 #pragma once
+#include <array>
 #include <string>
 #include <vector>
 
@@ -53,5 +54,22 @@ struct AssemblyPlan {
     std::vector<int> diag_of;     // per entry: the vertex whose diagonal it is, or -1
 };
 AssemblyPlan make_assembly_plan(const std::vector<int>& F, int nV);
+
+// What one coarsening step keeps about its collapses when asked to (the reference's decInfo / decIM, src/single_collapse_data.h and
+// src/SSP_collapse_edge.cpp:452-459): per successful collapse the faces of the pre-collapse one-ring with their flattened positions.
+// The post-collapse one-ring is the same flattening with the two end points standing at the merged vertex (local index lm) and the two
+// faces on the edge gone.  Consumed by query_coarse_to_fine (the reference's src/query_coarse_to_fine.cpp).
+struct DecimationLog {
+    struct Rec { int first_face, n_faces, first_uv, n_loc, la, lb, lm; };
+    std::vector<Rec> rec;
+    std::vector<int> face_id;                   // concatenated over the records: input-mesh ids of the pre one-ring faces ...
+    std::vector<std::array<int, 3>> tri;        // ... and their local vertex triples, corner by corner in the order of the face
+    std::vector<double> U, V;                   // concatenated: flattened position of every local vertex
+    std::vector<std::vector<int>> face_recs;    // per input face: the records whose pre one-ring held it, ascending (decIM)
+    std::vector<int> coarse_face;               // face of the coarse mesh -> input face it descends from (same corner order)
+};
+// Maps n points of the coarse mesh -- (coarse face, barycentric coordinates) -- onto the mesh the step started from by undoing the
+// collapses last to first.  out_face / out_bary: face of the fine mesh and coordinates with respect to its corners.
+void query_coarse_to_fine(const DecimationLog& log, int n, const int* face, const double* bary, int* out_face, double* out_bary);
 
 }  // namespace smg
