@@ -123,7 +123,8 @@ int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double 
  * src/query_fine_to_coarse.cpp): boundary closed by a vertex at infinity, greedy shortest-edge collapse to the mid-point with libigl's
  * refuse / re-cost queue discipline, joint conformal flattening of the 1-rings before / after every collapse in the reference's three
  * cases (interior, one boundary end point, boundary edge with its snap candidates), the reference's validity and quality thresholds;
- * same P structure (3 stored entries per row, rows sum to 1).  Written from the formulation on own data structures: ties between
+ * same P structure (3 stored entries per row, rows sum to 1).  Written from the formulation on own data structures; reproduces the
+ * reference's checked-in 08_subdiv_remesh outputs point for point (tests/golden/bunny_remesh_500.npz).  Ties between exactly
  * equal-cost edges may be broken differently than libigl's edge numbering does (csrc/smg_decimate.cpp). */
 int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                       smg_hierarchy **out);
