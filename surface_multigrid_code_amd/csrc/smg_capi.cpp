@@ -158,6 +158,8 @@ hipError_t SellBuf::upload(const Sell& S)
     view.order = S.region_order.empty() ? nullptr : order.p;
     view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.slice_w = slice_w.p; view.col = col.p; view.val = val.p;
     view.stride = S.stride; view.w_lo = S.w_lo;
+    view.w_max = 0;
+    for (int w : S.slice_w) view.w_max = std::max(view.w_max, w);
     if (env_int("SMG_DEBUG_SELL", 0)) {
         int hist[33] = {0};
         for (int w : S.slice_w) hist[std::min(w, 32)]++;

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
 // shared by the KW lanes of a group (one request), and all k columns go through ONE launch instead of k/4.
 // A wave owns 8*G consecutive rows of a slice (KW/8 waves per slice).  Per (row, column) the sum is still sequential in
 // ascending column order: bit-identical to the narrow kernel and to the oracle.
-template <int MODE, int KW, typename T>
+// R rows per lane, U panel columns requested per batch.  (2, 8) streams; (1, 8 / 16 / 32) is for launches of so few waves that the
+// chip is mostly idle and a row's chain of dependent batches IS the launch's duration (the Galerkin levels of decimated hierarchies:
+// 15 - 30 entries per row): one row per lane, the whole row requested at once.
+template <int MODE, int KW, typename T, int R = 2, int U = 8>
 __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                                    int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                                    const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld,
@@ -276,7 +279,6 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
     constexpr bool GS = sell_is_gs(MODE), OOP = sell_is_oop(MODE), JAC = sell_is_jacobi(MODE), CHEB = sell_is_cheby(MODE), HEAD = sell_is_head(MODE);
     const int stop = load_flag(done);
     constexpr int G = 64 / KW;        // rows in flight per wave-instruction
-    constexpr int R = 2;              // rows per lane
     constexpr int RW = R * G;         // rows per wave
     constexpr int SUB = 64 / RW;      // waves per slice
     const int lane = threadIdx.x & 63;
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
         }
         const int* cp = A.col + (size_t)off0 * 64;
         const T* vp = a_val + (size_t)off0 * 64;
-        constexpr int U = 8;
         for (int j0 = 0; j0 < w; j0 += U) {
             int cc[U][R];
             T vv[U][R], xv[U][R];
@@ -490,11 +491,33 @@ template <typename T> static CoarseInit<T> coarse_init(T* zero_rows, int c0, con
 template <> const double* host_vals<double>(const SellDev& A) { return A.val; }
 template <> const float* host_vals<float>(const SellDev& A) { return A.valf; }
 
+// one-row-per-lane variants (see k_sell_wide) up to this many waves
+static long wide_latency_max()
+{
+    static const long v = getenv("SMG_WIDE_LAT_MAX") ? atol(getenv("SMG_WIDE_LAT_MAX")) : 16384;
+    return v;
+}
+static bool wide_latency_variant(int n_slices, int kw) { return (long)n_slices * kw <= wide_latency_max(); }
+
 template <int MODE, int KW, typename T>
 static void launch_wide_one(const SellDev& A, int s_begin, int s_end, int use_order, const T* x, const T* b, T* y,
                             int k, const int* done, double* partials, CoarseInit<T> zero_rows, hipStream_t st, int* nb_out)
 {
-    const int waves = (s_end - s_begin) * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
+    const int ns = s_end - s_begin;
+    // (64 columns per wave: a wave spans one or two whole rows anyway, and the longer batches only cost there -- ogre.obj, k = 64:
+    // 239 -> 264 us per Chebyshev cycle with one row per lane, 292 with two rows and batches of 32)
+    if constexpr (KW < 64) if (wide_latency_variant(ns, KW)) {
+        const int nb = (ns * KW + 3) / 4;   // 64 / G = KW waves per slice with one row per lane
+#define SMG_WIDE_LAT(UU) hipLaunchKernelGGL((k_sell_wide<MODE, KW, T, 1, UU>), dim3(nb), dim3(256), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, \
+                                             s_begin, s_end, nb, use_order, x, A.slice_row, A.slice_w, b, y, k, done, partials, zero_rows)
+        if (A.w_max <= 8) SMG_WIDE_LAT(8);
+        else if (A.w_max <= 16) SMG_WIDE_LAT(16);
+        else SMG_WIDE_LAT(32);
+#undef SMG_WIDE_LAT
+        *nb_out = nb;
+        return;
+    }
+    const int waves = ns * (KW / 2);  // 64 / (R * G) waves per slice, R = 2
     const int nb = (waves + 3) / 4;
     hipLaunchKernelGGL((k_sell_wide<MODE, KW, T>), dim3(nb), dim3(256), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, s_begin, s_end, nb, use_order, x,
                        A.slice_row, A.slice_w, b, y, k, done, partials, zero_rows);
@@ -505,7 +528,7 @@ int sell_wide_blocks(int n_slices, int k)
 {
     // upper bound of the per-block partial sums the wide path writes for k columns
     int tot = 0, c0 = 0;
-    while (k - c0 >= 8) { int kw = 64; while (kw > k - c0) kw >>= 1; tot += (n_slices * (kw / 2) + 3) / 4; c0 += kw; }
+    while (k - c0 >= 8) { int kw = 64; while (kw > k - c0) kw >>= 1; tot += (n_slices * kw + 3) / 4; c0 += kw; }   // (one row per lane: the larger of the two variants' counts)
     return tot;
 }
 

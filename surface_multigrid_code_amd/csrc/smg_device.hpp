@@ -34,6 +34,7 @@ struct SellDev {
     const int* slice_w = nullptr;    // n_slices: panel columns used by the slice
     int stride = 0;                  // > 0: fixed panel pitch, addressing needs no table
     int w_lo = 0;                    // columns requested before the slice's width is known, <= stride (0 when stride == 0)
+    int w_max = 0;                   // widest slice (panel columns)
     const int* order = nullptr;      // optional launch order of the slices (region-major), whole-matrix kernels only
     const int* col = nullptr;
     const double* val = nullptr;
