@@ -606,7 +606,7 @@ def main():
     # ---- BASELINE config C4: k = 64 columns sharded over the ranks (strong scaling; N = 1 is the curve's first point)
     if not args.no_c4:
         try:
-            c4 = c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, sm_kw)
+            c4 = c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, sm_kw, steps=max(args.steps, 1), warmup=max(args.warmup, 0))
         except Exception as e:   # never lose the bench line over the secondary measurement
             c4 = {"error": repr(e)}
             if world > 1:

@@ -137,3 +137,25 @@ def test_handle_lives_on_the_device_that_was_current_at_precompute(smg_mod):
     free0 = torch.cuda.mem_get_info(0)[0]
     del mg1
     assert torch.cuda.mem_get_info(0)[0] <= free0 + (64 << 20)   # nothing of mg1 had been living on device 0
+
+
+def test_bench_runs_its_multi_rank_path_with_two_ranks(tmp_path):
+    """bench.py --gpus 2 launched the way the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on GPU 0
+    over gloo (SMG_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): the split-phase iteration with the all-reduce between
+    its halves, the weak-scaling `value` (one C3 column per rank) and the C4 leg (64 columns split by column_range) -- every rank records
+    the same residual history and the job converges in the cycles the unsharded solve needs."""
+    import json
+    import subprocess
+    env = dict(os.environ, SMG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-c5", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["allreduce"] == "torch.distributed"
+    c4 = d["c4_k64_sharded"]
+    assert c4["scaling"] == "strong" and c4["solve"]["converged"] and c4["solve"]["same_history_on_all_ranks"]
+    assert c4["solve"]["cycles"] == 16 and c4["solve"]["final_residual"] < 5e-7
