@@ -145,6 +145,11 @@ int smg_mg_precompute_logged(const double *V, int nV, const int *F, int nF, floa
  * smg_mg_precompute_logged(keep_log = 1); SMG_ERR_INVALID otherwise.  Host only (no GPU involved). */
 int smg_query_coarse_to_fine(const smg_hierarchy *h, int lv, int n, const int *face, const double *bary, int *out_face,
                              double *out_bary);
+/* query_fine_to_coarse (src/query_fine_to_coarse.h; what get_prolong does for the vertices, src/get_prolong.cpp:23-57): the other
+ * direction -- points of level lv - 1's mesh onto level lv's mesh, collapses first to last.  A vertex of the fine mesh (one-hot
+ * coordinates in any of its faces) arrives where its row of mg[lv].P_full says. */
+int smg_query_fine_to_coarse(const smg_hierarchy *h, int lv, int n, const int *face, const double *bary, int *out_face,
+                             double *out_bary);
 /* Hierarchy of a mid-point-subdivided mesh: the n_sub finest transfer operators are the subdivision operators
  * (09_random_subdiv_remesh/main.cpp:46-140), levels below the base mesh come from smg_mg_precompute's decimator
  * (ratio, nVCoarsest applied to the base mesh; pass n_extra_levels = -1 for the float rule).  Outputs the fine

@@ -48,6 +48,7 @@ def load():
         "smg_mg_precompute_capped": (i, [dp, i, ip, i, f, i, i, f, C.POINTER(vp)]),
         "smg_mg_precompute_logged": (i, [dp, i, ip, i, f, i, i, f, i, C.POINTER(vp)]),
         "smg_query_coarse_to_fine": (i, [vp, i, i, ip, dp, ip, dp]),
+        "smg_query_fine_to_coarse": (i, [vp, i, i, ip, dp, ip, dp]),
         "smg_mg_precompute_block": (i, [dp, i, ip, i, f, i, i, C.POINTER(vp)]),
         "smg_hierarchy_save": (i, [vp, C.c_char_p]),
         "smg_hierarchy_load": (i, [C.c_char_p, C.POINTER(vp)]),

@@ -354,6 +354,18 @@ def mg_precompute(V, F, ratio=0.25, nVCoarsest=500, dec_type=1, absorption_cap=0
     return Hierarchy(handle=out.value)
 
 
+def query_fine_to_coarse(mg, lv, face, bary):
+    """query_fine_to_coarse (src/query_fine_to_coarse.cpp): points (face of level lv - 1's mesh, barycentric coordinates) -> (face of level
+    lv's mesh, barycentric coordinates); the inverse of query_coarse_to_fine (needs keep_log=True)."""
+    face = np.ascontiguousarray(face, dtype=np.int32)
+    bary = np.ascontiguousarray(bary, dtype=np.float64).reshape(-1, 3)
+    assert bary.shape[0] == face.shape[0]
+    of = np.zeros(face.shape[0], dtype=np.int32)
+    ob = np.zeros_like(bary)
+    _chk(mg.L.smg_query_fine_to_coarse(mg.h, int(lv), face.shape[0], _ip(face), _dp(bary), _ip(of), _dp(ob)), "smg_query_fine_to_coarse")
+    return of, ob
+
+
 def query_coarse_to_fine(mg, lv, face, bary):
     """query_coarse_to_fine (src/query_coarse_to_fine.cpp): points (face of level lv's mesh, barycentric coordinates) -> (face of level
     lv - 1's mesh, barycentric coordinates) through the bijection of the decimation that built level lv (needs keep_log=True)."""

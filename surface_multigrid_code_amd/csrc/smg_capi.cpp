@@ -2404,6 +2404,24 @@ extern "C" int smg_query_coarse_to_fine(const smg_hierarchy* h, int lv, int n, c
     });
 }
 
+extern "C" int smg_query_fine_to_coarse(const smg_hierarchy* h, int lv, int n, const int* face, const double* bary, int* out_face,
+                                        double* out_bary)
+{
+    return guarded("smg_query_fine_to_coarse", [&]() {
+        if (!h || lv < 1 || lv >= h->n_levels || n < 0 || (n > 0 && (!face || !bary || !out_face || !out_bary)))
+            return fail(SMG_ERR_INVALID, "smg_query_fine_to_coarse: bad arguments");
+        const Level& Lv = h->lv[lv];
+        if (!Lv.dec_log) return fail(SMG_ERR_INVALID, "smg_query_fine_to_coarse: level %d keeps no decimation log (smg_mg_precompute_logged)", lv);
+        const int nFf = (int)Lv.dec_log->face_recs.size();
+        for (int i = 0; i < n; i++) {
+            if (face[i] < 0 || face[i] >= nFf) return fail(SMG_ERR_INVALID, "smg_query_fine_to_coarse: face %d out of range", face[i]);
+            for (int c = 0; c < 3; c++) if (!(bary[3 * i + c] == bary[3 * i + c])) return fail(SMG_ERR_INVALID, "smg_query_fine_to_coarse: NaN coordinate");
+        }
+        query_fine_to_coarse(*Lv.dec_log, n, face, bary, out_face, out_bary);
+        return (int)SMG_OK;
+    });
+}
+
 static int smg_mg_precompute_block_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
                                        smg_hierarchy** out)
 {

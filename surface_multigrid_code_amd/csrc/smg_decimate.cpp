@@ -840,4 +840,60 @@ void query_coarse_to_fine(const DecimationLog& L, int n, const int* face, const 
     }
 }
 
+// The reference's query_fine_to_coarse (src/query_fine_to_coarse.cpp:27-120), the other direction: collapses first to last; the point's
+// position from the PRE one-ring, located in the POST one-ring (the pre faces without the two on the edge, end points standing at the
+// merged vertex) by the same rule.  out_face: face of the coarse mesh.
+void query_fine_to_coarse(const DecimationLog& L, int n, const int* face, const double* bary, int* out_face, double* out_bary)
+{
+    std::vector<int> coarse_of(L.face_recs.size(), -1);
+    for (size_t c = 0; c < L.coarse_face.size(); c++) coarse_of[(size_t)L.coarse_face[c]] = (int)c;
+    for (int q = 0; q < n; q++) {
+        int f = face[q];
+        double w[3] = {bary[3 * q], bary[3 * q + 1], bary[3 * q + 2]};
+        int lower = -1;
+        while (true) {
+            const std::vector<int>& lst = L.face_recs[(size_t)f];
+            auto it = std::upper_bound(lst.begin(), lst.end(), lower);
+            if (it == lst.end()) break;
+            const int k = *it;
+            lower = k;
+            const DecimationLog::Rec& R = L.rec[(size_t)k];
+            const int* fid = &L.face_id[(size_t)R.first_face];
+            const std::array<int, 3>* tri = &L.tri[(size_t)R.first_face];
+            const double* U = &L.U[(size_t)R.first_uv];
+            const double* V = &L.V[(size_t)R.first_uv];
+            int t0 = -1;
+            for (int t = 0; t < R.n_faces; t++) if (fid[t] == f) { t0 = t; break; }
+            if (t0 < 0) break;
+            double pu = 0.0, pv = 0.0;
+            for (int c = 0; c < 3; c++) { pu += w[c] * U[tri[t0][c]]; pv += w[c] * V[tri[t0][c]]; }
+            double best = 1.0, bw[3] = {w[0], w[1], w[2]};
+            int bt = -1;
+            for (int t = 0; t < R.n_faces; t++) {
+                int g[3];
+                int ends = 0;
+                for (int c = 0; c < 3; c++) { g[c] = tri[t][c]; if (g[c] == R.la || g[c] == R.lb) { g[c] = R.lm; ends++; } }
+                if (ends == 2) continue;   // one of the two faces on the edge: gone after the collapse
+                const double ax = U[g[0]], ay = V[g[0]];
+                const double v0x = U[g[1]] - ax, v0y = V[g[1]] - ay, v1x = U[g[2]] - ax, v1y = V[g[2]] - ay;
+                const double v2x = -ax + pu, v2y = -ay + pv;
+                const double d00 = v0x * v0x + v0y * v0y, d01 = v0x * v1x + v0y * v1y, d11 = v1x * v1x + v1y * v1y;
+                const double d20 = v2x * v0x + v2y * v0y, d21 = v2x * v1x + v2y * v1y;
+                const double denom = d00 * d11 - d01 * d01;
+                const double bv = (d11 * d20 - d01 * d21) / denom, bwt = (d00 * d21 - d01 * d20) / denom;
+                const double bu = 1.0 - (bv + bwt);
+                const double dist = -std::min(bu, std::min(bv, bwt));
+                if (dist < best) { best = dist; bt = t; bw[0] = bu; bw[1] = bv; bw[2] = bwt; }
+            }
+            if (bt < 0) break;
+            double sw = 0.0;
+            for (int c = 0; c < 3; c++) { bw[c] = std::max(0.0, bw[c]); sw += bw[c]; }
+            for (int c = 0; c < 3; c++) w[c] = bw[c] / sw;
+            f = fid[bt];
+        }
+        out_face[q] = coarse_of[(size_t)f];
+        out_bary[3 * q] = w[0]; out_bary[3 * q + 1] = w[1]; out_bary[3 * q + 2] = w[2];
+    }
+}
+
 }  // namespace smg

@@ -71,5 +71,8 @@ struct DecimationLog {
 // Maps n points of the coarse mesh -- (coarse face, barycentric coordinates) -- onto the mesh the step started from by undoing the
 // collapses last to first.  out_face / out_bary: face of the fine mesh and coordinates with respect to its corners.
 void query_coarse_to_fine(const DecimationLog& log, int n, const int* face, const double* bary, int* out_face, double* out_bary);
+// The other direction (the reference's src/query_fine_to_coarse.cpp): points of the fine mesh onto the coarse mesh; out_face < 0 if the
+// walk ends in a face that did not survive (cannot happen for a consistent log).
+void query_fine_to_coarse(const DecimationLog& log, int n, const int* face, const double* bary, int* out_face, double* out_bary);
 
 }  // namespace smg

@@ -365,6 +365,36 @@ def test_kat_subdiv_remesh_outputs_of_the_reference(smg_mod):
     assert np.linalg.norm(back - V, axis=1).max() <= 1e-12 * diag
 
 
+def test_query_fine_to_coarse_is_the_prolongation_and_the_inverse_of_the_walk_back(smg_mod):
+    """smg_query_fine_to_coarse (the reference's query_fine_to_coarse, what get_prolong runs for the vertices, src/get_prolong.cpp:23-57):
+    a fine vertex given as a one-hot point of one of its faces arrives where its row of P_full says; arbitrary points of the fine mesh
+    return to themselves through query_coarse_to_fine (the map is a bijection: 2e-14 measured on a bounding box of 80)."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    diag = float(np.linalg.norm(V.max(0) - V.min(0)))
+    mg = smg.mg_precompute(V, F, float(np.float32(500 / 18555)), 200, 1, keep_log=True)
+    Vc, Fc = _level_mesh(smg, mg, 1)
+    face = np.full(V.shape[0], -1, np.int32); bary = np.zeros((V.shape[0], 3))
+    for f in range(F.shape[0] - 1, -1, -1):
+        for c in range(3):
+            face[F[f, c]] = f; bary[F[f, c]] = 0.0; bary[F[f, c], c] = 1.0
+    of, ob = smg.query_fine_to_coarse(mg, 1, face, bary)
+    assert of.min() >= 0 and of.max() < Fc.shape[0] and ob.min() >= 0.0
+    Q = sp.csr_matrix((ob.ravel(), (np.repeat(np.arange(V.shape[0]), 3), Fc[of].ravel())), shape=(V.shape[0], Vc.shape[0]))
+    Q.sum_duplicates()
+    assert abs(mg.matrix(1, "P_full").tocsr() - Q).max() <= 1e-13
+    rng = np.random.default_rng(1)
+    fq = rng.integers(0, F.shape[0], 2000).astype(np.int32); bq = rng.dirichlet(np.ones(3), 2000)
+    cf, cb = smg.query_fine_to_coarse(mg, 1, fq, bq)
+    ff, fb = smg.query_coarse_to_fine(mg, 1, cf, cb)
+    p0 = (bq[:, :, None] * V[F[fq]]).sum(1); p1 = (fb[:, :, None] * V[F[ff]]).sum(1)
+    assert np.linalg.norm(p0 - p1, axis=1).max() <= 1e-11 * diag
+    with pytest.raises(smg.SmgError):
+        smg.query_fine_to_coarse(mg, 1, np.array([F.shape[0]], np.int32), np.array([[1.0, 0.0, 0.0]]))
+    with pytest.raises(smg.SmgError):
+        smg.query_fine_to_coarse(smg.mg_precompute(V, F, 0.25, 500, 1), 1, np.zeros(1, np.int32), np.array([[1.0, 0.0, 0.0]]))
+
+
 def test_query_coarse_to_fine_contract(smg_mod):
     """smg_query_coarse_to_fine: needs the log (SMG_ERR_INVALID without), checks its arguments, works level by level on a deeper hierarchy
     (every point lands on the finer level's surface with valid coordinates; coarse vertices of level 2 carried to level 0 stay close to
