@@ -1451,7 +1451,7 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
 {
     Level& L0 = h->lv[0];
     int nb = 0;
-    if (head_fusable(h)) {
+    if (h->head_fuse) {
         ProfGuard pg(h, "MG: relaxation");
         const int kind = level_kind(h, 0);
         const SellDev& G = L0.dA.view;
@@ -1501,7 +1501,7 @@ static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
             if (rc) return rc;
             HIPCHK(launch_add_correction(L0.u.p, L0.u32.p, cnt, h->d_ctrl.p, h->stream));
         } else {
-            int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p, head_fusable(h) ? FIRST_SWEEP : FIRST_NONE);
+            int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p, h->head_fuse ? FIRST_SWEEP : FIRST_NONE);
             if (rc) return rc;
         }
     }
@@ -1542,7 +1542,7 @@ static int capture_split_graphs(smg_hierarchy* h, double* buf)
 static int ensure_graphs(smg_hierarchy* h)
 {
     if (h->g_iter && h->g_k == h->k && h->g_pre == h->pre && h->g_post == h->post && h->g_prec == h->precision &&
-        h->g_smoother == h->smoother && h->g_omega == h->omega && h->g_jmax == h->jacobi_max_rows && h->g_frac == h->cheby_fraction) return SMG_OK;
+        h->g_smoother == h->smoother && h->g_omega == h->omega && h->g_jmax == h->jacobi_max_rows && h->g_frac == h->cheby_fraction && h->g_head == h->head_fuse) return SMG_OK;
     drop_graphs(h);
     const int k = h->k;
     int rc = capture_graph(h, &h->g_iter, [&]() {
@@ -1554,7 +1554,7 @@ static int ensure_graphs(smg_hierarchy* h)
     rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
     if (rc) return rc;
     h->g_k = k; h->g_pre = h->pre; h->g_post = h->post; h->g_prec = h->precision;
-    h->g_smoother = h->smoother; h->g_omega = h->omega; h->g_jmax = h->jacobi_max_rows; h->g_frac = h->cheby_fraction;
+    h->g_smoother = h->smoother; h->g_omega = h->omega; h->g_jmax = h->jacobi_max_rows; h->g_frac = h->cheby_fraction; h->g_head = h->head_fuse;
     return SMG_OK;
 }
 
@@ -1654,6 +1654,7 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     if (memspace == SMG_HOST) HIPCHK(hipStreamSynchronize(h->stream));  // the caller's host blocks may change after this call
+    h->head_fuse = head_fusable(h);   // latched: both halves of every iteration of this solve follow it
     h->iters_enqueued = 0;
     h->in_solve = true;
     return SMG_OK;

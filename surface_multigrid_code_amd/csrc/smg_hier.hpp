@@ -173,6 +173,7 @@ struct smg_hierarchy {
     int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
     int g_smoother = 0, g_jmax = 0;   // the smoother selection the cached graphs were captured with
     double g_omega = 0.0, g_frac = 0.0;
+    bool head_fuse = false, g_head = false;   // this solve takes the outer residual out of the first sweep (latched at smg_solve_begin) / what the graphs were captured with
     // ---- profc mirror ----
     bool prof_on = false;
     std::vector<smg::ProfScope> scopes;
