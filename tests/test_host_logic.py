@@ -329,6 +329,7 @@ def test_kat_subdiv_remesh_outputs_of_the_reference(smg_mod):
     mg = smg.mg_precompute(V, F, ratio, 200, 1, keep_log=True)
     Vc, Fc = _level_mesh(smg, mg, 1)
     assert Vc.shape == (261, 3) and Fc.shape == (499, 3)
+    assert np.array_equal(Fc, G["s0_F"])      # the reference's coarse mesh face for face, corner for corner (and vertex for vertex, below)
     for k, den in ((0, 1), (1, 2), (2, 4)):
         faces, bar = [], []
         for f in range(Fc.shape[0]):       # all points with barycentric coordinates (i, j, den - i - j) / den of every coarse face
@@ -363,6 +364,41 @@ def test_kat_subdiv_remesh_outputs_of_the_reference(smg_mod):
     of, ob = smg.query_coarse_to_fine(mg, 1, np.array(faces, np.int32), np.array(bar))
     back = (ob[:, :, None] * V[F[of]]).sum(1)
     assert np.linalg.norm(back - V, axis=1).max() <= 1e-12 * diag
+
+
+def test_subdiv_remesh_example_writes_the_reference_s_files(smg_mod, tmp_path):
+    """examples/08_subdiv_remesh.cpp (the reference's 08_subdiv_remesh/main.cpp:113-166 on the C ABI, host only) writes output_s0/1/2.obj:
+    the first is the reference's checked-in file vertex for vertex and face for face (same numbering: the smaller index survives a
+    collapse on both sides), the other two hold the reference's points (the upsampled meshes are numbered by libigl's upsample there,
+    by sorted edges here) and the same face counts."""
+    import subprocess
+    from scipy.spatial import cKDTree
+    lib = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
+    src = os.path.join(ROOT, "examples", "08_subdiv_remesh.cpp")
+    exe = str(tmp_path / "08_subdiv_remesh")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", src, "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lsmg",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny.smgm"), str(tmp_path)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-1000:])
+    G = np.load(os.path.join(ROOT, "tests", "golden", "bunny_remesh_500.npz"))
+
+    def read_obj(path):
+        V, F = [], []
+        for ln in open(path):
+            t = ln.split()
+            if t and t[0] == "v":
+                V.append([float(x) for x in t[1:4]])
+            elif t and t[0] == "f":
+                F.append([int(x) - 1 for x in t[1:4]])
+        return np.array(V), np.array(F, np.int32)
+    V0, F0 = read_obj(str(tmp_path / "output_s0.obj"))
+    assert np.array_equal(F0, G["s0_F"]) and np.abs(V0 - G["s0_V"]).max() <= 1e-10          # 15 digits printed of numbers up to 50
+    for k, nF in ((1, 1996), (2, 7984)):
+        Vk, Fk = read_obj(str(tmp_path / ("output_s%d.obj" % k)))
+        ref = G["s%d_V" % k]
+        assert Vk.shape == ref.shape and Fk.shape == (nF, 3)
+        assert cKDTree(ref).query(Vk)[0].max() <= 1e-10 and cKDTree(Vk).query(ref)[0].max() <= 1e-10
 
 
 def test_query_fine_to_coarse_is_the_prolongation_and_the_inverse_of_the_walk_back(smg_mod):
