@@ -10,9 +10,33 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "smg.h"
+
+// igl::upsample's numbering (the reference's main.cpp:65-72 calls it): the new vertex of edge (F(i,j), F(i,j+1)) gets the next free index
+// the first time a face i = 0, 1, ... / corner j = 0, 1, 2 meets that edge, and face i becomes (v0,m0,m2), (v1,m1,m0), (m0,m1,m2), (m1,v2,m2).
+// (The convention is the one the faces of the reference's output_s1/_s2.obj follow -- tests/golden/bunny_remesh_500.npz;
+// smg_mesh_midpoint_upsample numbers the new vertices by sorted edges instead, which gives the same meshes in another order.)
+static void upsample_igl(int nV, const std::vector<int>& F, std::vector<std::pair<int, int>>& edge_of_new, std::vector<int>& NF)
+{
+    std::map<std::pair<int, int>, int> ids;
+    edge_of_new.clear();
+    NF.clear();
+    for (size_t i = 0; i < F.size() / 3; i++) {
+        int v[3] = {F[3 * i], F[3 * i + 1], F[3 * i + 2]}, m[3];
+        for (int j = 0; j < 3; j++) {
+            const int a = v[j], b = v[(j + 1) % 3];
+            const std::pair<int, int> key(a < b ? a : b, a < b ? b : a);
+            auto it = ids.find(key);
+            if (it == ids.end()) { it = ids.emplace(key, nV + (int)edge_of_new.size()).first; edge_of_new.push_back(key); }
+            m[j] = it->second;
+        }
+        const int sub[12] = {v[0], m[0], m[2], v[1], m[1], m[0], m[0], m[1], m[2], m[1], v[2], m[2]};
+        NF.insert(NF.end(), sub, sub + 12);
+    }
+}
 
 #define CHECK(call) do { if ((call) != SMG_OK) { std::fprintf(stderr, "%s: %s\n", #call, smg_last_error()); return 1; } } while (0)
 
@@ -41,20 +65,19 @@ int main(int argc, char* argv[])
     std::vector<std::map<int, double>> rows((size_t)nV);              // S: upsampled vertex -> {coarse vertex: weight}
     for (int v = 0; v < nV; v++) rows[v][v] = 1.0;
     for (int it = 0; it < num_subdivs; it++) {
-        const std::vector<int>& Fc = level_F.back();
-        const int nVc = level_nV.back(), nFc = (int)Fc.size() / 3;
-        int nE = 0;
-        CHECK(smg_mesh_midpoint_upsample(nVc, Fc.data(), nFc, &nE, nullptr, nullptr, nullptr, nullptr));
-        std::vector<int> sp((size_t)nVc + nE + 1), sc((size_t)nVc + 2 * nE), NF((size_t)nFc * 12);
-        std::vector<double> sv(sc.size());
-        CHECK(smg_mesh_midpoint_upsample(nVc, Fc.data(), nFc, &nE, sp.data(), sc.data(), sv.data(), NF.data()));
-        std::vector<std::map<int, double>> next((size_t)nVc + nE);
-        for (int r = 0; r < nVc + nE; r++)
-            for (int p = sp[r]; p < sp[r + 1]; p++)
-                for (const auto& kv : rows[sc[p]]) next[r][kv.first] += sv[p] * kv.second;
-        rows.swap(next);
+        const std::vector<int> Fc = level_F.back();
+        const int nVc = level_nV.back();
+        std::vector<std::pair<int, int>> edges;
+        std::vector<int> NF;
+        upsample_igl(nVc, Fc, edges, NF);
+        for (const auto& e : edges) {   // the mid-point: half of each end point's row
+            std::map<int, double> r;
+            for (const auto& kv : rows[e.first]) r[kv.first] += 0.5 * kv.second;
+            for (const auto& kv : rows[e.second]) r[kv.first] += 0.5 * kv.second;
+            rows.push_back(r);
+        }
         level_F.push_back(NF);
-        level_nV.push_back(nVc + nE);
+        level_nV.push_back(nVc + (int)edges.size());
     }
     const int nQ = (int)rows.size();
     std::vector<int> qface(nQ);

@@ -368,11 +368,9 @@ def test_kat_subdiv_remesh_outputs_of_the_reference(smg_mod):
 
 def test_subdiv_remesh_example_writes_the_reference_s_files(smg_mod, tmp_path):
     """examples/08_subdiv_remesh.cpp (the reference's 08_subdiv_remesh/main.cpp:113-166 on the C ABI, host only) writes output_s0/1/2.obj:
-    the first is the reference's checked-in file vertex for vertex and face for face (same numbering: the smaller index survives a
-    collapse on both sides), the other two hold the reference's points (the upsampled meshes are numbered by libigl's upsample there,
-    by sorted edges here) and the same face counts."""
+    all three are the reference's checked-in files vertex for vertex and face for face (same numbering of the coarse mesh: the smaller
+    index survives a collapse on both sides; the example numbers the upsampled meshes the way libigl's upsample does)."""
     import subprocess
-    from scipy.spatial import cKDTree
     lib = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
     src = os.path.join(ROOT, "examples", "08_subdiv_remesh.cpp")
     exe = str(tmp_path / "08_subdiv_remesh")
@@ -392,13 +390,12 @@ def test_subdiv_remesh_example_writes_the_reference_s_files(smg_mod, tmp_path):
             elif t and t[0] == "f":
                 F.append([int(x) - 1 for x in t[1:4]])
         return np.array(V), np.array(F, np.int32)
-    V0, F0 = read_obj(str(tmp_path / "output_s0.obj"))
-    assert np.array_equal(F0, G["s0_F"]) and np.abs(V0 - G["s0_V"]).max() <= 1e-10          # 15 digits printed of numbers up to 50
-    for k, nF in ((1, 1996), (2, 7984)):
+    for k, nF in ((0, 499), (1, 1996), (2, 7984)):
         Vk, Fk = read_obj(str(tmp_path / ("output_s%d.obj" % k)))
         ref = G["s%d_V" % k]
         assert Vk.shape == ref.shape and Fk.shape == (nF, 3)
-        assert cKDTree(ref).query(Vk)[0].max() <= 1e-10 and cKDTree(Vk).query(ref)[0].max() <= 1e-10
+        assert np.abs(Vk - ref).max() <= 1e-10          # vertex for vertex (15 digits printed of numbers up to 50)
+        assert np.array_equal(Fk, G["s%d_F" % k])       # face for face, corner for corner
 
 
 def test_query_fine_to_coarse_is_the_prolongation_and_the_inverse_of_the_walk_back(smg_mod):
