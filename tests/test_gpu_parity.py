@@ -806,3 +806,38 @@ def test_long_rows_of_decimated_restrictions_are_bit_exact(smg, oracle_mod):
         assert len(lines) == 8, r.stdout
         outs.append(lines)
     assert outs[0] == outs[1]
+
+
+def test_wide_kernel_with_the_whole_row_in_flight_is_bit_exact_on_decimated_levels(smg, oracle_mod):
+    """k_sell_wide<..., R = 1, U = 8 / 16 / 32> (8 <= k < 64 on launches of few waves): the Galerkin levels of a decimated hierarchy have
+    15 - 30 entries per row, so these are the launches that take the 16- and 32-column batches.  Every kernel of the cycle, bit for bit
+    against the oracle on the level's matrix in the device numbering: SpMV, Gauss-Seidel, damped Jacobi, Chebyshev, restriction,
+    prolongation; k = 8 (one group of 8), 20 (16 + 4 narrow), 40 (32 + 8)."""
+    mesh = smg.mesh
+    V, F = mesh.read_triangle_mesh("bunny.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+    A = (mesh.massmatrix(V, F, "barycentric") - 0.01 * mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    mg.precompute(A)
+    assert mg.n_levels >= 3
+    widths = [int(np.diff(mg.matrix(lv, "A", internal=True).tocsr().indptr).max()) for lv in range(mg.n_levels - 1)]
+    assert max(widths) > 16                                           # a level that needs the 32-column batch
+    rng = np.random.default_rng(11)
+    for lv in range(mg.n_levels - 1):
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        for k in (8, 20, 40):
+            x = rng.uniform(-1, 1, (mg.rows(lv), k)); b = rng.uniform(-1, 1, (mg.rows(lv), k))
+            xc = rng.uniform(-1, 1, (mg.rows(lv + 1), k))
+            tag = "level %d (widest row %d), k %d" % (lv, widths[lv], k)
+            assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), "A: " + tag
+            mg.set_smoother("gs"); oi.set_smoother(0, "gs", 1.0)
+            assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2)), "Gauss-Seidel: " + tag
+            mg.set_smoother("jacobi", 0.7); oi.set_smoother(0, "jacobi", 0.7)
+            assert np.array_equal(mg.relax(lv, b, x, 3)[perm], oi.relax(0, b[perm], x[perm], 3)), "Jacobi: " + tag
+            mg.set_smoother("chebyshev"); oi.set_smoother(0, "chebyshev", 0.1)
+            assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2)), "Chebyshev: " + tag
+            mg.set_smoother("gs")
+            assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm])), "restrict: " + tag
+            assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc])), "prolong: " + tag
