@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMG_VERSION 200
+#define SMG_VERSION 210
 
 enum {
     SMG_OK = 0,
