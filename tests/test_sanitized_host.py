@@ -25,7 +25,7 @@ def _run(args, timeout):
 
 def test_sanitized_library_is_the_one_loaded():
     out = _run(["-c", "import surface_multigrid_code_amd as s; from surface_multigrid_code_amd import _lib; print('LIB', _lib.LIB_PATH, _lib.load().smg_version())"], 300)
-    assert "libsmg_asan.so 200" in out
+    assert "libsmg_asan.so 210" in out
 
 
 def test_host_logic_and_abi_under_asan_ubsan():
