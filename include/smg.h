@@ -142,7 +142,8 @@ int smg_mg_precompute_logged(const double *V, int nV, const int *F, int nF, floa
  * face[i] a face of mg[lv].F, bary[3i..3i+2] barycentric coordinates with respect to its corners -- are carried through the bijection
  * of the successive self-parameterisation onto the mesh of level lv - 1 by undoing the collapses of that coarsening step, last to
  * first: out_face[i] a face of mg[lv-1].F, out_bary[3i..] coordinates there (>= 0, sum 1).  The level must have been built by
- * smg_mg_precompute_logged(keep_log = 1); SMG_ERR_INVALID otherwise.  Host only (no GPU involved). */
+ * smg_mg_precompute_logged(keep_log = 1); SMG_ERR_INVALID otherwise (also after smg_hierarchy_load: the record is not part of the
+ * .smgh file).  Host only (no GPU involved). */
 int smg_query_coarse_to_fine(const smg_hierarchy *h, int lv, int n, const int *face, const double *bary, int *out_face,
                              double *out_bary);
 /* query_fine_to_coarse (src/query_fine_to_coarse.h; what get_prolong does for the vertices, src/get_prolong.cpp:23-57): the other
