@@ -13,8 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmg.so")
-SOURCES = ["smg_device.hip", "smg_capi.cpp", "smg_sparse.cpp", "smg_mesh.cpp", "smg_order.cpp", "smg_decimate.cpp"]
-HEADERS = ["smg_device.hpp", "smg_hier.hpp", "smg_sparse.hpp", "smg_mesh.hpp", "smg_order.hpp",
+SOURCES = ["smg_device.hip", "smg_capi.cpp", "smg_precompute.cpp", "smg_cycle.cpp", "smg_hierarchy_io.cpp", "smg_sparse.cpp", "smg_mesh.cpp",
+           "smg_order.cpp", "smg_decimate.cpp"]
+HEADERS = ["smg_device.hpp", "smg_hier.hpp", "smg_internal.hpp", "smg_sparse.hpp", "smg_mesh.hpp", "smg_order.hpp",
            os.path.join("..", "..", "include", "smg.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar / pointer kernel arguments arrive in SGPRs with the wave (k_sell orders its
 # arguments for this: its first panel loads need no kernarg read at all).  SMG_KERNARG_PRELOAD=0 builds without it (A/B).
@@ -68,7 +69,7 @@ def build(force=False, verbose=True):
 
 
 # ---- sanitizer lane ("-fsanitize=address,undefined CPU test config") ------------------------------------------
-# The five host translation units -- decimator, colouring / ordering, sparse algebra, mesh numerics, the C ABI: the pointer-heavy
+# The host translation units -- decimator, colouring / ordering, sparse algebra, mesh numerics, the C ABI: the pointer-heavy
 # code -- compiled by g++ with AddressSanitizer + UndefinedBehaviorSanitizer; the device file keeps its normal hipcc object (device
 # code cannot carry host sanitizer instrumentation).  Result: lib/libsmg_asan.so, loaded through SMG_LIB by tests/test_sanitized_host.py
 # with LD_PRELOAD=libasan (python itself is not instrumented).

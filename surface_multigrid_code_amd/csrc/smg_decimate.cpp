@@ -824,6 +824,7 @@ void query_coarse_to_fine(const DecimationLog& L, int n, const int* face, const 
                 const double d00 = v0x * v0x + v0y * v0y, d01 = v0x * v1x + v0y * v1y, d11 = v1x * v1x + v1y * v1y;
                 const double d20 = v2x * v0x + v2y * v0y, d21 = v2x * v1x + v2y * v1y;
                 const double denom = d00 * d11 - d01 * d01;
+                if (!(denom != 0.0)) continue;   // a degenerate flattened triangle (zero area or NaN) locates nothing
                 const double bv = (d11 * d20 - d01 * d21) / denom, bwt = (d00 * d21 - d01 * d20) / denom;
                 const double bu = 1.0 - (bv + bwt);
                 const double dist = -std::min(bu, std::min(bv, bwt));
@@ -832,6 +833,7 @@ void query_coarse_to_fine(const DecimationLog& L, int n, const int* face, const 
             if (bt < 0) break;   // every face is further than a whole triangle away (the reference leaves this case undefined)
             double sw = 0.0;
             for (int c = 0; c < 3; c++) { bw[c] = std::max(0.0, bw[c]); sw += bw[c]; }
+            if (!(sw > 0.0)) break;   // nothing to renormalise by: the point stays where it is, with the weights it came with
             for (int c = 0; c < 3; c++) w[c] = bw[c] / sw;
             f = fid[bt];
         }
@@ -880,6 +882,7 @@ void query_fine_to_coarse(const DecimationLog& L, int n, const int* face, const 
                 const double d00 = v0x * v0x + v0y * v0y, d01 = v0x * v1x + v0y * v1y, d11 = v1x * v1x + v1y * v1y;
                 const double d20 = v2x * v0x + v2y * v0y, d21 = v2x * v1x + v2y * v1y;
                 const double denom = d00 * d11 - d01 * d01;
+                if (!(denom != 0.0)) continue;   // a degenerate flattened triangle (zero area or NaN) locates nothing
                 const double bv = (d11 * d20 - d01 * d21) / denom, bwt = (d00 * d21 - d01 * d20) / denom;
                 const double bu = 1.0 - (bv + bwt);
                 const double dist = -std::min(bu, std::min(bv, bwt));
@@ -888,6 +891,7 @@ void query_fine_to_coarse(const DecimationLog& L, int n, const int* face, const 
             if (bt < 0) break;
             double sw = 0.0;
             for (int c = 0; c < 3; c++) { bw[c] = std::max(0.0, bw[c]); sw += bw[c]; }
+            if (!(sw > 0.0)) break;   // nothing to renormalise by: the point stays where it is, with the weights it came with
             for (int c = 0; c < 3; c++) w[c] = bw[c] / sw;
             f = fid[bt];
         }

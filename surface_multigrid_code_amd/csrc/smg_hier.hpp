@@ -104,6 +104,21 @@ struct Level {
     int n = 0;
 };
 
+// Everything a captured outer iteration bakes in besides device pointers: a cached graph is reused only while the handle's current
+// selection compares equal to the key it was captured with.  A new mode that changes the launch sequence or a kernel argument of the
+// cycle gets a field HERE (one place), not a hand-written comparison.
+struct GraphKey {
+    int k = 0, pre = 0, post = 0, precision = 0, smoother = 0, jacobi_max_rows = 0;
+    double omega = 0.0, cheby_fraction = 0.0;
+    bool head_fuse = false;
+    bool operator==(const GraphKey& o) const
+    {
+        return k == o.k && pre == o.pre && post == o.post && precision == o.precision && smoother == o.smoother &&
+               jacobi_max_rows == o.jacobi_max_rows && omega == o.omega && cheby_fraction == o.cheby_fraction && head_fuse == o.head_fuse;
+    }
+    bool operator!=(const GraphKey& o) const { return !(*this == o); }
+};
+
 struct ProfScope { std::string name; long count = 0; double ms = 0.0; };
 struct ProfRec { int scope; hipEvent_t e0, e1; };
 
@@ -170,10 +185,8 @@ struct smg_hierarchy {
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
     double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
-    int g_k = 0, g_pre = 0, g_post = 0, g_prec = 0;
-    int g_smoother = 0, g_jmax = 0;   // the smoother selection the cached graphs were captured with
-    double g_omega = 0.0, g_frac = 0.0;
-    bool head_fuse = false, g_head = false;   // this solve takes the outer residual out of the first sweep (latched at smg_solve_begin) / what the graphs were captured with
+    smg::GraphKey g_key;             // what the cached graphs were captured with (k == 0: nothing cached)
+    bool head_fuse = false;          // this solve takes the outer residual out of the first sweep (latched at smg_solve_begin)
     // ---- profc mirror ----
     bool prof_on = false;
     std::vector<smg::ProfScope> scopes;

@@ -1,0 +1,715 @@
+// smg_precompute.cpp -- min_quad_with_fixed_mg_precompute (reference src/min_quad_with_fixed_mg.cpp:3-51, :137-257) behind smg_precompute:
+// the reference's sparse algebra on the host (caller numbering, bit-compatible accumulation order), the device images (colour-major
+// numbering, SELL panels, coarse inverse), the value-only re-precompute on the device and the operator assembly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "smg_internal.hpp"
+
+using namespace smg;
+
+// ------------------------------------------------------------------------------------------------ precompute
+// Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
+static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known)
+{
+    const int n = A.nr;
+    const int L = h->n_levels;
+    h->n_full = n;
+    h->has_known = (known != nullptr && n_known > 0);
+    h->known.clear(); h->unknown.clear();
+    for (int lv = 1; lv < L; lv++) {
+        if (h->lv[lv].P_full.empty()) return fail(SMG_ERR_INVALID, "level %d has no prolongation (smg_level_set_prolong)", lv);
+        h->lv[lv].P = h->lv[lv].P_full;  // always restart from P_full (see smg.h)
+    }
+    if (L > 1 && h->lv[1].P_full.nr != n)
+        return fail(SMG_ERR_INVALID, "A is %d x %d but P_1 has %d rows", n, n, h->lv[1].P_full.nr);
+    h->nnz_input = (int)A.nnz();
+    StageTimer tm;
+    if (!h->has_known) {
+        // reference src/min_quad_with_fixed_mg.cpp:17-22
+        h->lhs_src.resize(A.nnz());
+        std::iota(h->lhs_src.begin(), h->lhs_src.end(), 0);
+        h->auk_src.clear();
+        h->lv[0].A = std::move(A);
+        h->Auk = Csr();
+        {
+            std::vector<std::function<void()>> tasks;
+            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });
+            parallel_tasks(tasks);
+        }
+    } else {
+        // unknown = setdiff(0..n-1, known), ascending (:155-158); known keeps the caller's order (:178)
+        std::vector<char> isk(n, 0);
+        for (int i = 0; i < n_known; i++) {
+            if (known[i] < 0 || known[i] >= n) return fail(SMG_ERR_INVALID, "known[%d] = %d out of range", i, known[i]);
+            if (isk[known[i]]) return fail(SMG_ERR_INVALID, "known[%d] = %d appears twice", i, known[i]);
+            isk[known[i]] = 1;
+        }
+        h->known.assign(known, known + n_known);
+        for (int i = 0; i < n; i++) if (!isk[i]) h->unknown.push_back(i);
+        h->lv[0].A = slice(A, &h->unknown, &h->unknown, &h->lhs_src);  // LHS = A(unknown, unknown)   (:166-167, :175)
+        h->Auk = slice(A, &h->unknown, &h->known, &h->auk_src);        // Auk = A(unknown, known)     (:169-170, :176)
+        if (L > 1) {
+            h->lv[1].P = slice(h->lv[1].P_full, &h->unknown, nullptr);  // :185
+            for (int lv = 1; lv < L; lv++) {
+                Csr& P = h->lv[lv].P;
+                // keep the columns holding at least one entry > 1e-15 (:190-203)
+                std::vector<char> keepflag(P.nc, 0);
+                for (long p = 0; p < P.nnz(); p++) if (P.val[p] > 1e-15) keepflag[P.col[p]] = 1;
+                std::vector<int> keep;
+                for (int c = 0; c < P.nc; c++) if (keepflag[c]) keep.push_back(c);
+                if ((int)keep.size() < P.nc) {                                   // :206
+                    P = slice(P, nullptr, &keep);                                // :210-211
+                    if (lv < L - 1) h->lv[lv + 1].P = slice(h->lv[lv + 1].P_full, &keep, nullptr);  // :213-214
+                } else break;                                                    // :216-219
+            }
+        }
+        {
+            std::vector<std::function<void()>> tasks;
+            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });  // :226
+            parallel_tasks(tasks);
+        }
+    }
+    tm.lap("host: slices / transposes of P");
+    // The locality order of the finest level is the longest sequential piece of the whole precompute (a Cuthill-McKee search over
+    // all rows) and needs nothing but A_0's pattern: it starts now, on its own thread, beside the Galerkin products.
+    auto pattern_key = [&](int lv) {
+        const Csr& M = h->lv[lv].A;
+        uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
+        auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
+        const int hdr[2] = {M.nr, lv < L - 1 ? 1 : 0};
+        mix(hdr, 2); mix(M.ptr.data(), M.ptr.size()); mix(M.col.data(), M.col.size());
+        return key;
+    };
+    static const bool use_rcm = [] { const char* v = std::getenv("SMG_ORDER"); return !(v && std::string(v) == "induced"); }();
+    std::vector<int> rcm0;
+    std::thread rcm0_thread;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } rcm0_joiner{rcm0_thread};
+    uint64_t key0 = 0;
+    if (L >= 3 && use_rcm && host_threads() > 1) {
+        key0 = pattern_key(0);
+        const Level& L0 = h->lv[0];
+        if (!(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) rcm0_thread = std::thread([&] {
+            const auto t0 = std::chrono::steady_clock::now();
+            rcm0 = rcm_order(h->lv[0].A);
+            if (tm.on) std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        });
+    }
+    // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
+    for (int lv = 1; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        if (Lv.P.nc == 0) return fail(SMG_ERR_INVALID, "level %d has no unknowns left after constraint elimination", lv);
+        if (Lv.P.nr != h->lv[lv - 1].A.nr)
+            return fail(SMG_ERR_INVALID, "P_%d has %d rows but level %d has %d unknowns", lv, Lv.P.nr, lv - 1, h->lv[lv - 1].A.nr);
+        Csr tmp = spgemm(Lv.PT, h->lv[lv - 1].A);
+        Lv.A = spgemm(tmp, Lv.P);
+    }
+    tm.lap("host: Galerkin products");
+    // small diagonal shift on the coarsest level only (:32-36, :236-241)
+    {
+        Csr& Ac = h->lv[L - 1].A;
+        for (int i = 0; i < Ac.nr; i++) {
+            bool found = false;
+            for (int p = Ac.ptr[i]; p < Ac.ptr[i + 1]; p++) if (Ac.col[p] == i) { Ac.val[p] += 1e-12; found = true; break; }
+            if (!found) return fail(SMG_ERR_INVALID, "coarsest matrix has no stored diagonal at row %d", i);
+        }
+    }
+    for (int lv = 0; lv < L; lv++) {                       // A_diag (:39-41, :244-246)
+        h->lv[lv].A_diag = diagonal(h->lv[lv].A);
+        h->lv[lv].n = h->lv[lv].A.nr;
+        // relax() divides by A_diag (src/mg_VCycle.cpp:157): a missing or zero diagonal would give Inf/NaN there
+        if (lv < L - 1)
+            for (int i = 0; i < h->lv[lv].n; i++)
+                if (h->lv[lv].A_diag[i] == 0.0) return fail(SMG_ERR_INVALID, "level %d: zero or missing diagonal at row %d", lv, i);
+    }
+    tm.lap("host: shift, diagonals");
+    // ---- device numbering (still host work): colour-major ordering of every smoothed level and the operators
+    // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.
+    // coarse to fine, so that a subdivision level can inherit a 4-colouring from its parent; the RCM orders (the expensive,
+    // sequential part of an ordering) of all levels that need one are computed concurrently first
+    std::vector<uint64_t> keys(L);
+    std::vector<char> need(L, 0);
+    {
+        std::vector<std::function<void()>> tasks;
+        for (int lv = 0; lv < L; lv++) tasks.push_back([&, lv] {
+            Level& Lv = h->lv[lv];
+            const uint64_t key = (lv == 0 && key0) ? key0 : pattern_key(lv);
+            keys[lv] = key;
+            need[lv] = !(key == Lv.ord_key && (int)Lv.ord.perm.size() == Lv.n);   // else: same pattern as last time
+        });
+        parallel_tasks(tasks);
+    }
+    // Locality order of every smoothed level (new -> old).  Default: reverse Cuthill-McKee of each level's matrix (the per-level
+    // searches run concurrently).  SMG_ORDER=induced: RCM on the coarsest smoothed level only, every finer level takes the
+    // order induced by its parent level through P -- O(nnz) instead of a sequential search over a million rows; measured at C3:
+    // 0.1 s less setup, sweeps 1-3 % slower.
+    tm.lap("host:   pattern hashes");
+    std::vector<std::vector<int>> rcm(L);
+    const bool any_need = std::any_of(need.begin(), need.end(), [](char c) { return c != 0; });
+    if (any_need) {
+        if (use_rcm) {
+            // the coarsest smoothed level is coloured from scratch (a search that can take longer than all the RCMs together):
+            // it goes first in the task list and runs beside the finer levels' searches
+            std::vector<std::function<void()>> tasks;
+            if (L >= 2 && need[L - 2]) tasks.push_back([&] {
+                Level& Lv = h->lv[L - 2];
+                const auto t0 = std::chrono::steady_clock::now();
+                rcm[L - 2] = rcm_order(Lv.A);
+                Lv.ord = make_ordering(Lv.A, 512, nullptr, &rcm[L - 2]);
+                if (tm.on) std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring from scratch %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                Lv.ord_key = keys[L - 2];
+                need[L - 2] = 0;
+            });
+            const bool early0 = rcm0_thread.joinable();
+            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(h->lv[lv].A); });
+            parallel_tasks(tasks);
+            if (early0) { rcm0_thread.join(); rcm[0] = std::move(rcm0); }
+        } else {
+            std::vector<int> rank;
+            for (int lv = L - 2; lv >= 0; lv--) {
+                rcm[lv] = (lv == L - 2) ? rcm_order(h->lv[lv].A) : induced_order(h->lv[lv + 1].P, rank);
+                rank.assign(h->lv[lv].n, 0);
+                for (int t = 0; t < h->lv[lv].n; t++) rank[rcm[lv][t]] = t;
+            }
+        }
+    }
+    tm.lap("host:   locality orders (RCM) + coarsest colouring");
+    for (int lv = L - 1; lv >= 0; lv--) {
+        Level& Lv = h->lv[lv];
+        if (!need[lv]) continue;
+        if (lv == L - 1) Lv.ord = identity_ordering(Lv.n);
+        else {
+            std::vector<int> inherited;
+            const Level& Lc = h->lv[lv + 1];
+            const bool ok = (lv + 1 < L - 1) && Lc.ord.n_colors() <= 4 && (int)Lc.ord.color_of.size() == Lc.n &&
+                            subdivision_colors(Lc.P, Lc.ord.color_of, Lv.A, inherited);
+            if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
+            Lv.ord = make_ordering(Lv.A, 512, ok ? &inherited : nullptr, &rcm[lv]);
+            if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
+        }
+        Lv.ord_key = keys[lv];
+    }
+    tm.lap("host: orderings + colourings");
+    {
+        std::vector<std::function<void()>> tasks;
+        for (int lv = 0; lv < L; lv++) {
+            tasks.push_back([h, lv, L] {
+                Level& Lv = h->lv[lv];
+                if (lv < L - 1) Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
+                else { Lv.A_int = Lv.A; Lv.A_int_src.resize(Lv.A.nnz()); std::iota(Lv.A_int_src.begin(), Lv.A_int_src.end(), 0); }
+            });
+            if (lv >= 1) {
+                tasks.push_back([h, lv] { Level& Lv = h->lv[lv]; Lv.P_int = permute(Lv.P, h->lv[lv - 1].ord.perm, Lv.ord.perm); });
+                tasks.push_back([h, lv] { Level& Lv = h->lv[lv]; Lv.PT_int = permute(Lv.PT, Lv.ord.perm, h->lv[lv - 1].ord.perm); });
+            }
+        }
+        parallel_tasks(tasks);
+    }
+    tm.lap("host: permuted operators");
+    return SMG_OK;
+}
+
+// Gershgorin bound of D^-1 A per smoothed level (what the Chebyshev-Jacobi smoother is built on), from the SELL image the smoother
+// streams, i.e. in the device numbering's summation order -- the same value the oracle computes on the level matrix in that numbering.
+int smg::spectral_bounds(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    if (L < 2) return SMG_OK;
+    HIPCHK(h->d_lam.ensure((size_t)L));
+    for (int lv = 0; lv < L - 1; lv++) {
+        Level& Lv = h->lv[lv];
+        HIPCHK(launch_gershgorin(Lv.gs_on_transpose ? Lv.dAT.view : Lv.dA.view, h->d_lam.p + lv, h->stream));
+    }
+    std::vector<double> lam((size_t)L, 0.0);
+    HIPCHK(hipMemcpyAsync(lam.data(), h->d_lam.p, (size_t)(L - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int lv = 0; lv < L - 1; lv++) {
+        if (!(lam[lv] > 0.0) || !std::isfinite(lam[lv])) return fail(SMG_ERR_INVALID, "level %d: no positive diagonal to scale by", lv);
+        if (lam[lv] != h->lv[lv].lam) drop_graphs(h);   // the coefficients are kernel arguments of the captured launches
+        h->lv[lv].lam = lam[lv];
+    }
+    h->lam_valid = true;
+    return SMG_OK;
+}
+// lazily: only handles that smooth with Chebyshev-Jacobi pay the four small launches and the read-back
+int smg::ensure_spectral_bounds(smg_hierarchy* h)
+{
+    if (h->lam_valid) return SMG_OK;
+    bool need = false;
+    for (int lv = 0; lv < h->n_levels - 1; lv++) if (level_kind(h, lv) == 2 /* LV_CHEBY */) need = true;
+    return need ? spectral_bounds(h) : SMG_OK;
+}
+
+// Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
+static int precompute_device(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    const int sellC = SELL_C;
+    const bool region = env_int("SMG_REGION_ORDER", 1) != 0;   // A/B knob: region-major launch order
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release(); Lv.d.release();
+        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release(); Lv.d32.release();
+    }
+    h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
+    StageTimer tm;
+    // all SELL images concurrently on host threads, each uploaded by the task that built it (pageable-memory copies are bound by
+    // the host-side staging copy, so they overlap with the other tasks' work and with each other)
+    std::vector<int> bad(L, 0);
+    {
+        std::vector<std::function<void()>> tasks;
+        std::vector<hipError_t> errs;
+        errs.reserve((size_t)4 * L);
+        if (L == 1) {
+            // a single level goes straight to coarseSolve (src/mg_VCycle.cpp:28-33); the outer loop still needs A_0 for its residual
+            errs.push_back(hipSuccess);
+            hipError_t* eA = &errs.back();
+            tasks.push_back([&, eA] {
+                DeviceScope ds(h->device);
+                Sell S = build_sell(h->lv[0].A_int, nullptr, sellC, false);
+                *eA = h->lv[0].dA.upload(S);
+            });
+        }
+        for (int lv = 0; lv < L; lv++) {
+            if (lv < L - 1) {
+                errs.push_back(hipSuccess);
+                hipError_t* eA = &errs.back();
+                tasks.push_back([&, lv, eA] {
+                    DeviceScope ds(h->device);   // worker threads start on device 0
+                    Sell S = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region);
+                    *eA = h->lv[lv].dA.upload(S);
+                });
+                // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
+                // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
+                // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
+                errs.push_back(hipSuccess);
+                hipError_t* eT = &errs.back();
+                tasks.push_back([&, lv, eT] {
+                    DeviceScope ds(h->device);
+                    Level& Lw = h->lv[lv];
+                    Csr AT = transpose(Lw.A_int);
+                    Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
+                    Lw.dAT = SellBuf();
+                    if (Lw.gs_on_transpose) {
+                        if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad[lv] = 1; return; }
+                        Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false);
+                        *eT = Lw.dAT.upload(S);
+                    }
+                });
+            }
+            if (lv >= 1) {
+                errs.push_back(hipSuccess);
+                hipError_t* eP = &errs.back();
+                // P and PT are launched whole: with their rows cut at the colour boundaries of the level they belong to, the slices get
+                // the same region-major launch order as A, and the workgroups an XCD receives (a contiguous piece of that order) read
+                // their gathers from one region of the mesh instead of from all over it (restriction at C3: 54 MB of HBM traffic per
+                // launch for 33 MB of algorithmic bytes before)
+                static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
+                tasks.push_back([&, lv, eP] {
+                    DeviceScope ds(h->device);
+                    const bool cut = tr_region && region && h->lv[lv - 1].ord.color_ptr.size() > 2;
+                    Sell S = build_sell(h->lv[lv].P_int, cut ? &h->lv[lv - 1].ord.color_ptr : nullptr, sellC, cut);
+                    *eP = h->lv[lv].dP.upload(S);
+                });
+                errs.push_back(hipSuccess);
+                hipError_t* eQ = &errs.back();
+                tasks.push_back([&, lv, eQ] {
+                    DeviceScope ds(h->device);
+                    const bool cut = tr_region && region && lv < L - 1 && h->lv[lv].ord.color_ptr.size() > 2;
+                    // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
+                    // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
+                    // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
+                    static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+                    const Csr& M = h->lv[lv].PT_int;
+                    std::vector<int> lrow, lptr{0}, lcol;
+                    std::vector<double> lval;
+                    if (long_min > 0)
+                        for (int r = 0; r < M.nr; r++)
+                            if (M.ptr[r + 1] - M.ptr[r] >= long_min) {
+                                lrow.push_back(r);
+                                lcol.insert(lcol.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]);
+                                lval.insert(lval.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]);
+                                lptr.push_back((int)lcol.size());
+                            }
+                    if (lrow.empty()) {
+                        Sell S = build_sell(M, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                        *eQ = h->lv[lv].dPT.upload(S);
+                        if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
+                        return;
+                    }
+                    Csr Ms;     // M with the long rows emptied
+                    Ms.nr = M.nr; Ms.nc = M.nc; Ms.ptr.assign((size_t)M.nr + 1, 0);
+                    {
+                        size_t li = 0;
+                        for (int r = 0; r < M.nr; r++) {
+                            const bool is_long = li < lrow.size() && lrow[li] == r;
+                            if (is_long) li++;
+                            else { Ms.col.insert(Ms.col.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]); Ms.val.insert(Ms.val.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]); }
+                            Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
+                        }
+                    }
+                    Sell S = build_sell(Ms, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                    *eQ = h->lv[lv].dPT.upload(S);
+                    if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
+                });
+            }
+        }
+        parallel_tasks(tasks);
+        for (int lv = 0; lv < L; lv++)
+            if (bad[lv]) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+        for (hipError_t e : errs) HIPCHK(e);
+    }
+    tm.lap("device: SELL images built and uploaded");
+    // level-0 index maps
+    {
+        const Level& L0 = h->lv[0];
+        std::vector<int> map0(L0.n);
+        for (int i = 0; i < L0.n; i++) map0[i] = h->has_known ? h->unknown[L0.ord.perm[i]] : L0.ord.perm[i];
+        HIPCHK(h->d_map0.upload(map0));
+        HIPCHK(h->d_perm0.upload(L0.ord.perm));
+        if (h->has_known) {
+            HIPCHK(h->d_unknown.upload(h->unknown));
+            HIPCHK(h->d_known.upload(h->known));
+            HIPCHK(h->d_auk_ptr.upload(h->Auk.ptr));
+            HIPCHK(h->d_auk_col.upload(h->Auk.col));
+            HIPCHK(h->d_auk_val.upload(h->Auk.val));
+        }
+    }
+    tm.lap("device: index maps");
+    // coarsest level: dense inverse on the device (stands in for solver.compute(Ac), :47-48 / :253-254)
+    {
+        const Level& Lc = h->lv[L - 1];
+        const int nc = Lc.n;
+        const int np = ((nc + 63) / 64) * 64;
+        h->nc = nc; h->nc_pad = np;
+        if ((double)np * np * 8.0 > 96e9)
+            return fail(SMG_ERR_ALLOC, "coarsest level has %d unknowns: its dense inverse (%.0f GB) is out of range -- add levels", nc, (double)np * np * 8e-9);
+        // dense image on the device: the few entries travel, not n^2 zeros
+        std::vector<long long> pos(Lc.A.nnz());
+        for (int i = 0; i < nc; i++)
+            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) pos[p] = (long long)i * np + Lc.A.col[p];
+        DevBuf<long long> d_pos;
+        DevBuf<double> d_val;
+        HIPCHK(d_pos.upload(pos));
+        HIPCHK(d_val.upload(Lc.A.val));
+        HIPCHK(h->d_Ainv.ensure((size_t)np * np));
+        HIPCHK(launch_dense_from_csr(h->d_Ainv.p, np, nc, d_val.p, d_pos.p, (int)Lc.A.nnz(), h->stream));
+        if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(h->d_sympart.ensure((size_t)(np / 64) * (np / 64) * 64)); else h->d_sympart.release();
+        DevBuf<double> work;
+        HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
+        HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    tm.lap("device: coarse dense inverse");
+    h->lam_valid = false;   // the Gershgorin bounds are computed when a Chebyshev smoother first asks for them (ensure_spectral_bounds)
+    return SMG_OK;
+}
+
+// ---- value-only re-precompute --------------------------------------------------------
+// Time-stepping callers hand in a new matrix with the SAME sparsity every step (05_example_mean_curvature_flow/
+// main.cpp:74, 06_example_balloon_sim/implicit_euler_mg_balloon.h:75).  Then everything structural (unknown set,
+// sliced P, Galerkin patterns, colouring, SELL layout, graphs) is unchanged and the numeric work moves to the GPU:
+// slice gathers, two fixed-recipe SpGEMM stages per level (bit-identical to the host spgemm), SELL value refresh and
+// the dense coarse inverse.
+
+static uint64_t fnv_mix(uint64_t key, const int* p, size_t cnt)
+{
+    // hashed in fixed blocks of 64 Ki entries, the blocks concurrently on the host threads, the block hashes chained in order:
+    // the value does not depend on the number of threads (a time step's re-precompute hashes the 8 M pattern entries of a
+    // 1 M-vertex mesh before anything else: 6.5 ms as one sequential chain)
+    constexpr size_t B = 65536;
+    const size_t nblk = (cnt + B - 1) / B;
+    if (nblk <= 1) {
+        for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; }
+        return key;
+    }
+    std::vector<uint64_t> part(nblk);
+    parallel_for((long)nblk, 4, [&](long b0, long b1) {
+        for (long b = b0; b < b1; b++) {
+            uint64_t k = 1469598103934665603ull;
+            const size_t e = std::min(cnt, (size_t)(b + 1) * B);
+            for (size_t i = (size_t)b * B; i < e; i++) { k ^= (uint32_t)p[i]; k *= 1099511628211ull; }
+            part[b] = k;
+        }
+    });
+    for (size_t b = 0; b < nblk; b++) { key ^= part[b]; key *= 1099511628211ull; }
+    return key;
+}
+
+static uint64_t precompute_key(const smg_hierarchy* h, int n, const int* rowptr, const int* col, const int* known, int n_known)
+{
+    uint64_t key = 1469598103934665603ull;
+    const int hdr[4] = {n, n_known, h->p_version, h->n_levels};
+    key = fnv_mix(key, hdr, 4);
+    key = fnv_mix(key, rowptr, (size_t)n + 1);
+    key = fnv_mix(key, col, (size_t)rowptr[n]);
+    if (known) key = fnv_mix(key, known, (size_t)n_known);
+    return key ? key : 1;
+}
+
+static int build_recipes(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    const int sellC = SELL_C;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);  // the GS launches move to the A^T images on every level
+    // all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes); every task uploads what it built
+    std::vector<int> bad(L, 0);
+    std::vector<hipError_t> errs((size_t)2 * L, hipSuccess);
+    StageTimer tm;
+    {
+        std::vector<std::function<void()>> tasks;
+        auto up = [](hipError_t& acc, hipError_t e) { if (acc == hipSuccess) acc = e; };
+        for (int lv = 0; lv < L; lv++) {
+            if (lv < L - 1) tasks.push_back([&, lv] {
+                DeviceScope ds(h->device);
+                // SELL slot -> caller CSR entry, for A and for A^T (the sweep always reads A^T in this mode: whether new
+                // values are bit-symmetric cannot be known in advance)
+                Level& Lv = h->lv[lv];
+                hipError_t& er = errs[2 * lv];
+                std::vector<int> m;
+                {
+                    Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
+                    m.resize(S.entry.size());
+                    for (size_t i = 0; i < S.entry.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
+                }
+                up(er, Lv.mapA.upload(m));
+                std::vector<int> tsrc;
+                Csr AT = transpose(Lv.A_int, &tsrc);
+                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) { bad[lv] = 1; return; }
+                Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
+                m.resize(ST.entry.size());
+                for (size_t i = 0; i < ST.entry.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
+                up(er, Lv.mapAT.upload(m));
+                if (!Lv.gs_on_transpose) { up(er, Lv.dAT.upload(ST)); Lv.gs_on_transpose = true; }
+            });
+            tasks.push_back([&, lv] {
+                DeviceScope ds(h->device);
+                Level& Lv = h->lv[lv];
+                hipError_t& er = errs[2 * lv + 1];
+                up(er, Lv.d_Aval.upload(Lv.A.val));
+                if (lv == 0) return;
+                const Csr& Af = h->lv[lv - 1].A;
+                Csr T = spgemm(Lv.PT, Af);
+                Recipe r;
+                spgemm_recipe(Lv.PT, Af, true, T, r);      // T = PT * A_{lv-1}:  PT constant
+                up(er, Lv.r1_ptr.upload(r.ptr)); up(er, Lv.r1_idx.upload(r.idx)); up(er, Lv.r1_coef.upload(r.coef));
+                spgemm_recipe(T, Lv.P, false, Lv.A, r);    // A_lv = T * P:       P constant
+                up(er, Lv.r2_ptr.upload(r.ptr)); up(er, Lv.r2_idx.upload(r.idx)); up(er, Lv.r2_coef.upload(r.coef));
+                Lv.nnzT = (int)T.nnz();
+                up(er, Lv.d_Tval.alloc(T.nnz()));
+            });
+        }
+        parallel_tasks(tasks);
+    }
+    for (int lv = 0; lv < L; lv++)
+        if (bad[lv]) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+    for (hipError_t e : errs) HIPCHK(e);
+    tm.lap("recipes: host work + uploads");
+    {
+        const Level& Lc = h->lv[L - 1];
+        std::vector<long long> pos(Lc.A.nnz());
+        std::vector<int> dg;
+        for (int i = 0; i < Lc.n; i++)
+            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) {
+                pos[p] = (long long)i * h->nc_pad + Lc.A.col[p];
+                if (Lc.A.col[p] == i) dg.push_back(p);
+            }
+        HIPCHK(h->d_dense_pos.upload(pos));
+        HIPCHK(h->d_diag_idx.upload(dg));
+    }
+    HIPCHK(h->d_lhs_src.upload(h->lhs_src));
+    if (h->has_known) HIPCHK(h->d_auk_src.upload(h->auk_src));
+    HIPCHK(h->d_Afull.alloc((size_t)std::max(h->nnz_input, 1)));
+    h->recipes_built = true;
+    return SMG_OK;
+}
+
+// d_val: the caller's new values (device, caller CSR order)
+static int precompute_values_device(smg_hierarchy* h, const double* d_val)
+{
+    const int L = h->n_levels;
+    hipStream_t st = h->stream;
+    Level& L0 = h->lv[0];
+    HIPCHK(launch_gather_vals(L0.d_Aval.p, d_val, h->d_lhs_src.p, (size_t)L0.A.nnz(), st));          // LHS = A(unknown, unknown)
+    if (h->has_known) HIPCHK(launch_gather_vals(h->d_auk_val.p, d_val, h->d_auk_src.p, (size_t)h->Auk.nnz(), st));  // Auk
+    for (int lv = 0; lv < L; lv++) {
+        Level& Lv = h->lv[lv];
+        if (lv >= 1) {
+            Level& Lf = h->lv[lv - 1];
+            HIPCHK(launch_recipe(Lv.nnzT, Lv.r1_ptr.p, Lv.r1_idx.p, Lv.r1_coef.p, Lf.d_Aval.p, Lv.d_Tval.p, st));
+            HIPCHK(launch_recipe((int)Lv.A.nnz(), Lv.r2_ptr.p, Lv.r2_idx.p, Lv.r2_coef.p, Lv.d_Tval.p, Lv.d_Aval.p, st));
+        }
+        if (lv == L - 1) {
+            HIPCHK(launch_add_at(Lv.d_Aval.p, h->d_diag_idx.p, (int)h->d_diag_idx.n, 1e-12, st));          // :32-36 / :236-241
+        } else {
+            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dA.view.val), Lv.d_Aval.p, Lv.mapA.p, (size_t)Lv.dA.padded, st));
+            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dAT.view.val), Lv.d_Aval.p, Lv.mapAT.p, (size_t)Lv.dAT.padded, st));
+        }
+    }
+    // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254)
+    {
+        const Level& Lc = h->lv[L - 1];
+        HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));
+        DevBuf<double> work;
+        HIPCHK(work.alloc((size_t)2 * h->nc_pad * 64 + 2 * 64 * 64));
+        HIPCHK(launch_spd_inverse(h->d_Ainv.p, h->nc_pad, work.p, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    h->host_stale = true;
+    h->f32_valid = false;   // the fp32 copies are re-made from the new values when a mixed solve asks for them
+    h->lam_valid = false;
+    return SMG_OK;
+}
+
+// bring the host copies (mg[l].A, A_diag, Auk, A_int) up to date after a device-side re-precompute
+int smg::refresh_host_values(smg_hierarchy* h)
+{
+    if (!h->host_stale) return SMG_OK;
+    for (int lv = 0; lv < h->n_levels; lv++) {
+        Level& Lv = h->lv[lv];
+        HIPCHK(hipMemcpy(Lv.A.val.data(), Lv.d_Aval.p, Lv.A.val.size() * sizeof(double), hipMemcpyDeviceToHost));
+        Lv.A_diag = diagonal(Lv.A);
+        for (size_t e = 0; e < Lv.A_int.val.size(); e++) Lv.A_int.val[e] = Lv.A.val[Lv.A_int_src[e]];
+    }
+    if (h->has_known && h->Auk.nnz() > 0)
+        HIPCHK(hipMemcpy(h->Auk.val.data(), h->d_auk_val.p, h->Auk.val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    h->host_stale = false;
+    return SMG_OK;
+}
+
+extern "C" int smg_precompute_values_device(smg_hierarchy* h, const double* d_val)
+{
+    if (!h || !d_val) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: bad arguments");
+    if (!h->precomputed || h->device < 0) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: run a full smg_precompute with this sparsity first");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute_values_device called during a split-phase solve");
+    if (!h->input_canonical) return fail(SMG_ERR_INVALID, "the matrix given to smg_precompute had unsorted or duplicate entries: entry indices are not stable");
+    if (h->n_levels < 2) return fail(SMG_ERR_INVALID, "smg_precompute_values_device: single-level hierarchies take the full smg_precompute");
+    DeviceScope dsc(h->device);
+    if (!h->recipes_built) { int rc = build_recipes(h); if (rc) return rc; }
+    int rc = precompute_values_device(h, d_val);
+    if (rc != SMG_OK) h->precomputed = false;
+    return rc;
+}
+
+struct smg_assembler {
+    smg::AssemblyPlan plan;
+    smg::DevBuf<int> F, l_ptr, l_idx, m_ptr, m_idx, diag_of;
+    smg::DevBuf<signed char> l_sgn;
+    smg::DevBuf<double> Qc, Qm, Md;
+};
+
+static int smg_assembler_create_impl(const int* F, int nF, int nV, smg_assembler** out)
+{
+    if (!F || nF <= 0 || nV <= 0 || !out) return fail(SMG_ERR_INVALID, "smg_assembler_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SMG_ERR_NO_DEVICE, "no HIP device: libsmg has no CPU fallback");
+    smg_assembler* a = new (std::nothrow) smg_assembler();
+    if (!a) return fail(SMG_ERR_ALLOC, "out of memory");
+    std::vector<int> Fv(F, F + (size_t)nF * 3);
+    for (int v : Fv) if (v < 0 || v >= nV) { delete a; return fail(SMG_ERR_INVALID, "face index out of range"); }
+    a->plan = make_assembly_plan(Fv, nV);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = a->F.upload(Fv);
+    if (e == hipSuccess) e = a->l_ptr.upload(a->plan.l_ptr);
+    if (e == hipSuccess) e = a->l_idx.upload(a->plan.l_idx);
+    if (e == hipSuccess) e = a->l_sgn.upload(a->plan.l_sgn);
+    if (e == hipSuccess) e = a->m_ptr.upload(a->plan.m_ptr);
+    if (e == hipSuccess) e = a->m_idx.upload(a->plan.m_idx);
+    if (e == hipSuccess) e = a->diag_of.upload(a->plan.diag_of);
+    if (e == hipSuccess) e = a->Qc.alloc((size_t)nF * 3);
+    if (e == hipSuccess) e = a->Qm.alloc((size_t)nF * 3);
+    if (e == hipSuccess) e = a->Md.alloc((size_t)nV);
+    if (e != hipSuccess) { delete a; return fail(SMG_ERR_HIP, "smg_assembler_create: %s", hipGetErrorString(e)); }
+    *out = a;
+    return SMG_OK;
+}
+
+extern "C" int smg_assembler_create(const int* F, int nF, int nV, smg_assembler** out)
+{
+    return guarded("smg_assembler_create", [&]() { return smg_assembler_create_impl(F, nF, nV, out); });
+}
+extern "C" void smg_assembler_destroy(smg_assembler* a) { delete a; }
+extern "C" int smg_assembler_pattern(const smg_assembler* a, int* nnz, int* rowptr, int* col)
+{
+    if (!a) return fail(SMG_ERR_INVALID, "null assembler");
+    if (nnz) *nnz = (int)a->plan.pattern.nnz();
+    if (rowptr) std::copy(a->plan.pattern.ptr.begin(), a->plan.pattern.ptr.end(), rowptr);
+    if (col) std::copy(a->plan.pattern.col.begin(), a->plan.pattern.col.end(), col);
+    return SMG_OK;
+}
+extern "C" int smg_assemble(smg_assembler* a, const double* d_V, int voronoi, double mass_coef, double lap_coef, double* d_val,
+                            double* d_mass, double* d_Lval, void* hip_stream)
+{
+    if (!a || !d_V || !d_val) return fail(SMG_ERR_INVALID, "smg_assemble: bad arguments");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(launch_assemble(a->plan.nV, a->plan.nF, (int)a->plan.pattern.nnz(), d_V, a->F.p, voronoi, a->l_ptr.p, a->l_idx.p, a->l_sgn.p,
+                           a->m_ptr.p, a->m_idx.p, a->diag_of.p, a->Qc.p, a->Qm.p, a->Md.p, mass_coef, lap_coef, d_val, d_Lval, st));
+    if (d_mass) HIPCHK(hipMemcpyAsync(d_mass, a->Md.p, (size_t)a->plan.nV * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return SMG_OK;
+}
+
+static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
+                              const int* known, int n_known)
+{
+    if (!h || n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_precompute: bad arguments");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_precompute called between smg_solve_begin and smg_solve_end");
+    if (known == nullptr) n_known = 0;
+    if (n_known < 0 || n_known >= n) return fail(SMG_ERR_INVALID, "smg_precompute: n_known = %d must be in [0, n)", n_known);
+    StageTimer tmv;
+    if (const char* e = check_compressed(n, n, rowptr, col)) return fail(SMG_ERR_INVALID, "smg_precompute: %s", e);
+    tmv.lap("precompute: input check");
+    const uint64_t key = precompute_key(h, n, rowptr, col, known, n_known);
+    tmv.lap("precompute: pattern key");
+    if (h->precomputed && h->device >= 0 && key == h->pre_key && h->input_canonical && h->n_levels > 1 && env_int("SMG_NO_FAST_PRECOMPUTE", 0) == 0) {
+        DeviceScope dsc(h->device);
+        // same sparsity, same constraints, same prolongations: only the values changed
+        int rc = SMG_OK;
+        if (!h->recipes_built) rc = build_recipes(h);
+        if (rc == SMG_OK) {
+            hipError_t e = hipMemcpyAsync(h->d_Afull.p, val, (size_t)rowptr[n] * sizeof(double), hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) rc = fail(SMG_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+        if (rc == SMG_OK && tmv.on) { (void)hipStreamSynchronize(h->stream); tmv.lap("precompute: values to the device"); }
+        if (rc == SMG_OK) rc = precompute_values_device(h, h->d_Afull.p);
+        tmv.lap("precompute: value-only device work");
+        if (rc != SMG_OK) h->precomputed = false;
+        return rc;
+    }
+    h->precomputed = false;
+    h->recipes_built = false;
+    h->host_stale = false;
+    Csr A = csr_from_arrays(n, n, rowptr, col, val);
+    h->input_canonical = (A.nnz() == (long)rowptr[n]) && std::equal(A.col.begin(), A.col.end(), col);
+    int rc = precompute_host(h, std::move(A), known, n_known);
+    if (rc != SMG_OK) return rc;
+    rc = ensure_device(h);
+    if (rc != SMG_OK) return rc;
+    DeviceScope dsc(h->device);
+    rc = precompute_device(h);
+    if (rc != SMG_OK) return rc;
+    h->pre_key = key;
+    h->precomputed = true;
+    return SMG_OK;
+}
+
+extern "C" int smg_precompute(smg_hierarchy* h, int n, const int* rowptr, const int* col, const double* val,
+                              const int* known, int n_known)
+{
+    return guarded("smg_precompute", [&]() { return smg_precompute_impl(h, n, rowptr, col, val, known, n_known); });
+}

@@ -20,11 +20,16 @@ class EmptyEngine:
     """A rank that owns no column (k < world size): it contributes 0 to the reduction and follows the others' decision, so that
     every rank still takes part in every all-reduce."""
 
-    def __init__(self, tol, device=None):
+    def __init__(self, tol, device=None, sync=None):
+        """sync: callable that waits for the stream the reduction was enqueued on (StreamAllReduce runs on a raw HIP stream that
+        torch's current stream is not ordered after); default: torch.cuda.synchronize() for a CUDA tensor."""
         import torch
         self.tol = tol
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
         self.done, self.r_his = False, []
+        if sync is None and self.sumsq.is_cuda:
+            sync = torch.cuda.synchronize
+        self._sync = sync
 
     def begin(self):
         pass
@@ -36,6 +41,8 @@ class EmptyEngine:
     def cycle(self, sumsq):
         if self.done:
             return
+        if self._sync is not None:
+            self._sync()
         r = float(sumsq.item()) ** 0.5
         self.r_his.append(r)
         if r < self.tol or r != r:
@@ -102,7 +109,7 @@ def sharded_solve_overlapped(engine, max_iter, all_reduce_async, check_every=1):
     engine.begin()
     it = 0
     while it < max_iter:
-        chunk = min(check_every, max_iter - it)
+        chunk = min(max(1, check_every), max_iter - it)   # check_every = 0 (the library's "adaptive") means 1 here
         for _ in range(chunk):
             t = engine.residual_sumsq()
             work = all_reduce_async(t)
@@ -127,7 +134,7 @@ def sharded_solve(engine, max_iter, all_reduce, check_every=1):
     engine.begin()
     it = 0
     while it < max_iter:
-        chunk = min(check_every, max_iter - it)
+        chunk = min(max(1, check_every), max_iter - it)   # check_every = 0 (the library's "adaptive") means 1 here
         for _ in range(chunk):
             t = engine.residual_sumsq()
             all_reduce(t)
@@ -216,10 +223,11 @@ class StreamAllReduce:
         bootstrap hang on this rank, the rank gives up after `timeout_s`, and the final agreement turns that into False everywhere."""
         import threading
         import torch.distributed as dist
-        group = None
+        group = final_group = None
         if self.world > 1:
             import datetime
             group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=2 * timeout_s + 60))
+            final_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=2 * timeout_s + 60))
         finished = threading.Event()
         verdict = [False]
 
@@ -229,18 +237,20 @@ class StreamAllReduce:
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        if not finished.wait(timeout_s):
+        timed_out = not finished.wait(timeout_s)
+        if timed_out:
             self.err = "RCCL bootstrap timed out after %.0f s" % timeout_s
-            self._abandoned = True
+            self._abandoned = True     # a communicator that still arrives on the helper thread is destroyed there (_connect)
             verdict[0] = False
-            # the helper thread may still sit in a bootstrap-group collective: the final agreement must not share the group with it
-            self.ok = False
-            return False
+        # The final agreement runs on ITS OWN group (the helper thread of a timed-out rank may still sit in a collective of the
+        # bootstrap group), so a rank that gave up still says so and its peers leave at once instead of waiting out their own deadline.
         try:
-            self.ok = self._agree(group, bool(verdict[0])) and bool(verdict[0])
-        except Exception as e:   # a rank gave up on its deadline and never reached the agreement
+            self.ok = self._agree(final_group, bool(verdict[0])) and bool(verdict[0])
+        except Exception as e:
             self.err = self.err or repr(e)
             self.ok = False
+        if timed_out:
+            return False
         if not self.ok and self.comm is not None:
             try:
                 self.L.ncclCommDestroy(self.comm)
@@ -293,7 +303,14 @@ class StreamAllReduce:
             if not self._agree(group, good):
                 self.err = self.err or "known-answer all-reduce gave %r (rc=%d)" % (got, rc)
                 return False
-            return not getattr(self, "_abandoned", False)
+            if getattr(self, "_abandoned", False):   # connect() gave up on this rank meanwhile: nobody will use (or close) this communicator
+                try:
+                    self.L.ncclCommDestroy(self.comm)
+                except Exception:
+                    pass
+                self.comm = None
+                return False
+            return True
         except Exception as e:   # pragma: no cover
             self.err = repr(e)
             return False

@@ -1,5 +1,5 @@
 """CPU: the AddressSanitizer + UndefinedBehaviorSanitizer lane for the host C++ ("Race detection / sanitizers").
-Builds lib/libsmg_asan.so (surface_multigrid_code_amd/build.py: the five host translation units through g++ -fsanitize=address,undefined,
+Builds lib/libsmg_asan.so (surface_multigrid_code_amd/build.py: the host translation units through g++ -fsanitize=address,undefined,
 the device object unchanged) and runs, in a child python with libasan preloaded and SMG_LIB pointing at it,
   * the host-logic and ABI tests (precompute slices / Galerkin products / orderings / decimator invariants / malformed inputs / save+load),
   * tools/fuzz_host.py: random meshes through all three decimators and the host half of the precompute.
