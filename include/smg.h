@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMG_VERSION 210
+#define SMG_VERSION 300
 
 enum {
     SMG_OK = 0,
@@ -163,6 +163,28 @@ int smg_mg_precompute_subdiv(const double *V, int nV, const int *F, int nF, int 
  * To the V-cycle the block system is a plain sparse matrix. */
 int smg_mg_precompute_block(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                             smg_hierarchy **out);
+/* Block (3 x 3) kernels for such hierarchies.  The reference runs its scalar kernels on the 3n x 3n system its caller assembles
+ * (06_example_balloon_sim/sim_utils/implicit_euler_mg_balloon.h:63-76: an elasticity Hessian, one 3 x 3 block per vertex pair).
+ * smg_precompute recognises the structure -- every prolongation of the form Pv (x) I_3 (however the handle got them: this builder,
+ * smg_level_set_prolong, a file), no constraints, n % 3 == 0 -- and then keeps the level matrices in 3 x 3 blocks (76 instead of
+ * 108 bytes per block), numbers VERTICES colour-major and lets one lane update the three DOFs 3v, 3v+1, 3v+2 of its vertex in order:
+ * the reference's lexicographic Gauss-Seidel sweep (src/mg_VCycle.cpp:146-160) on that numbering, with as many launches per sweep as
+ * the vertex graph has colours; P (x) I_3 is applied from Pv.  Results: the reference algorithm on the scalar matrix, bit for bit
+ * per kernel in the device numbering (smg_level_get_matrix(..., internal = 1) is the scalar matrix in it).
+ * mode: -1 (default) decide at smg_precompute: structure present AND the blocks of A at least half full (kron(S, I_3) is better
+ * served as three right-hand sides of a scalar problem); 0 never; 3 required (smg_precompute fails when the structure is absent).
+ * Not available on block hierarchies: constraints (`known` selects the scalar path), the mixed-precision cycle. */
+int smg_hierarchy_set_block_mode(smg_hierarchy *h, int mode);
+int smg_hierarchy_block_size(const smg_hierarchy *h);   /* 1 or 3: what the last smg_precompute decided */
+/* block image of A_lv (lv < n_levels - 1, block hierarchies only): stored 3 x 3 blocks, allocated block slots (SELL padding
+ * included), vertex colours = launches per Gauss-Seidel sweep */
+int smg_level_block_stats(const smg_hierarchy *h, int lv, long *n_blocks, long *n_block_slots, int *n_vertex_colors);
+/* The block SELL image of A_lv as the device holds it (tests; built on the host, works without a GPU once the host half of
+ * smg_precompute has run on a block hierarchy).  Slices of <= 64 vertices, one lane per vertex; panel column j of slice s: block column
+ * col[(slice_off[s] + j) * 64 + lane] (-1 = padding) and value plane e = 3 * row_in_block + col_in_block at
+ * val[((slice_off[s] + j) * 9 + e) * 64 + lane].  Query n_slices / n_panel_cols with NULL arrays first. */
+int smg_level_get_block_image(const smg_hierarchy *h, int lv, int *n_slices, int *n_panel_cols, int *slice_row, int *slice_off, int *slice_w,
+                              int *col, double *val);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],
  * and for lv >= 1: i32 n_rows i32 n_cols i32 nnz i32 ptr[n_rows+1] i32 col[nnz] f64 val[nnz]. */
@@ -270,7 +292,8 @@ int smg_level_get_colors(const smg_hierarchy *h, int lv, int *n_colors, int *col
 int smg_level_get_Adiag(const smg_hierarchy *h, int lv, double *diag);          /* mg[lv].A_diag, caller numbering */
 int smg_get_unknown(const smg_hierarchy *h, int *n_unknown, int *unknown /* or NULL */);
 int smg_level_sell_stats(const smg_hierarchy *h, int lv, int which, long *stored, long *padded, int *n_slices);
-/* algorithmic bytes of one y = A_lv x with k columns: 12 nnz + 4 (n+1) + 16 n k   */
+/* algorithmic bytes of one y = A_lv x with k columns: 12 nnz + 4 (n+1) + 16 n k  (SURVEY.md section 8d); on a block hierarchy
+ * 76 per 3 x 3 block (72 of values + 4 of block column) + 4 (n/3 + 1) + 16 n k */
 long smg_level_spmv_bytes(const smg_hierarchy *h, int lv, int k);
 /* algorithmic bytes of one V(pre,post) cycle incl. the outer residual evaluation, k columns */
 long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);

@@ -88,6 +88,10 @@ def load():
         "smg_level_get_Adiag": (i, [vp, i, dp]),
         "smg_get_unknown": (i, [vp, ip, ip]),
         "smg_level_sell_stats": (i, [vp, i, i, lp, lp, ip]),
+        "smg_hierarchy_set_block_mode": (i, [vp, i]),
+        "smg_hierarchy_block_size": (i, [vp]),
+        "smg_level_block_stats": (i, [vp, i, lp, lp, ip]),
+        "smg_level_get_block_image": (i, [vp, i, ip, ip, ip, ip, ip, ip, dp]),
         "smg_level_spmv_bytes": (C.c_long, [vp, i, i]),
         "smg_vcycle_bytes": (C.c_long, [vp, i, i, i]),
         "smg_prof_enable": (i, [vp, i]),

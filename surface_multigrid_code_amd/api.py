@@ -257,6 +257,29 @@ class Hierarchy:
                                          C.byref(ns)), "smg_level_sell_stats")
         return {"stored": st.value, "padded": pd.value, "n_slices": ns.value}
 
+    # ---- block (3-DOF) variant
+    def set_block_mode(self, mode="auto"):
+        """'auto' (decide at precompute), 'scalar' (never), 'block' (3 x 3 kernels required)."""
+        _chk(self.L.smg_hierarchy_set_block_mode(self.h, {"auto": -1, "scalar": 0, "block": 3}.get(mode, mode)), "smg_hierarchy_set_block_mode")
+
+    def block_size(self):
+        return self.L.smg_hierarchy_block_size(self.h)
+
+    def block_stats(self, lv=0):
+        nb, ns, nc = C.c_long(), C.c_long(), C.c_int()
+        _chk(self.L.smg_level_block_stats(self.h, lv, C.byref(nb), C.byref(ns), C.byref(nc)), "smg_level_block_stats")
+        return {"blocks": nb.value, "block_slots": ns.value, "vertex_colors": nc.value}
+
+    def block_image(self, lv=0):
+        """The block SELL image of A_lv (host-built twin of what the device holds): dict of slice_row, slice_off, slice_w, col (slots x 64),
+        val (slots x 9 x 64)."""
+        ns, npc = C.c_int(), C.c_int()
+        _chk(self.L.smg_level_get_block_image(self.h, lv, C.byref(ns), C.byref(npc), None, None, None, None, None), "smg_level_get_block_image")
+        sr, so, sw = np.zeros(ns.value + 1, np.int32), np.zeros(ns.value + 1, np.int32), np.zeros(ns.value, np.int32)
+        col, val = np.zeros(npc.value * 64, np.int32), np.zeros(npc.value * 9 * 64, np.float64)
+        _chk(self.L.smg_level_get_block_image(self.h, lv, None, None, _ip(sr), _ip(so), _ip(sw), _ip(col), _dp(val)), "smg_level_get_block_image")
+        return {"slice_row": sr, "slice_off": so, "slice_w": sw, "col": col.reshape(-1, 64), "val": val.reshape(-1, 9, 64)}
+
     def spmv_bytes(self, lv=0, k=1):
         return self.L.smg_level_spmv_bytes(self.h, lv, k)
 

@@ -1,0 +1,254 @@
+// smg_bsr3_device.hip -- gfx950 kernels of the block (3 degrees of freedom per vertex) variant.
+// Layout and rationale: smg_bsr3.hpp.  One wavefront = one slice of 64 VERTICES, one lane = one vertex = three matrix rows
+// (3v, 3v+1, 3v+2); a wave's load of one value plane of one panel column is 512 contiguous bytes, of the block columns 256.
+// HBM-bound like the scalar kernels (76 bytes per 3 x 3 block against 18 flops): no MFMA.
+//
+// Arithmetic: per row the products are added sequentially in ascending column order (block by block, inside a block by column),
+// multiply and add separate (-ffp-contract=off) -- the reference's Eigen kernels on the scalar 3n x 3n matrix, bit for bit; a
+// Gauss-Seidel lane finishes row 3v before it starts row 3v+1, which reads the new value of 3v (the reference's lexicographic
+// sweep, src/mg_VCycle.cpp:146-160, on the colour-major vertex numbering).
+#include <hip/hip_runtime.h>
+
+#include "smg_device.hpp"
+#include "smg_device_inl.hpp"
+
+namespace smg {
+
+template <bool LD1>
+__device__ __forceinline__ void gather3(const double* x, int c, int ld, bool use, double (&out)[3])
+{
+    if constexpr (LD1) {
+        gather_kb<3, double>(x + (size_t)3 * (size_t)(c < 0 ? 0 : c), use, out);
+    } else {
+        const size_t o = (size_t)3 * (size_t)(c < 0 ? 0 : c) * (size_t)ld;
+        out[0] = use ? x[o] : 0.0;
+        out[1] = use ? x[o + (size_t)ld] : 0.0;
+        out[2] = use ? x[o + 2 * (size_t)ld] : 0.0;
+    }
+}
+
+// MODE: SELL_AX, SELL_RESID, SELL_RESID_SS, SELL_GS, SELL_JACOBI, SELL_CHEBY (smg_device.hpp; same meaning per scalar row).
+// x / b / y / dvec: row-major (3 n_v) x ld blocks, already offset to the column this launch handles.
+template <int MODE, bool LD1>
+__global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_val, const int* a_slice_off, const int* a_slice_row, const int* a_slice_w,
+                                              const int* a_order, int s_begin, int s_end, int n_blocks, int use_order, const double* x, const double* b,
+                                              double* y, int ld, const int* done, double* partials, double omega, double c1, double* dvec)
+{
+    constexpr bool GS = MODE == SELL_GS, JAC = MODE == SELL_JACOBI, CHEB = MODE == SELL_CHEBY, SS = MODE == SELL_RESID_SS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bid = xcd_remap(blockIdx.x, n_blocks);
+    const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
+    double ss = 0.0;
+    int stop = 0;
+    if (ls < s_end) {
+        const int s = (!GS && use_order) ? a_order[ls] : ls;
+        stop = load_flag(done);
+        const int off = a_slice_off[s], w = a_slice_w[s];
+        const int row0 = a_slice_row[s], nrow = a_slice_row[s + 1] - row0;
+        const int vtx = row0 + lane;
+        const bool live = lane < nrow;
+        const int* cp = a_col + (size_t)off * 64 + lane;
+        const double* vp = a_val + (size_t)off * 9 * 64 + lane;
+        const size_t o0 = (size_t)3 * (size_t)vtx * (size_t)ld;
+        double bv[3] = {0.0, 0.0, 0.0}, dold[3] = {0.0, 0.0, 0.0};
+        if (MODE != SELL_AX && live) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) bv[d] = b[o0 + (size_t)d * ld];
+        }
+        if (CHEB && live && c1 != 0.0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) dold[d] = dvec[o0 + (size_t)d * ld];
+        }
+        double out[3] = {0.0, 0.0, 0.0};
+        if constexpr (!GS) {
+            // the three rows of a vertex are independent: one pass over the block row
+            constexpr int U = 4;
+            double acc[3] = {0.0, 0.0, 0.0}, diag[3] = {1.0, 1.0, 1.0}, xi[3] = {0.0, 0.0, 0.0};
+            for (int j0 = 0; j0 < w; j0 += U) {
+                int c[U];
+                double v[U][9], xg[U][3];
+#pragma unroll
+                for (int t = 0; t < U; t++) {
+                    if (j0 + t < w) {   // wave-uniform
+                        c[t] = cp[(size_t)(j0 + t) * 64];
+#pragma unroll
+                        for (int e = 0; e < 9; e++) v[t][e] = vp[((size_t)(j0 + t) * 9 + e) * 64];
+                    } else {
+                        c[t] = -1;
+#pragma unroll
+                        for (int e = 0; e < 9; e++) v[t][e] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < U; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
+#pragma unroll
+                for (int t = 0; t < U; t++) {
+                    if (c[t] >= 0) {
+                        const bool own = c[t] == vtx;
+#pragma unroll
+                        for (int d = 0; d < 3; d++)
+#pragma unroll
+                            for (int e = 0; e < 3; e++) {
+                                if ((JAC || CHEB) && own && e == d) { diag[d] = v[t][3 * d + e]; xi[d] = xg[t][e]; }
+                                else acc[d] += v[t][3 * d + e] * xg[t][e];
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                if (MODE == SELL_AX) out[d] = acc[d];
+                else if (MODE == SELL_RESID) out[d] = bv[d] - acc[d];
+                else if (JAC) { const double t = (bv[d] - acc[d]) / diag[d]; out[d] = xi[d] + omega * (t - xi[d]); }
+                else if (CHEB) {
+                    const double t = (bv[d] - acc[d]) / diag[d];
+                    const double r = t - xi[d];
+                    const double dn = c1 != 0.0 ? c1 * dold[d] + omega * r : omega * r;
+                    out[d] = xi[d] + dn;
+                    dold[d] = dn;
+                }
+                else if (live) { const double t = bv[d] - acc[d]; ss += t * t; }
+            }
+        } else {
+            // Gauss-Seidel: row 3v, then 3v+1 with the new value of 3v, then 3v+2 with both.  Each row streams its own three value
+            // planes; the block columns and the gathers are repeated (they hit L1/L2: the same lines as a moment ago).
+            constexpr int U = 8;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                double acc = 0.0, diag = 1.0;
+                for (int j0 = 0; j0 < w; j0 += U) {
+                    int c[U];
+                    double v[U][3], xg[U][3];
+#pragma unroll
+                    for (int t = 0; t < U; t++) {
+                        if (j0 + t < w) {
+                            c[t] = cp[(size_t)(j0 + t) * 64];
+#pragma unroll
+                            for (int e = 0; e < 3; e++) v[t][e] = vp[((size_t)(j0 + t) * 9 + 3 * d + e) * 64];
+                        } else {
+                            c[t] = -1;
+#pragma unroll
+                            for (int e = 0; e < 3; e++) v[t][e] = 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < U; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
+#pragma unroll
+                    for (int t = 0; t < U; t++) {
+                        if (c[t] >= 0) {
+                            const bool own = c[t] == vtx;
+#pragma unroll
+                            for (int e = 0; e < 3; e++) {
+                                if (own && e == d) diag = v[t][e];
+                                else acc += v[t][e] * ((own && e < d) ? out[e] : xg[t][e]);
+                            }
+                        }
+                    }
+                }
+                out[d] = (bv[d] - acc) / diag;
+            }
+        }
+        if (live && !stop && !SS) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                y[o0 + (size_t)d * ld] = out[d];
+                if (CHEB) dvec[o0 + (size_t)d * ld] = dold[d];
+            }
+        }
+        if (SS && stop) ss = 0.0;
+    }
+    if constexpr (SS) {
+        __shared__ double red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0 && !stop) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+int bsr3_blocks(int n_slices) { return (n_slices + 3) / 4; }
+
+template <int MODE>
+static hipError_t launch_bsr3_mode(const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
+                                   double* partials, int* n_blocks, hipStream_t st, double omega, double c1, double* dvec)
+{
+    const int ns = s_end - s_begin;
+    if (n_blocks) *n_blocks = 0;
+    if (ns <= 0) return hipSuccess;
+    const int nb = bsr3_blocks(ns);
+    const int* done = ctrl ? &ctrl->done : never_done();
+    const int use_order = (A.order && s_begin == 0 && s_end == A.n_slices) ? 1 : 0;
+    for (int c = 0; c < k; c++) {
+        const double* xx = x ? x + c : nullptr;
+        const double* bb = b ? b + c : nullptr;
+        double* yy = y ? y + c : nullptr;
+        double* dd = dvec ? dvec + c : nullptr;
+        double* pp = partials ? partials + (size_t)c * nb : nullptr;
+        if (k == 1)
+            hipLaunchKernelGGL((k_bsr3<MODE, true>), dim3(nb), dim3(256), 0, st, A.col, A.val, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
+                               use_order, xx, bb, yy, k, done, pp, omega, c1, dd);
+        else
+            hipLaunchKernelGGL((k_bsr3<MODE, false>), dim3(nb), dim3(256), 0, st, A.col, A.val, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
+                               use_order, xx, bb, yy, k, done, pp, omega, c1, dd);
+    }
+    if (n_blocks) *n_blocks = nb * k;
+    return hipGetLastError();
+}
+
+hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
+                       double* partials, int* n_blocks, hipStream_t st, double omega, double c1, double* dvec)
+{
+    switch (mode) {
+        case SELL_AX: return launch_bsr3_mode<SELL_AX>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_RESID: return launch_bsr3_mode<SELL_RESID>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_RESID_SS: return launch_bsr3_mode<SELL_RESID_SS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_GS: return launch_bsr3_mode<SELL_GS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_JACOBI: return launch_bsr3_mode<SELL_JACOBI>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_CHEBY: return launch_bsr3_mode<SELL_CHEBY>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Gershgorin bound of D^-1 A over the scalar rows of the block matrix (see k_gershgorin): explicit zeros add |0| = 0.
+__global__ __launch_bounds__(256) void k_bsr3_gershgorin(const int* a_col, const double* a_val, const int* a_slice_off, const int* a_slice_row, const int* a_slice_w,
+                                                         int n_slices, unsigned long long* out)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double ratio = 0.0;
+    if (s < n_slices) {
+        const int row0 = a_slice_row[s], nrow = a_slice_row[s + 1] - row0, w = a_slice_w[s], off = a_slice_off[s];
+        const int* cp = a_col + (size_t)off * 64 + lane;
+        const double* vp = a_val + (size_t)off * 9 * 64 + lane;
+        double sum[3] = {0.0, 0.0, 0.0}, diag[3] = {0.0, 0.0, 0.0};
+        for (int j = 0; j < w; j++) {
+            const int c = cp[(size_t)j * 64];
+            if (c < 0) continue;
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const double v = vp[((size_t)j * 9 + 3 * d + e) * 64];
+                    sum[d] += fabs(v);
+                    if (c == row0 + lane && e == d) diag[d] = v;
+                }
+        }
+        if (lane < nrow)
+#pragma unroll
+            for (int d = 0; d < 3; d++) if (diag[d] > 0.0) ratio = fmax(ratio, sum[d] / diag[d]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ratio = fmax(ratio, __shfl_down(ratio, o, 64));
+    if (lane == 0 && ratio > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(ratio));
+}
+
+hipError_t launch_bsr3_gershgorin(const Bsr3Dev& A, double* out, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess || A.n_slices <= 0) return e;
+    hipLaunchKernelGGL(k_bsr3_gershgorin, dim3((A.n_slices + 3) / 4), dim3(256), 0, st, A.col, A.val, A.slice_off, A.slice_row, A.slice_w, A.n_slices,
+                       (unsigned long long*)out);
+    return hipGetLastError();
+}
+
+}  // namespace smg

@@ -157,6 +157,23 @@ hipError_t SellBuf::upload_long(const std::vector<int>& rows, const std::vector<
     return hipSuccess;
 }
 
+hipError_t Bsr3Buf::upload(const Bsr3Sell& S)
+{
+    hipError_t e;
+    if ((e = slice_row.upload(S.slice_row)) != hipSuccess) return e;
+    if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
+    if ((e = slice_w.upload(S.slice_w)) != hipSuccess) return e;
+    if ((e = col.upload(S.col)) != hipSuccess) return e;
+    if ((e = val.upload(S.val)) != hipSuccess) return e;
+    if ((e = order.upload(S.region_order)) != hipSuccess) return e;
+    view.n_vert = S.n_vert; view.n_slices = S.n_slices; view.w_max = S.w_max;
+    view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.slice_w = slice_w.p; view.col = col.p; view.val = val.p;
+    view.order = S.region_order.empty() ? nullptr : order.p;
+    color_slice_ptr = S.color_slice_ptr;
+    stored = S.nnz_scalar; blocks = S.n_blocks; padded = (long)S.val.size();
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------------ profc mirror
 int smg::prof_scope_id(smg_hierarchy* h, const char* name)
 {
@@ -231,6 +248,46 @@ extern "C" int smg_hierarchy_set_smoother(smg_hierarchy* h, int smoother, double
     if (omega > 0.0) h->omega = omega;
     if (jacobi_max_rows >= 0) h->jacobi_max_rows = jacobi_max_rows;
     return SMG_OK;
+}
+
+extern "C" int smg_hierarchy_set_block_mode(smg_hierarchy* h, int mode)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "null handle");
+    if (mode != -1 && mode != 0 && mode != 3) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_block_mode: mode must be -1 (automatic), 0 (scalar) or 3");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_block_mode called during a split-phase solve");
+    if (mode != h->block_mode) { h->block_mode = mode; h->precomputed = false; }   // the next smg_precompute is a full one
+    return SMG_OK;
+}
+extern "C" int smg_hierarchy_block_size(const smg_hierarchy* h) { return h ? h->bs : SMG_ERR_INVALID; }
+extern "C" int smg_level_block_stats(const smg_hierarchy* h, int lv, long* n_blocks, long* n_block_slots, int* n_vertex_colors)
+{
+    if (!h || lv < 0 || lv >= h->n_levels - 1) return fail(SMG_ERR_INVALID, "smg_level_block_stats: bad level");
+    if (h->bs != 3 || !h->precomputed) return fail(SMG_ERR_INVALID, "smg_level_block_stats: not a precomputed block hierarchy");
+    const Bsr3Buf& B = h->lv[lv].bA;
+    if (n_blocks) *n_blocks = B.blocks;
+    if (n_block_slots) *n_block_slots = B.padded / 9;
+    if (n_vertex_colors) *n_vertex_colors = h->lv[lv].vord.n_colors();
+    return SMG_OK;
+}
+
+extern "C" int smg_level_get_block_image(const smg_hierarchy* h, int lv, int* n_slices, int* n_panel_cols, int* slice_row, int* slice_off, int* slice_w,
+                                         int* col, double* val)
+{
+    return guarded("smg_level_get_block_image", [&]() {
+        if (!h || lv < 0 || lv >= h->n_levels - 1) return fail(SMG_ERR_INVALID, "smg_level_get_block_image: bad level");
+        const Level& Lv = h->lv[lv];
+        if (h->bs != 3 || Lv.A_int.nr != Lv.n || Lv.n == 0 || (int)Lv.vord.perm.size() * 3 != Lv.n)
+            return fail(SMG_ERR_INVALID, "smg_level_get_block_image: the host half of smg_precompute has not run on a block hierarchy");
+        const Bsr3Sell S = build_bsr3(Lv.A_int, &Lv.vord.color_ptr, false);
+        if (n_slices) *n_slices = S.n_slices;
+        if (n_panel_cols) *n_panel_cols = S.slice_off.back();
+        if (slice_row) std::copy(S.slice_row.begin(), S.slice_row.end(), slice_row);
+        if (slice_off) std::copy(S.slice_off.begin(), S.slice_off.end(), slice_off);
+        if (slice_w) std::copy(S.slice_w.begin(), S.slice_w.end(), slice_w);
+        if (col) std::copy(S.col.begin(), S.col.end(), col);
+        if (val) std::copy(S.val.begin(), S.val.end(), val);
+        return (int)SMG_OK;
+    });
 }
 
 extern "C" int smg_hierarchy_set_chebyshev(smg_hierarchy* h, double cheby_fraction)
@@ -396,6 +453,13 @@ extern "C" int smg_level_sell_stats(const smg_hierarchy* h, int lv, int which, l
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_sell_stats: bad level");
     const SellBuf* S = which == 0 ? &h->lv[lv].dA : which == 1 ? &h->lv[lv].dP : which == 2 ? &h->lv[lv].dPT : nullptr;
     if (!S) return fail(SMG_ERR_INVALID, "smg_level_sell_stats: which must be 0,1,2");
+    if (which == 0 && h->bs == 3) {   // scalar entries stored / scalar slots of the 3 x 3 block image
+        const Bsr3Buf& B = h->lv[lv].bA;
+        if (stored) *stored = B.stored;
+        if (padded) *padded = B.padded;
+        if (n_slices) *n_slices = B.view.n_slices;
+        return SMG_OK;
+    }
     if (stored) *stored = S->stored;
     if (padded) *padded = S->used;   // slots read per pass (the allocation may be larger: fixed-stride panels)
     if (n_slices) *n_slices = S->view.n_slices;
@@ -406,6 +470,7 @@ extern "C" long smg_level_spmv_bytes(const smg_hierarchy* h, int lv, int k)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return -1;
     const Csr& A = h->lv[lv].A;
+    if (h->bs == 3 && lv < h->n_levels - 1) return 76L * h->lv[lv].bA.blocks + 4L * (A.nr / 3 + 1) + 16L * A.nr * k;
     return 12L * A.nnz() + 4L * (A.nr + 1) + 16L * A.nr * k;
 }
 

@@ -40,7 +40,10 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.u.p, 0, rows * k * sizeof(double), h->stream));
             Lv.t.release(); Lv.d.release();
             if (lv < L - 1 || L == 1) HIPCHK(Lv.r.alloc(rows * k));
-            if (lv < L - 1 || L == 1) maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
+            if (lv < L - 1 || L == 1) {
+                if (h->bs == 3) maxblocks = std::max(maxblocks, (size_t)bsr3_blocks(Lv.bA.view.n_slices) * (size_t)k);
+                else maxblocks = std::max(maxblocks, (size_t)sell_blocks(Lv.dA.view.n_slices) * ((k + 3) / 4) + (size_t)sell_wide_blocks(Lv.dA.view.n_slices, k));
+            }
         }
         // colour by colour (the level-0 head of an outer iteration, enqueue_residual_ss) every launch rounds its block count up on its own
         maxblocks += (h->lv[0].dA.color_slice_ptr.size() + 1) * (size_t)((k + 3) / 4 + 8);
@@ -69,6 +72,7 @@ static int ensure_work(smg_hierarchy* h, int k)
 static int ensure_fp32(smg_hierarchy* h, int k)
 {
     const int L = h->n_levels;
+    if (h->bs == 3) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available for block (3-DOF) hierarchies");
     if (!h->f32_valid) {
         drop_graphs(h);
         auto mk = [&](SellBuf& src, DevBuf<float>& dst, SellDev& view) -> int {
@@ -185,6 +189,18 @@ template <> struct Prec<double> {
     { return launch_sell(m, V, s0, s1, x, bb, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega); }
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
     { return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p); }
+    // an operation with the level's matrix in whatever format it lives in: SELL panels, or 3 x 3 blocks on block hierarchies.
+    // smoother_image: the matrix the smoother streams (A^T where A is not bit-symmetric), else A.  s1 < 0: all slices.
+    static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const double* x, const double* bb, double* y, int k,
+                          const Ctrl* ctrl, const FirstColour* fc = nullptr, double omega = 1.0)
+    {
+        if (h->bs == 3) {
+            const Bsr3Dev& V = (smoother_image && L.gs_on_transpose) ? L.bAT.view : L.bA.view;
+            return launch_bsr3(m, V, s0, s1 < 0 ? V.n_slices : s1, x, bb, y, k, ctrl, nullptr, nullptr, h->stream, omega, fc ? fc->c1 : 0.0, fc ? fc->d : nullptr);
+        }
+        const SellDev& V = smoother_image ? G(L) : A(L);
+        return sell(m, V, s0, s1 < 0 ? V.n_slices : s1, x, bb, y, k, ctrl, h->stream, nullptr, fc, omega);
+    }
 };
 template <> struct Prec<float> {
     static float* b(Level& L) { return L.b32.p; }
@@ -203,7 +219,20 @@ template <> struct Prec<float> {
     { return launch_sell_f32(m, V, s0, s1, x, bb, y, k, ctrl, st, zero_rows, first, omega); }
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
     { return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p); }
+    static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const float* x, const float* bb, float* y, int k,
+                          const Ctrl* ctrl, const FirstColour* fc = nullptr, double omega = 1.0)
+    {   // (block hierarchies have no fp32 images: ensure_fp32 refuses them)
+        const SellDev& V = smoother_image ? G(L) : A(L);
+        return sell(m, V, s0, s1 < 0 ? V.n_slices : s1, x, bb, y, k, ctrl, h->stream, nullptr, fc, omega);
+    }
 };
+
+// slice ranges of the colours of the matrix the smoother streams
+static const std::vector<int>& colour_slices(const smg_hierarchy* h, const Level& Lv)
+{
+    if (h->bs == 3) return (Lv.gs_on_transpose ? Lv.bAT : Lv.bA).color_slice_ptr;
+    return (Lv.gs_on_transpose ? Lv.dAT : Lv.dA).color_slice_ptr;
+}
 
 // what of a level's first pre-smoothing sweep exists when its V-cycle starts
 enum { FIRST_NONE = 0,
@@ -220,12 +249,11 @@ static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int ite
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
-    const SellBuf& G = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
-    const std::vector<int>& cs = G.color_slice_ptr;
+    const std::vector<int>& cs = colour_slices(h, Lv);
     for (int it = first == FIRST_SWEEP ? 1 : 0; it < iters; it++)
         for (size_t c = (it == 0 && first == FIRST_LAUNCH) ? 1 : 0; c + 1 < cs.size(); c++) {
-            if (it == 1 && first == FIRST_SWEEP) HIPCHK(Prec<T>::sell(SELL_GS_OOP, Prec<T>::G(Lv), cs[c], cs[c + 1], t, b, u, k, ctrl, h->stream));
-            else HIPCHK(Prec<T>::sell(SELL_GS, Prec<T>::G(Lv), cs[c], cs[c + 1], u, b, u, k, ctrl, h->stream));
+            if (it == 1 && first == FIRST_SWEEP) HIPCHK(Prec<T>::sell(SELL_GS_OOP, Prec<T>::G(Lv), cs[c], cs[c + 1], t, b, u, k, ctrl, h->stream));   // (scalar levels only)
+            else HIPCHK(Prec<T>::opA(h, Lv, true, SELL_GS, cs[c], cs[c + 1], u, b, u, k, ctrl));
         }
     return SMG_OK;
 }
@@ -236,9 +264,8 @@ static int enqueue_jacobi(smg_hierarchy* h, int lv, const T* b, T* const buf[2],
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");
-    const SellDev& G = Prec<T>::G(Lv);
     for (int it = 0; it < iters; it++) {
-        HIPCHK(Prec<T>::sell(SELL_JACOBI, G, 0, G.n_slices, buf[*cur], b, buf[1 - *cur], k, ctrl, h->stream, nullptr, nullptr, h->omega));
+        HIPCHK(Prec<T>::opA(h, Lv, true, SELL_JACOBI, 0, -1, buf[*cur], b, buf[1 - *cur], k, ctrl, nullptr, h->omega));
         *cur ^= 1;
     }
     return SMG_OK;
@@ -252,14 +279,13 @@ static int enqueue_cheby(smg_hierarchy* h, int lv, const T* b, T* const buf[2], 
     if (iters <= 0) return SMG_OK;
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");
-    const SellDev& G = Prec<T>::G(Lv);
     std::vector<ChebyCoef> cf;
     cheby_coefs(Lv.lam, h->cheby_fraction, iters + 1, cf);
     for (int s = first_done ? 1 : 0; s <= iters; s++) {
         FirstColour fc;
         Prec<T>::set_d(fc, Lv);
         fc.c1 = cf[s].c1;
-        HIPCHK(Prec<T>::sell(SELL_CHEBY, G, 0, G.n_slices, buf[*cur], b, buf[1 - *cur], k, ctrl, h->stream, nullptr, &fc, cf[s].c2));
+        HIPCHK(Prec<T>::opA(h, Lv, true, SELL_CHEBY, 0, -1, buf[*cur], b, buf[1 - *cur], k, ctrl, &fc, cf[s].c2));
         *cur ^= 1;
     }
     return SMG_OK;
@@ -296,7 +322,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     if (rc) return rc;
     {   // r = B - A u  (:40-42)
         ProfGuard pg(h, "MG: residual");
-        HIPCHK(Prec<T>::sell(SELL_RESID, Prec<T>::A(Lv), 0, Prec<T>::A(Lv).n_slices, buf[cur], Prec<T>::b(Lv), Prec<T>::r(Lv), k, ctrl, h->stream));
+        HIPCHK(Prec<T>::opA(h, Lv, false, SELL_RESID, 0, -1, buf[cur], Prec<T>::b(Lv), Prec<T>::r(Lv), k, ctrl));
     }
     // With uc = 0 the first launch of the coarse level's first pre-smoothing sweep computes (rc_i - 0) / a_ii for the rows it covers
     // (the first colour / with Jacobi all rows, damped): the restriction launch writes that itself, bit for bit the same value, and
@@ -304,7 +330,9 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     const SellBuf& Gc = Lc.gs_on_transpose ? Lc.dAT : Lc.dA;
     const int kind_c = level_kind(h, lv + 1);
     const bool jac_c = kind_c != LV_GS;
-    const bool fuse = fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    // (block hierarchies: the first launch of a coarse sweep is not a plain division -- row 3v+1 of the first colour already reads 3v)
+    const bool fuse = h->bs == 1 && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    const int kt = k * h->bs;   // block hierarchies: dP / dPT hold the vertex-level factor of P (x) I_3, applied to 3 k columns
     {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
         FirstColour fc;
@@ -321,7 +349,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         }
         // Jacobi + fuse: the first sweep's output buffer (t) receives the sweep, u = 0 is never read
         T* init = (fuse && jac_c) ? Prec<T>::t(Lc) : Prec<T>::u(Lc);
-        HIPCHK(Prec<T>::sell(SELL_AX, Prec<T>::PT(Lc), 0, Prec<T>::PT(Lc).n_slices, Prec<T>::r(Lv), nullptr, Prec<T>::b(Lc), k, ctrl, h->stream, init,
+        HIPCHK(Prec<T>::sell(SELL_AX, Prec<T>::PT(Lc), 0, Prec<T>::PT(Lc).n_slices, Prec<T>::r(Lv), nullptr, Prec<T>::b(Lc), kt, ctrl, h->stream, init,
                              fuse ? &fc : nullptr));
     }
     rc = enqueue_vcycle_t<T>(h, lv + 1, k, pre, post, ctrl, fuse ? FIRST_LAUNCH : FIRST_NONE);  // :48
@@ -332,7 +360,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         int dst = cur;
         const int flips = kind == LV_CHEBY ? (post > 0 ? post + 1 : 0) : post;   // buffer switches of the post-smoothing
         if (jac && ((cur + flips) & 1)) dst = 1 - cur;
-        HIPCHK(Prec<T>::sell(SELL_ADD, Prec<T>::P(Lc), 0, Prec<T>::P(Lc).n_slices, Prec<T>::u(Lc), buf[cur], buf[dst], k, ctrl, h->stream));
+        HIPCHK(Prec<T>::sell(SELL_ADD, Prec<T>::P(Lc), 0, Prec<T>::P(Lc).n_slices, Prec<T>::u(Lc), buf[cur], buf[dst], kt, ctrl, h->stream));
         cur = dst;
     }
     if (kind == LV_CHEBY) return enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
@@ -372,7 +400,7 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
 static bool head_fusable(smg_hierarchy* h)
 {
     static const int on = env_int("SMG_FUSE_HEAD", 1);
-    if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on) return false;
+    if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on || h->bs != 1) return false;
     Level& L0 = h->lv[0];
     if (L0.gs_on_transpose) return false;
     const int kind = level_kind(h, 0);
@@ -412,6 +440,8 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
     ProfGuard pg(h, "MG: outer residual");
     if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
         HIPCHK(launch_sell(SELL_RESID_BOTH, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
+    else if (h->bs == 3)
+        HIPCHK(launch_bsr3(SELL_RESID_SS, L0.bA.view, 0, L0.bA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     else
         HIPCHK(launch_sell(SELL_RESID_SS, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     if (fuse_decide) HIPCHK(launch_ss_finalize_decide(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
@@ -892,7 +922,7 @@ extern "C" int smg_apply_A(smg_hierarchy* h, int lv, const double* u, int k, dou
     DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
-    HIPCHK(launch_sell(SELL_AX, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
+    HIPCHK(Prec<double>::opA(h, Lv, false, SELL_AX, 0, -1, Lv.u.p, nullptr, Lv.r.p, k, nullptr));
     return get_block(h, lv, Lv.r.p, k, Au);
 }
 
@@ -903,7 +933,7 @@ extern "C" int smg_restrict(smg_hierarchy* h, int lv, const double* x, int k, do
     DeviceScope dsc(h->device);
     Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
     if ((rc = put_block(h, lv, x, k, Lv.r.p))) return rc;
-    HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k, nullptr, nullptr, nullptr, h->stream));
+    HIPCHK(launch_sell(SELL_AX, Lc.dPT.view, 0, Lc.dPT.view.n_slices, Lv.r.p, nullptr, Lc.b.p, k * h->bs, nullptr, nullptr, nullptr, h->stream));
     return get_block(h, lv + 1, Lc.b.p, k, Rx);
 }
 
@@ -914,7 +944,7 @@ extern "C" int smg_prolong(smg_hierarchy* h, int lv, const double* x, int k, dou
     DeviceScope dsc(h->device);
     Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
     if ((rc = put_block(h, lv + 1, x, k, Lc.u.p))) return rc;
-    HIPCHK(launch_sell(SELL_AX, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.r.p, k, nullptr, nullptr, nullptr, h->stream));
+    HIPCHK(launch_sell(SELL_AX, Lc.dP.view, 0, Lc.dP.view.n_slices, Lc.u.p, nullptr, Lv.r.p, k * h->bs, nullptr, nullptr, nullptr, h->stream));
     return get_block(h, lv, Lv.r.p, k, Px);
 }
 
@@ -968,7 +998,8 @@ extern "C" int smg_residual_norm(smg_hierarchy* h, int lv, const double* B, cons
     std::memset(&zero, 0, sizeof(zero));
     zero.r_his = h->d_rhis.p; zero.his_cap = (int)h->d_rhis.n;
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(launch_sell(SELL_RESID_SS, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, nullptr, k, nullptr, h->d_partials.p, &nb, h->stream));
+    if (h->bs == 3) HIPCHK(launch_bsr3(SELL_RESID_SS, Lv.bA.view, 0, Lv.bA.view.n_slices, Lv.u.p, Lv.b.p, nullptr, k, nullptr, h->d_partials.p, &nb, h->stream));
+    else HIPCHK(launch_sell(SELL_RESID_SS, Lv.dA.view, 0, Lv.dA.view.n_slices, Lv.u.p, Lv.b.p, nullptr, k, nullptr, h->d_partials.p, &nb, h->stream));
     HIPCHK(launch_ss_finalize(h->d_partials.p, nb, h->d_ctrl.p, h->stream));
     double ss = 0.0;
     HIPCHK(hipMemcpyAsync(&ss, &h->d_ctrl.p->sumsq, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -986,6 +1017,11 @@ extern "C" int smg_raw_spmv(smg_hierarchy* h, int lv, int mode, const double* x,
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1 || (mode != SELL_AX && mode != SELL_RESID && mode != SELL_ADD))
         return fail(SMG_ERR_INVALID, "smg_raw_spmv: bad level/mode");
     Level& Lv = h->lv[lv];
+    if (h->bs == 3) {
+        if (mode == SELL_ADD) return fail(SMG_ERR_INVALID, "smg_raw_spmv: y += A x is not available on block (3-DOF) hierarchies");
+        HIPCHK(launch_bsr3((SellMode)mode, Lv.bA.view, 0, Lv.bA.view.n_slices, x, b, y, k, nullptr, nullptr, nullptr, h->stream));
+        return SMG_OK;
+    }
     HIPCHK(launch_sell((SellMode)mode, Lv.dA.view, 0, Lv.dA.view.n_slices, x, b, y, k, nullptr, nullptr, nullptr, h->stream));
     return SMG_OK;
 }
@@ -1027,15 +1063,19 @@ extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int pos
     const int L = h->n_levels;
     for (int lv = 0; lv < L - 1; lv++) {
         const Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
-        const long n = Lv.n, nc = Lc.n, nnz = Lv.A.nnz(), nnzP = Lc.P.nnz();
-        const long sweep = 12 * nnz + 4 * (n + 1) + 24 * n * k;
+        const long n = Lv.n, nc = Lc.n, nnz = Lv.A.nnz();
+        // block hierarchies: 76 bytes per 3 x 3 block and one row pointer per vertex; P (x) I_3 streams the vertex-level factor once
+        const long nnzP = h->bs == 3 ? Lc.Pv.nnz() : Lc.P.nnz();
+        const long matA = h->bs == 3 ? 76 * Lv.bA.blocks + 4 * (n / 3 + 1) : 12 * nnz + 4 * (n + 1);
+        const long sweep = matA + 24 * n * k;
         tot += (long)(pre + post) * sweep;
-        tot += 12 * nnz + 4 * (n + 1) + 24 * n * k;
+        tot += matA + 24 * n * k;
         tot += 12 * nnzP + 4 * (nc + 1) + 8 * n * k + 8 * nc * k;
         tot += 12 * nnzP + 4 * (n + 1) + 8 * nc * k + 16 * n * k;
     }
     const long nc = h->lv[L - 1].n;
     tot += 8 * nc * nc + 24 * nc * k;
-    tot += 12 * h->lv[0].A.nnz() + 4L * (h->lv[0].n + 1) + 16L * h->lv[0].n * k;
+    if (h->bs == 3) tot += 76 * h->lv[0].bA.blocks + 4L * (h->lv[0].n / 3 + 1) + 16L * h->lv[0].n * k;
+    else tot += 12 * h->lv[0].A.nnz() + 4L * (h->lv[0].n + 1) + 16L * h->lv[0].n * k;
     return tot;
 }

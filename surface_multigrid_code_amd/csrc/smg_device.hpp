@@ -110,6 +110,24 @@ hipError_t launch_sell_f32(SellMode mode, const SellDev& A, int s_begin, int s_e
                            const FirstColour* first = nullptr, double omega = 1.0);
 // *out (device double) = max_i (sum_j |a_ij|) / a_ii over the rows of A: the Gershgorin bound of the spectrum of D^-1 A
 hipError_t launch_gershgorin(const SellDev& A, double* out, hipStream_t st);
+// ---- block (3 degrees of freedom per vertex) matrices: smg_bsr3.hpp (layout), smg_bsr3_device.hip (kernels) ------------------------
+struct Bsr3Dev {
+    int n_vert = 0, n_slices = 0, w_max = 0;
+    const int* slice_row = nullptr;  // n_slices + 1 vertex offsets
+    const int* slice_off = nullptr;  // n_slices + 1 panel-column offsets
+    const int* slice_w = nullptr;    // n_slices
+    const int* order = nullptr;      // optional region-major launch order, whole-matrix launches only
+    const int* col = nullptr;        // block columns (vertices), -1 = padding
+    const double* val = nullptr;     // nine planes per panel column
+};
+// modes SELL_AX, _RESID, _RESID_SS, _GS (one vertex colour = slices [s_begin, s_end), in place: y == x), _JACOBI, _CHEBY with the meaning
+// they have per scalar row of the 3n x 3n matrix.  x / b / y / dvec: row-major (3 n_vert) x k.  omega, c1, dvec: as in launch_sell
+// (Jacobi damping; Chebyshev: omega = c2, c1, the update vector).  partials / n_blocks: SELL_RESID_SS, one double per launched block.
+hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
+                       double* partials, int* n_blocks, hipStream_t st, double omega = 1.0, double c1 = 0.0, double* dvec = nullptr);
+hipError_t launch_bsr3_gershgorin(const Bsr3Dev& A, double* out, hipStream_t st);
+int bsr3_blocks(int n_slices);
+
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

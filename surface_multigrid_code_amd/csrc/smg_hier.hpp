@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "smg_bsr3.hpp"
 #include "smg_device.hpp"
 #include "smg_mesh.hpp"
 #include "smg_order.hpp"
@@ -64,6 +65,15 @@ struct SellBuf {  // device image of one SELL matrix
     hipError_t upload_long(const std::vector<int>& rows, const std::vector<int>& ptr, const std::vector<int>& col, const std::vector<double>& val);
 };
 
+struct Bsr3Buf {  // device image of one block (3 x 3) SELL matrix, smg_bsr3.hpp
+    DevBuf<int> slice_row, slice_off, slice_w, col, order;
+    DevBuf<double> val;
+    Bsr3Dev view;
+    std::vector<int> color_slice_ptr;
+    long stored = 0, blocks = 0, padded = 0;   // scalar CSR entries / 3 x 3 blocks / allocated value slots (9 per panel slot)
+    hipError_t upload(const Bsr3Sell& S);
+};
+
 // one element of std::vector<mg_data> (reference src/mg_data.h:11-27)
 struct Level {
     // ---- host, caller numbering: the mg_data fields ----
@@ -79,6 +89,12 @@ struct Level {
     uint64_t ord_key = 0;   // hash of the sparsity pattern `ord` was built for (time-stepping callers re-precompute
                             // with the same pattern every step: the colouring is reused)
     Csr A_int, P_int, PT_int;  // host copies in the internal numbering (introspection / tests)
+    // ---- block (3-DOF) hierarchies (smg_hierarchy::bs == 3): the numbering is a VERTEX colouring, ord = its expansion to DOFs 3v+d;
+    //      A lives in 3 x 3 blocks (bA / bAT instead of dA / dAT), dP / dPT hold the vertex-level factor of P (x) I_3 ----
+    Ordering vord;          // colour-major numbering of the level's vertices
+    Csr Pv, PTv;            // vertex-level factor of P = Pv (x) I_3 and its transpose, caller numbering
+    Bsr3Buf bA, bAT;
+    DevBuf<int> mapB, mapBT;   // value slot of bA / bAT -> index into d_Aval (-1: explicit zero / padding); value-only re-precompute
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
@@ -155,6 +171,10 @@ struct smg_hierarchy {
     smg::DevBuf<double> d_sympart;  // (nc_pad/64)^2 x 64 partial products of the symmetric k = 1 coarse solve (also used as float)
     bool f32_valid = false;
     int kcap32 = 0;
+    // ---- block (3-DOF) variant: 1 = scalar kernels, 3 = the level matrices live in 3 x 3 blocks ----
+    int block_mode = -1;           // smg_hierarchy_set_block_mode: -1 decide at precompute (P = Pv (x) I_3 on every level, no constraints,
+                                   // blocks at least half full), 0 never, 3 required (precompute fails if the structure is not there)
+    int bs = 1;                    // what the last precompute decided
     // ---- execution ----
     int device = -1;
     hipStream_t stream = nullptr;

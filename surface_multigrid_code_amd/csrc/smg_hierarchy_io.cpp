@@ -137,24 +137,17 @@ extern "C" int smg_query_fine_to_coarse(const smg_hierarchy* h, int lv, int n, c
 static int smg_mg_precompute_block_impl(const double* V, int nV, const int* F, int nF, float ratio, int nVCoarsest, int dec_type,
                                        smg_hierarchy** out)
 {
-    int rc = smg_mg_precompute(V, nV, F, nF, ratio, nVCoarsest, dec_type, out);
+    if (!out) return fail(SMG_ERR_INVALID, "smg_mg_precompute_block: bad arguments");
+    smg_hierarchy* raw = nullptr;
+    int rc = smg_mg_precompute(V, nV, F, nF, ratio, nVCoarsest, dec_type, &raw);
     if (rc) return rc;
-    smg_hierarchy* h = *out;
+    HierarchyOwner own(raw);
+    smg_hierarchy* h = own.h;
     for (int lv = 1; lv < h->n_levels; lv++) {
-        const Csr& P = h->lv[lv].P_full;
-        Csr B;
-        B.nr = 3 * P.nr; B.nc = 3 * P.nc;
-        B.ptr.resize((size_t)B.nr + 1);
-        B.col.resize((size_t)3 * P.nnz()); B.val.resize((size_t)3 * P.nnz());
-        int q = 0;
-        for (int r = 0; r < P.nr; r++)
-            for (int d = 0; d < 3; d++) {   // row 3r+d holds P(r,c) at column 3c+d  (src/get_prolong.cpp:108-110)
-                B.ptr[3 * r + d] = q;
-                for (int p = P.ptr[r]; p < P.ptr[r + 1]; p++) { B.col[q] = 3 * P.col[p] + d; B.val[q] = P.val[p]; q++; }
-            }
-        B.ptr[B.nr] = q;
+        Csr B = kron3(h->lv[lv].P_full);   // row 3r+d holds P(r,c) at column 3c+d  (src/get_prolong.cpp:108-110)
         set_prolong(h, lv, std::move(B));
     }
+    *out = own.release();
     return SMG_OK;
 }
 

@@ -84,14 +84,42 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         }
     }
     tm.lap("host: slices / transposes of P");
+    // ---- block (3-DOF) variant?  (smg_bsr3.hpp)  Every prolongation must be Pv (x) I_3 (mg_precompute_block builds them so), no
+    // constraints (they break the Kronecker structure; 06_example_balloon_sim has none), and -- unless the caller insists -- the
+    // 3 x 3 blocks of A must be at least half full (a system like kron(S, I_3) is three scalar problems: the scalar kernels with
+    // k = 3 columns serve it better).
+    h->bs = 1;
+    std::vector<Csr> pat(L);      // bs == 3: the n_v x n_v pattern of the blocks of A_l, the graph the numbering is built on
+    if (h->block_mode != 0 && !h->has_known && L >= 2 && n % 3 == 0) {
+        bool ok = true;
+        for (int lv = 1; lv < L && ok; lv++) ok = kron3_factor(h->lv[lv].P, h->lv[lv].Pv);
+        if (ok) {
+            pat[0] = block_pattern3(h->lv[0].A);
+            const double fill = (double)h->lv[0].A.nnz() / (9.0 * (double)std::max<long>(pat[0].nnz(), 1));
+            if (h->block_mode == 3 || fill >= 0.5) h->bs = 3;
+        }
+        if (h->bs == 3) {
+            std::vector<std::function<void()>> tasks;
+            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); });
+            parallel_tasks(tasks);
+        }
+        tm.lap("host: block structure (P = Pv (x) I_3, block pattern of A_0)");
+    }
+    if (h->block_mode == 3 && h->bs != 3)
+        return fail(SMG_ERR_INVALID, "smg_precompute: block mode was required (smg_hierarchy_set_block_mode) but %s",
+                    h->has_known ? "constraints are given" : (n % 3 || L < 2) ? "the system is not a multi-level 3-DOF system" : "a prolongation is not of the form Pv (x) I_3");
+    const bool blk = h->bs == 3;
+    if (!blk) for (int lv = 0; lv < L; lv++) { h->lv[lv].Pv = Csr(); h->lv[lv].PTv = Csr(); h->lv[lv].vord = Ordering(); }
+    auto graph = [&](int lv) -> const Csr& { return blk ? pat[lv] : h->lv[lv].A; };                 // what a level's numbering is built on
+    auto order_of = [&](int lv) -> Ordering& { return blk ? h->lv[lv].vord : h->lv[lv].ord; };      // ... and where it goes
     // The locality order of the finest level is the longest sequential piece of the whole precompute (a Cuthill-McKee search over
     // all rows) and needs nothing but A_0's pattern: it starts now, on its own thread, beside the Galerkin products.
     auto pattern_key = [&](int lv) {
         const Csr& M = h->lv[lv].A;
         uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
         auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
-        const int hdr[2] = {M.nr, lv < L - 1 ? 1 : 0};
-        mix(hdr, 2); mix(M.ptr.data(), M.ptr.size()); mix(M.col.data(), M.col.size());
+        const int hdr[3] = {M.nr, lv < L - 1 ? 1 : 0, h->bs};
+        mix(hdr, 3); mix(M.ptr.data(), M.ptr.size()); mix(M.col.data(), M.col.size());
         return key;
     };
     static const bool use_rcm = [] { const char* v = std::getenv("SMG_ORDER"); return !(v && std::string(v) == "induced"); }();
@@ -104,7 +132,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         const Level& L0 = h->lv[0];
         if (!(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) rcm0_thread = std::thread([&] {
             const auto t0 = std::chrono::steady_clock::now();
-            rcm0 = rcm_order(h->lv[0].A);
+            rcm0 = rcm_order(graph(0));
             if (tm.on) std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         });
     }
@@ -118,6 +146,12 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         Lv.A = spgemm(tmp, Lv.P);
     }
     tm.lap("host: Galerkin products");
+    if (blk) {
+        std::vector<std::function<void()>> tasks;
+        for (int lv = 1; lv < L - 1; lv++) tasks.push_back([&, lv] { pat[lv] = block_pattern3(h->lv[lv].A); });
+        parallel_tasks(tasks);
+        tm.lap("host: block patterns of the Galerkin levels");
+    }
     // small diagonal shift on the coarsest level only (:32-36, :236-241)
     {
         Csr& Ac = h->lv[L - 1].A;
@@ -167,22 +201,24 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
             if (L >= 2 && need[L - 2]) tasks.push_back([&] {
                 Level& Lv = h->lv[L - 2];
                 const auto t0 = std::chrono::steady_clock::now();
-                rcm[L - 2] = rcm_order(Lv.A);
-                Lv.ord = make_ordering(Lv.A, 512, nullptr, &rcm[L - 2]);
+                rcm[L - 2] = rcm_order(graph(L - 2));
+                order_of(L - 2) = make_ordering(graph(L - 2), 512, nullptr, &rcm[L - 2]);
+                (void)Lv;
                 if (tm.on) std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring from scratch %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 Lv.ord_key = keys[L - 2];
                 need[L - 2] = 0;
             });
             const bool early0 = rcm0_thread.joinable();
-            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(h->lv[lv].A); });
+            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(graph(lv)); });
             parallel_tasks(tasks);
             if (early0) { rcm0_thread.join(); rcm[0] = std::move(rcm0); }
         } else {
             std::vector<int> rank;
             for (int lv = L - 2; lv >= 0; lv--) {
-                rcm[lv] = (lv == L - 2) ? rcm_order(h->lv[lv].A) : induced_order(h->lv[lv + 1].P, rank);
-                rank.assign(h->lv[lv].n, 0);
-                for (int t = 0; t < h->lv[lv].n; t++) rank[rcm[lv][t]] = t;
+                rcm[lv] = (lv == L - 2) ? rcm_order(graph(lv)) : induced_order(blk ? h->lv[lv + 1].Pv : h->lv[lv + 1].P, rank);
+                const int ng = graph(lv).nr;
+                rank.assign(ng, 0);
+                for (int t = 0; t < ng; t++) rank[rcm[lv][t]] = t;
             }
         }
     }
@@ -190,18 +226,35 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     for (int lv = L - 1; lv >= 0; lv--) {
         Level& Lv = h->lv[lv];
         if (!need[lv]) continue;
-        if (lv == L - 1) Lv.ord = identity_ordering(Lv.n);
+        if (lv == L - 1) { Lv.ord = identity_ordering(Lv.n); if (blk) Lv.vord = identity_ordering(Lv.n / 3); }
         else {
             std::vector<int> inherited;
             const Level& Lc = h->lv[lv + 1];
-            const bool ok = (lv + 1 < L - 1) && Lc.ord.n_colors() <= 4 && (int)Lc.ord.color_of.size() == Lc.n &&
-                            subdivision_colors(Lc.P, Lc.ord.color_of, Lv.A, inherited);
+            const Ordering& Oc = order_of(lv + 1);
+            const bool ok = (lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
+                            subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited);
             if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
-            Lv.ord = make_ordering(Lv.A, 512, ok ? &inherited : nullptr, &rcm[lv]);
+            order_of(lv) = make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
             if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
         }
         Lv.ord_key = keys[lv];
     }
+    if (blk)   // the DOF numbering a vertex numbering induces: DOF 3v+d of vertex v, colours = vertex colours
+        for (int lv = 0; lv < L - 1; lv++) {
+            Level& Lv = h->lv[lv];
+            if (!need[lv] && (int)Lv.ord.perm.size() == Lv.n) continue;
+            const Ordering& O = Lv.vord;
+            const int nv = (int)O.perm.size();
+            Lv.ord = Ordering();
+            Lv.ord.perm.resize((size_t)3 * nv); Lv.ord.iperm.resize((size_t)3 * nv); Lv.ord.color_of.resize((size_t)3 * nv);
+            for (int i = 0; i < nv; i++)
+                for (int d = 0; d < 3; d++) {
+                    Lv.ord.perm[(size_t)3 * i + d] = 3 * O.perm[i] + d;
+                    Lv.ord.iperm[(size_t)3 * O.perm[i] + d] = 3 * i + d;
+                    Lv.ord.color_of[(size_t)3 * i + d] = O.color_of.empty() ? 0 : O.color_of[i];   // (caller numbering, like O.color_of)
+                }
+            for (int c : O.color_ptr) Lv.ord.color_ptr.push_back(3 * c);
+        }
     tm.lap("host: orderings + colourings");
     {
         std::vector<std::function<void()>> tasks;
@@ -231,7 +284,8 @@ int smg::spectral_bounds(smg_hierarchy* h)
     HIPCHK(h->d_lam.ensure((size_t)L));
     for (int lv = 0; lv < L - 1; lv++) {
         Level& Lv = h->lv[lv];
-        HIPCHK(launch_gershgorin(Lv.gs_on_transpose ? Lv.dAT.view : Lv.dA.view, h->d_lam.p + lv, h->stream));
+        if (h->bs == 3) HIPCHK(launch_bsr3_gershgorin(Lv.gs_on_transpose ? Lv.bAT.view : Lv.bA.view, h->d_lam.p + lv, h->stream));
+        else HIPCHK(launch_gershgorin(Lv.gs_on_transpose ? Lv.dAT.view : Lv.dA.view, h->d_lam.p + lv, h->stream));
     }
     std::vector<double> lam((size_t)L, 0.0);
     HIPCHK(hipMemcpyAsync(lam.data(), h->d_lam.p, (size_t)(L - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -259,6 +313,7 @@ static int precompute_device(smg_hierarchy* h)
     const int L = h->n_levels;
     const int sellC = SELL_C;
     const bool region = env_int("SMG_REGION_ORDER", 1) != 0;   // A/B knob: region-major launch order
+    const bool blk = h->bs == 3;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
     for (int lv = 0; lv < L; lv++) {
@@ -291,6 +346,13 @@ static int precompute_device(smg_hierarchy* h)
                 hipError_t* eA = &errs.back();
                 tasks.push_back([&, lv, eA] {
                     DeviceScope ds(h->device);   // worker threads start on device 0
+                    if (blk) {
+                        h->lv[lv].dA = SellBuf();
+                        Bsr3Sell S = build_bsr3(h->lv[lv].A_int, &h->lv[lv].vord.color_ptr, region);
+                        *eA = h->lv[lv].bA.upload(S);
+                        return;
+                    }
+                    h->lv[lv].bA = Bsr3Buf();
                     Sell S = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region);
                     *eA = h->lv[lv].dA.upload(S);
                 });
@@ -305,10 +367,11 @@ static int precompute_device(smg_hierarchy* h)
                     Csr AT = transpose(Lw.A_int);
                     Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
                     Lw.dAT = SellBuf();
+                    Lw.bAT = Bsr3Buf();
                     if (Lw.gs_on_transpose) {
                         if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad[lv] = 1; return; }
-                        Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false);
-                        *eT = Lw.dAT.upload(S);
+                        if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false); *eT = Lw.bAT.upload(S); }
+                        else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false); *eT = Lw.dAT.upload(S); }
                     }
                 });
             }
@@ -322,20 +385,27 @@ static int precompute_device(smg_hierarchy* h)
                 static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
                 tasks.push_back([&, lv, eP] {
                     DeviceScope ds(h->device);
-                    const bool cut = tr_region && region && h->lv[lv - 1].ord.color_ptr.size() > 2;
-                    Sell S = build_sell(h->lv[lv].P_int, cut ? &h->lv[lv - 1].ord.color_ptr : nullptr, sellC, cut);
+                    // block hierarchies: the device applies the VERTEX-level factor of P (x) I_3 to 3 k columns (smg_bsr3.hpp)
+                    const Ordering& Of = blk ? h->lv[lv - 1].vord : h->lv[lv - 1].ord;
+                    const bool cut = tr_region && region && Of.color_ptr.size() > 2;
+                    Csr Pvi;
+                    if (blk) Pvi = permute(h->lv[lv].Pv, Of.perm, h->lv[lv].vord.perm);
+                    Sell S = build_sell(blk ? Pvi : h->lv[lv].P_int, cut ? &Of.color_ptr : nullptr, sellC, cut);
                     *eP = h->lv[lv].dP.upload(S);
                 });
                 errs.push_back(hipSuccess);
                 hipError_t* eQ = &errs.back();
                 tasks.push_back([&, lv, eQ] {
                     DeviceScope ds(h->device);
-                    const bool cut = tr_region && region && lv < L - 1 && h->lv[lv].ord.color_ptr.size() > 2;
+                    const Ordering& Oc = blk ? h->lv[lv].vord : h->lv[lv].ord;
+                    const bool cut = tr_region && region && lv < L - 1 && Oc.color_ptr.size() > 2;
                     // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
                     // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
                     // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
                     static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
-                    const Csr& M = h->lv[lv].PT_int;
+                    Csr PTvi;
+                    if (blk) PTvi = permute(h->lv[lv].PTv, Oc.perm, h->lv[lv - 1].vord.perm);
+                    const Csr& M = blk ? PTvi : h->lv[lv].PT_int;
                     std::vector<int> lrow, lptr{0}, lcol;
                     std::vector<double> lval;
                     if (long_min > 0)
@@ -347,7 +417,7 @@ static int precompute_device(smg_hierarchy* h)
                                 lptr.push_back((int)lcol.size());
                             }
                     if (lrow.empty()) {
-                        Sell S = build_sell(M, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                        Sell S = build_sell(M, cut ? &Oc.color_ptr : nullptr, sellC, cut);
                         *eQ = h->lv[lv].dPT.upload(S);
                         if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
                         return;
@@ -363,7 +433,7 @@ static int precompute_device(smg_hierarchy* h)
                             Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
                         }
                     }
-                    Sell S = build_sell(Ms, cut ? &h->lv[lv].ord.color_ptr : nullptr, sellC, cut);
+                    Sell S = build_sell(Ms, cut ? &Oc.color_ptr : nullptr, sellC, cut);
                     *eQ = h->lv[lv].dPT.upload(S);
                     if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
                 });
@@ -483,15 +553,29 @@ static int build_recipes(smg_hierarchy* h)
                 Level& Lv = h->lv[lv];
                 hipError_t& er = errs[2 * lv];
                 std::vector<int> m;
+                std::vector<int> tsrc;
+                Csr AT = transpose(Lv.A_int, &tsrc);
+                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) { bad[lv] = 1; return; }
+                if (h->bs == 3) {   // the same maps for the value planes of the block images
+                    {
+                        Bsr3Sell S = build_bsr3(Lv.A_int, &Lv.vord.color_ptr, false);
+                        m.resize(S.entry.size());
+                        for (size_t i = 0; i < S.entry.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
+                    }
+                    up(er, Lv.mapB.upload(m));
+                    Bsr3Sell ST = build_bsr3(AT, &Lv.vord.color_ptr, false);
+                    m.resize(ST.entry.size());
+                    for (size_t i = 0; i < ST.entry.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
+                    up(er, Lv.mapBT.upload(m));
+                    if (!Lv.gs_on_transpose) { up(er, Lv.bAT.upload(ST)); Lv.gs_on_transpose = true; }
+                    return;
+                }
                 {
                     Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
                     m.resize(S.entry.size());
                     for (size_t i = 0; i < S.entry.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
                 }
                 up(er, Lv.mapA.upload(m));
-                std::vector<int> tsrc;
-                Csr AT = transpose(Lv.A_int, &tsrc);
-                if (!(AT.ptr == Lv.A_int.ptr && AT.col == Lv.A_int.col)) { bad[lv] = 1; return; }
                 Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
                 m.resize(ST.entry.size());
                 for (size_t i = 0; i < ST.entry.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
@@ -558,8 +642,13 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
         if (lv == L - 1) {
             HIPCHK(launch_add_at(Lv.d_Aval.p, h->d_diag_idx.p, (int)h->d_diag_idx.n, 1e-12, st));          // :32-36 / :236-241
         } else {
-            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dA.view.val), Lv.d_Aval.p, Lv.mapA.p, (size_t)Lv.dA.padded, st));
-            HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dAT.view.val), Lv.d_Aval.p, Lv.mapAT.p, (size_t)Lv.dAT.padded, st));
+            if (h->bs == 3) {
+                HIPCHK(launch_gather_vals(Lv.bA.val.p, Lv.d_Aval.p, Lv.mapB.p, (size_t)Lv.bA.padded, st));
+                HIPCHK(launch_gather_vals(Lv.bAT.val.p, Lv.d_Aval.p, Lv.mapBT.p, (size_t)Lv.bAT.padded, st));
+            } else {
+                HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dA.view.val), Lv.d_Aval.p, Lv.mapA.p, (size_t)Lv.dA.padded, st));
+                HIPCHK(launch_gather_vals(const_cast<double*>(Lv.dAT.view.val), Lv.d_Aval.p, Lv.mapAT.p, (size_t)Lv.dAT.padded, st));
+            }
         }
     }
     // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254)

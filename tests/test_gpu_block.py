@@ -1,0 +1,204 @@
+"""GPU (-m gpu): the block (3 degrees of freedom per vertex) variant -- SURVEY.md section 8 row f-4.
+
+Reference: mg_precompute_block / get_prolong_block (src/mg_precompute_block.cpp:23-95, src/get_prolong.cpp:59-115) build P (x) I_3, the
+caller (06_example_balloon_sim/sim_utils/implicit_euler_mg_balloon.h:63-76) hands in a 3n x 3n system with 3 x 3 blocks, and the reference
+runs its scalar kernels on it (src/mg_VCycle.cpp).  libsmg keeps such level matrices in 3 x 3 blocks and colours vertices; the checker
+is the oracle run on the SCALAR matrix in the device numbering (mg.matrix(lv, "A", internal=True)), the same bar as for the scalar
+kernels: bit-exact per kernel (fp64, no FMA contraction), stated tolerances for norm / coarse solve / solve.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import mesh_np as M
+from test_gpu_parity import oracle_on_device_numbering, smg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def elastic_like_system(V, F, rng, mass=1.0):
+    """A vector-valued SPD system with a different full 3 x 3 block on every edge (what an elasticity Hessian looks like): the block of
+    edge (i, j) is -w_ij (t t^T + 0.3 I) with t the unit edge direction, the diagonal block the negated row sum plus a lumped mass.
+    DOF index 3 v + d, like the reference's 06 example."""
+    n = V.shape[0]
+    E = np.vstack([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]])
+    E = np.unique(np.sort(E, axis=1), axis=0)
+    t = V[E[:, 1]] - V[E[:, 0]]
+    ln = np.linalg.norm(t, axis=1)
+    t = t / ln[:, None]
+    w = rng.uniform(0.5, 2.0, len(E)) / ln
+    W = w[:, None, None] * (t[:, :, None] * t[:, None, :] + 0.3 * np.eye(3)[None])          # PSD per edge
+    rows, cols, vals = [], [], []
+    D = np.zeros((n, 3, 3))
+    for a, b, sgn in ((0, 1, -1.0), (1, 0, -1.0)):
+        i, j = E[:, a], E[:, b]
+        for d in range(3):
+            for e in range(3):
+                rows.append(3 * i + d); cols.append(3 * j + e); vals.append(sgn * W[:, d, e])
+        np.add.at(D, i, W)
+    m = M.massmatrix(V, F, "barycentric").diagonal() * mass
+    for d in range(3):
+        for e in range(3):
+            rows.append(3 * np.arange(n) + d); cols.append(3 * np.arange(n) + e); vals.append(D[:, d, e] + (m if d == e else 0.0))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(3 * n, 3 * n))
+    A.sum_duplicates(); A.sort_indices()
+    return A
+
+
+def build_block(smg, oracle_mod, seed=5, mesh="ogre_sim.smgm", nVCoarsest=100, kron=False):
+    V, F = M.read_smgm(mesh)
+    V = M.normalize_unit_area(V, F)
+    rng = np.random.default_rng(seed)
+    if kron:
+        S = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+        B3 = rng.uniform(-1, 1, (3, 3))
+        A = sp.kron(S, sp.csr_matrix(B3 @ B3.T + 3.0 * np.eye(3)), format="csr")
+        A.sort_indices()
+    else:
+        A = elastic_like_system(V, F, rng, mass=50.0)
+    mg = smg.mg_precompute_block(V, F, 0.25, nVCoarsest, 1)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    mg.precompute(A)
+    assert mg.block_size() == 3
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A)
+    return V, F, A, Ps, mg, orc
+
+
+@pytest.mark.parametrize("k,kron", [(1, False), (1, True), (2, False), (3, False)])
+def test_block_kernels_bit_exact_in_device_numbering(smg, oracle_mod, k, kron):
+    """y = A x, the Gauss-Seidel sweep, restriction and prolongation of a block hierarchy against the oracle on the scalar 3n x 3n
+    matrices in the device numbering: bit for bit.  Launches per sweep = vertex colours."""
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod, kron=kron)
+    rng = np.random.default_rng(3)
+    assert mg.n_levels >= 3
+    for lv in range(mg.n_levels - 1):
+        n, nc = mg.rows(lv), mg.rows(lv + 1)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        st = mg.block_stats(lv)
+        assert st["vertex_colors"] == len(mg.colors(lv)) - 1 and st["blocks"] * 9 >= mg.matrix(lv, "A").nnz
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        x, b, xc = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (nc, k))
+        assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), "block SpMV not bit-exact on level %d" % lv
+        for sweeps in (1, 2):
+            assert np.array_equal(mg.relax(lv, b, x, sweeps)[perm], oi.relax(0, b[perm], x[perm], sweeps)), "block GS sweep not bit-exact on level %d" % lv
+        assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm])), "restriction through Pv not bit-exact on level %d" % lv
+        assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc])), "prolongation through Pv not bit-exact on level %d" % lv
+        # caller numbering: summation order only
+        ref = orc.A(lv, x)
+        assert abs(mg.A(lv, x) - ref).max() <= 1e-13 * abs(ref).max()
+        nr = mg.residual_norm(lv, b, x)
+        assert abs(nr - np.linalg.norm(b - orc.A(lv, x))) <= 1e-12 * nr
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_block_jacobi_and_chebyshev_bit_exact(smg, oracle_mod, k):
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod)
+    rng = np.random.default_rng(8)
+    for lv in range(mg.n_levels - 1):
+        n, perm = mg.rows(lv), mg.perm(lv)
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        x, b = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+        mg.set_smoother("jacobi", 0.8)
+        oi.set_smoother(0, "jacobi", 0.8)
+        for iters in (1, 2, 3):
+            assert np.array_equal(mg.relax(lv, b, x, iters)[perm], oi.relax(0, b[perm], x[perm], iters)), "block Jacobi, level %d, %d sweeps" % (lv, iters)
+        mg.set_smoother("chebyshev", cheby_fraction=0.1)
+        oi.set_smoother(0, "chebyshev", 0.1)
+        assert mg.spectral_bound(lv) == oi.spectral_bound(0)
+        for iters in (1, 2, 3):
+            assert np.array_equal(mg.relax(lv, b, x, iters)[perm], oi.relax(0, b[perm], x[perm], iters)), "block Chebyshev, level %d, degree %d" % (lv, iters + 1)
+    mg.set_smoother("gs")
+
+
+def test_block_two_level_cycle_in_device_numbering(smg, oracle_mod):
+    """One V(2,2) cycle from the coarsest smoothed level down: only the dense coarse solve differs from the oracle (<= 1e-11)."""
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod)
+    lv = mg.n_levels - 2
+    oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+    rng = np.random.default_rng(4)
+    n, perm = mg.rows(lv), mg.perm(lv)
+    B, u = rng.uniform(-1, 1, (n, 2)), rng.uniform(-1, 1, (n, 2))
+    got = mg.vcycle(B, u, lv=lv)[perm]
+    ref = oi.vcycle(B[perm], u[perm])
+    assert abs(got - ref).max() <= 1e-10 * abs(ref).max()
+
+
+@pytest.mark.parametrize("kron,smoother", [(False, "gs"), (True, "gs"), (False, "hybrid_chebyshev")])
+def test_block_solve_matches_the_reference_algorithm(smg, oracle_mod, kron, smoother):
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod, kron=kron)
+    n3 = A.shape[0]
+    rng = np.random.default_rng(6)
+    rhs, z0 = rng.uniform(-1, 1, (n3, 1)), np.zeros((n3, 1))
+    if smoother != "gs":
+        thr = mg.rows(1)
+        for lv in range(orc.n_levels - 1):
+            orc.set_smoother(lv, "chebyshev" if orc.rows(lv) <= thr else "gs", 0.1)
+        opts = smg.SolveOpts(tol=1e-10, max_iter=80, smoother=smoother, jacobi_max_rows=thr)
+    else:
+        opts = smg.SolveOpts(tol=1e-10, max_iter=80)
+    a = mg.solve(rhs, z0, None, opts)
+    b = orc.solve(rhs, z0, tol=1e-10, max_iter=80)
+    assert a[0] and b[0] and abs(len(a[2]) - len(b[2])) <= max(2, len(b[2]) // 5)
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-8 * np.linalg.norm(b[1])
+    assert np.linalg.norm(rhs - A @ a[1]) < 1.5e-10
+    # the scalar kernels on the same handle's hierarchy: same problem, same answer (another numbering, another sweep order)
+    mgs = smg.Hierarchy.from_prolongs(Ps)
+    mgs.set_block_mode("scalar")
+    mgs.precompute(A)
+    assert mgs.block_size() == 1 and len(mgs.colors(0)) - 1 >= 3 * (len(mg.colors(0)) - 1)
+    c = mgs.solve(rhs, z0, None, opts)
+    assert c[0] and np.linalg.norm(a[1] - c[1]) <= 1e-8 * np.linalg.norm(c[1])
+    # a hierarchy that arrives through smg_level_set_prolong is recognised just the same
+    mgp = smg.Hierarchy.from_prolongs(Ps)
+    mgp.precompute(A)
+    assert mgp.block_size() == 3
+    d = mgp.solve(rhs, z0, None, opts)
+    assert np.array_equal(d[1], a[1]) and np.array_equal(d[2], a[2])
+
+
+def test_block_value_only_reprecompute_is_bit_exact(smg, oracle_mod):
+    """The 06 caller re-precomputes with a new Hessian of the same pattern ten times per time step
+    (implicit_euler_mg_balloon.h:48-76): the value-only device path works on the block pattern and gives the bits of a fresh handle."""
+    V, F, A1, Ps, mg, orc = build_block(smg, oracle_mod)
+    rng = np.random.default_rng(42)
+    D = sp.diags(1.0 + 0.01 * rng.uniform(size=A1.shape[0]))
+    A2 = (D @ A1 @ D + sp.diags(rng.uniform(0, 0.5, A1.shape[0]) * A1.diagonal())).tocsr()
+    A2.sort_indices()
+    assert np.array_equal(A2.indices, A1.indices) and abs(A2 - A2.T).max() > 0
+    mg.precompute(A2)                                     # value-only path
+    assert mg.block_size() == 3
+    fresh = smg.Hierarchy.from_prolongs(Ps)
+    fresh.precompute(A2)
+    orc2 = oracle_mod.OracleMG(Ps)
+    orc2.precompute(A2)
+    for l in range(mg.n_levels):
+        a, b = mg.matrix(l, "A"), fresh.matrix(l, "A")
+        assert np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data), "level %d differs" % l
+        Ao = orc2.level_A(l).tocsr(); Ao.sort_indices()
+        assert np.array_equal(a.data, Ao.data)
+    n3 = A1.shape[0]
+    rhs, z0 = rng.uniform(-1, 1, (n3, 1)), np.zeros((n3, 1))
+    o = smg.SolveOpts(tol=1e-9, max_iter=60)
+    r1, r2 = mg.solve(rhs, z0, None, o), fresh.solve(rhs, z0, None, o)
+    assert r1[0] and np.array_equal(r1[2], r2[2]) and np.array_equal(r1[1], r2[1])
+    # kernels after the refresh: still the oracle's bits in the device numbering
+    lv = 0
+    oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+    perm = mg.perm(lv)
+    x, b = rng.uniform(-1, 1, (n3, 1)), rng.uniform(-1, 1, (n3, 1))
+    assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm]))
+    assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2))
+
+
+def test_block_mode_refusals(smg):
+    V, F = M.read_smgm("ogre_sim.smgm")
+    V = M.normalize_unit_area(V, F)
+    A = elastic_like_system(V, F, np.random.default_rng(1), mass=50.0)
+    mg = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    mg.precompute(A)
+    n3 = A.shape[0]
+    rhs, z0 = np.ones((n3, 1)), np.zeros((n3, 1))
+    with pytest.raises(smg.SmgError):
+        mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=10, precision="mixed"))
+    assert mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=60))[0]      # the handle is still usable

@@ -492,3 +492,76 @@ def test_mg_precompute_hierarchies_converge(smg_mod, oracle_mod, mesh_name, boun
         factor = np.linalg.norm(e2) / np.linalg.norm(e)
         e = e2 / np.linalg.norm(e2)
     assert factor < bound
+
+
+# ----------------------------------------------------------------------------------------------- block (3-DOF) hierarchies
+def _block_problem(seed=5, mesh="ogre_sim.smgm", coupled=True):
+    V, F = M.read_smgm(mesh)
+    V = M.normalize_unit_area(V, F)
+    S = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+    rng = np.random.default_rng(seed)
+    B3 = rng.uniform(-1, 1, (3, 3))
+    C3 = B3 @ B3.T + 3.0 * np.eye(3) if coupled else np.eye(3)
+    A = sp.kron(S, sp.csr_matrix(C3), format="csr")          # DOF index 3 v + d
+    A.sort_indices()
+    return V, F, A
+
+
+def test_block_hierarchy_host_half(smg_mod):
+    """SURVEY 8 f-4, host half (no GPU): a hierarchy whose prolongations are Pv (x) I_3 (mg_precompute_block,
+    reference src/get_prolong.cpp:104-114) and a system with full 3 x 3 blocks switch the library to the block variant: VERTICES are
+    coloured (as many Gauss-Seidel launches per sweep as the mesh has colours, not three times as many), the DOF numbering is 3 v + d on the
+    colour-major vertex numbering, and the 3 x 3 block SELL image reproduces the scalar matrix in that numbering entry for entry."""
+    smg = smg_mod
+    V, F, A = _block_problem()
+    n = V.shape[0]
+    mg = _host_precompute(smg, smg.mg_precompute_block(V, F, 0.25, 100, 1), A)
+    assert mg.block_size() == 3
+    for lv in range(mg.n_levels - 1):
+        perm = mg.perm(lv)
+        nv = len(perm) // 3
+        assert np.array_equal(perm.reshape(nv, 3) % 3, np.tile(np.arange(3), (nv, 1)))          # DOFs of a vertex stay together, in order
+        assert np.array_equal(perm.reshape(nv, 3)[:, 0] // 3, perm.reshape(nv, 3)[:, 2] // 3)
+        cp = mg.colors(lv)
+        # (a mesh level: 4-6 classes; the Galerkin levels of a decimated hierarchy couple second neighbours: about 10)
+        assert np.all(cp % 3 == 0) and len(cp) - 1 <= (6 if lv == 0 else 14), "vertex colours expected, got %d classes" % (len(cp) - 1)
+        Ai = mg.matrix(lv, "A", internal=True)
+        # a valid VERTEX colouring: inside a colour class only the 3 x 3 diagonal blocks are populated
+        for c in range(len(cp) - 1):
+            blk = sp.coo_matrix(Ai[cp[c]:cp[c + 1], cp[c]:cp[c + 1]])
+            assert np.all(blk.row // 3 == blk.col // 3)
+        # the block image is the scalar matrix: rebuild it from the panels
+        img = mg.block_image(lv)
+        rows, cols, vals = [], [], []
+        for s in range(len(img["slice_w"])):
+            r0, r1, off, w = img["slice_row"][s], img["slice_row"][s + 1], img["slice_off"][s], img["slice_w"][s]
+            assert r1 - r0 <= 64
+            for j in range(w):
+                c = img["col"][off + j, :r1 - r0]
+                ok = c >= 0
+                if j > 0:   # block columns ascend inside a block row
+                    prev = img["col"][off + j - 1, :r1 - r0]
+                    assert np.all((c[ok] > prev[ok]))
+                for e in range(9):
+                    rows.append(3 * (r0 + np.nonzero(ok)[0]) + e // 3); cols.append(3 * c[ok] + e % 3); vals.append(img["val"][off + j, e, :r1 - r0][ok])
+        R = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=Ai.shape)
+        assert abs(R - Ai).max() == 0.0
+        assert R.nnz >= Ai.nnz and (R != 0).sum() == (Ai != 0).sum()       # explicit zeros only where the scalar matrix stores nothing
+    # the scalar path of the same problem needs at least three times the colours on level 0
+    mg2 = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    mg2.set_block_mode("scalar")
+    _host_precompute(smg, mg2, A)
+    assert mg2.block_size() == 1 and len(mg2.colors(0)) - 1 >= 3 * (len(mg.colors(0)) - 1)
+    # kron(S, I_3): three scalar problems -- the automatic choice stays scalar, 'block' can be forced, constraints select the scalar path
+    V, F, Ad = _block_problem(coupled=False)
+    mg3 = _host_precompute(smg, smg.mg_precompute_block(V, F, 0.25, 100, 1), Ad)
+    assert mg3.block_size() == 1
+    mg3.set_block_mode("block")
+    _host_precompute(smg, mg3, Ad)
+    assert mg3.block_size() == 3
+    mg4 = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    _host_precompute(smg, mg4, A, known=np.array([0, 1, 2, 30], np.int32))
+    assert mg4.block_size() == 1
+    mg4.set_block_mode("block")
+    with pytest.raises(smg.SmgError):
+        mg4.precompute(A, np.array([0, 1, 2, 30], np.int32))
