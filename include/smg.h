@@ -37,7 +37,8 @@ enum {
     SMG_ERR_HIP = -3,         /* a HIP runtime call failed */
     SMG_ERR_NONFINITE = -4,   /* residual became NaN/Inf */
     SMG_ERR_ALLOC = -5,
-    SMG_ERR_IO = -6
+    SMG_ERR_IO = -6,
+    SMG_ERR_REDUCE = -7       /* the caller's reduction (smg_solve_sharded) reported a failure */
 };
 
 enum { SMG_HOST = 0, SMG_DEVICE = 1 };         /* where the dense blocks handed to smg_solve live */
@@ -254,6 +255,25 @@ int smg_solve_iter_cycle_speculative(smg_hierarchy *h);
 int smg_solve_iter_commit(smg_hierarchy *h, const double *d_sumsq);
 int smg_solve_poll(smg_hierarchy *h, int *done, int *n_his);      /* synchronising read of the control block */
 int smg_solve_end(smg_hierarchy *h, double *z, int ld_z, int memspace, double *r_his, int *n_his, int *converged);
+
+/* The column-sharded solve as ONE call (BASELINE north_star: "C++ host code ... RCCL over xGMI only for the
+ * residual-norm all-reduce"): this rank owns k_local of the k right-hand-side columns (RHS / z0 / z / known_val hold just those), the
+ * hierarchy is replicated, and the library runs the reference's loop (src/min_quad_with_fixed_mg.cpp:108-125)
+ *     for (iter < maxIter) { r = |RHS - A z|_F over ALL ranks' columns; push; if (r < tol) break; V-cycle }
+ * itself: residual graph -> reduce(d_sumsq, 1, stream, ctx) -> cycle graph, the break test on the device from the reduced value, so
+ * every rank records the same history and stops at the same iteration.  The only communication is `reduce`:
+ *     int reduce(double *d_sumsq, int count, void *hip_stream, void *ctx)
+ * must leave the sum over all ranks of the `count` device doubles at d_sumsq in place, ordered on hip_stream (enqueue it there --
+ * ncclAllReduce(d, d, count, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream) is the whole closure, examples/
+ * 05_mean_curvature_flow_sharded.cpp -- or synchronise the stream and do it on the host), and return 0; any other value aborts the
+ * solve with SMG_ERR_REDUCE.  It is called exactly once per loop entry, the same number of times on every rank.
+ * k_local == 0 is legal (more ranks than columns): the rank contributes 0 to every reduction and follows the others' decision;
+ * RHS / z0 / z may then be NULL.  Everything else (arguments, r_his / n_his / converged, memspace) as in smg_solve.
+ * With world size 1 and a reduce that does nothing this IS smg_solve's loop (same graphs' kernels, same bits). */
+typedef int (*smg_reduce_fn)(double *d_sumsq, int count, void *hip_stream, void *ctx);
+int smg_solve_sharded(smg_hierarchy *h, const double *RHS, int ld_rhs, const double *known_val, int ld_kv, const double *z0,
+                      int ld_z0, int k_local, int memspace, const smg_solve_opts *opts, smg_reduce_fn reduce, void *ctx,
+                      double *z, int ld_z, double *r_his, int *n_his, int *converged);
 
 /* ---- mg_VCycle.h pieces, host column-major blocks in the level's own (caller) numbering ------------------------ */
 /* Level lv has smg_level_rows(h, lv) unknowns (after constraint elimination). */

@@ -17,6 +17,10 @@ class SolveOptsC(C.Structure):
 _lib = None
 
 
+# int reduce(double *d_sumsq, int count, void *hip_stream, void *ctx)   (include/smg.h: smg_reduce_fn)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -60,6 +64,7 @@ def load():
         "smg_assembler_pattern": (i, [vp, ip, ip, ip]),
         "smg_assemble": (i, [vp, vp, i, d, d, vp, vp, vp, vp]),
         "smg_solve": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC), vp, i, dp, ip, ip]),
+        "smg_solve_sharded": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC), REDUCE_FN, vp, vp, i, dp, ip, ip]),
         "smg_solve_begin": (i, [vp, vp, i, vp, i, vp, i, i, i, C.POINTER(SolveOptsC)]),
         "smg_solve_iter_residual": (i, [vp, vp]),
         "smg_solve_iter_cycle": (i, [vp, vp]),

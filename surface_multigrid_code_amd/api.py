@@ -174,6 +174,31 @@ class Hierarchy:
                               _dp(r_his), C.byref(n_his), C.byref(conv)), "smg_solve")
         return bool(conv.value), r_his[: n_his.value].copy()
 
+    def solve_sharded(self, rhs_ptr, z0_ptr, z_ptr, n, k_local, reduce, known_val_ptr=None, ld_kv=0, opts=None):
+        """smg_solve_sharded: this rank's k_local columns (device pointers, leading dimension n; k_local = 0: no columns, pointers may be
+        None), the library runs the whole loop and calls reduce(d_sumsq_ptr, count, hip_stream_ptr) -- which must sum the device doubles
+        over the ranks in place, ordered on that stream -- once per loop entry.  Returns (converged, r_his)."""
+        from ._lib import REDUCE_FN
+        opts = opts or SolveOpts()
+        r_his = np.zeros(max(opts.c.max_iter, 1))
+        n_his, conv = C.c_int(0), C.c_int(0)
+        failure = []
+
+        def _cb(ptr, count, stream, _ctx):
+            try:
+                reduce(ptr, count, stream)
+                return 0
+            except BaseException as e:   # an exception must not unwind through the C frames
+                failure.append(e)
+                return 1
+        cb = REDUCE_FN(_cb)
+        rc = self.L.smg_solve_sharded(self.h, rhs_ptr, n, known_val_ptr, ld_kv, z0_ptr, n, k_local, SMG_DEVICE, C.byref(opts.c), cb, None,
+                                      z_ptr, n, _dp(r_his), C.byref(n_his), C.byref(conv))
+        if failure:
+            raise failure[0]
+        _chk(rc, "smg_solve_sharded")
+        return bool(conv.value), r_his[: n_his.value].copy()
+
     # ---- mg_VCycle.h pieces (host blocks in the level's caller numbering)
     def rows(self, lv):
         return self.L.smg_level_rows(self.h, lv)

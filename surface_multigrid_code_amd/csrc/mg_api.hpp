@@ -63,6 +63,11 @@ struct smgCoarseSolver {  // stands in for Eigen::SimplicialLDLT<Eigen::SparseMa
     // e.g.  coarseSolver.opts.smoother = SMG_SMOOTH_HYBRID_CHEBYSHEV; coarseSolver.opts.jacobi_max_rows = 300000;
     // tol / max_iter are overwritten by the solve overloads' arguments.
     smg_solve_opts opts;
+    // Column-sharded multi-GPU runs: every rank calls the solve with ITS columns of RHS / z0 and sets `reduce` to
+    // the all-reduce of the residual sum of squares (include/smg.h: smg_reduce_fn; ncclAllReduce on an ncclComm_t the caller created,
+    // examples/05_mean_curvature_flow_sharded.cpp).  nullptr (default): the single-GPU loop.
+    smg_reduce_fn reduce = nullptr;
+    void* reduce_ctx = nullptr;
     smgCoarseSolver() { smg_solve_opts_default(&opts); }
 };
 
@@ -196,6 +201,11 @@ inline bool solve_impl(const smgDense& RHS, const smgDense* known_val, const smg
     z.resize(z0.rows, z0.cols);
     r_his.assign((size_t)(maxIter > 0 ? maxIter : 1), 0.0);
     int n_his = 0, conv = 0;
+    if (solver.reduce)   // this rank's columns of a column-sharded solve; the library runs the loop and calls the reduction
+        check(smg_solve_sharded(solver.h.get(), RHS.data.data(), RHS.rows, known_val ? known_val->data.data() : nullptr,
+                                known_val ? known_val->rows : 0, z0.data.data(), z0.rows, RHS.cols, SMG_HOST, &o, solver.reduce, solver.reduce_ctx,
+                                z.data.data(), z.rows, r_his.data(), &n_his, &conv), "min_quad_with_fixed_mg_solve (sharded)");
+    else
     check(smg_solve(solver.h.get(), RHS.data.data(), RHS.rows, known_val ? known_val->data.data() : nullptr,
                     known_val ? known_val->rows : 0, z0.data.data(), z0.rows, RHS.cols, SMG_HOST, &o, z.data.data(), z.rows,
                     r_his.data(), &n_his, &conv), "min_quad_with_fixed_mg_solve");

@@ -768,32 +768,30 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     return SMG_OK;
 }
 
-extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
-                         const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts, double* z, int ld_z,
-                         double* r_his, int* n_his, int* converged)
+// for (iter < maxIter) { residual; push; if (residual < tol) break; V-cycle }   (:108-125 / :330-347)
+// The break happens on the device; the host only decides how many iterations to enqueue before it looks at the flag again.
+// check_every >= 1: that many.  check_every == 0 (default): adaptive -- from the two most recent residuals the host extrapolates
+// how many more cycles the tolerance needs and enqueues all but the last of them before the next look (the results do not depend
+// on this: an iteration enqueued after the break stores nothing).  The schedule is a function of the residual history alone, so the
+// ranks of a column-sharded solve -- who all see the same reduced residuals -- enqueue (and reduce) the same number of times.
+template <typename Iter>
+static int run_outer_loop(smg_hierarchy* h, Iter&& one_iteration)
 {
-    int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
-    if (rc) return rc;
-    // for (iter < maxIter) { residual; push; if (residual < tol) break; V-cycle }   (:108-125 / :330-347)
-    // The break happens on the device; the host only decides how many iterations to enqueue before it looks at the flag again.
-    // check_every >= 1: that many.  check_every == 0 (default): adaptive -- from the two most recent residuals the host extrapolates
-    // how many more cycles the tolerance needs and enqueues all but the last of them before the next look (the results do not depend
-    // on this: an iteration enqueued after the break stores nothing).
     int it = 0;
     int chunk_next = 1;
     while (it < h->max_iter) {
         const int want = h->check_every > 0 ? h->check_every : chunk_next;
         const int chunk = std::min(want, h->max_iter - it);
         for (int c = 0; c < chunk; c++) {
-            rc = enqueue_outer_iteration(h);
-            if (rc) { h->in_solve = false; return rc; }
+            int rc = one_iteration();
+            if (rc) return rc;
         }
         it += chunk;
         if (it < h->max_iter) {
             Ctrl hc;
             hipError_t e = hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { h->in_solve = false; return fail(SMG_ERR_HIP, "smg_solve: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) return fail(SMG_ERR_HIP, "smg_solve: %s", hipGetErrorString(e));
             if (hc.done) break;
             chunk_next = 1;
             if (h->check_every == 0 && hc.n_his >= 2 && hc.r_last > 0.0 && hc.r_last < hc.r_prev && h->tol > 0.0 && hc.r_last > h->tol) {
@@ -802,7 +800,86 @@ extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const 
             }
         }
     }
+    return SMG_OK;
+}
+
+extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
+                         const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts, double* z, int ld_z,
+                         double* r_his, int* n_his, int* converged)
+{
+    int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
+    if (rc) return rc;
+    rc = run_outer_loop(h, [&]() { return enqueue_outer_iteration(h); });
+    if (rc) { h->in_solve = false; return rc; }
     return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
+}
+
+// ---- column-sharded solve (include/smg.h: smg_solve_sharded) ------------------------------------------------------------------------
+// A rank without columns: no vectors, no cycle -- it adds 0 to every reduction and lets the device take the same decision from the
+// reduced value as everybody else (same control block, same launch_decide, same polling schedule).
+static int solve_sharded_empty(smg_hierarchy* h, const smg_solve_opts* opts, smg_reduce_fn reduce, void* ctx, double* r_his, int* n_his, int* converged)
+{
+    int rc = check_ready(h, "smg_solve_sharded");
+    if (rc) return rc;
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_sharded: a split-phase solve is in progress");
+    smg_solve_opts o;
+    smg_solve_opts_default(&o);
+    if (opts) o = *opts;
+    if (o.max_iter < 0) return fail(SMG_ERR_INVALID, "max_iter must be >= 0");
+    DeviceScope dsc(h->device);
+    h->tol = o.tol; h->max_iter = o.max_iter; h->check_every = std::max(0, o.check_every); h->verbosity = o.verbosity;
+    HIPCHK(h->d_rhis.ensure((size_t)std::max(h->max_iter, 1)));
+    Ctrl& zero = h->host_ctrl;
+    std::memset(&zero, 0, sizeof(zero));
+    zero.tol = h->tol;
+    zero.r_his = h->d_rhis.p;
+    zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
+    HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    double* buf = &h->d_ctrl.p->sumsq;
+    int n_it = 0;
+    rc = run_outer_loop(h, [&]() -> int {
+        HIPCHK(hipMemsetAsync(buf, 0, sizeof(double), h->stream));
+        if (reduce(buf, 1, (void*)h->stream, ctx) != 0) return fail(SMG_ERR_REDUCE, "smg_solve_sharded: the caller's reduction failed");
+        HIPCHK(launch_decide(h->d_ctrl.p, buf, h->stream));
+        n_it++;
+        return SMG_OK;
+    });
+    if (rc) return rc;
+    Ctrl hc;
+    std::vector<double> his((size_t)std::max(std::min(n_it, std::max(h->max_iter, 1)), 1));
+    HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(his.data(), h->d_rhis.p, his.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int cnt = std::max(0, std::min(std::min(hc.n_his, hc.his_cap), (int)his.size()));
+    if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = his[(size_t)i];
+    if (n_his) *n_his = cnt;
+    const double last = cnt > 0 ? his[(size_t)cnt - 1] : HUGE_VAL;
+    if (converged) *converged = (last > h->tol) ? 0 : 1;
+    if (hc.status != 0) return fail(SMG_ERR_NONFINITE, "non-finite residual at iteration %d", cnt - 1);
+    return SMG_OK;
+}
+
+extern "C" int smg_solve_sharded(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv, const double* z0,
+                                 int ld_z0, int k_local, int memspace, const smg_solve_opts* opts, smg_reduce_fn reduce, void* ctx,
+                                 double* z, int ld_z, double* r_his, int* n_his, int* converged)
+{
+    return guarded("smg_solve_sharded", [&]() -> int {
+        if (!reduce) return fail(SMG_ERR_INVALID, "smg_solve_sharded: no reduction given");
+        if (k_local < 0) return fail(SMG_ERR_INVALID, "smg_solve_sharded: k_local must be >= 0");
+        if (k_local == 0) return solve_sharded_empty(h, opts, reduce, ctx, r_his, n_his, converged);
+        int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k_local, memspace, opts);
+        if (rc) return rc;
+        DeviceScope dsc(h->device);
+        double* buf = &h->d_ctrl.p->sumsq;   // the word both halves of an iteration work on in place; the reduction too
+        rc = run_outer_loop(h, [&]() -> int {
+            int r = smg_solve_iter_residual(h, buf);
+            if (r) return r;
+            if (reduce(buf, 1, (void*)h->stream, ctx) != 0) return fail(SMG_ERR_REDUCE, "smg_solve_sharded: the caller's reduction failed");
+            return smg_solve_iter_cycle(h, buf);
+        });
+        if (rc) { h->in_solve = false; return rc; }
+        return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
+    });
 }
 
 extern "C" int smg_raw_outer_iteration(smg_hierarchy* h, int n_iter)

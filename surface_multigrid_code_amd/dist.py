@@ -147,6 +147,55 @@ def sharded_solve(engine, max_iter, all_reduce, check_every=1):
     return engine.end()
 
 
+class HostReduce:
+    """A reduction closure for smg_solve_sharded that works with ANY torch.distributed backend (gloo on the test box, where two ranks
+    share one GPU and RCCL refuses to run): wait for the solve's stream, fetch the doubles, all-reduce them on the host, put them back.
+    The production closure is StreamAllReduce (RCCL on the solve's stream, no host round trip)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.group = group
+        self.calls = 0
+
+    def __call__(self, ptr, count, stream):
+        import torch
+        import torch.distributed as dist
+        C = self.C
+        buf = (C.c_double * count)()
+        if self.hip.hipStreamSynchronize(stream) != 0 or self.hip.hipMemcpy(buf, ptr, 8 * count, 2) != 0:   # hipMemcpyDeviceToHost
+            raise RuntimeError("HostReduce: device -> host copy failed")
+        t = torch.tensor(list(buf), dtype=torch.float64)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(t, group=self.group)
+        for i in range(count):
+            buf[i] = float(t[i])
+        if self.hip.hipMemcpy(ptr, buf, 8 * count, 1) != 0:                                                  # hipMemcpyHostToDevice
+            raise RuntimeError("HostReduce: host -> device copy failed")
+        self.calls += 1
+
+
+def sharded_solve_native(mg, rhs, z0, reduce, known_val=None, opts=None):
+    """The column-sharded solve through the library's own loop (smg_solve_sharded, include/smg.h): ONE call, the residual / reduce /
+    cycle sequence, the device-side break test and the polling all happen in C++; `reduce(ptr, count, stream)` is the only thing the
+    caller supplies (StreamAllReduce for RCCL: `lambda p, c, s: sar(p, c)`; HostReduce for any other backend).
+    rhs, z0: (k_local, n) contiguous CUDA tensors = this rank's columns, column-major; None when the rank owns no column.
+    `sharded_solve` above is the engine-agnostic model of the same loop that the CPU tests drive with the oracle."""
+    import torch
+    if rhs is None or rhs.shape[0] == 0:
+        conv, r_his = mg.solve_sharded(None, None, None, 0, 0, reduce, opts=opts)
+        return conv, None, r_his
+    k, n = rhs.shape
+    z = torch.empty_like(z0)
+    kvp = known_val.data_ptr() if known_val is not None else None
+    ldkv = known_val.shape[1] if known_val is not None else 0
+    conv, r_his = mg.solve_sharded(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, k, reduce, kvp, ldkv, opts)
+    return conv, z, r_his
+
+
 # rccl.h (ROCm 7.2, NCCL API 2.27): the enum values of the two constants ncclAllReduce is called with.  They have been stable
 # since NCCL 2.0; `StreamAllReduce` refuses libraries older than that and proves the whole binding (struct layout, enum values,
 # stream) with a known-answer reduction before it reports `ok`.

@@ -78,6 +78,10 @@ def _worker(rank, world, port, q):
     eng2 = OracleEngine(orc, p["RHS"][:, lo:hi], p["z0"][:, lo:hi], tol)
     conv2, z2, rh2 = sharded_solve_overlapped(eng2, 20, lambda t: dist.all_reduce(t, async_op=True), check_every=3)
     assert conv2 == conv and np.array_equal(rh2, rh) and np.array_equal(z2, z)
+    # check_every = 0 is the library's "adaptive" (SolveOpts' default): the model loop must treat it as 1, not spin forever on empty chunks
+    eng3 = OracleEngine(orc, p["RHS"][:, lo:hi], p["z0"][:, lo:hi], tol)
+    conv3, z3, rh3 = sharded_solve(eng3, 20, lambda t: dist.all_reduce(t), check_every=0)
+    assert conv3 == conv and np.array_equal(rh3, rh) and np.array_equal(z3, z)
     # unsharded reference on every rank
     conv_ref, z_ref, rh_ref = orc.solve(p["RHS"], p["z0"], tol=tol, max_iter=20)
     zs = [torch.zeros(z_ref.shape[0], hi2 - lo2, dtype=torch.float64) for (lo2, hi2) in (column_range(k, r, world) for r in range(world))]

@@ -132,3 +132,42 @@ def test_eigen_adapter_runs_through_the_reference_signatures(smg_mod):
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny.smgm")], env=env, text=True, capture_output=True)
     assert out.returncode == 0 and "ADAPTER_CHECK OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
     assert "MG iteration: 0, residual:" in out.stdout and "residual norm:" in out.stdout      # the reference's prints (.cpp:111,127)
+
+
+def test_cpp_sharded_mean_curvature_flow_example(smg_mod):
+    """examples/05_mean_curvature_flow_sharded.cpp: the C++ caller shards its right-hand-side columns through the C++ mirror
+    (smgCoarseSolver::reduce -> smg_solve_sharded) with an RCCL closure on a communicator it created.  On this box: world size 1 (the
+    driver's 8-GPU job runs the same binary per rank); the first step's 3 + 5 columns must converge exactly like the python path's
+    fused 8-column solve of the same system, and the reduction must have been issued once per loop entry."""
+    smg, mesh = smg_mod, smg_mod.mesh
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers")
+    exe = os.path.join(ROOT, "examples", "05_mean_curvature_flow_sharded")
+    src = os.path.join(ROOT, "examples", "05_mean_curvature_flow_sharded.cpp")
+    libdir = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
+    if _stale(exe, [src]):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-I/opt/rocm/include", "-L" + libdir, "-lsmg", "-L/opt/rocm/lib", "-lrccl",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "ogre_sim.smgm"), "2", "8"], env=env, text=True, timeout=600)
+    steps = re.findall(r"step (\d+): 8 columns on 1 rank\(s\) \(this rank: 8\), converged (\d) in (\d+) iterations, last residual ([0-9.eE+-]+), \|U\|\^2 = ([0-9.eE+-]+)", out)
+    assert len(steps) == 2 and all(st[1] == "1" for st in steps), out[-2000:]
+    calls = int(re.search(r"reductions issued by rank 0: (\d+)", out).group(1))
+    assert calls >= sum(int(st[2]) for st in steps)
+    # step 0 through the python mirror: same hierarchy, same matrix, the same 8 columns in one fused solve
+    V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg = smg.mg_precompute(V, F, 0.25, 100, 1)
+    Mb = mesh.massmatrix(V, F, "barycentric")
+    A = (Mb - 0.01 * mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    Z0 = np.zeros((V.shape[0], 8))
+    Z0[:, :3] = V
+    for c in range(3, 8):
+        q = c - 3
+        Z0[:, c] = np.sin(0.7 * (q + 1) * V[:, q % 3]) + 0.25 * V[:, (q + 1) % 3]
+    mg.precompute(A)
+    conv, z, rh = mg.solve(Mb @ Z0, Z0, None, smg.SolveOpts(tol=5e-7, max_iter=20))
+    assert conv and len(rh) == int(steps[0][2])
+    assert abs(float(steps[0][3]) - rh[-1]) <= 1e-5 * rh[-1]      # printed with %.6e

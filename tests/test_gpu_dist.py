@@ -28,7 +28,7 @@ def _worker(rank, world, port, q, smoother):
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         import surface_multigrid_code_amd as smg
-        from surface_multigrid_code_amd.dist import EmptyEngine, GpuEngine, column_range, sharded_solve, sharded_solve_overlapped
+        from surface_multigrid_code_amd.dist import EmptyEngine, GpuEngine, HostReduce, column_range, sharded_solve, sharded_solve_native, sharded_solve_overlapped
         from problems import subdiv_problem
         k, tol = 6, 5e-7
         p = subdiv_problem(kind="mcf", k=k, n_sub=2)
@@ -56,6 +56,14 @@ def _worker(rank, world, port, q, smoother):
                     conv, z, rh = sharded_solve(eng, 30, allreduce, check_every=2 if form == "plain" else 1)
                 stream.synchronize()
                 outs.append((conv, z.cpu().numpy().T.copy(), np.asarray(rh)))
+            # the library's own loop (smg_solve_sharded: residual graph -> the caller's reduction -> cycle graph, all in C++), with a
+            # host closure over gloo; adaptive polling (check_every = 0) and every-other-iteration polling
+            red = HostReduce()
+            for ce in (0, 2):
+                conv, z, rh = sharded_solve_native(mg, rhs, z0, red, None, smg.SolveOpts(tol=tol, max_iter=30, check_every=ce, **kw))
+                stream.synchronize()
+                outs.append((conv, z.cpu().numpy().T.copy(), np.asarray(rh)))
+            native_calls = red.calls
             # a rank without columns (k < world) still takes part in every reduction: k = 1 on two ranks
             lo1, hi1 = column_range(1, rank, world)
             if hi1 > lo1:
@@ -66,12 +74,18 @@ def _worker(rank, world, port, q, smoother):
                 e1 = EmptyEngine(tol, dev)
             c1, z1, rh1 = sharded_solve(e1, 30, allreduce)
             stream.synchronize()
+            # ... and through smg_solve_sharded with k_local = 0 on the rank that owns nothing
+            if hi1 > lo1:
+                c1n, z1n, rh1n = sharded_solve_native(mg, r1, s1, red, None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
+            else:
+                c1n, z1n, rh1n = sharded_solve_native(mg, None, None, red, None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
+            stream.synchronize()
             # the fused k-column solve (rank 0's reference for everything)
             conv_f, z_f, rh_f = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
             conv_1, z_1, rh_1 = mg.solve(p["RHS"][:, :1], p["z0"][:, :1], None, smg.SolveOpts(tol=tol, max_iter=30, **kw))
         ok = True
         msg = ""
-        for form, (conv, z, rh) in zip(("plain", "speculative", "eager"), outs):
+        for form, (conv, z, rh) in zip(("plain", "speculative", "eager", "native", "native-poll2"), outs):
             good = (conv == conv_f and len(rh) == len(rh_f) and np.allclose(rh, rh_f, rtol=1e-12, atol=0)
                     and np.array_equal(z, z_f[:, lo:hi]))
             if not good:
@@ -81,6 +95,17 @@ def _worker(rank, world, port, q, smoother):
         if not (np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])):
             ok = False
             msg += "the three forms of the loop disagree; "
+        if not (np.array_equal(outs[3][1], outs[0][1]) and np.array_equal(outs[3][2], outs[0][2]) and np.array_equal(outs[4][1], outs[0][1])
+                and np.array_equal(outs[4][2], outs[0][2])):
+            ok = False
+            msg += "smg_solve_sharded disagrees with the split-phase loop; "
+        if not (c1n == conv_1 and len(rh1n) == len(rh_1) and np.allclose(rh1n, rh_1, rtol=1e-12, atol=0) and np.array_equal(rh1n, rh1)
+                and (z1n is None or np.array_equal(z1n.cpu().numpy().T, z_1))):
+            ok = False
+            msg += "smg_solve_sharded, k=1 on two ranks: %s its %d/%d; " % (c1n, len(rh1n), len(rh_1))
+        if native_calls < 2 * len(outs[0][2]):
+            ok = False
+            msg += "the reduction was called %d times for %d loop entries; " % (native_calls, 2 * len(outs[0][2]))
         if not (c1 == conv_1 and len(rh1) == len(rh_1) and np.allclose(rh1, rh_1, rtol=1e-12, atol=0)):
             ok = False
             msg += "k=1 on two ranks: %s its %d/%d; " % (c1, len(rh1), len(rh_1))
