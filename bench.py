@@ -11,8 +11,15 @@ area, 3x mid-point subdivision -> 1 011 330 vertices, 5 levels, system M_bary + 
 N > 1: every rank owns one independent RHS column of the same mesh (weak scaling); the only communication is the
 8-byte all-reduce of the residual sum of squares per iteration (RCCL), exactly SURVEY.md section 8e.
 
+Timing: `--steps K` iterations are timed R = --repeats (default 9) times, each repeat bracketed by barrier + synchronize on both
+sides and measured with HIP events on the solve's stream (max over ranks per repeat); `ms_per_step` / `value` are the MEDIAN repeat
+(min / max alongside) -- a 20-step region is 6 ms, and one scheduling hiccup must not move the headline.
+The timed cycle is the REFERENCE's: V(2,2) with Gauss-Seidel on every level (`--smoother gs`, the library default); libsmg's
+Chebyshev-Jacobi hybrid is reported next to it in `smoothers` as an extension, with its own byte count.
+
 Prints ONE JSON line on rank 0.
 """
+import hashlib
 import argparse
 import json
 import os
@@ -69,6 +76,30 @@ def build_workload(name, smg, mesh):
     A = (Mb - 0.01 * L).tocsr()       # 05_example_mean_curvature_flow/main.cpp:68
     A.sort_indices()
     return mg, A, Mb, Vf, Ff, label, time.time() - t0
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/traffic.json carries the hash of the sources its PMC passes ran on
+    (tools/make_traffic.py); a committed traffic figure is only reported while it still describes the kernels that are timed."""
+    hsh = hashlib.sha256()
+    for f in ("smg_device.hip", "smg_device.hpp", "smg_device_inl.hpp"):
+        with open(os.path.join(ROOT, "surface_multigrid_code_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def committed_traffic(workload):
+    """(bytes per launch or None, note)"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None, "no profiles/traffic.json"
+    ent = tj.get(workload, {})
+    if not ent.get("hbm_bytes_per_launch"):
+        return None, "no entry for %s in profiles/traffic.json" % workload
+    if tj.get("kernel_source_sha") != kernel_source_hash():
+        return None, "profiles/traffic.json was measured on other kernel sources (%s, now %s): stale, not reported -- rerun tools/profile_round.sh" % (tj.get("kernel_source_sha"), kernel_source_hash())
+    return ent["hbm_bytes_per_launch"], "profiles/traffic.json: committed rocprofv3 --pmc passes of this kernel on these sources (%s), NOT a measurement of this run" % ent.get("source", "")
 
 
 def cpu_baseline(mg, A, rhs, budget_s=15.0):
@@ -172,19 +203,162 @@ def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
     gs_bytes = 12 * A.nnz + 4 * (n + 1) + 24 * n
     st = mg.sell_stats(0, "A")
     ws = 12 * st["padded"] + 16 * n
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("C5", {}).get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    traffic, traffic_note = committed_traffic("C5")
     gbs = spmv_bytes / (spmv_us * 1e-6) / 1e9
-    return {"workload": label, "kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # ---- BASELINE config 5: fp32 vs fp64 -- the same SpMV on the fp32 image, and the mixed-precision solve (fp32 V-cycle inside the fp64
+    # outer loop) against the fp64 one: ms per iteration, cycles and the residual each reaches
+    f32 = None
+    try:
+        x32 = x.float()
+        y32 = torch.empty_like(x32)
+        us32 = timed(lambda: mg.raw_spmv_f32(0, x32.data_ptr(), y32.data_ptr()), reps)
+        b32 = 8 * A.nnz + 4 * (n + 1) + 8 * n
+        mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
+        torch.cuda.synchronize()
+        rel = float((y32.double() - y).abs().max() / y.abs().max())
+        z0 = torch.zeros_like(x)
+        zz = torch.empty_like(x)
+        prec = {}
+        for pr in ("f64", "mixed"):
+            o = smg.SolveOpts(tol=0.0, max_iter=40, precision=pr)
+            mg.solve_begin(b.data_ptr(), n, z0.data_ptr(), n, 1, opts=o)
+            mg.outer_iterations(40)
+            _, rh = mg.solve_end(zz.data_ptr(), n, max_iter=40)
+            mg.solve_begin(b.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=140, precision=pr))
+            mg.outer_iterations(20)
+            torch.cuda.synchronize()
+            e0.record(stream)
+            mg.outer_iterations(100)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            mg.solve_end(zz.data_ptr(), n, max_iter=140)
+            prec[pr] = {"ms_per_iteration": e0.elapsed_time(e1) / 100, "first_residual": float(rh[0]), "residual_floor_40_cycles": float(rh.min()),
+                        "cycles_to_1e-10_relative": int(np.argmax(rh < 1e-10 * rh[0])) if (rh < 1e-10 * rh[0]).any() else None}
+        f32 = {"spmv_f32": {"kernel": "k_sell<SELL_AX,1,float> (fp32 values and vectors, same slots)", "us_per_launch": us32, "bytes_per_launch": int(b32),
+                            "achieved": b32 / (us32 * 1e-6) / 1e9, "unit": "GB/s", "frac": b32 / (us32 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "max_rel_diff_vs_f64": rel, "speedup_vs_f64": spmv_us / us32},
+               "solve_f64": prec["f64"], "solve_mixed": prec["mixed"],
+               "tolerance_note": "mixed = fp32 V-cycle as the correction inside the fp64 outer loop (residual in fp64): it reaches the fp64 floor; the fp32 SpMV alone differs from fp64 by max_rel_diff_vs_f64"}
+        del x32, y32, z0, zz
+    except Exception as e:
+        f32 = {"error": repr(e)}
+    return {"workload": label, "f32": f32, "kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "frac_of_sustainable": gbs / HBM_SUSTAINABLE_GBS, "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
             "working_set_bytes": int(ws), "infinity_cache_resident": bool(ws < INFINITY_CACHE_BYTES),
-            "traffic_committed_pmc": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate passes; not measured by this run)" if traffic else None,
+            "traffic_committed_pmc": traffic, "traffic_source": traffic_note,
             "gs_sweep": {"us_per_sweep": gs_us, "bytes_per_sweep": int(gs_bytes), "achieved": gs_bytes / (gs_us * 1e-6) / 1e9,
                          "frac": gs_bytes / (gs_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
             "vcycle_us": cyc_us, "vcycle_bytes": int(mg.vcycle_bytes(1, 2, 2)), "setup_s": t_host}
+
+
+def timed_repeats(torch, dist, world, dev, stream, block, K, R):
+    """R repeats of block(K), each bracketed by barrier + synchronize on both sides and timed with HIP events on the solve's stream;
+    per repeat the MAX over ranks.  Returns the list of R times in ms."""
+    times = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(R):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        block(K)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        times.append(ms)
+    return times
+
+
+def reduce_closure(world, stream_ar):
+    """the reduction smg_solve_sharded calls between the two halves of an iteration"""
+    if world == 1:
+        return lambda p, c, s: None
+    if stream_ar is not None:
+        return lambda p, c, s: stream_ar(p, c)       # RCCL, enqueued on the solve's own stream
+    from surface_multigrid_code_amd.dist import HostReduce
+    return HostReduce()                               # any other backend: through the host
+
+
+def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream_ar, steps=20, warmup=3, repeats=3):
+    """A column-sharded job that DOES shard usefully (ogre.obj's 64 columns are launch-latency-bound, strong scaling of that
+    job is bounded at about 1.7x): the C3 mesh (1 011 330 vertices, bandwidth-bound) with k = 64 right-hand-side columns, column_range
+    over the ranks, STRONG scaling (the 64 columns are the whole job at every N; N = 1 is the curve's first point).  The reference's
+    Gauss-Seidel cycle; the solve runs through smg_solve_sharded (the library's own loop, RCCL closure)."""
+    from surface_multigrid_code_amd.dist import column_range, sharded_solve_native
+    K64, tol = 64, 1e-10
+    lo, hi = column_range(K64, rank, world)
+    kl = hi - lo
+    cols = np.stack([Mb @ np.random.default_rng(1000 + j).uniform(-1.0, 1.0, n) for j in range(lo, hi)], axis=0) if kl else np.zeros((0, n))
+    rhs = torch.from_numpy(np.ascontiguousarray(cols)).to(dev)          # (k_local, n): column-major n x k_local
+    z0 = torch.zeros_like(rhs)
+    red = reduce_closure(world, stream_ar)
+    opts = smg.SolveOpts(tol=tol, max_iter=60, smoother="gs")
+    sharded_solve_native(mg, rhs if kl else None, z0 if kl else None, red, None, opts)      # warm: graph capture for this k
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tw = time.perf_counter()
+    conv, z, rh = sharded_solve_native(mg, rhs if kl else None, z0 if kl else None, red, None, opts)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - tw
+    ms = None
+    if kl:      # steady state (every rank owns columns at N <= 64)
+        HIS = (warmup + steps * repeats) + 4
+        sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs"))
+
+        def block(m):
+            if world == 1:
+                mg.outer_iterations(m)
+                return
+            for _ in range(m):
+                mg.iter_residual(sumsq.data_ptr())
+                red(sumsq.data_ptr(), 1, stream.cuda_stream)
+                mg.iter_cycle(sumsq.data_ptr())
+        block(warmup)
+        times = timed_repeats(torch, dist, world, dev, stream, block, steps, repeats)
+        zt = torch.empty_like(z0)
+        mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
+        ms = float(np.median(times)) / steps
+    same = True
+    if world > 1:
+        hbuf = torch.zeros(64, dtype=torch.float64, device=dev)
+        hbuf[: min(len(rh), 64)] = torch.from_numpy(np.asarray(rh[:64])).to(dev)
+        hmin, hmax = hbuf.clone(), hbuf.clone()
+        dist.all_reduce(hmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(hmin, hmax))
+    del rhs, z0
+    if rank != 0:
+        return None
+    return {"workload": "C3 mesh (1 011 330 verts, 5 levels), k = 64 RHS columns M g_j, column-sharded", "k": K64, "columns_per_gpu": kl, "n_gpus": world,
+            "scaling": "strong", "smoother": "gs", "loop": "smg_solve_sharded (C++ loop, %s)" % ("no reduction at N = 1" if world == 1 else "RCCL closure on the solve stream" if stream_ar is not None else "host closure"),
+            "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms if ms else None, "column_cycles_per_s": K64 * 1e3 / ms if ms else None,
+            "solve": {"tol": tol, "converged": bool(conv), "cycles": len(rh) - 1, "wall_ms": 1e3 * wall, "same_history_on_all_ranks": same,
+                      "final_residual": float(rh[-1]) if len(rh) else None}}
+
+
+def block3_leg(smg, mesh, torch, with_scalar=True):
+    """the block (3-DOF) kernels against the scalar kernels on the same 3n x 3n system -- C3 mesh, kron(S, C3) with a full
+    SPD 3 x 3 coupling, hierarchy P (x) I_3 -- Gauss-Seidel V(2,2): ms per iteration, launches per sweep (colours), algorithmic bytes
+    (76 B per 3 x 3 block against 108 B for nine scalar entries)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import block3_time as B3
+    A, Ps, label = B3.block_system(smg, mesh, "C3")
+    out = {"workload": label + " -> kron(S, C3): %d DOFs, %d stored entries, DOF = 3 v + d, P (x) I_3" % (A.shape[0], A.nnz)}
+    out["block"] = B3.measure(smg, torch, A, Ps, "block", "gs", reps=100)
+    if with_scalar:
+        out["scalar"] = B3.measure(smg, torch, A, Ps, "scalar", "gs", reps=50)
+        out["speedup_block_vs_scalar"] = out["scalar"]["ms_per_iteration"] / out["block"]["ms_per_iteration"]
+    return out
 
 
 def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, smoother_kw, steps=200, warmup=20):
@@ -318,12 +492,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the out-of-cache roofline leg (C5, 4.19 M vertices)")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (ogre.obj, k = 64, column-sharded) leg")
+    ap.add_argument("--no-block3", action="store_true", help="skip the block (3-DOF) leg (C3 mesh, kron(S, C3) system)")
+    ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
+    ap.add_argument("--no-c3k64", action="store_true", help="skip the C3 x 64 columns column-sharded (strong scaling) leg")
+    ap.add_argument("--repeats", type=int, default=9, help="the --steps iterations are timed this many times; the line reports the median repeat")
     ap.add_argument("--spmv-reps", type=int, default=500)
-    ap.add_argument("--smoother", default="hybrid_chebyshev", choices=["gs", "jacobi", "hybrid", "chebyshev", "hybrid_chebyshev"],
-                    help="gs: the reference's Gauss-Seidel on every level (the library's default); hybrid_chebyshev (the benchmark's "
-                         "default): GS on the levels with more than --jacobi-max-rows unknowns, Chebyshev-accelerated Jacobi (degree 3) "
-                         "below -- as many cycles as GS everywhere, a third of the launches on the latency-bound levels; hybrid: damped "
-                         "Jacobi instead (cheaper per cycle, but 30-70 %% more cycles on anisotropic meshes); jacobi / chebyshev: everywhere")
+    ap.add_argument("--smoother", default="gs", choices=["gs", "jacobi", "hybrid", "chebyshev", "hybrid_chebyshev"],
+                    help="gs (default): the reference's Gauss-Seidel on every level = the cycle the metric is defined on; hybrid_chebyshev: "
+                         "GS on the levels with more than --jacobi-max-rows unknowns, Chebyshev-accelerated Jacobi (degree 3) "
+                         "below -- as many cycles as GS everywhere, a third of the launches on the latency-bound levels (reported as an "
+                         "extension in `smoothers` whatever is timed); hybrid: damped Jacobi instead; jacobi / chebyshev: everywhere")
     ap.add_argument("--omega", type=float, default=0.8)
     ap.add_argument("--jacobi-max-rows", type=int, default=300000)
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
@@ -436,29 +614,17 @@ def main():
 
     mg_in_solve = [False]
     run(W)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    NREP = max(1, args.repeats)
+    rep_ms = timed_repeats(torch, dist, world, dev, stream, run, K, NREP)
+    dt = float(np.median(rep_ms)) * 1e-3           # the median repeat of K steps
     conv, r_his = mg.solve_end(z.data_ptr(), n, max_iter=HIS)
     if state["his"] is not None and len(r_his) < 6:
         r_his = state["his"]   # the last segment was short: report the head of the previous one
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     out = None
     if rank == 0:
         ms_step = 1e3 * dt / K
-        vcyc_bytes = mg.vcycle_bytes(1, 2, 2)
+        vcyc_bytes = mg.vcycle_bytes(1, 2, 2)      # of the cycle just timed (the handle still carries its smoother selection)
         # ---- smoother comparison: the reference's Gauss-Seidel everywhere vs the timed configuration.  What counts is the time
         # to the tolerance: cycles needed to 1e-10 (the drop-in solve on resident vectors, device-side break test, adaptive host
         # polling) x the steady-state time of an outer iteration.
@@ -482,7 +648,9 @@ def main():
                 mg.solve_end(z.data_ptr(), n, max_iter=HIS)
                 ms = ea.elapsed_time(eb) / 300
             cyc = len(rh_) - 1
-            return {"smoother": kw["smoother"], "omega": kw.get("omega"), "jacobi_max_rows": kw.get("jacobi_max_rows"),
+            byt = mg.vcycle_bytes(1, 2, 2)      # bytes of THIS cycle (a Chebyshev relax(2) streams its level three times, Gauss-Seidel twice)
+            return {"bytes_per_step": int(byt), "gbs": byt / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "smoother": kw["smoother"], "omega": kw.get("omega"), "jacobi_max_rows": kw.get("jacobi_max_rows"),
                     "jacobi_levels": [l for l in range(mg.n_levels - 1) if kw["smoother"] in ("jacobi", "chebyshev") or
                                       (kw["smoother"].startswith("hybrid") and mg.rows(l) <= kw["jacobi_max_rows"])],
                     "converged": bool(cv), "cycles_to_tol": cyc, "tol": 1e-10, "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms,
@@ -492,6 +660,8 @@ def main():
             smoothers = {"timed": smoother_line(sm_kw, ms_step)}
             if args.smoother != "gs":
                 smoothers["reference_gs"] = smoother_line(dict(smoother="gs", omega=args.omega, jacobi_max_rows=args.jacobi_max_rows))
+            if args.smoother != "hybrid_chebyshev":   # libsmg's extension: same cycle count as GS, a third of the launches on the small levels
+                smoothers["hybrid_chebyshev"] = smoother_line(dict(smoother="hybrid_chebyshev", omega=args.omega, jacobi_max_rows=300000))
             if args.smoother != "hybrid":
                 smoothers["hybrid_damped_jacobi"] = smoother_line(dict(smoother="hybrid", omega=args.omega, jacobi_max_rows=100000))
             mg.set_smoother("gs")   # the kernel-level measurements below are of the reference smoother
@@ -533,17 +703,19 @@ def main():
         prof = mg.prof_table()
         mg.prof_enable(False)
         st = mg.sell_stats(0, "A")
-        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot profile itself)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot profile itself): reported only while
+        # the committed figure was measured on the kernel sources that are being timed (hash stamped by tools/make_traffic.py)
+        traffic, traffic_note = committed_traffic(args.workload)
+        ref = smoothers["timed"] if (smoothers and args.smoother == "gs") else (smoothers or {}).get("reference_gs")
         out = {
             "metric": "V-cycles/sec + fine-level SpMV GB/s (% HBM peak), 1M-vert mesh fp64",
             "value": world * K / dt, "unit": "V-cycles/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step,
+            "timing": {"repeats": NREP, "what": "each repeat = --steps outer iterations between barrier + synchronize, HIP events on the solve stream, max over ranks; ms_per_step / value = the median repeat",
+                       "ms_per_step_min": min(rep_ms) / K, "ms_per_step_median": float(np.median(rep_ms)) / K, "ms_per_step_max": max(rep_ms) / K},
+            # the reference's cycle -- V(2,2), Gauss-Seidel on every level (src/mg_VCycle.cpp) -- whatever --smoother timed
+            "reference_cycle": {"v_cycles_per_s": ref["v_cycles_per_s"], "ms_per_step": ref["ms_per_step"], "cycles_to_1e-10": ref["cycles_to_tol"],
+                                "bytes_per_step": ref["bytes_per_step"], "frac_of_hbm_peak": ref["frac_of_hbm_peak"]} if ref else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f64 outer loop + f32 V-cycle (mixed)", "data": "synthetic",
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
@@ -562,7 +734,7 @@ def main():
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          # the committed PMC figure of this kernel at this grid (rocprofv3 cannot run inside the benchmark): fabric-side
                          # requests, which do not tell Infinity-Cache hits from HBM reads
-                         "traffic": traffic, "traffic_source": "profiles/traffic.json: committed rocprofv3 --pmc passes of this kernel, NOT a measurement of this run" if traffic else None,
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
                          "sell_padding": st["padded"] / max(st["stored"], 1) - 1.0,
                          # what the launch streams (SELL slots incl. padding + x + y): below 256 MiB the matrix survives in the
@@ -575,7 +747,7 @@ def main():
                                   "achieved": gs_bytes / (gs_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gs_bytes / (gs_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "us_per_sweep": gs_us,
                                   "bytes_per_sweep": int(gs_bytes)},
-            "roofline_vcycle": {"bound": "hbm", "bytes_per_step": int(vcyc_bytes),
+            "roofline_vcycle": {"bound": "hbm", "cycle": args.smoother, "bytes_per_step": int(vcyc_bytes),
                                 "achieved": vcyc_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": vcyc_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "smoothers": smoothers,
@@ -599,10 +771,35 @@ def main():
     # ---- the same kernels beyond the Infinity Cache (BASELINE config C5), rank 0 at N = 1 only
     if rank == 0 and world == 1 and not args.no_c5 and args.workload == "C3":
         try:
-            del x, y, bvec, u
+            try:
+                del x, y, bvec, u
+            except NameError:
+                pass
             out["roofline_c5"] = roofline_c5(smg, mesh, torch, dev, stream)
         except Exception as e:
             out["roofline_c5"] = {"error": repr(e)}
+    # ---- a column-sharded job that shards usefully: the C3 mesh x 64 columns (strong scaling), through smg_solve_sharded
+    if not args.no_c3k64 and args.workload == "C3":
+        try:
+            if rank == 0 and world == 1:
+                try:
+                    del x, y, bvec, u
+                except NameError:
+                    pass
+            c3k = c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream_ar, steps=max(1, min(args.steps, 20)), warmup=3)
+        except Exception as e:
+            c3k = {"error": repr(e)}
+            if world > 1:
+                raise
+        if rank == 0:
+            out["c3_k64_sharded"] = c3k
+    # ---- block (3-DOF) kernels, rank 0 at N = 1 only
+    if rank == 0 and world == 1 and not args.no_block3 and args.workload == "C3":
+        try:
+            out["block3_c3"] = block3_leg(smg, mesh, torch, with_scalar=not args.no_block3_scalar)
+            torch.cuda.set_stream(stream)
+        except Exception as e:
+            out["block3_c3"] = {"error": repr(e)}
     # ---- BASELINE config C4: k = 64 columns sharded over the ranks (strong scaling; N = 1 is the curve's first point)
     if not args.no_c4:
         try:

@@ -315,7 +315,8 @@ int smg_level_sell_stats(const smg_hierarchy *h, int lv, int which, long *stored
 /* algorithmic bytes of one y = A_lv x with k columns: 12 nnz + 4 (n+1) + 16 n k  (SURVEY.md section 8d); on a block hierarchy
  * 76 per 3 x 3 block (72 of values + 4 of block column) + 4 (n/3 + 1) + 16 n k */
 long smg_level_spmv_bytes(const smg_hierarchy *h, int lv, int k);
-/* algorithmic bytes of one V(pre,post) cycle incl. the outer residual evaluation, k columns */
+/* algorithmic bytes of one V(pre,post) cycle incl. the outer residual evaluation, k columns -- of the cycle the handle is set to run:
+ * a Chebyshev-Jacobi relax(iters) is iters + 1 passes over the level matrix, a Gauss-Seidel / Jacobi one iters passes */
 long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);
 
 /* ---- profc.h mirror: named scopes accumulated with hipEvents (src/profc.h:9-13; mg_VCycle.cpp:121) ------------- */

@@ -1126,13 +1126,18 @@ extern "C" int smg_raw_relax(smg_hierarchy* h, int lv, const double* b, double* 
     return enqueue_relax(h, lv, b, u, k, iters, nullptr);
 }
 
-// Algorithmic bytes of one outer iteration: per smoothed level
-//   (pre+post) GS sweeps: 12 nnz + 4(n+1) + 24 n k [b, u read, u write]   (the reference also reads A_diag: +8n; the
-//                          HIP kernel takes the diagonal from the row, so it is not counted)
-//   residual:             12 nnz + 4(n+1) + 24 n k
+// Algorithmic bytes of one outer iteration OF THE CYCLE THE HANDLE IS SET TO RUN (smoother selection of the
+// last solve / smg_hierarchy_set_smoother): per smoothed level
+//   relax(iters), Gauss-Seidel:      iters sweeps of  matA + 24 n k  [b, u read, u write]   (the reference also reads A_diag: +8n; the
+//                                    HIP kernel takes the diagonal from the row, so it is not counted)
+//   relax(iters), damped Jacobi:     iters sweeps of  matA + 24 n k
+//   relax(iters), Chebyshev-Jacobi:  ONE polynomial of degree iters + 1 = iters + 1 passes of  matA + 40 n k  [b, u, d read; u, d write],
+//                                    the first without the read of d
+//   residual:             matA + 24 n k
 //   restrict:             12 nnzPT + 4(nc+1) + 8 n k + 8 nc k
 //   prolong-add:          12 nnzP + 4(n+1) + 8 nc k + 16 n k
-//   + coarsest dense solve 8 nc^2 + 24 nc k, + outer residual 12 nnz0 + 4(n0+1) + 16 n0 k.
+//   + coarsest dense solve 8 nc^2 + 24 nc k, + outer residual matA_0 + 16 n0 k.
+// matA = 12 nnz + 4(n+1); on a block hierarchy 76 bytes per 3 x 3 block + 4(n/3+1), and P (x) I_3 streams its vertex-level factor once.
 extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int post)
 {
     if (!h || !h->precomputed) return -1;
@@ -1141,11 +1146,14 @@ extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int pos
     for (int lv = 0; lv < L - 1; lv++) {
         const Level &Lv = h->lv[lv], &Lc = h->lv[lv + 1];
         const long n = Lv.n, nc = Lc.n, nnz = Lv.A.nnz();
-        // block hierarchies: 76 bytes per 3 x 3 block and one row pointer per vertex; P (x) I_3 streams the vertex-level factor once
         const long nnzP = h->bs == 3 ? Lc.Pv.nnz() : Lc.P.nnz();
         const long matA = h->bs == 3 ? 76 * Lv.bA.blocks + 4 * (n / 3 + 1) : 12 * nnz + 4 * (n + 1);
-        const long sweep = matA + 24 * n * k;
-        tot += (long)(pre + post) * sweep;
+        auto relax_bytes = [&](int iters) -> long {
+            if (iters <= 0) return 0;
+            if (level_kind(h, lv) == LV_CHEBY) return (long)(iters + 1) * (matA + 40 * n * k) - 8 * n * k;
+            return (long)iters * (matA + 24 * n * k);
+        };
+        tot += relax_bytes(pre) + relax_bytes(post);
         tot += matA + 24 * n * k;
         tot += 12 * nnzP + 4 * (nc + 1) + 8 * n * k + 8 * nc * k;
         tot += 12 * nnzP + 4 * (n + 1) + 8 * nc * k + 16 * n * k;

@@ -3,8 +3,11 @@
 y = A x kernel, per workload.  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request,
 MI355X_MICROARCH.md HBM section), cross-checked by TCC_MISS_sum * 128 B.
 usage: make_traffic.py pmc_summary_C3.json pmc_summary_C5.json tag"""
-import json, sys
-out = {}
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+# the kernel sources these passes ran on: bench.py reports a committed traffic figure only while this hash matches the tree it runs from
+out = {"kernel_source_sha": bench.kernel_source_hash()}
 tag = sys.argv[3]
 for wl, path in (("C3", sys.argv[1]), ("C5", sys.argv[2])):
     d = json.load(open(path))
