@@ -25,6 +25,101 @@ using namespace smg;
 
 // ------------------------------------------------------------------------------------------------ V-cycle
 
+// ---- overlapped tiling of the Gauss-Seidel sweeps of the latency-bound levels (smg_tiled.hpp): relax(sweeps) as ONE launch ----------
+// Which levels: scalar fp64 hierarchies, one column, Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
+// 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 16 entries per row.
+// SMG_TILED=0 switches it off (A/B knob; the results are bit-identical either way).
+static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
+{
+    static const int on = env_int("SMG_TILED", 1);
+    static const int max_rows = env_int("SMG_TILED_MAX_ROWS", 100000), min_rows = env_int("SMG_TILED_MIN_ROWS", 2048);
+    if (!on || h->bs != 1 || k != 1 || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || sweeps > 3) return false;
+    if (level_kind(h, lv) != LV_GS) return false;
+    const int n = h->lv[lv].n;
+    return n >= min_rows && n <= max_rows;
+}
+// the plan of relax(sweeps) on level lv, or nullptr (not wanted / the level does not qualify / not built yet)
+static const TiledDev* tiled_plan(const smg_hierarchy* h, int lv, int k, int sweeps)
+{
+    if (!tiled_wanted(h, lv, k, sweeps)) return nullptr;
+    const TiledBuf& B = h->lv[lv].tiled[sweeps];
+    return B.view.n_tiles > 0 ? &B.view : nullptr;
+}
+static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
+{
+    Level& Lv = h->lv[lv];
+    TiledBuf& B = Lv.tiled[sweeps];
+    if (B.tried) return SMG_OK;
+    B.tried = true;
+    // Tile size (measured at C3, tools/_tiled_sweep.sh): parts of 128 .. 256 rows, 512 threads (one row of every colour per thread).
+    // Smaller tiles put more CUs to work but the halo of P rings then dominates (6x redundant row updates at 64 rows: slower);
+    // larger ones run too few workgroups.
+    static const int rows_env = env_int("SMG_TILED_ROWS", 0), nt_env = env_int("SMG_TILED_NT", 0);
+    const int tile_rows0 = rows_env > 0 ? rows_env : 256;
+    constexpr int max_ext = 8192;    // 64 KB of LDS
+    // the matrix the smoother streams, in the internal numbering; entry -> index into the level's values in the caller's CSR order
+    std::vector<int> tsrc;
+    Csr AT;
+    if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
+    const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
+    // a tile whose halo makes a colour's panel longer than the workgroup gets smaller tiles
+    TiledGs P;
+    int threads = 512;
+    for (int tile_rows = tile_rows0, tries = 0; tries < 3 && P.empty(); tile_rows = tile_rows * 2 / 3, tries++) {
+        threads = nt_env > 0 ? nt_env : 512;
+        P = build_tiled_gs(G, Lv.ord.color_ptr, sweeps, tile_rows, max_ext, threads);
+    }
+    if (P.empty()) return SMG_OK;
+    std::vector<int> map(P.pentry.size());
+    for (size_t i = 0; i < map.size(); i++) {
+        const int e = P.pentry[i];
+        map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
+    }
+    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.ext_rows.upload(P.ext_rows)); HIPCHK(B.pcol.upload(P.pcol)); HIPCHK(B.pval.upload(P.pval));
+    HIPCHK(B.prow.upload(P.prow)); HIPCHK(B.map.upload(map));
+    HIPCHK(tiled_gs_prepare(P.max_ext));
+    int wmax = 0;
+    for (int t = 0; t < P.n_tiles; t++) wmax = std::max(wmax, P.hdr[(size_t)t * TILED_HDR + 2]);
+    B.view.threads = threads;
+    B.view.n_tiles = P.n_tiles; B.view.nc = P.nc; B.view.P = P.P; B.view.sweeps = sweeps; B.view.max_ext = P.max_ext; B.view.w_max = wmax;
+    B.view.hdr = B.hdr.p; B.view.ext_rows = B.ext_rows.p; B.view.pcol = B.pcol.p; B.view.pval = B.pval.p; B.view.prow = B.prow.p;
+    B.updates = P.updates;
+    // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
+    if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.pval.p, Lv.d_Aval.p, B.map.p, B.pval.n, h->stream));
+    if (env_int("SMG_DEBUG_TILED", 0))
+        std::fprintf(stderr, "tiled relax(%d) level %d: %d rows, %d tiles x %d threads, %d phases, extended tile <= %d rows, %.2fx row updates, entries per row <= %d\n", sweeps, lv, Lv.n,
+                     P.n_tiles, threads, P.P, P.max_ext, (double)P.updates / ((double)sweeps * Lv.n), wmax);
+    return SMG_OK;
+}
+int smg::refresh_tiled_values(smg_hierarchy* h)
+{
+    for (int lv = 0; lv < h->n_levels - 1; lv++)
+        for (int s = 1; s <= 3; s++) {
+            TiledBuf& B = h->lv[lv].tiled[s];
+            if (B.view.n_tiles > 0) HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
+        }
+    return SMG_OK;
+}
+void smg::drop_tiled(smg_hierarchy* h)
+{
+    for (auto& Lv : h->lv) for (auto& B : Lv.tiled) B = TiledBuf();
+}
+
+// plans + second iterate for relax(sa) / relax(sb) wherever they are wanted (host work and uploads: never inside a graph capture)
+static int prepare_tiled(smg_hierarchy* h, int k, int sa, int sb)
+{
+    for (int lv = 0; lv < h->n_levels - 1; lv++) {
+        Level& Lv = h->lv[lv];
+        for (int sw : {sa, sb}) if (tiled_wanted(h, lv, k, sw)) { int rc = ensure_tiled(h, lv, sw); if (rc) return rc; }
+        if ((tiled_plan(h, lv, k, sa) || tiled_plan(h, lv, k, sb)) && Lv.t.n < (size_t)Lv.n * std::max(h->kcap, 1)) {
+            drop_graphs(h);
+            HIPCHK(Lv.t.alloc((size_t)Lv.n * std::max(h->kcap, 1)));
+            HIPCHK(hipMemsetAsync(Lv.t.p, 0, Lv.t.n * sizeof(double), h->stream));
+        }
+    }
+    return SMG_OK;
+}
+
 static int ensure_work(smg_hierarchy* h, int k)
 {
     const int L = h->n_levels;
@@ -65,6 +160,8 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.d.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
         }
     }
+    int rc = prepare_tiled(h, k, h->pre, h->post);
+    if (rc) return rc;
     return ensure_spectral_bounds(h);
 }
 
@@ -258,6 +355,27 @@ static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int ite
     return SMG_OK;
 }
 
+// relax(iters) as one launch (overlapped tiling): from buf[*cur] into the other buffer, flips *cur.  fp64 only.
+static int enqueue_gs_tiled(smg_hierarchy* h, int lv, const TiledDev& plan, const double* b, double* const buf[2], int* cur, int k, const Ctrl* ctrl)
+{
+    ProfGuard pg(h, "MG: relaxation");
+    HIPCHK(launch_tiled_gs(plan, buf[*cur], b, buf[1 - *cur], k, ctrl, h->stream));
+    *cur ^= 1;
+    return SMG_OK;
+}
+template <typename T> static const TiledDev* tiled_for(const smg_hierarchy*, Level&, int, int, int) { return nullptr; }
+template <> const TiledDev* tiled_for<double>(const smg_hierarchy* h, Level& Lv, int lv, int k, int sweeps)
+{
+    const TiledDev* p = tiled_plan(h, lv, k, sweeps);
+    return (p && Lv.t.p) ? p : nullptr;
+}
+template <typename T> static int enqueue_gs_tiled_t(smg_hierarchy*, int, const TiledDev&, const T*, T* const*, int*, int, const Ctrl*) { return SMG_ERR_INVALID; }
+template <> int enqueue_gs_tiled_t<double>(smg_hierarchy* h, int lv, const TiledDev& plan, const double* b, double* const* buf, int* cur, int k, const Ctrl* ctrl)
+{
+    double* const two[2] = {buf[0], buf[1]};
+    return enqueue_gs_tiled(h, lv, plan, b, two, cur, k, ctrl);
+}
+
 // `iters` damped-Jacobi sweeps, ping-pong between buf[0] and buf[1]: sweep s reads buf[*cur], writes the other, flips *cur.
 template <typename T>
 static int enqueue_jacobi(smg_hierarchy* h, int lv, const T* b, T* const buf[2], int* cur, int k, int iters, const Ctrl* ctrl)
@@ -311,6 +429,10 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     const bool jac = kind != LV_GS;
     T* const buf[2] = {Prec<T>::u(Lv), Prec<T>::t(Lv)};   // Jacobi-type levels ping-pong; the level's result always ends in buf[0] = u
     int cur = 0;
+    // Gauss-Seidel levels whose relax() runs as one out-of-place launch (overlapped tiling): they ping-pong like the Jacobi-type ones.
+    // (Not when the first sweep already exists: level 0 inside an outer iteration, FIRST_SWEEP.)
+    const TiledDev* tl_pre = (kind == LV_GS && pre > 0 && first != FIRST_SWEEP) ? tiled_for<T>(h, Lv, lv, k, pre) : nullptr;
+    const TiledDev* tl_post = (kind == LV_GS && post > 0) ? tiled_for<T>(h, Lv, lv, k, post) : nullptr;
     int rc;
     if (kind == LV_JACOBI) {
         if (first_done) cur = 1;
@@ -318,7 +440,8 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     } else if (kind == LV_CHEBY) {
         if (first_done) cur = 1;
         rc = enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, pre, ctrl, first_done);                         // :36
-    } else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first, buf[1]);                         // :36
+    } else if (tl_pre) rc = enqueue_gs_tiled_t<T>(h, lv, *tl_pre, Prec<T>::b(Lv), buf, &cur, k, ctrl);               // :36, one launch
+    else rc = enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, pre, ctrl, first, buf[1]);                          // :36
     if (rc) return rc;
     {   // r = B - A u  (:40-42)
         ProfGuard pg(h, "MG: residual");
@@ -331,7 +454,8 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     const int kind_c = level_kind(h, lv + 1);
     const bool jac_c = kind_c != LV_GS;
     // (block hierarchies: the first launch of a coarse sweep is not a plain division -- row 3v+1 of the first colour already reads 3v)
-    const bool fuse = h->bs == 1 && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    const bool tiled_c = level_kind(h, lv + 1) == LV_GS && pre > 0 && tiled_for<T>(h, Lc, lv + 1, k, pre) != nullptr;   // the coarse level runs all its phases itself
+    const bool fuse = h->bs == 1 && !tiled_c && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
     const int kt = k * h->bs;   // block hierarchies: dP / dPT hold the vertex-level factor of P (x) I_3, applied to 3 k columns
     {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
@@ -358,13 +482,15 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
         // the last sweep lands in u.
         ProfGuard pg(h, "MG: prolong");
         int dst = cur;
-        const int flips = kind == LV_CHEBY ? (post > 0 ? post + 1 : 0) : post;   // buffer switches of the post-smoothing
-        if (jac && ((cur + flips) & 1)) dst = 1 - cur;
+        const int flips = tl_post ? 1 : kind == LV_CHEBY ? (post > 0 ? post + 1 : 0) : post;   // buffer switches of the post-smoothing
+        if ((jac || tl_post) && ((cur + flips) & 1)) dst = 1 - cur;
+        if (!jac && !tl_post && cur == 1) dst = 0;      // in-place Gauss-Seidel sweeps follow: they work on u
         HIPCHK(Prec<T>::sell(SELL_ADD, Prec<T>::P(Lc), 0, Prec<T>::P(Lc).n_slices, Prec<T>::u(Lc), buf[cur], buf[dst], kt, ctrl, h->stream));
         cur = dst;
     }
     if (kind == LV_CHEBY) return enqueue_cheby<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
     if (jac) return enqueue_jacobi<T>(h, lv, Prec<T>::b(Lv), buf, &cur, k, post, ctrl);   // :57  (ends with cur == 0)
+    if (tl_post) return enqueue_gs_tiled_t<T>(h, lv, *tl_post, Prec<T>::b(Lv), buf, &cur, k, ctrl);   // :57  (ends with cur == 0)
     return enqueue_gs<T>(h, lv, Prec<T>::b(Lv), buf[0], k, post, ctrl);                    // :57
 }
 
@@ -380,7 +506,18 @@ static int enqueue_vcycle32(smg_hierarchy* h, int lv, int k, int pre, int post, 
 // relax() on caller-provided device vectors (pieces, raw interface): the result always ends in u
 static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, int k, int iters, const Ctrl* ctrl)
 {
-    if (!level_is_jacobi(h, lv)) return enqueue_gs<double>(h, lv, b, u, k, iters, ctrl);
+    if (!level_is_jacobi(h, lv)) {
+        Level& Lg = h->lv[lv];
+        if (const TiledDev* tl = tiled_for<double>(h, Lg, lv, k, iters)) {
+            double* const two[2] = {u, Lg.t.p};
+            int c2 = 0;
+            int rc = enqueue_gs_tiled(h, lv, *tl, b, two, &c2, k, ctrl);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(u, Lg.t.p, (size_t)Lg.n * k * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            return SMG_OK;
+        }
+        return enqueue_gs<double>(h, lv, b, u, k, iters, ctrl);
+    }
     Level& Lv = h->lv[lv];
     double* const buf[2] = {u, Lv.t.p};
     int cur = 0;
@@ -901,6 +1038,7 @@ extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int po
     if (rc) return rc;
     DeviceScope dsc(h->device);
     if (reps < 1 || !us_per_cycle) return fail(SMG_ERR_INVALID, "smg_bench_vcycle: bad arguments");
+    if ((rc = prepare_tiled(h, k, pre, post))) return rc;
     hipGraphExec_t g = nullptr;
     rc = capture_graph(h, &g, [&]() { return enqueue_vcycle(h, lv, k, pre, post, nullptr); });
     if (rc) return rc;
@@ -925,6 +1063,7 @@ extern "C" int smg_bench_relax(smg_hierarchy* h, int lv, int k, int sweeps, int 
     if (rc) return rc;
     DeviceScope dsc(h->device);
     if (reps < 1 || sweeps < 1 || !us_per_call) return fail(SMG_ERR_INVALID, "smg_bench_relax: bad arguments");
+    if ((rc = prepare_tiled(h, k, sweeps, sweeps))) return rc;
     Level& Lv = h->lv[lv];
     hipGraphExec_t g = nullptr;
     rc = capture_graph(h, &g, [&]() { return enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, sweeps, nullptr); });
@@ -1031,6 +1170,7 @@ extern "C" int smg_relax(smg_hierarchy* h, int lv, const double* B, int k, int i
     if (rc) return rc;
     DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
+    if ((rc = prepare_tiled(h, k, iters, iters))) return rc;
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
     if ((rc = enqueue_relax(h, lv, Lv.b.p, Lv.u.p, k, iters, nullptr))) return rc;
@@ -1056,6 +1196,7 @@ extern "C" int smg_vcycle(smg_hierarchy* h, const double* B, int pre, int post, 
     if (rc) return rc;
     DeviceScope dsc(h->device);
     Level& Lv = h->lv[lv];
+    if ((rc = prepare_tiled(h, k, pre, post))) return rc;
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
     if ((rc = enqueue_vcycle(h, lv, k, pre, post, nullptr))) return rc;
@@ -1123,6 +1264,7 @@ extern "C" int smg_raw_relax(smg_hierarchy* h, int lv, const double* b, double* 
     DeviceScope dsc(h->device);
     if (lv < 0 || lv >= h->n_levels - 1 || k < 1) return fail(SMG_ERR_INVALID, "smg_raw_relax: bad level");
     if ((rc = ensure_work(h, k))) return rc;   // second iterate / update vector / spectral bound of a Jacobi-type level
+    if ((rc = prepare_tiled(h, k, iters, iters))) return rc;
     return enqueue_relax(h, lv, b, u, k, iters, nullptr);
 }
 

@@ -128,6 +128,19 @@ hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, 
 hipError_t launch_bsr3_gershgorin(const Bsr3Dev& A, double* out, hipStream_t st);
 int bsr3_blocks(int n_slices);
 
+// ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------
+struct TiledDev {
+    int n_tiles = 0, nc = 0, P = 0, sweeps = 0, max_ext = 0, w_max = 0, threads = 512;
+    const int* hdr = nullptr;
+    const int* ext_rows = nullptr;
+    const int* pcol = nullptr;
+    const double* pval = nullptr;
+    const int* prow = nullptr;
+};
+// y = relax(sweeps) of x with right-hand side b, x != y, row-major n x k blocks
+hipError_t launch_tiled_gs(const TiledDev& T, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st);
+hipError_t tiled_gs_prepare(int max_ext);
+
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

@@ -14,6 +14,7 @@
 #include "smg_mesh.hpp"
 #include "smg_order.hpp"
 #include "smg_sparse.hpp"
+#include "smg_tiled.hpp"
 
 namespace smg {
 
@@ -74,6 +75,14 @@ struct Bsr3Buf {  // device image of one block (3 x 3) SELL matrix, smg_bsr3.hpp
     hipError_t upload(const Bsr3Sell& S);
 };
 
+struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
+    DevBuf<int> hdr, ext_rows, pcol, prow, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute)
+    DevBuf<double> pval;
+    TiledDev view;
+    long updates = 0;
+    bool tried = false;      // a plan was attempted for this (level, sweeps): empty view = the level does not qualify
+};
+
 // one element of std::vector<mg_data> (reference src/mg_data.h:11-27)
 struct Level {
     // ---- host, caller numbering: the mg_data fields ----
@@ -98,6 +107,7 @@ struct Level {
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
+    TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
     std::vector<int> A_int_src;   // A_int entry -> index into A.val
     DevBuf<double> d_Aval;        // values of A in the caller's CSR order: the canonical device copy

@@ -122,4 +122,7 @@ enum { LV_GS = 0, LV_JACOBI = 1, LV_CHEBY = 2 };
 int level_kind(const smg_hierarchy* h, int lv);   // the smoother of a level under the handle's selection
 inline bool level_is_jacobi(const smg_hierarchy* h, int lv) { return level_kind(h, lv) != LV_GS; }   // needs the second iterate buffer
 
+int refresh_tiled_values(smg_hierarchy* h);     // the overlapped-tiling plans hold copies of the level values (value-only re-precompute)
+void drop_tiled(smg_hierarchy* h);              // ... and describe one matrix image: dropped when the images are rebuilt
+
 }  // namespace smg

@@ -316,6 +316,7 @@ static int precompute_device(smg_hierarchy* h)
     const bool blk = h->bs == 3;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
+    drop_tiled(h);
     for (int lv = 0; lv < L; lv++) {
         Level& Lv = h->lv[lv];
         Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release(); Lv.d.release();
@@ -538,6 +539,7 @@ static int build_recipes(smg_hierarchy* h)
     const int sellC = SELL_C;
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);  // the GS launches move to the A^T images on every level
+    drop_tiled(h);   // ... and so do the overlapped-tiling plans (rebuilt on demand)
     // all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes); every task uploads what it built
     std::vector<int> bad(L, 0);
     std::vector<hipError_t> errs((size_t)2 * L, hipSuccess);
@@ -659,6 +661,10 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
         HIPCHK(work.alloc((size_t)2 * h->nc_pad * 64 + 2 * 64 * 64));
         HIPCHK(launch_spd_inverse(h->d_Ainv.p, h->nc_pad, work.p, st));
         HIPCHK(hipStreamSynchronize(st));
+    }
+    {
+        int rc = refresh_tiled_values(h);   // the tiling plans hold copies of the level values
+        if (rc) return rc;
     }
     h->host_stale = true;
     h->f32_valid = false;   // the fp32 copies are re-made from the new values when a mixed solve asks for them

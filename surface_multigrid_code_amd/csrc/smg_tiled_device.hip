@@ -1,0 +1,117 @@
+// smg_tiled_device.hip -- relax(iters) of a latency-bound level in ONE launch: overlapped tiling of the multi-colour Gauss-Seidel
+// sweeps (plan and rationale: smg_tiled.hpp).  One workgroup per tile; the iterate of the extended tile (tile + halo rings) lives in
+// LDS, the phases (sweep, colour) are separated by workgroup barriers, every row update is the expression of k_sell<SELL_GS> on the
+// same operands in the same order -- bit-identical results.  fp64, one column per launch.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "smg_device.hpp"
+#include "smg_device_inl.hpp"
+#include "smg_tiled.hpp"
+
+namespace smg {
+
+constexpr int TILED_NT = TILED_THREADS;   // most threads of a tile's workgroup (the plan says how many: TiledDev::threads)
+
+// x -> y (x != y).  ld: columns of the row-major blocks (the launch handles one column; pointers are offset to it).
+// Thread t owns row t of every colour's panel (the plan guarantees m_c <= TILED_NT): the matrix rows are loaded ONCE, all requests
+// in flight together, and stay in registers for all sweeps -- after the prologue the phases touch nothing but LDS.
+template <int NC, int W>
+__global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ hdr, const int* __restrict__ ext_rows, const int* __restrict__ pcol,
+                                                       const double* __restrict__ pval, const int* __restrict__ prow, const double* __restrict__ b,
+                                                       const double* __restrict__ x, double* __restrict__ y, int ld, int nc, int sweeps, const int* done, int dbg_phases)
+{
+    extern __shared__ double xs[];
+    __shared__ int Hs[TILED_HDR];
+    const int tid = threadIdx.x;
+    if (tid < TILED_HDR) Hs[tid] = hdr[(size_t)blockIdx.x * TILED_HDR + tid];
+    const int stop = load_flag(done);
+    __syncthreads();
+    const int ext_off = Hs[0], n_ext = Hs[1], w = Hs[2];
+    const int P = sweeps * nc;
+    for (int i = tid; i < n_ext; i += (int)blockDim.x) xs[i] = x[(size_t)ext_rows[ext_off + i] * ld];
+    int cR[NC][W], gR[NC];
+    double vR[NC][W], bR[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        gR[c] = -1; bR[c] = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; j++) { cR[c][j] = -1; vR[c][j] = 0.0; }
+        if (c < nc) {
+            const int* C = Hs + 4 + c * TILED_CSTRIDE;
+            const int pan = C[0], m = C[1];
+            if (tid < m) {
+                gR[c] = prow[C[2] + tid];
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (j < w) { cR[c][j] = pcol[(size_t)pan + (size_t)j * m + tid]; vR[c][j] = pval[(size_t)pan + (size_t)j * m + tid]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) if (gR[c] >= 0) bR[c] = b[(size_t)gR[c] * ld];
+    __syncthreads();
+    for (int s = 0; s < sweeps; s++) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c < nc && s * nc + c < dbg_phases) {       // uniform
+                const int p = s * nc + c + 1;
+                const int* C = Hs + 4 + c * TILED_CSTRIDE;
+                const int lrow = C[3] + tid, cnt = C[4 + (P - p)];
+                if (tid < cnt) {
+                    double xv[W];
+#pragma unroll
+                    for (int j = 0; j < W; j++) xv[j] = (cR[c][j] >= 0 && cR[c][j] != lrow) ? xs[cR[c][j]] : 0.0;
+                    double acc = 0.0, diag = 1.0;
+#pragma unroll
+                    for (int j = 0; j < W; j++) {
+                        if (cR[c][j] >= 0) {
+                            if (cR[c][j] == lrow) diag = vR[c][j];
+                            else acc += vR[c][j] * xv[j];
+                        }
+                    }
+                    xs[lrow] = (bR[c] - acc) / diag;      // rows of one colour never read each other: no hazard inside a phase
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!stop) {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (c < nc) {
+                const int* C = Hs + 4 + c * TILED_CSTRIDE;
+                if (tid < C[4]) y[(size_t)gR[c] * ld] = xs[C[3] + tid];      // the owned rows lead the colour's panel
+            }
+    }
+}
+
+template <int NC, int W>
+static void launch_tiled_one(const TiledDev& Tl, const double* x, const double* b, double* y, int k, const int* done, hipStream_t st)
+{
+    const size_t lds = (size_t)Tl.max_ext * sizeof(double);
+    static const int dbg = getenv("SMG_DEBUG_TILED_PHASES") ? atoi(getenv("SMG_DEBUG_TILED_PHASES")) : 1 << 20;   // timing probe (wrong results)
+    hipLaunchKernelGGL((k_tiled_gs<NC, W>), dim3(Tl.n_tiles), dim3(Tl.threads), lds, st, Tl.hdr, Tl.ext_rows, Tl.pcol, Tl.pval, Tl.prow, b, x, y, k, Tl.nc, Tl.sweeps, done, dbg);
+}
+
+hipError_t launch_tiled_gs(const TiledDev& Tl, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st)
+{
+    if (Tl.n_tiles <= 0) return hipErrorInvalidValue;
+    const int* done = ctrl ? &ctrl->done : never_done();
+    for (int c = 0; c < k; c++) {
+        const bool w8 = Tl.w_max <= 8;
+        if (Tl.nc <= 3) { if (w8) launch_tiled_one<3, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<3, 12>(Tl, x + c, b + c, y + c, k, done, st); }
+        else if (Tl.nc == 4) { if (w8) launch_tiled_one<4, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<4, 12>(Tl, x + c, b + c, y + c, k, done, st); }
+        else { if (w8) launch_tiled_one<5, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<5, 12>(Tl, x + c, b + c, y + c, k, done, st); }
+    }
+    return hipGetLastError();
+}
+
+hipError_t tiled_gs_prepare(int max_ext)
+{
+    // the plans are built with at most 8192 local rows: 64 KB of LDS, what a workgroup may ask for without further ado
+    return max_ext * (int)sizeof(double) <= 64 * 1024 ? hipSuccess : hipErrorInvalidValue;
+}
+
+}  // namespace smg

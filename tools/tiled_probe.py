@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""us per relax(2) call per level (graph replay), C3.  usage: tools/tiled_probe.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B
+import surface_multigrid_code_amd as smg
+from surface_multigrid_code_amd import mesh
+mg, A, Mb, Vf, Ff, label, _ = B.build_workload("C3", smg, mesh)
+mg.precompute(A)
+print(" ".join("L%d %.2f" % (lv, mg.bench_relax(lv, 1, 2, 200)) for lv in range(mg.n_levels - 1)), "| env", {k: v for k, v in os.environ.items() if k.startswith("SMG_")})
