@@ -48,8 +48,8 @@ template <typename T> struct CoarseInit { T* u; const T* gs_val; const int* diag
 // for leading scalar / pointer arguments, hence no struct up front).  The rest is fetched in one batch.
 // W0C: the number of panel columns requested ahead, fixed at compile time (7: the one-ring of a regular mesh vertex plus the
 // diagonal, by far the most common slice width of A) -- straight-line loads, no branch per column; -1: taken from a_w_lo.
-template <int MODE, int KB, typename T, int W0C = -1>
-__global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
+template <int MODE, int KB, typename T, int W0C = -1, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_sell(const int* a_col, const T* a_val, const int* a_order, const int* a_slice_off, int a_stride,
                                               int a_w_lo, int s_begin, int s_end, int n_blocks, int use_order, const T* x,
                                               const int* a_slice_row, const int* a_slice_w, const T* b, T* y, int ld, const int* done,
                                               double* partials, CoarseInit<T> z)
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_sell(const int* a_col, const T* a_val, 
     constexpr int C = 64;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    constexpr int wpb = 4;            // waves (= slices) per block
+    constexpr int wpb = WPB;          // waves (= slices) per block
     // n_blocks < 0 (small colour sweeps only): the launch has 8x the workgroups and only those that land on XCD 0 work, so the
     // values one colour launch writes are still in that XCD's L2 when the next launch gathers them -- a small level's launch chain
     // is pure latency, and this takes the trip to the Infinity Cache out of it (tools/micro/xcd_local.hip: 3.6 -> 2.85 us per launch)
@@ -495,6 +495,7 @@ int sell_wide_blocks(int n_slices, int k)
 
 // 4 slices (waves) per 256-thread block; 1, 2 and 8 measured the same within noise on C3
 static constexpr int sell_wpb() { return 4; }
+static int gs_wpb() { static const int v = getenv("SMG_GS_WPB") ? atoi(getenv("SMG_GS_WPB")) : 4; return v; }   // A/B knob: waves per workgroup of the big colour launches
 int sell_blocks(int n_slices) { return (n_slices + sell_wpb() - 1) / sell_wpb(); }
 
 template <int MODE, typename T>
@@ -557,6 +558,8 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
                 static const int pitch_env = getenv("SMG_PITCH_SPEC_MAX") ? atoi(getenv("SMG_PITCH_SPEC_MAX")) : -1;
                 const int pitch_max = pitch_env >= 0 ? pitch_env : (sell_is_gs(MODE) ? 32 : 64);
                 if (nb <= pitch_max && A.stride == 12 && w0 >= 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 12>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 7 && MODE == SELL_GS && !one_xcd && gs_wpb() == 8) hipLaunchKernelGGL((k_sell<MODE == SELL_GS ? MODE : SELL_GS, 1, T, 7, 8>), dim3((ns + 7) / 8), dim3(512), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, (ns + 7) / 8, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
+                else if (w0 == 7 && MODE == SELL_GS && !one_xcd && gs_wpb() == 2) hipLaunchKernelGGL((k_sell<MODE == SELL_GS ? MODE : SELL_GS, 1, T, 7, 2>), dim3((ns + 1) / 2), dim3(128), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, (ns + 1) / 2, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 7) hipLaunchKernelGGL((k_sell<MODE, 1, T, 7>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 8) hipLaunchKernelGGL((k_sell<MODE, 1, T, 8>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);
                 else if (w0 == 2) hipLaunchKernelGGL((k_sell<MODE, 1, T, 2>), dim3(grid), dim3(64 * sell_wpb()), 0, st, A.col, host_vals<T>(A), A.order, A.slice_off, A.stride, A.w_lo, s_begin, s_end, nbarg, use_order, xx, A.slice_row, A.slice_w, bb, yy, k, done, pp, zz);

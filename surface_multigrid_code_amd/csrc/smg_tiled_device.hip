@@ -32,7 +32,7 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
     const int P = sweeps * nc;
     for (int i = tid; i < n_ext; i += (int)blockDim.x) xs[i] = x[(size_t)ext_rows[ext_off + i] * ld];
     int cR[NC][W], gR[NC];
-    double vR[NC][W], bR[NC];
+    double vR[NC][W], bR[NC], dR[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         gR[c] = -1; bR[c] = 0.0;
@@ -51,6 +51,19 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
     }
 #pragma unroll
     for (int c = 0; c < NC; c++) if (gR[c] >= 0) bR[c] = b[(size_t)gR[c] * ld];
+    // Branch-free phases: the diagonal leaves the row (its slot keeps a zero that multiplies the row's own, finite, value) and padding
+    // slots point at the row itself with a zero -- a sum that starts at +0 is not changed by adding +-0 (it never holds -0), so the bits
+    // are those of the sum that skips these slots, and the phase loop is W straight-line LDS reads and multiply-adds.
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int lrow = (c < nc ? Hs[4 + c * TILED_CSTRIDE + 3] : 0) + tid;
+        dR[c] = 1.0;
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            if (cR[c][j] == lrow) { dR[c] = vR[c][j]; vR[c][j] = 0.0; }
+            else if (cR[c][j] < 0) { cR[c][j] = gR[c] >= 0 ? lrow : 0; vR[c][j] = 0.0; }
+        }
+    }
     __syncthreads();
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
@@ -62,16 +75,11 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
                 if (tid < cnt) {
                     double xv[W];
 #pragma unroll
-                    for (int j = 0; j < W; j++) xv[j] = (cR[c][j] >= 0 && cR[c][j] != lrow) ? xs[cR[c][j]] : 0.0;
-                    double acc = 0.0, diag = 1.0;
+                    for (int j = 0; j < W; j++) xv[j] = xs[cR[c][j]];
+                    double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < W; j++) {
-                        if (cR[c][j] >= 0) {
-                            if (cR[c][j] == lrow) diag = vR[c][j];
-                            else acc += vR[c][j] * xv[j];
-                        }
-                    }
-                    xs[lrow] = (bR[c] - acc) / diag;      // rows of one colour never read each other: no hazard inside a phase
+                    for (int j = 0; j < W; j++) acc += vR[c][j] * xv[j];
+                    xs[lrow] = (bR[c] - acc) / dR[c];      // rows of one colour never read each other: no hazard inside a phase
                 }
                 __syncthreads();
             }
