@@ -186,6 +186,16 @@ int smg_level_block_stats(const smg_hierarchy *h, int lv, long *n_blocks, long *
  * val[((slice_off[s] + j) * 9 + e) * 64 + lane].  Query n_slices / n_panel_cols with NULL arrays first. */
 int smg_level_get_block_image(const smg_hierarchy *h, int lv, int *n_slices, int *n_panel_cols, int *slice_row, int *slice_off, int *slice_w,
                               int *col, double *val);
+/* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).
+ * Up to n_max unknowns (default 8192, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device and applied as a dense,
+ * bandwidth-bound product (8 n^2 bytes; <= 1e-11 from LDL^T).  Above: a sparse Cholesky factorisation P A P^T = L L^T -- what the
+ * reference's Eigen::SimplicialLDLT does -- computed on the host during smg_precompute (nested-dissection order), with the two
+ * triangular solves on the device (one launch each, rows wait for the rows they read; deterministic).  So mg_precompute's nVCoarsest
+ * may be anything the reference accepts, down to a 1-level call on the whole mesh, in O(n log n) memory.  Not available with the sparse
+ * factorisation: the mixed-precision cycle.  smg_hierarchy_coarse_solver: 0 dense inverse / 1 sparse Cholesky after a precompute;
+ * *factor_entries: n^2 resp. the entries of L. */
+int smg_hierarchy_set_coarse_dense_max(smg_hierarchy *h, int n_max);
+int smg_hierarchy_coarse_solver(const smg_hierarchy *h, long *factor_entries);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],
  * and for lv >= 1: i32 n_rows i32 n_cols i32 nnz i32 ptr[n_rows+1] i32 col[nnz] f64 val[nnz]. */

@@ -282,6 +282,16 @@ class Hierarchy:
                                          C.byref(ns)), "smg_level_sell_stats")
         return {"stored": st.value, "padded": pd.value, "n_slices": ns.value}
 
+    # ---- coarsest-level solver
+    def set_coarse_dense_max(self, n_max):
+        """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""
+        _chk(self.L.smg_hierarchy_set_coarse_dense_max(self.h, int(n_max)), "smg_hierarchy_set_coarse_dense_max")
+
+    def coarse_solver(self):
+        ne = C.c_long()
+        kind = self.L.smg_hierarchy_coarse_solver(self.h, C.byref(ne))
+        return {"kind": "sparse_cholesky" if kind == 1 else "dense_inverse", "factor_entries": ne.value}
+
     # ---- block (3-DOF) variant
     def set_block_mode(self, mode="auto"):
         """'auto' (decide at precompute), 'scalar' (never), 'block' (3 x 3 kernels required)."""

@@ -209,6 +209,7 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     if (!h) { fail(SMG_ERR_ALLOC, "out of memory"); return nullptr; }
     h->n_levels = n_levels;
     h->lv.resize(n_levels);
+    h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 8192);
     return h;
 }
 
@@ -288,6 +289,20 @@ extern "C" int smg_level_get_block_image(const smg_hierarchy* h, int lv, int* n_
         if (val) std::copy(S.val.begin(), S.val.end(), val);
         return (int)SMG_OK;
     });
+}
+
+extern "C" int smg_hierarchy_set_coarse_dense_max(smg_hierarchy* h, int n_max)
+{
+    if (!h || n_max < 0) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_dense_max: bad arguments");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_dense_max called during a split-phase solve");
+    if (n_max != h->coarse_dense_max) { h->coarse_dense_max = n_max; h->precomputed = false; }   // the next smg_precompute is a full one
+    return SMG_OK;
+}
+extern "C" int smg_hierarchy_coarse_solver(const smg_hierarchy* h, long* factor_entries)
+{
+    if (!h) return SMG_ERR_INVALID;
+    if (factor_entries) *factor_entries = h->coarse_sparse ? h->chol.nnzL() : (long)h->nc_pad * h->nc_pad;
+    return h->coarse_sparse ? 1 : 0;
 }
 
 extern "C" int smg_hierarchy_set_chebyshev(smg_hierarchy* h, double cheby_fraction)

@@ -170,6 +170,7 @@ static int ensure_fp32(smg_hierarchy* h, int k)
 {
     const int L = h->n_levels;
     if (h->bs == 3) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available for block (3-DOF) hierarchies");
+    if (h->coarse_sparse) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available with a sparse coarse factorisation (coarsest level of %d unknowns)", h->nc);
     if (!h->f32_valid) {
         drop_graphs(h);
         auto mk = [&](SellBuf& src, DevBuf<float>& dst, SellDev& view) -> int {
@@ -285,7 +286,10 @@ template <> struct Prec<double> {
                            hipStream_t st, double* zero_rows = nullptr, const FirstColour* first = nullptr, double omega = 1.0)
     { return launch_sell(m, V, s0, s1, x, bb, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega); }
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
-    { return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p); }
+    {
+        if (h->coarse_sparse) return launch_sparse_coarse_solve(h->c_view, L.b.p, L.u.p, k, ctrl, h->stream);
+        return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p);
+    }
     // an operation with the level's matrix in whatever format it lives in: SELL panels, or 3 x 3 blocks on block hierarchies.
     // smoother_image: the matrix the smoother streams (A^T where A is not bit-symmetric), else A.  s1 < 0: all slices.
     static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const double* x, const double* bb, double* y, int k,
@@ -901,6 +905,11 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
         for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, his[i]);  // :111
         if (cnt) std::printf("residual norm: %g\n", his[cnt - 1]);                                    // :127
     }
+    if (h->coarse_sparse) {
+        int cerr = 0;
+        HIPCHK(hipMemcpy(&cerr, h->c_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (cerr) { (void)hipMemset(h->c_err.p, 0, sizeof(int)); return fail(SMG_ERR_HIP, "the triangular solves of the sparse coarse factorisation stalled"); }
+    }
     if (hc.status != 0) return fail(SMG_ERR_NONFINITE, "non-finite residual at iteration %d", cnt - 1);
     return SMG_OK;
 }
@@ -1186,7 +1195,7 @@ extern "C" int smg_coarse_solve(smg_hierarchy* h, const double* B, int k, double
     Level& Lv = h->lv[lv];
     if ((rc = put_block(h, lv, B, k, Lv.b.p))) return rc;
     if ((rc = put_block(h, lv, u, k, Lv.u.p))) return rc;
-    HIPCHK(launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, Lv.b.p, Lv.u.p, k, nullptr, h->stream, h->d_sympart.p));
+    HIPCHK(Prec<double>::coarse(h, Lv, k, nullptr));
     return get_block(h, lv, Lv.u.p, k, u);
 }
 
@@ -1301,7 +1310,8 @@ extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int pos
         tot += 12 * nnzP + 4 * (n + 1) + 8 * nc * k + 16 * n * k;
     }
     const long nc = h->lv[L - 1].n;
-    tot += 8 * nc * nc + 24 * nc * k;
+    if (h->coarse_sparse) tot += (2 * 12 * h->chol.nnzL() + 3 * 8 * nc + 24 * nc) * k;    // both triangles of L, once per column
+    else tot += 8 * nc * nc + 24 * nc * k;
     if (h->bs == 3) tot += 76 * h->lv[0].bA.blocks + 4L * (h->lv[0].n / 3 + 1) + 16L * h->lv[0].n * k;
     else tot += 12 * h->lv[0].A.nnz() + 4L * (h->lv[0].n + 1) + 16L * h->lv[0].n * k;
     return tot;

@@ -141,6 +141,20 @@ struct TiledDev {
 hipError_t launch_tiled_gs(const TiledDev& T, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st);
 hipError_t tiled_gs_prepare(int max_ext);
 
+// ---- sparse coarse solver (smg_coarse.hpp): P A P^T = L L^T factored on the host, the triangular solves here --------------------------
+struct SparseCholDev {
+    int n = 0;
+    const int* perm = nullptr;                       // new -> old
+    const int *rptr = nullptr, *rcol = nullptr;      // strict lower triangle by rows
+    const int *cptr = nullptr, *crow = nullptr;      // ... and by columns
+    const double *rval = nullptr, *cval = nullptr, *diag = nullptr;
+    double* work = nullptr;                          // n
+    int* flags = nullptr;                            // 2 n
+    int* err = nullptr;                              // raised when a wait gave up
+};
+// u[:, c] += (L L^T)^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)
+hipError_t launch_sparse_coarse_solve(const SparseCholDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "smg_bsr3.hpp"
+#include "smg_coarse.hpp"
 #include "smg_device.hpp"
 #include "smg_mesh.hpp"
 #include "smg_order.hpp"
@@ -179,6 +180,13 @@ struct smg_hierarchy {
     smg::DevBuf<double> d_Ainv;
     smg::DevBuf<float> d_Ainv32;
     smg::DevBuf<double> d_sympart;  // (nc_pad/64)^2 x 64 partial products of the symmetric k = 1 coarse solve (also used as float)
+    // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
+    bool coarse_sparse = false;
+    int coarse_dense_max = 8192;   // smg_hierarchy_set_coarse_dense_max
+    smg::SparseChol chol;
+    smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_flags, c_err;
+    smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;
+    smg::SparseCholDev c_view;
     bool f32_valid = false;
     int kcap32 = 0;
     // ---- block (3-DOF) variant: 1 = scalar kernels, 3 = the level matrices live in 3 x 3 blocks ----

@@ -307,6 +307,30 @@ int smg::ensure_spectral_bounds(smg_hierarchy* h)
     return need ? spectral_bounds(h) : SMG_OK;
 }
 
+// ---- sparse coarse solver (smg_coarse.hpp): coarsest levels beyond the dense range -----------------------------------------------
+// solver.compute(Ac) (reference src/min_quad_with_fixed_mg.cpp:47-48, :253-254) on the host, like the reference; the factor goes to HBM.
+// reuse: same pattern as the last factorisation (value-only re-precompute): the ordering is kept.
+static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
+{
+    StageTimer tm;
+    if (!sparse_cholesky(Ac, h->chol, reuse && h->coarse_sparse))
+        return fail(SMG_ERR_INVALID, "coarsest matrix (%d unknowns) is not positive definite: sparse Cholesky met a non-positive pivot", Ac.nr);
+    tm.lap("host: sparse Cholesky of the coarsest matrix");
+    const SparseChol& F = h->chol;
+    HIPCHK(h->c_perm.upload(F.perm)); HIPCHK(h->c_rptr.upload(F.rptr)); HIPCHK(h->c_rcol.upload(F.rcol)); HIPCHK(h->c_cptr.upload(F.cptr));
+    HIPCHK(h->c_crow.upload(F.crow)); HIPCHK(h->c_rval.upload(F.rval)); HIPCHK(h->c_cval.upload(F.cval)); HIPCHK(h->c_diag.upload(F.diag));
+    HIPCHK(h->c_work.ensure((size_t)F.n)); HIPCHK(h->c_flags.ensure((size_t)2 * F.n));
+    HIPCHK(h->c_err.ensure(1));
+    HIPCHK(hipMemset(h->c_err.p, 0, sizeof(int)));
+    SparseCholDev& V = h->c_view;
+    V.n = F.n; V.perm = h->c_perm.p; V.rptr = h->c_rptr.p; V.rcol = h->c_rcol.p; V.cptr = h->c_cptr.p; V.crow = h->c_crow.p;
+    V.rval = h->c_rval.p; V.cval = h->c_cval.p; V.diag = h->c_diag.p; V.work = h->c_work.p; V.flags = h->c_flags.p; V.err = h->c_err.p;
+    h->coarse_sparse = true;
+    h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release();
+    tm.lap("device: sparse coarse factor uploaded");
+    return SMG_OK;
+}
+
 // Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
 static int precompute_device(smg_hierarchy* h)
 {
@@ -462,14 +486,19 @@ static int precompute_device(smg_hierarchy* h)
         }
     }
     tm.lap("device: index maps");
-    // coarsest level: dense inverse on the device (stands in for solver.compute(Ac), :47-48 / :253-254)
-    {
+    // coarsest level: dense inverse on the device (stands in for solver.compute(Ac), :47-48 / :253-254) up to SMG_COARSE_DENSE_MAX
+    // unknowns; beyond, the reference's own method: sparse Cholesky (smg_coarse.hpp)
+    if (h->lv[L - 1].n > h->coarse_dense_max) {
+        const Level& Lc = h->lv[L - 1];
+        h->nc = Lc.n; h->nc_pad = Lc.n;
+        int rc = coarse_factor_sparse(h, Lc.A, false);
+        if (rc) return rc;
+    } else {
+        h->coarse_sparse = false;
         const Level& Lc = h->lv[L - 1];
         const int nc = Lc.n;
         const int np = ((nc + 63) / 64) * 64;
         h->nc = nc; h->nc_pad = np;
-        if ((double)np * np * 8.0 > 96e9)
-            return fail(SMG_ERR_ALLOC, "coarsest level has %d unknowns: its dense inverse (%.0f GB) is out of range -- add levels", nc, (double)np * np * 8e-9);
         // dense image on the device: the few entries travel, not n^2 zeros
         std::vector<long long> pos(Lc.A.nnz());
         for (int i = 0; i < nc; i++)
@@ -486,7 +515,7 @@ static int precompute_device(smg_hierarchy* h)
         HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    tm.lap("device: coarse dense inverse");
+    tm.lap("device: coarse factorisation");
     h->lam_valid = false;   // the Gershgorin bounds are computed when a Chebyshev smoother first asks for them (ensure_spectral_bounds)
     return SMG_OK;
 }
@@ -616,7 +645,7 @@ static int build_recipes(smg_hierarchy* h)
                 pos[p] = (long long)i * h->nc_pad + Lc.A.col[p];
                 if (Lc.A.col[p] == i) dg.push_back(p);
             }
-        HIPCHK(h->d_dense_pos.upload(pos));
+        if (!h->coarse_sparse) HIPCHK(h->d_dense_pos.upload(pos));
         HIPCHK(h->d_diag_idx.upload(dg));
     }
     HIPCHK(h->d_lhs_src.upload(h->lhs_src));
@@ -653,8 +682,14 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
             }
         }
     }
-    // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254)
-    {
+    // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254), or the sparse factorisation on the host from the new values
+    if (h->coarse_sparse) {
+        Level& Lc = h->lv[L - 1];
+        HIPCHK(hipMemcpyAsync(Lc.A.val.data(), Lc.d_Aval.p, Lc.A.val.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int rc = coarse_factor_sparse(h, Lc.A, true);
+        if (rc) return rc;
+    } else {
         const Level& Lc = h->lv[L - 1];
         HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));
         DevBuf<double> work;

@@ -1,0 +1,86 @@
+"""GPU (-m gpu): coarsest levels too large for a dense inverse (VERDICT r02 missing #2).
+
+The reference factors whatever size mg_precompute's nVCoarsest leaves with Eigen::SimplicialLDLT (src/min_quad_with_fixed_mg.cpp:47-48,
+:253-254) and solves with it in coarseSolve() (src/mg_VCycle.cpp:181-201).  libsmg: dense inverse up to 8192 unknowns, above a sparse
+Cholesky factorisation (host, nested dissection) with the triangular solves on the device.  Checker: the oracle's LDL^T path."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import mesh_np as M
+from problems import subdiv_problem
+from test_gpu_parity import smg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_sparse_coarse_solver_on_small_hierarchies_matches_the_dense_one(smg, oracle_mod, k):
+    """The sparse factorisation forced onto an ordinary hierarchy (coarsest level of a few thousand unknowns): coarse_solve agrees with
+    the oracle's LDL^T to 1e-11, the solve takes the iterations of the dense-inverse handle and returns the same solution to 1e-9."""
+    p = subdiv_problem(kind="mcf", k=k, n_sub=2)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.set_coarse_dense_max(0)
+    mg.precompute(p["A"])
+    cs = mg.coarse_solver()
+    nc = mg.rows(mg.n_levels - 1)
+    assert cs["kind"] == "sparse_cholesky" and nc < cs["factor_entries"] < nc * 80
+    orc = oracle_mod.OracleMG(p["Ps"]); orc.precompute(p["A"])
+    rng = np.random.default_rng(2)
+    B, u = rng.uniform(-1, 1, (nc, k)), rng.uniform(-1, 1, (nc, k))
+    got, ref = mg.coarse_solve(B, u), orc.coarse_solve(B, u)
+    assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
+    assert np.array_equal(got, mg.coarse_solve(B, u))                       # deterministic
+    dense = smg.Hierarchy.from_prolongs(p["Ps"]); dense.precompute(p["A"])
+    assert dense.coarse_solver()["kind"] == "dense_inverse"
+    o = smg.SolveOpts(tol=1e-10, max_iter=40)
+    a, b = mg.solve(p["RHS"], p["z0"], None, o), dense.solve(p["RHS"], p["z0"], None, o)
+    assert a[0] and b[0] and len(a[2]) == len(b[2])
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
+    # value-only re-precompute: the factorisation is redone from the new values (same ordering)
+    A2 = (p["A"] + 0.25 * sp.diags(p["A"].diagonal())).tocsr(); A2.sort_indices()
+    mg.precompute(A2); dense.precompute(A2)
+    a, b = mg.solve(p["RHS"], p["z0"], None, o), dense.solve(p["RHS"], p["z0"], None, o)
+    assert a[0] and len(a[2]) == len(b[2]) and np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
+    with pytest.raises(smg.SmgError):
+        mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-8, max_iter=10, precision="mixed"))
+
+
+def test_one_and_two_level_calls_on_a_15k_mesh(smg, oracle_mod):
+    """What the reference accepts and round 2 refused or paid 2 GB for: mg_precompute with an nVCoarsest that leaves a coarsest level of
+    15 804 / 3 952 unknowns.  A 1-level hierarchy goes straight to coarseSolve (src/mg_VCycle.cpp:28-33): one 'cycle' is the direct
+    solve."""
+    V, F = M.read_smgm("bunny_15K_init.smgm")
+    V = M.normalize_unit_area(V, F)
+    n = V.shape[0]
+    A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+    rng = np.random.default_rng(9)
+    rhs, z0 = rng.uniform(-1, 1, (n, 2)), np.zeros((n, 2))
+    import scipy.sparse.linalg as sla
+    xref = sla.spsolve(A.tocsc(), rhs)
+    # 1 level: the whole mesh is the coarsest level
+    mg1 = smg.Hierarchy(1)
+    mg1.precompute(A)
+    cs = mg1.coarse_solver()
+    assert cs["kind"] == "sparse_cholesky" and cs["factor_entries"] < 60 * n        # O(n log n), not 2 GB
+    a = mg1.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=5))
+    # (the coarsest matrix carries the reference's +1e-12 on its diagonal, src/min_quad_with_fixed_mg.cpp:32-36: 2e-8 relative to the lumped
+    #  masses of this mesh -- the comparison that must be tight is the one with the oracle, which adds it too)
+    assert a[0] and len(a[2]) == 2 and np.linalg.norm(a[1] - xref) <= 1e-6 * np.linalg.norm(xref)
+    o1 = oracle_mod.OracleMG([]); o1.precompute(A)
+    b = o1.solve(rhs, z0, tol=1e-9, max_iter=5)
+    assert len(b[2]) == len(a[2]) and np.linalg.norm(a[1] - b[1]) <= 1e-10 * np.linalg.norm(b[1])
+    # 2 levels through mg_precompute (nVCoarsest just below a quarter of the mesh): coarsest level ~3 950 unknowns -> dense; and the same
+    # hierarchy with the dense range closed -> sparse: same convergence
+    mg2 = smg.mg_precompute(V, F, 0.25, 3000, 1)
+    assert mg2.n_levels == 2
+    mg2.precompute(A)
+    assert mg2.coarse_solver()["kind"] == "dense_inverse"
+    r_dense = mg2.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=60))
+    mg2.set_coarse_dense_max(1000)
+    mg2.precompute(A)
+    assert mg2.coarse_solver()["kind"] == "sparse_cholesky"
+    r_sparse = mg2.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=60))
+    assert r_dense[0] and r_sparse[0] and len(r_dense[2]) == len(r_sparse[2])
+    assert np.linalg.norm(r_dense[1] - r_sparse[1]) <= 1e-9 * np.linalg.norm(r_dense[1])
+    assert np.linalg.norm(r_sparse[1] - xref) <= 1e-7 * np.linalg.norm(xref)
