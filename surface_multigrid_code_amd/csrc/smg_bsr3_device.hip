@@ -110,42 +110,76 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
                 else if (live) { const double t = bv[d] - acc[d]; ss += t * t; }
             }
         } else {
-            // Gauss-Seidel: row 3v, then 3v+1 with the new value of 3v, then 3v+2 with both.  Each row streams its own three value
-            // planes; the block columns and the gathers are repeated (they hit L1/L2: the same lines as a moment ago).
-            constexpr int U = 8;
+            // Gauss-Seidel: row 3v, then 3v+1 with the new value of 3v, then 3v+2 with both.  The block columns and the gathered values of
+            // the first WR panel columns (all of them on mesh matrices: a vertex has 7 - 8 blocks) are fetched ONCE and stay in registers for
+            // the three rows; each row streams its own three value planes, the next row's planes requested while this one is summed.
+            // Panel columns beyond WR (wide Galerkin rows) repeat their gathers per row.
+            constexpr int WR = 8;
+            int c[WR];
+            double xg[WR][3];
+#pragma unroll
+            for (int t = 0; t < WR; t++) c[t] = t < w ? cp[(size_t)t * 64] : -1;
+            double v[WR][3], vn[WR][3];
+#pragma unroll
+            for (int t = 0; t < WR; t++)
+#pragma unroll
+                for (int e = 0; e < 3; e++) v[t][e] = t < w ? vp[((size_t)t * 9 + e) * 64] : 0.0;
+#pragma unroll
+            for (int t = 0; t < WR; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
 #pragma unroll
             for (int d = 0; d < 3; d++) {
+                if (d < 2) {
+#pragma unroll
+                    for (int t = 0; t < WR; t++)
+#pragma unroll
+                        for (int e = 0; e < 3; e++) vn[t][e] = t < w ? vp[((size_t)t * 9 + 3 * (d + 1) + e) * 64] : 0.0;
+                }
                 double acc = 0.0, diag = 1.0;
-                for (int j0 = 0; j0 < w; j0 += U) {
-                    int c[U];
-                    double v[U][3], xg[U][3];
 #pragma unroll
-                    for (int t = 0; t < U; t++) {
+                for (int t = 0; t < WR; t++) {
+                    if (c[t] >= 0) {
+                        const bool own = c[t] == vtx;
+#pragma unroll
+                        for (int e = 0; e < 3; e++) {
+                            if (own && e == d) diag = v[t][e];
+                            else acc += v[t][e] * ((own && e < d) ? out[e] : xg[t][e]);
+                        }
+                    }
+                }
+                for (int j0 = WR; j0 < w; j0 += 4) {      // the tail of a wide block row
+                    int c2[4];
+                    double v2[4][3], x2[4][3];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
                         if (j0 + t < w) {
-                            c[t] = cp[(size_t)(j0 + t) * 64];
+                            c2[t] = cp[(size_t)(j0 + t) * 64];
 #pragma unroll
-                            for (int e = 0; e < 3; e++) v[t][e] = vp[((size_t)(j0 + t) * 9 + 3 * d + e) * 64];
+                            for (int e = 0; e < 3; e++) v2[t][e] = vp[((size_t)(j0 + t) * 9 + 3 * d + e) * 64];
                         } else {
-                            c[t] = -1;
+                            c2[t] = -1;
 #pragma unroll
-                            for (int e = 0; e < 3; e++) v[t][e] = 0.0;
+                            for (int e = 0; e < 3; e++) v2[t][e] = 0.0;
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < U; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
+                    for (int t = 0; t < 4; t++) gather3<LD1>(x, c2[t], ld, c2[t] >= 0, x2[t]);
 #pragma unroll
-                    for (int t = 0; t < U; t++) {
-                        if (c[t] >= 0) {
-                            const bool own = c[t] == vtx;
+                    for (int t = 0; t < 4; t++) {
+                        if (c2[t] >= 0) {
+                            const bool own = c2[t] == vtx;
 #pragma unroll
                             for (int e = 0; e < 3; e++) {
-                                if (own && e == d) diag = v[t][e];
-                                else acc += v[t][e] * ((own && e < d) ? out[e] : xg[t][e]);
+                                if (own && e == d) diag = v2[t][e];
+                                else acc += v2[t][e] * ((own && e < d) ? out[e] : x2[t][e]);
                             }
                         }
                     }
                 }
                 out[d] = (bv[d] - acc) / diag;
+#pragma unroll
+                for (int t = 0; t < WR; t++)
+#pragma unroll
+                    for (int e = 0; e < 3; e++) v[t][e] = vn[t][e];
             }
         }
         if (live && !stop && !SS) {

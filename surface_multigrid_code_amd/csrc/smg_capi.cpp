@@ -209,7 +209,7 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     if (!h) { fail(SMG_ERR_ALLOC, "out of memory"); return nullptr; }
     h->n_levels = n_levels;
     h->lv.resize(n_levels);
-    h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 8192);
+    h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 16384);
     return h;
 }
 

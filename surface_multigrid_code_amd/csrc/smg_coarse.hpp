@@ -1,7 +1,7 @@
 // smg_coarse.hpp -- coarseSolve() for coarsest levels too large for a dense inverse (reference src/mg_VCycle.cpp:181-201,
 // src/min_quad_with_fixed_mg.cpp:47-48, :253-254: Eigen::SimplicialLDLT factors whatever size mg_precompute's nVCoarsest left).
 //
-// Up to SMG_COARSE_DENSE_MAX unknowns (default 8192) the coarsest matrix is inverted on the device and the solve is a bandwidth-bound
+// Up to smg_hierarchy_set_coarse_dense_max unknowns (default 16384) the coarsest matrix is inverted on the device and the solve is a bandwidth-bound
 // dense product (smg_device.hip: launch_spd_inverse, k_sym_gemv_*): 8 n^2 bytes.  Above, the reference's own method: a sparse Cholesky
 // factorisation  P A P^T = L L^T  -- nested-dissection ordering by breadth-first bisection, up-looking numeric factorisation, both on the
 // host as part of the precompute (the reference factors on the host, too) -- and the two triangular solves on the device, each ONE launch:

@@ -182,7 +182,7 @@ struct smg_hierarchy {
     smg::DevBuf<double> d_sympart;  // (nc_pad/64)^2 x 64 partial products of the symmetric k = 1 coarse solve (also used as float)
     // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
     bool coarse_sparse = false;
-    int coarse_dense_max = 8192;   // smg_hierarchy_set_coarse_dense_max
+    int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
     smg::SparseChol chol;
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_flags, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;

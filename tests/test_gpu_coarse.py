@@ -1,7 +1,7 @@
 """GPU (-m gpu): coarsest levels too large for a dense inverse (VERDICT r02 missing #2).
 
 The reference factors whatever size mg_precompute's nVCoarsest leaves with Eigen::SimplicialLDLT (src/min_quad_with_fixed_mg.cpp:47-48,
-:253-254) and solves with it in coarseSolve() (src/mg_VCycle.cpp:181-201).  libsmg: dense inverse up to 8192 unknowns, above a sparse
+:253-254) and solves with it in coarseSolve() (src/mg_VCycle.cpp:181-201).  libsmg: dense inverse up to smg_hierarchy_set_coarse_dense_max unknowns (default 16384), above a sparse
 Cholesky factorisation (host, nested dissection) with the triangular solves on the device.  Checker: the oracle's LDL^T path."""
 import numpy as np
 import pytest
@@ -60,6 +60,7 @@ def test_one_and_two_level_calls_on_a_15k_mesh(smg, oracle_mod):
     xref = sla.spsolve(A.tocsc(), rhs)
     # 1 level: the whole mesh is the coarsest level
     mg1 = smg.Hierarchy(1)
+    mg1.set_coarse_dense_max(8192)            # (the default, 16384, would still invert these 15 804 unknowns densely: 2 GB, 0.3 ms per solve)
     mg1.precompute(A)
     cs = mg1.coarse_solver()
     assert cs["kind"] == "sparse_cholesky" and cs["factor_entries"] < 60 * n        # O(n log n), not 2 GB

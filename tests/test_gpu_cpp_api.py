@@ -171,3 +171,14 @@ def test_cpp_sharded_mean_curvature_flow_example(smg_mod):
     conv, z, rh = mg.solve(Mb @ Z0, Z0, None, smg.SolveOpts(tol=5e-7, max_iter=20))
     assert conv and len(rh) == int(steps[0][2])
     assert abs(float(steps[0][3]) - rh[-1]) <= 1e-5 * rh[-1]      # printed with %.6e
+
+
+def test_eigen_adapter_against_real_eigen():
+    """If __graft_entry__.build() found an Eigen header tree (and the reference's headers) it compiled examples/smg_eigen_adapter.cpp
+    against them: run that binary.  Skipped in this image (no Eigen anywhere: the adapter has only met tests/mock_eigen)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check_eigen")
+    if not os.path.exists(exe):
+        pytest.skip("no Eigen in the image: oracle/_ref/adapter_check_eigen was not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "surface_multigrid_code_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "bunny.smgm")], env=env, text=True, timeout=600)
+    assert "converged: 1" in out or "converged 1" in out, out[-1500:]
