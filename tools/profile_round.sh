@@ -1,12 +1,13 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun).  Outputs under gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# 1. kernel trace + stats of the very command the driver runs (C3 main loop, smoother comparison, C5 and C4 legs)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 200 --warmup 20 --no-cpu > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err
+# 1. kernel trace + stats of the very command the driver runs (C3 main loop = the reference's Gauss-Seidel cycle, smoother comparison, C5, C3 x 64 columns,
+#    C4 legs; the block leg's scalar comparison is left out: 17 s of host precompute that add nothing to the kernel table)
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 200 --warmup 20 --no-cpu --no-block3-scalar > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err
 python tools/rocpd_stats.py $OUT/trace/bench_results.db $OUT/${TAG}_bench_kernel_stats.csv > /dev/null
 # 2. one outer iteration of the timed configuration (GS above 300 k rows, Chebyshev-Jacobi below), kernel by kernel -- and of the
 #    reference's Gauss-Seidel everywhere; and of the wide (k = 64) kernels of C4
@@ -29,5 +30,10 @@ done
 rocprofv3 --kernel-trace --stats -d $OUT/c5t -o t -- python tools/prof_kernels.py --workload C5 --reps 50 --cycles 5 > $OUT/c5t.log 2>&1
 python tools/rocpd_stats.py $OUT/c5t/t_results.db $OUT/${TAG}_c5_kernel_stats.csv > /dev/null
 python tools/make_traffic.py $OUT/${TAG}_pmc_summary_C3.json $OUT/${TAG}_pmc_summary_C5.json $TAG > $OUT/traffic.json
+# 4. where the cycle's time goes, level by level (graph replay, hipEvents): the reference's Gauss-Seidel cycle with and without the one-launch
+#    relax() of the small levels, and the Chebyshev hybrid
+{ echo "== Gauss-Seidel everywhere (reference cycle)"; python tools/level_times.py 2>/dev/null; echo "== the same with SMG_TILED=0 (one launch per colour on every level)"; SMG_TILED=0 python tools/level_times.py 2>/dev/null;
+  echo "== hybrid Chebyshev (GS above 300 k rows)"; SMG_TOOL_SMOOTHER=hybrid_chebyshev:300000 python tools/level_times.py 2>/dev/null; } > $OUT/${TAG}_level_times.txt
+python tools/block3_time.py C3 > $OUT/${TAG}_block3_c3.txt 2>/dev/null
 rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5  # keep the summaries only (the dbs are large)
 ls -la $OUT
