@@ -170,7 +170,13 @@ class HostReduce:
             raise RuntimeError("HostReduce: device -> host copy failed")
         t = torch.tensor(list(buf), dtype=torch.float64)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(t, group=self.group)
+            if dist.get_backend(self.group) == "nccl":      # RCCL reduces device tensors only: through torch's own stream, then back
+                t = t.cuda()
+                dist.all_reduce(t, group=self.group)
+                torch.cuda.synchronize()
+                t = t.cpu()
+            else:
+                dist.all_reduce(t, group=self.group)
         for i in range(count):
             buf[i] = float(t[i])
         if self.hip.hipMemcpy(ptr, buf, 8 * count, 1) != 0:                                                  # hipMemcpyHostToDevice

@@ -842,3 +842,31 @@ def test_wide_kernel_with_the_whole_row_in_flight_is_bit_exact_on_decimated_leve
             mg.set_smoother("gs")
             assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm])), "restrict: " + tag
             assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc])), "prolong: " + tag
+
+
+def test_solve_sharded_with_one_rank_is_smg_solve_and_reports_a_failing_reduction(smg, oracle_mod):
+    """smg_solve_sharded at world size 1 with a reduction that does nothing is smg_solve's loop (same bits: iterate and history); a reduction
+    that reports failure aborts the solve with SMG_ERR_REDUCE and leaves the handle usable; k_local = 0 alone converges on its zero residual."""
+    import torch
+    p, mg, orc = build(smg, oracle_mod, kind="mcf", k=3, n_sub=2)
+    dev = torch.device("cuda", 0)
+    n = mg.rows(0)
+    rhs = torch.from_numpy(np.ascontiguousarray(p["RHS"].T)).to(dev)
+    z0 = torch.from_numpy(np.ascontiguousarray(p["z0"].T)).to(dev)
+    z = torch.empty_like(z0)
+    o = smg.SolveOpts(tol=1e-9, max_iter=40)
+    calls = []
+    conv, rh = mg.solve_sharded(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 3, lambda ptr, cnt, st: calls.append(cnt), opts=o)
+    torch.cuda.synchronize()
+    ref = mg.solve(p["RHS"], p["z0"], None, o)
+    assert conv == ref[0] and np.array_equal(rh, ref[2]) and np.array_equal(z.cpu().numpy().T, ref[1])
+    assert len(calls) >= len(rh) and set(calls) == {1}
+
+    def broken(ptr, cnt, st):
+        raise RuntimeError("link down")
+    with pytest.raises(RuntimeError, match="link down"):
+        mg.solve_sharded(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 3, broken, opts=o)
+    again = mg.solve(p["RHS"], p["z0"], None, o)
+    assert np.array_equal(again[1], ref[1])
+    conv0, rh0 = mg.solve_sharded(None, None, None, 0, 0, lambda ptr, cnt, st: None, opts=o)
+    assert conv0 and len(rh0) == 1 and rh0[0] == 0.0
