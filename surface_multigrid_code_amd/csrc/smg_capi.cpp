@@ -98,8 +98,14 @@ hipError_t SellBuf::upload(const Sell& S)
     if ((e = slice_row.upload(S.slice_row)) != hipSuccess) return e;
     if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
     if ((e = slice_w.upload(S.slice_w)) != hipSuccess) return e;
-    if ((e = col.upload(S.col)) != hipSuccess) return e;
-    if ((e = val.upload(S.val)) != hipSuccess) return e;
+    const bool layout_only = S.col.empty() && S.padded() > 0;     // sell_layout(): the panels are filled on the device
+    if (layout_only) {
+        if ((e = col.alloc((size_t)S.padded())) != hipSuccess) return e;
+        if ((e = val.alloc((size_t)S.padded())) != hipSuccess) return e;
+    } else {
+        if ((e = col.upload(S.col)) != hipSuccess) return e;
+        if ((e = val.upload(S.val)) != hipSuccess) return e;
+    }
     if ((e = order.upload(S.region_order)) != hipSuccess) return e;
     view.n_rows = S.n_rows; view.n_cols = S.n_cols; view.n_slices = S.n_slices; view.C = S.C;
     view.order = S.region_order.empty() ? nullptr : order.p;
@@ -119,7 +125,7 @@ hipError_t SellBuf::upload(const Sell& S)
     // where the diagonal of each row sits in the value array (restriction launches that produce the first launch of the coarse
     // level's first sweep themselves: the first colour of a Gauss-Seidel sweep / the whole first Jacobi sweep)
     n_first = 0; n_all = 0;
-    if (S.n_rows == S.n_cols && S.color_slice_ptr.size() >= 2) {
+    if (S.n_rows == S.n_cols && S.color_slice_ptr.size() >= 2 && !layout_only) {
         const int s1 = S.color_slice_ptr.size() >= 3 ? S.color_slice_ptr[1] : S.n_slices;
         const int nf = S.slice_row[s1];
         std::vector<int> slot((size_t)S.n_rows, -1);
@@ -417,6 +423,7 @@ extern "C" int smg_level_get_matrix(const smg_hierarchy* h, int lv, int which, i
 {
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: bad level");
     if (h->host_stale) { int rc = refresh_host_values(const_cast<smg_hierarchy*>(h)); if (rc) return rc; }
+    if (which == 0 && internal) { int rc = ensure_A_int(const_cast<smg_hierarchy*>(h), lv); if (rc) return rc; }
     const Csr* M = pick_matrix(h, lv, which, internal);
     if (!M) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: no such matrix");
     if (n_rows) *n_rows = M->nr;

@@ -60,6 +60,7 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
     // the matrix the smoother streams, in the internal numbering; entry -> index into the level's values in the caller's CSR order
     std::vector<int> tsrc;
     Csr AT;
+    { int rc = ensure_A_int(h, lv); if (rc) return rc; }
     if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
     const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
     // a tile whose halo makes a colour's panel longer than the workgroup gets smaller tiles

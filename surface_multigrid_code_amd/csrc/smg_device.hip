@@ -1555,6 +1555,40 @@ hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double
     hipLaunchKernelGGL(k_recipe, dim3(grid1d(n_out, 256)), dim3(256), 0, st, n_out, ptr, idx, coef, src, out);
     return hipGetLastError();
 }
+// SELL panels of B(i, j) = A(perm[i], perm[j]) filled on the device from A's CSR arrays in the caller's numbering (first precompute of a big
+// level: the host neither builds the permuted matrix nor ships 1.7x padded panels).  One wave per slice, one lane per row; an entry's panel
+// column is its rank among the row's new column numbers (rows have a handful of entries: the quadratic count is cheaper than a sort and
+// needs no scratch).  The panels must hold col = -1, val = 0 on entry.  Entry order inside a row: ascending new column, the order of the
+// host's permute() + build_sell(): the very same image.
+__global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                   const int* __restrict__ perm, const int* __restrict__ iperm, const int* __restrict__ slice_row,
+                                                   const int* __restrict__ slice_off, int stride, int n_slices, int* s_col, double* s_val)
+{
+    const int lane = threadIdx.x & 63, s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const int row0 = slice_row[s], nrow = slice_row[s + 1] - row0;
+    if (lane >= nrow) return;
+    const int old = perm[row0 + lane];
+    const int p0 = ptr[old], p1 = ptr[old + 1];
+    const size_t base = (size_t)(stride ? s * stride : slice_off[s]) * 64 + lane;
+    for (int p = p0; p < p1; p++) {
+        const int c = iperm[col[p]];
+        int rank = 0;
+        for (int q = p0; q < p1; q++) rank += iperm[col[q]] < c ? 1 : 0;
+        s_col[base + (size_t)rank * 64] = c;
+        s_val[base + (size_t)rank * 64] = val[p];
+    }
+}
+hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(const_cast<int*>(S.col), 0xFF, padded * sizeof(int), st);       // col = -1
+    if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(S.val), 0, padded * sizeof(double), st);
+    if (e != hipSuccess || S.n_slices <= 0) return e;
+    hipLaunchKernelGGL(k_sell_fill, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, val, perm, iperm, S.slice_row, S.slice_off, S.stride, S.n_slices,
+                       const_cast<int*>(S.col), const_cast<double*>(S.val));
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_vals(double* dst, const double* src, const int* map, size_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;

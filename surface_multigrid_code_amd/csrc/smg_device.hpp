@@ -187,6 +187,8 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);
 // value-only re-precompute (same sparsity as the last full precompute) -------------------------------------------
 // out[e] = sum_t coef[t] * src[idx[t]]  (numeric Galerkin stage with a fixed recipe, smg_sparse.hpp)
 hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out, hipStream_t st);
+// SELL panels of A(perm, perm) from A's CSR arrays (caller numbering, on the device): S.col / S.val (padded slots) are cleared and filled
+hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st);
 // dst[i] = map[i] >= 0 ? src[map[i]] : 0   (refresh of SELL value panels / LHS and Auk slices)
 hipError_t launch_gather_vals(double* dst, const double* src, const int* map, size_t n, hipStream_t st);
 // dense (np x np, row-major) = identity on the padding rows, zero elsewhere, then dense[pos[i]] = src[i]

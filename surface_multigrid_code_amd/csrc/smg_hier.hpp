@@ -59,7 +59,7 @@ struct SellBuf {  // device image of one SELL matrix
     int n_first = 0;                         // ... rows of the first colour (they lead the numbering; 0: not available) and
     int n_all = 0;                           // ... all rows (0: some row has no stored diagonal), see FirstColour in smg_device.hpp
     long stored = 0, padded = 0, used = 0;   // CSR entries / allocated slots / slots the kernels read
-    hipError_t upload(const Sell& S);
+    hipError_t upload(const Sell& S);          // S.col / S.val empty: the panels are allocated only (filled on the device, launch_sell_fill)
     // long rows kept out of the panels (SellDev::long_*), see csrc/smg_device.hpp
     DevBuf<int> long_row, long_ptr, long_col;
     DevBuf<double> long_val;
@@ -108,6 +108,8 @@ struct Level {
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
+    bool device_filled = false;    // dA was filled on the device from A and the permutation: A_int is built on demand (ensure_A_int)
+    bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
     std::vector<int> A_int_src;   // A_int entry -> index into A.val

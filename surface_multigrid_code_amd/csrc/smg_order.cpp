@@ -23,9 +23,16 @@ std::vector<int> rcm_order(const Csr& A)
     std::vector<int> deg(n);
     for (int i = 0; i < n; i++) deg[i] = A.ptr[i + 1] - A.ptr[i];
     // component seeds in ascending degree (cheap stand-in for a pseudo-peripheral search)
+    // (a counting sort: the same sequence a stable sort by degree gives, without its 1 M-element merge passes)
     std::vector<int> seeds(n);
-    std::iota(seeds.begin(), seeds.end(), 0);
-    std::stable_sort(seeds.begin(), seeds.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    {
+        int dmax = 0;
+        for (int i = 0; i < n; i++) dmax = std::max(dmax, deg[i]);
+        std::vector<int> start((size_t)dmax + 2, 0);
+        for (int i = 0; i < n; i++) start[(size_t)deg[i] + 1]++;
+        for (int d = 0; d <= dmax; d++) start[(size_t)d + 1] += start[(size_t)d];
+        for (int i = 0; i < n; i++) seeds[(size_t)start[(size_t)deg[i]]++] = i;
+    }
     std::vector<int> nb;
     for (int s : seeds) {
         if (seen[s]) continue;
@@ -44,7 +51,8 @@ std::vector<int> rcm_order(const Csr& A)
                     int w = A.col[p];
                     if (w != v && !seen[w]) { seen[w] = 1; nb.push_back(w); }
                 }
-                std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+                // (the first round only looks for a far vertex: any breadth-first order ends in the last level)
+                if (round == 1) std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
                 order.insert(order.end(), nb.begin(), nb.end());
             }
             if (round == 0) {
@@ -490,14 +498,15 @@ std::vector<int> induced_order(const Csr& P, const std::vector<int>& coarse_rank
     return order;
 }
 
-Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order)
+Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const std::vector<int>* row_breaks, int C, bool region_order)
 {
     Sell S;
     S.C = C;
-    S.n_rows = A.nr; S.n_cols = A.nc; S.nnz = A.nnz();
+    const int n_rows = (int)row_len.size();
+    S.n_rows = n_rows; S.n_cols = n_cols; S.nnz = nnz;
     std::vector<int> breaks;
     if (row_breaks) breaks = *row_breaks;
-    else breaks = {0, A.nr};
+    else breaks = {0, n_rows};
     S.slice_row.push_back(0);
     S.color_slice_ptr.push_back(0);
     long sum_w = 0;
@@ -506,7 +515,7 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
         for (int r0 = breaks[c]; r0 < breaks[c + 1]; r0 += C) {
             int r1 = std::min(r0 + C, breaks[c + 1]);
             int w = 0;
-            for (int r = r0; r < r1; r++) w = std::max(w, A.ptr[r + 1] - A.ptr[r]);
+            for (int r = r0; r < r1; r++) w = std::max(w, row_len[(size_t)r]);
             S.slice_row.push_back(r1);
             S.slice_w.push_back(w);
             sum_w += w; wmax = std::max(wmax, w); wmin = std::min(wmin, w);
@@ -528,6 +537,26 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
     }
     S.slice_off.assign(S.n_slices + 1, 0);
     for (int s = 0; s < S.n_slices; s++) S.slice_off[s + 1] = S.stride ? (s + 1) * S.stride : S.slice_off[s] + S.slice_w[s];
+    if (region_order && S.color_slice_ptr.size() > 2) {
+        // key = position of the slice inside its colour block, in [0,1): rows of a colour are in RCM order, so equal
+        // keys across colours are the same region of the mesh
+        std::vector<std::pair<double, int>> key(S.n_slices);
+        for (size_t c = 0; c + 1 < S.color_slice_ptr.size(); c++) {
+            const int b = S.color_slice_ptr[c], e = S.color_slice_ptr[c + 1];
+            for (int s = b; s < e; s++) key[s] = {(s - b + 0.5) / (double)(e - b), s};
+        }
+        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
+        S.region_order.resize(S.n_slices);
+        for (int i = 0; i < S.n_slices; i++) S.region_order[i] = key[i].second;
+    }
+    return S;
+}
+
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order)
+{
+    std::vector<int> row_len((size_t)A.nr);
+    for (int r = 0; r < A.nr; r++) row_len[(size_t)r] = A.ptr[(size_t)r + 1] - A.ptr[(size_t)r];
+    Sell S = sell_layout(row_len, A.nc, A.nnz(), row_breaks, C, region_order);
     size_t tot = (size_t)C * (size_t)S.slice_off.back();
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);
@@ -546,18 +575,6 @@ Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool re
             }
         }
     });
-    if (region_order && S.color_slice_ptr.size() > 2) {
-        // key = position of the slice inside its colour block, in [0,1): rows of a colour are in RCM order, so equal
-        // keys across colours are the same region of the mesh
-        std::vector<std::pair<double, int>> key(S.n_slices);
-        for (size_t c = 0; c + 1 < S.color_slice_ptr.size(); c++) {
-            const int b = S.color_slice_ptr[c], e = S.color_slice_ptr[c + 1];
-            for (int s = b; s < e; s++) key[s] = {(s - b + 0.5) / (double)(e - b), s};
-        }
-        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
-        S.region_order.resize(S.n_slices);
-        for (int i = 0; i < S.n_slices; i++) S.region_order[i] = key[i].second;
-    }
     return S;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -22,6 +23,43 @@
 using namespace smg;
 
 // ------------------------------------------------------------------------------------------------ precompute
+// A == A^T, bit for bit?  (row-parallel: every entry looks its mirror image up by bisection; no transpose is materialised)
+static bool bit_symmetric(const Csr& A)
+{
+    if (A.nr != A.nc) return false;
+    std::atomic<int> any{0};
+    parallel_for(A.nr, 4096, [&](long r0, long r1) {
+        for (long i = r0; i < r1 && !any.load(std::memory_order_relaxed); i++)
+            for (int p = A.ptr[(size_t)i]; p < A.ptr[(size_t)i + 1]; p++) {
+                const int j = A.col[(size_t)p];
+                const int* b = A.col.data() + A.ptr[(size_t)j];
+                const int* e = A.col.data() + A.ptr[(size_t)j + 1];
+                const int* q = std::lower_bound(b, e, (int)i);
+                if (q == e || *q != (int)i || std::memcmp(&A.val[(size_t)(q - A.col.data())], &A.val[(size_t)p], sizeof(double)) != 0) { any.store(1); break; }
+            }
+    });
+    return any.load() == 0;
+}
+// The panels of a big level's A can be filled on the device straight from the caller's arrays and the permutation (launch_sell_fill):
+// the host then skips the permuted copy and the transposition test of 7 M entries, and ships 85 MB instead of 145 MB of padded
+// panels (C3 level 0: ~ 100 ms of the first precompute).  Conditions: scalar path, a level that is smoothed, at least
+// SMG_DEVICE_FILL_MIN rows (default 200 000; smaller levels are done before it would pay), A bit-symmetric (no A^T image needed).
+static bool device_fill_candidate(const smg_hierarchy* h, int lv)
+{
+    static const int on = env_int("SMG_DEVICE_FILL", 1), min_rows = env_int("SMG_DEVICE_FILL_MIN", 200000);
+    return on && h->bs == 1 && lv < h->n_levels - 1 && h->lv[lv].A.nr >= min_rows;
+}
+int smg::ensure_A_int(smg_hierarchy* h, int lv)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "bad level");
+    Level& Lv = h->lv[lv];
+    if (Lv.A_int.nr == Lv.A.nr && (long)Lv.A_int.nnz() == Lv.A.nnz()) return SMG_OK;
+    if ((int)Lv.ord.perm.size() != Lv.A.nr) return SMG_OK;        // no numbering yet: nothing to express
+    if (h->host_stale) { int rc = refresh_host_values(h); if (rc) return rc; }
+    Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
+    return SMG_OK;
+}
+
 // Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
 static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known)
 {
@@ -261,7 +299,12 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         for (int lv = 0; lv < L; lv++) {
             tasks.push_back([h, lv, L] {
                 Level& Lv = h->lv[lv];
-                if (lv < L - 1) Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
+                Lv.device_filled = false;
+                if (lv < L - 1 && device_fill_candidate(h, lv) && (Lv.A_bit_symmetric = bit_symmetric(Lv.A))) {
+                    Lv.A_int = Csr(); Lv.A_int_src.clear();      // built on demand (ensure_A_int): the device fills the panels from A itself
+                    Lv.device_filled = true;
+                }
+                else if (lv < L - 1) Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
                 else { Lv.A_int = Lv.A; Lv.A_int_src.resize(Lv.A.nnz()); std::iota(Lv.A_int_src.begin(), Lv.A_int_src.end(), 0); }
             });
             if (lv >= 1) {
@@ -378,8 +421,29 @@ static int precompute_device(smg_hierarchy* h)
                         return;
                     }
                     h->lv[lv].bA = Bsr3Buf();
-                    Sell S = build_sell(h->lv[lv].A_int, &h->lv[lv].ord.color_ptr, sellC, region);
-                    *eA = h->lv[lv].dA.upload(S);
+                    Level& Lw = h->lv[lv];
+                    if (Lw.device_filled) {
+                        // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device
+                        std::vector<int> row_len((size_t)Lw.n);
+                        for (int r = 0; r < Lw.n; r++) { const int o = Lw.ord.perm[(size_t)r]; row_len[(size_t)r] = Lw.A.ptr[(size_t)o + 1] - Lw.A.ptr[(size_t)o]; }
+                        Sell S = sell_layout(row_len, Lw.n, Lw.A.nnz(), &Lw.ord.color_ptr, sellC, region);
+                        *eA = Lw.dA.upload(S);
+                        DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
+                        DevBuf<double> d_val;
+                        if (*eA == hipSuccess) *eA = d_ptr.upload(Lw.A.ptr);
+                        if (*eA == hipSuccess) *eA = d_col.upload(Lw.A.col);
+                        if (*eA == hipSuccess) *eA = d_val.upload(Lw.A.val);
+                        if (*eA == hipSuccess) *eA = d_perm.upload(Lw.ord.perm);
+                        if (*eA == hipSuccess) *eA = d_iperm.upload(Lw.ord.iperm);
+                        hipStream_t st2 = nullptr;      // own stream: the other tasks' uploads go on beside it
+                        if (*eA == hipSuccess) *eA = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+                        if (*eA == hipSuccess) *eA = launch_sell_fill(d_ptr.p, d_col.p, d_val.p, d_perm.p, d_iperm.p, Lw.dA.view, (size_t)Lw.dA.padded, st2);
+                        if (*eA == hipSuccess) *eA = hipStreamSynchronize(st2);
+                        if (st2) (void)hipStreamDestroy(st2);
+                        return;
+                    }
+                    Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
+                    *eA = Lw.dA.upload(S);
                 });
                 // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
                 // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
@@ -389,6 +453,7 @@ static int precompute_device(smg_hierarchy* h)
                 tasks.push_back([&, lv, eT] {
                     DeviceScope ds(h->device);
                     Level& Lw = h->lv[lv];
+                    if (Lw.device_filled) { Lw.gs_on_transpose = false; Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf(); return; }   // A == A^T was checked on the host half
                     Csr AT = transpose(Lw.A_int);
                     Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
                     Lw.dAT = SellBuf();
@@ -567,6 +632,7 @@ static int build_recipes(smg_hierarchy* h)
     const int L = h->n_levels;
     const int sellC = SELL_C;
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int lv = 0; lv < L; lv++) { int rc = ensure_A_int(h, lv); if (rc) return rc; }
     drop_graphs(h);  // the GS launches move to the A^T images on every level
     drop_tiled(h);   // ... and so do the overlapped-tiling plans (rebuilt on demand)
     // all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes); every task uploads what it built
@@ -715,7 +781,8 @@ int smg::refresh_host_values(smg_hierarchy* h)
         Level& Lv = h->lv[lv];
         HIPCHK(hipMemcpy(Lv.A.val.data(), Lv.d_Aval.p, Lv.A.val.size() * sizeof(double), hipMemcpyDeviceToHost));
         Lv.A_diag = diagonal(Lv.A);
-        for (size_t e = 0; e < Lv.A_int.val.size(); e++) Lv.A_int.val[e] = Lv.A.val[Lv.A_int_src[e]];
+        if (Lv.A_int_src.size() == Lv.A_int.val.size())
+            for (size_t e = 0; e < Lv.A_int.val.size(); e++) Lv.A_int.val[e] = Lv.A.val[Lv.A_int_src[e]];
     }
     if (h->has_known && h->Auk.nnz() > 0)
         HIPCHK(hipMemcpy(h->Auk.val.data(), h->d_auk_val.p, h->Auk.val.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -826,13 +893,17 @@ static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const
     h->host_stale = false;
     Csr A = csr_from_arrays(n, n, rowptr, col, val);
     h->input_canonical = (A.nnz() == (long)rowptr[n]) && std::equal(A.col.begin(), A.col.end(), col);
+    tmv.lap("precompute: input copy (sorted, duplicates summed)");
     int rc = precompute_host(h, std::move(A), known, n_known);
     if (rc != SMG_OK) return rc;
+    tmv.lap("precompute: host half");
     rc = ensure_device(h);
     if (rc != SMG_OK) return rc;
+    tmv.lap("precompute: device / stream");
     DeviceScope dsc(h->device);
     rc = precompute_device(h);
     if (rc != SMG_OK) return rc;
+    tmv.lap("precompute: device half");
     h->pre_key = key;
     h->precomputed = true;
     return SMG_OK;

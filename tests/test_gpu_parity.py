@@ -693,8 +693,9 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
     outs = []
     for off in (False, True):
         env = dict(os.environ)
+        env["SMG_DEVICE_FILL_MIN"] = "1000"     # the panels of every big enough A filled on the device from the caller's arrays + the permutation ...
         if off:
-            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0")
+            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0", SMG_DEVICE_FILL="0")   # ... or built on the host
         r = subprocess.run([sys.executable, "-c", _SHORTCUT_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("mcf", "poisson"))]
