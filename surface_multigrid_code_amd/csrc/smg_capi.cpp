@@ -424,6 +424,7 @@ extern "C" int smg_level_get_matrix(const smg_hierarchy* h, int lv, int which, i
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: bad level");
     if (h->host_stale) { int rc = refresh_host_values(const_cast<smg_hierarchy*>(h)); if (rc) return rc; }
     if (which == 0 && internal) { int rc = ensure_A_int(const_cast<smg_hierarchy*>(h), lv); if (rc) return rc; }
+    if ((which == 1 || which == 2) && internal) { int rc = ensure_P_int(const_cast<smg_hierarchy*>(h), lv); if (rc) return rc; }
     const Csr* M = pick_matrix(h, lv, which, internal);
     if (!M) return fail(SMG_ERR_INVALID, "smg_level_get_matrix: no such matrix");
     if (n_rows) *n_rows = M->nr;

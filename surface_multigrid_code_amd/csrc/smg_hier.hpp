@@ -108,6 +108,7 @@ struct Level {
     SellBuf dA, dP, dPT;
     SellBuf dAT;            // SELL image of A^T, only when A is not bitwise symmetric (Galerkin levels)
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
+    bool P_device_filled = false, PT_device_filled = false;   // likewise dP / dPT (P_int / PT_int on demand: ensure_P_int)
     bool device_filled = false;    // dA was filled on the device from A and the permutation: A_int is built on demand (ensure_A_int)
     bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)

@@ -116,6 +116,7 @@ Mesh wrap_mesh(const double* V, int nV, const int* F, int nF);
 int spectral_bounds(smg_hierarchy* h);          // Gershgorin bounds of D^-1 A on every smoothed level (Chebyshev-Jacobi)
 int ensure_spectral_bounds(smg_hierarchy* h);   // ... only when a level is smoothed that way and the values changed
 int refresh_host_values(smg_hierarchy* h);      // host copies of mg[l].A after a device-side value-only re-precompute
+int ensure_P_int(smg_hierarchy* h, int lv);     // ... and P / PT of the level
 int ensure_A_int(smg_hierarchy* h, int lv);     // the level matrix in the internal numbering on the host (built on demand where the device filled the panels)
 
 // ---- cycle (smg_cycle.cpp) -----------------------------------------------------------------------------------------------------------

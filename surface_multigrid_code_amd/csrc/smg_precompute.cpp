@@ -49,6 +49,44 @@ static bool device_fill_candidate(const smg_hierarchy* h, int lv)
     static const int on = env_int("SMG_DEVICE_FILL", 1), min_rows = env_int("SMG_DEVICE_FILL_MIN", 200000);
     return on && h->bs == 1 && lv < h->n_levels - 1 && h->lv[lv].A.nr >= min_rows;
 }
+static bool device_fill_rows(const smg_hierarchy* h, int n_rows)
+{
+    static const int on = env_int("SMG_DEVICE_FILL", 1), min_rows = env_int("SMG_DEVICE_FILL_MIN", 200000);
+    return on && h->bs == 1 && n_rows >= min_rows;
+}
+// SELL image of B(i, j) = M(rperm[i], cperm[j]) (ciperm = the inverse of cperm) built on the device from M's arrays: layout from the
+// row lengths on the host, panels by launch_sell_fill.  Called from the precompute's worker threads (own stream).
+static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector<int>& rperm, const std::vector<int>& ciperm, const std::vector<int>* breaks,
+                                   bool region)
+{
+    std::vector<int> row_len((size_t)M.nr);
+    for (int r = 0; r < M.nr; r++) { const int o = rperm[(size_t)r]; row_len[(size_t)r] = M.ptr[(size_t)o + 1] - M.ptr[(size_t)o]; }
+    Sell S = sell_layout(row_len, M.nc, M.nnz(), breaks, SELL_C, region);
+    hipError_t e = dst.upload(S);
+    DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
+    DevBuf<double> d_val;
+    if (e == hipSuccess) e = d_ptr.upload(M.ptr);
+    if (e == hipSuccess) e = d_col.upload(M.col);
+    if (e == hipSuccess) e = d_val.upload(M.val);
+    if (e == hipSuccess) e = d_perm.upload(rperm);
+    if (e == hipSuccess) e = d_iperm.upload(ciperm);
+    hipStream_t st2 = nullptr;      // own stream: the other tasks' uploads go on beside it
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = launch_sell_fill(d_ptr.p, d_col.p, d_val.p, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2);
+    if (e == hipSuccess) e = hipStreamSynchronize(st2);
+    if (st2) (void)hipStreamDestroy(st2);
+    return e;
+}
+int smg::ensure_P_int(smg_hierarchy* h, int lv)
+{
+    if (!h || lv < 1 || lv >= h->n_levels) return SMG_OK;
+    Level& Lv = h->lv[lv];
+    const Level& Lf = h->lv[lv - 1];
+    if ((int)Lf.ord.perm.size() != Lv.P.nr || (int)Lv.ord.perm.size() != Lv.P.nc) return SMG_OK;
+    if (Lv.P_int.nr != Lv.P.nr || Lv.P_int.nnz() != Lv.P.nnz()) Lv.P_int = permute(Lv.P, Lf.ord.perm, Lv.ord.perm);
+    if (Lv.PT_int.nr != Lv.PT.nr || Lv.PT_int.nnz() != Lv.PT.nnz()) Lv.PT_int = permute(Lv.PT, Lv.ord.perm, Lf.ord.perm);
+    return SMG_OK;
+}
 int smg::ensure_A_int(smg_hierarchy* h, int lv)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "bad level");
@@ -308,8 +346,20 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 else { Lv.A_int = Lv.A; Lv.A_int_src.resize(Lv.A.nnz()); std::iota(Lv.A_int_src.begin(), Lv.A_int_src.end(), 0); }
             });
             if (lv >= 1) {
-                tasks.push_back([h, lv] { Level& Lv = h->lv[lv]; Lv.P_int = permute(Lv.P, h->lv[lv - 1].ord.perm, Lv.ord.perm); });
-                tasks.push_back([h, lv] { Level& Lv = h->lv[lv]; Lv.PT_int = permute(Lv.PT, Lv.ord.perm, h->lv[lv - 1].ord.perm); });
+                // (the transfer operators of a big level are filled on the device as well: their permuted host copies are built on demand)
+                tasks.push_back([h, lv] {
+                    Level& Lv = h->lv[lv];
+                    Lv.P_device_filled = device_fill_rows(h, Lv.P.nr);
+                    if (Lv.P_device_filled) Lv.P_int = Csr(); else Lv.P_int = permute(Lv.P, h->lv[lv - 1].ord.perm, Lv.ord.perm);
+                });
+                tasks.push_back([h, lv] {
+                    Level& Lv = h->lv[lv];
+                    static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+                    bool ok = device_fill_rows(h, Lv.PT.nr);
+                    if (ok && long_min > 0) for (int r = 0; r < Lv.PT.nr && ok; r++) if (Lv.PT.ptr[(size_t)r + 1] - Lv.PT.ptr[(size_t)r] >= long_min) ok = false;   // long rows leave the panels: host path
+                    Lv.PT_device_filled = ok;
+                    if (ok) Lv.PT_int = Csr(); else Lv.PT_int = permute(Lv.PT, Lv.ord.perm, h->lv[lv - 1].ord.perm);
+                });
             }
         }
         parallel_tasks(tasks);
@@ -424,22 +474,7 @@ static int precompute_device(smg_hierarchy* h)
                     Level& Lw = h->lv[lv];
                     if (Lw.device_filled) {
                         // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device
-                        std::vector<int> row_len((size_t)Lw.n);
-                        for (int r = 0; r < Lw.n; r++) { const int o = Lw.ord.perm[(size_t)r]; row_len[(size_t)r] = Lw.A.ptr[(size_t)o + 1] - Lw.A.ptr[(size_t)o]; }
-                        Sell S = sell_layout(row_len, Lw.n, Lw.A.nnz(), &Lw.ord.color_ptr, sellC, region);
-                        *eA = Lw.dA.upload(S);
-                        DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
-                        DevBuf<double> d_val;
-                        if (*eA == hipSuccess) *eA = d_ptr.upload(Lw.A.ptr);
-                        if (*eA == hipSuccess) *eA = d_col.upload(Lw.A.col);
-                        if (*eA == hipSuccess) *eA = d_val.upload(Lw.A.val);
-                        if (*eA == hipSuccess) *eA = d_perm.upload(Lw.ord.perm);
-                        if (*eA == hipSuccess) *eA = d_iperm.upload(Lw.ord.iperm);
-                        hipStream_t st2 = nullptr;      // own stream: the other tasks' uploads go on beside it
-                        if (*eA == hipSuccess) *eA = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
-                        if (*eA == hipSuccess) *eA = launch_sell_fill(d_ptr.p, d_col.p, d_val.p, d_perm.p, d_iperm.p, Lw.dA.view, (size_t)Lw.dA.padded, st2);
-                        if (*eA == hipSuccess) *eA = hipStreamSynchronize(st2);
-                        if (st2) (void)hipStreamDestroy(st2);
+                        *eA = device_fill_sell(Lw.dA, Lw.A, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region);
                         return;
                     }
                     Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
@@ -478,6 +513,10 @@ static int precompute_device(smg_hierarchy* h)
                     // block hierarchies: the device applies the VERTEX-level factor of P (x) I_3 to 3 k columns (smg_bsr3.hpp)
                     const Ordering& Of = blk ? h->lv[lv - 1].vord : h->lv[lv - 1].ord;
                     const bool cut = tr_region && region && Of.color_ptr.size() > 2;
+                    if (!blk && h->lv[lv].P_device_filled) {
+                        *eP = device_fill_sell(h->lv[lv].dP, h->lv[lv].P, Of.perm, h->lv[lv].ord.iperm, cut ? &Of.color_ptr : nullptr, cut);
+                        return;
+                    }
                     Csr Pvi;
                     if (blk) Pvi = permute(h->lv[lv].Pv, Of.perm, h->lv[lv].vord.perm);
                     Sell S = build_sell(blk ? Pvi : h->lv[lv].P_int, cut ? &Of.color_ptr : nullptr, sellC, cut);
@@ -493,6 +532,11 @@ static int precompute_device(smg_hierarchy* h)
                     // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
                     // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
                     static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+                    if (!blk && h->lv[lv].PT_device_filled) {
+                        *eQ = device_fill_sell(h->lv[lv].dPT, h->lv[lv].PT, Oc.perm, h->lv[lv - 1].ord.iperm, cut ? &Oc.color_ptr : nullptr, cut);
+                        if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long({}, {0}, {}, {});
+                        return;
+                    }
                     Csr PTvi;
                     if (blk) PTvi = permute(h->lv[lv].PTv, Oc.perm, h->lv[lv - 1].vord.perm);
                     const Csr& M = blk ? PTvi : h->lv[lv].PT_int;
