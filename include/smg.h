@@ -330,6 +330,19 @@ long smg_level_spmv_bytes(const smg_hierarchy *h, int lv, int k);
  * a Chebyshev-Jacobi relax(iters) is iters + 1 passes over the level matrix, a Gauss-Seidel / Jacobi one iters passes */
 long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);
 
+/* ---- host-side self-checks (tests on boxes without a GPU; they return diagnostics only, never a solution: no CPU solve path) -------- */
+/* The overlapped-tiling plan of relax(sweeps) on level lv (csrc/smg_tiled.hpp), executed on the HOST exactly as the kernel executes it
+ * (tile by tile, phase by phase, tile-local numbering) on a deterministic test vector, against the plain colour-by-colour sweeps on the
+ * level's matrix in the internal numbering: *max_abs_diff must be exactly 0.  Needs the host half of smg_precompute only.
+ * *n_tiles = 0: the level does not qualify for tiling (too many colours, rows wider than 12 entries). */
+int smg_debug_check_tiling_plan(smg_hierarchy *h, int lv, int sweeps, int tile_rows, int *n_tiles, int *max_ext_rows, double *redundancy,
+                                double *max_abs_diff);
+/* Sparse Cholesky of the coarse solver (csrc/smg_coarse.hpp) on an SPD matrix given in CSR (both triangles): nested-dissection order,
+ * factorisation, and the relative residual |b - A x| / |b| of a host solve with the factor for a deterministic right-hand side.
+ * Returns SMG_ERR_INVALID when a pivot is not positive. */
+int smg_debug_check_sparse_cholesky(int n, const int *rowptr, const int *col, const double *val, long *factor_entries, int *dependency_depth,
+                                    double *rel_residual);
+
 /* ---- profc.h mirror: named scopes accumulated with hipEvents (src/profc.h:9-13; mg_VCycle.cpp:121) ------------- */
 int smg_prof_enable(smg_hierarchy *h, int on);     /* forces eager launches while on */
 int smg_prof_reset(smg_hierarchy *h);

@@ -497,6 +497,98 @@ extern "C" long smg_level_spmv_bytes(const smg_hierarchy* h, int lv, int k)
     return 12L * A.nnz() + 4L * (A.nr + 1) + 16L * A.nr * k;
 }
 
+// ------------------------------------------------------------------------------------------------ host-side self-checks
+extern "C" int smg_debug_check_tiling_plan(smg_hierarchy* h, int lv, int sweeps, int tile_rows, int* n_tiles, int* max_ext_rows, double* redundancy,
+                                           double* max_abs_diff)
+{
+    return guarded("smg_debug_check_tiling_plan", [&]() -> int {
+        if (!h || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || tile_rows < 8) return fail(SMG_ERR_INVALID, "smg_debug_check_tiling_plan: bad arguments");
+        int rc = ensure_A_int(h, lv);
+        if (rc) return rc;
+        Level& Lv = h->lv[lv];
+        if (Lv.A_int.nr != Lv.n || Lv.n == 0 || h->bs != 1) return fail(SMG_ERR_INVALID, "smg_debug_check_tiling_plan: the host half of smg_precompute has not run (scalar hierarchies only)");
+        const Csr& G = Lv.A_int;
+        const int n = G.nr;
+        const TiledGs P = build_tiled_gs(G, Lv.ord.color_ptr, sweeps, tile_rows, 1 << 20, 1 << 20);
+        if (n_tiles) *n_tiles = P.n_tiles;
+        if (max_ext_rows) *max_ext_rows = P.max_ext;
+        if (redundancy) *redundancy = P.n_tiles ? (double)P.updates / ((double)sweeps * n) : 0.0;
+        if (max_abs_diff) *max_abs_diff = 0.0;
+        if (P.empty()) return SMG_OK;
+        std::vector<double> x((size_t)n), b((size_t)n), ref, y((size_t)n, 0.0), xs;
+        for (int i = 0; i < n; i++) { x[(size_t)i] = std::sin(0.37 * i) + 0.25 * std::cos(1.3 * i); b[(size_t)i] = std::cos(0.11 * i) - 0.5 * std::sin(2.1 * i); }
+        // reference: the colour-by-colour sweeps in place (what one launch per colour computes)
+        ref = x;
+        const std::vector<int>& cp = Lv.ord.color_ptr;
+        for (int s = 0; s < sweeps; s++)
+            for (size_t c = 0; c + 1 < cp.size(); c++)
+                for (int i = cp[c]; i < cp[c + 1]; i++) {
+                    double acc = 0.0, diag = 1.0;
+                    for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                        if (G.col[(size_t)p] == i) diag = G.val[(size_t)p];
+                        else acc += G.val[(size_t)p] * ref[(size_t)G.col[(size_t)p]];
+                    }
+                    ref[(size_t)i] = (b[(size_t)i] - acc) / diag;
+                }
+        // the plan, executed like k_tiled_gs: x -> y
+        const int nc = P.nc, PP = P.P;
+        for (int t = 0; t < P.n_tiles; t++) {
+            const int* H = P.hdr.data() + (size_t)t * TILED_HDR;
+            const int ext_off = H[0], n_ext = H[1], w = H[2];
+            xs.assign((size_t)n_ext, 0.0);
+            for (int i = 0; i < n_ext; i++) xs[(size_t)i] = x[(size_t)P.ext_rows[(size_t)ext_off + i]];
+            for (int p = 1; p <= PP; p++) {
+                const int* C = H + 4 + ((p - 1) % nc) * TILED_CSTRIDE;
+                const int pan = C[0], m = C[1], ro = C[2], lbase = C[3], cnt = C[4 + (PP - p)];
+                for (int i = 0; i < cnt; i++) {
+                    double acc = 0.0, diag = 1.0;
+                    for (int j = 0; j < w; j++) {
+                        const int cl = P.pcol[(size_t)pan + (size_t)j * m + i];
+                        const double v = P.pval[(size_t)pan + (size_t)j * m + i];
+                        if (cl < 0) continue;
+                        if (cl == lbase + i) diag = v; else acc += v * xs[(size_t)cl];
+                    }
+                    xs[(size_t)lbase + i] = (b[(size_t)P.prow[(size_t)ro + i]] - acc) / diag;
+                }
+            }
+            for (int c = 0; c < nc; c++) {
+                const int* C = H + 4 + c * TILED_CSTRIDE;
+                for (int i = 0; i < C[4]; i++) y[(size_t)P.prow[(size_t)C[2] + i]] = xs[(size_t)C[3] + i];
+            }
+        }
+        double d = 0.0;
+        for (int i = 0; i < n; i++) d = std::max(d, std::fabs(y[(size_t)i] - ref[(size_t)i]));
+        if (max_abs_diff) *max_abs_diff = d;
+        return SMG_OK;
+    });
+}
+
+extern "C" int smg_debug_check_sparse_cholesky(int n, const int* rowptr, const int* col, const double* val, long* factor_entries, int* dependency_depth,
+                                               double* rel_residual)
+{
+    return guarded("smg_debug_check_sparse_cholesky", [&]() -> int {
+        if (n <= 0 || !rowptr || !col || !val) return fail(SMG_ERR_INVALID, "smg_debug_check_sparse_cholesky: bad arguments");
+        if (const char* e = check_compressed(n, n, rowptr, col)) return fail(SMG_ERR_INVALID, "smg_debug_check_sparse_cholesky: %s", e);
+        const Csr A = csr_from_arrays(n, n, rowptr, col, val);
+        SparseChol F;
+        if (!sparse_cholesky(A, F)) return fail(SMG_ERR_INVALID, "smg_debug_check_sparse_cholesky: not positive definite");
+        std::vector<double> b((size_t)n), z((size_t)n), x((size_t)n);
+        for (int i = 0; i < n; i++) b[(size_t)i] = std::sin(0.01 * i) + 1.0;
+        for (int i = 0; i < n; i++) { double s = b[(size_t)F.perm[(size_t)i]]; for (int p = F.rptr[(size_t)i]; p < F.rptr[(size_t)i + 1]; p++) s -= F.rval[(size_t)p] * z[(size_t)F.rcol[(size_t)p]]; z[(size_t)i] = s / F.diag[(size_t)i]; }
+        for (int i = n - 1; i >= 0; i--) { double s = z[(size_t)i]; for (int p = F.cptr[(size_t)i]; p < F.cptr[(size_t)i + 1]; p++) s -= F.cval[(size_t)p] * z[(size_t)F.crow[(size_t)p]]; z[(size_t)i] = s / F.diag[(size_t)i]; }
+        for (int i = 0; i < n; i++) x[(size_t)F.perm[(size_t)i]] = z[(size_t)i];
+        double rn = 0.0, bn = 0.0;
+        for (int i = 0; i < n; i++) { double s = b[(size_t)i]; for (int p = A.ptr[(size_t)i]; p < A.ptr[(size_t)i + 1]; p++) s -= A.val[(size_t)p] * x[(size_t)A.col[(size_t)p]]; rn += s * s; bn += b[(size_t)i] * b[(size_t)i]; }
+        std::vector<int> depth((size_t)n, 0);
+        int dmax = 0;
+        for (int i = 0; i < n; i++) { int d = 0; for (int p = F.rptr[(size_t)i]; p < F.rptr[(size_t)i + 1]; p++) d = std::max(d, depth[(size_t)F.rcol[(size_t)p]] + 1); depth[(size_t)i] = d; dmax = std::max(dmax, d); }
+        if (factor_entries) *factor_entries = F.nnzL();
+        if (dependency_depth) *dependency_depth = dmax;
+        if (rel_residual) *rel_residual = std::sqrt(rn / bn);
+        return SMG_OK;
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ profc mirror (API)
 extern "C" int smg_prof_enable(smg_hierarchy* h, int on)
 {

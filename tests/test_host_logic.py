@@ -565,3 +565,52 @@ def test_block_hierarchy_host_half(smg_mod):
     mg4.set_block_mode("block")
     with pytest.raises(smg.SmgError):
         mg4.precompute(A, np.array([0, 1, 2, 30], np.int32))
+
+
+# ----------------------------------------------------------------------------------------------- round-3 host components
+def test_tiling_plan_reproduces_the_colour_sweeps_bit_for_bit(smg_mod):
+    """relax(sweeps) as ONE launch per level (csrc/smg_tiled.hpp): the plan -- compact tiles, halo rings, tile-local panels -- executed on
+    the host exactly as the kernel executes it gives the bits of the plain colour-by-colour Gauss-Seidel sweeps (the reference's relax(),
+    src/mg_VCycle.cpp:113-178, on the colour-major numbering), for several tile sizes and sweep counts, on mesh levels and Galerkin levels."""
+    import ctypes as C
+    smg = smg_mod
+    p = subdiv_problem(kind="poisson", k=1, n_sub=2)
+    mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"])
+    L = smg._lib.load()
+    for lv in range(mg.n_levels - 1):
+        for sweeps, tile_rows in ((1, 64), (2, 256), (2, 100), (3, 512)):
+            nt, me, red, diff = C.c_int(), C.c_int(), C.c_double(), C.c_double(-1.0)
+            rc = L.smg_debug_check_tiling_plan(mg.h, lv, sweeps, tile_rows, C.byref(nt), C.byref(me), C.byref(red), C.byref(diff))
+            assert rc == 0
+            ncol = len(mg.colors(lv)) - 1
+            if ncol * sweeps > 15 or ncol > 5:
+                assert nt.value == 0           # too many phases: the level keeps one launch per colour
+                continue
+            assert nt.value >= mg.rows(lv) // tile_rows and red.value >= 1.0 and me.value >= min(tile_rows // 2, mg.rows(lv))
+            assert diff.value == 0.0, "level %d, %d sweeps, tiles of %d rows: the tiled sweeps differ by %g" % (lv, sweeps, tile_rows, diff.value)
+
+
+def test_sparse_cholesky_of_the_coarse_solver(smg_mod):
+    """csrc/smg_coarse.cpp (coarsest levels beyond the dense range; the reference: Eigen::SimplicialLDLT, src/min_quad_with_fixed_mg.cpp:47-48):
+    nested dissection + up-looking Cholesky on mesh operators -- residual of a host solve with the factor at rounding level, fill O(n log n),
+    dependency depth (= the length of the device's triangular-solve chain) O(sqrt n); an indefinite matrix is refused."""
+    import ctypes as C
+    smg = smg_mod
+    L = smg._lib.load()
+    for name in ("ogre_sim.smgm", "bunny.smgm", "bunny_15K_init.smgm"):
+        V, F = M.read_smgm(name)
+        V = M.normalize_unit_area(V, F)
+        A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+        A.sort_indices()
+        n = A.shape[0]
+        ne, dep, res = C.c_long(), C.c_int(), C.c_double()
+        ptr, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        rc = L.smg_debug_check_sparse_cholesky(n, ptr.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)),
+                                               val.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ne), C.byref(dep), C.byref(res))
+        assert rc == 0 and res.value < 1e-11
+        assert n < ne.value < 12 * n * np.log2(n) and dep.value < 12 * np.sqrt(n)
+    bad = val.copy()
+    bad[A.indptr[:-1][0] + list(A.indices[A.indptr[0]:A.indptr[1]]).index(0)] = -1.0      # a negative diagonal entry
+    rc = L.smg_debug_check_sparse_cholesky(n, ptr.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)),
+                                           bad.ctypes.data_as(C.POINTER(C.c_double)), None, None, None)
+    assert rc == -1
