@@ -51,7 +51,7 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
     TiledBuf& B = Lv.tiled[sweeps];
     if (B.tried) return SMG_OK;
     B.tried = true;
-    // Tile size (measured at C3, tools/_tiled_sweep.sh): parts of 128 .. 256 rows, 512 threads (one row of every colour per thread).
+    // Tile size (measured at C3, tools/tiled_sweep.sh): parts of 128 .. 256 rows, 512 threads (one row of every colour per thread).
     // Smaller tiles put more CUs to work but the halo of P rings then dominates (6x redundant row updates at 64 rows: slower);
     // larger ones run too few workgroups.
     static const int rows_env = env_int("SMG_TILED_ROWS", 0), nt_env = env_int("SMG_TILED_NT", 0);
