@@ -728,6 +728,7 @@ def main():
                                  "chebyshev": "V(2,2), Chebyshev-Jacobi (degree 3) on every level, dense coarsest solve",
                                  "hybrid_chebyshev": "V(2,2), multi-colour Gauss-Seidel on levels > %d rows, Chebyshev-Jacobi (degree 3) below, dense coarsest solve" % args.jacobi_max_rows}[args.smoother],
                        "smoother": args.smoother,
+                       "relax_launches": "one launch per colour and sweep; on Gauss-Seidel levels of 2 048 - 100 000 rows the whole relax(2) is ONE launch (overlapped tiling, bit-identical; SMG_TILED=0 switches it off)",
                        "parallelism": "1 RHS column per GPU, hierarchy replicated, all-reduce of residual sumsq" if world > 1 else "single GPU",
                        "allreduce": ("RCCL on the solve stream (dist.StreamAllReduce)" if stream_ar is not None else "torch.distributed") if (world > 1 or force_split) else None},
             "roofline": {"kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm",
