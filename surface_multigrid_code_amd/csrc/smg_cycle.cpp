@@ -27,7 +27,7 @@ using namespace smg;
 
 // ---- overlapped tiling of the Gauss-Seidel sweeps of the latency-bound levels (smg_tiled.hpp): relax(sweeps) as ONE launch ----------
 // Which levels: scalar fp64 hierarchies, one column, Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
-// 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 16 entries per row.
+// 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 12 entries per row.
 // SMG_TILED=0 switches it off (A/B knob; the results are bit-identical either way).
 static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
 {
