@@ -189,7 +189,7 @@ int smg_level_get_block_image(const smg_hierarchy *h, int lv, int *n_slices, int
 /* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).
  * Up to n_max unknowns (default 16384, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device and applied as a dense,
  * bandwidth-bound product (8 n^2 bytes of HBM -- 2 GB at 16 k --, half of them streamed per cycle and column; <= 1e-11 from LDL^T):
- * 0.02 ms per cycle at 4 k unknowns, 0.15 ms at 12 k, against 2.9 ms for the sparse solves at 16 k -- lower n_max to trade time for memory.  Above: a sparse Cholesky factorisation P A P^T = L L^T -- what the
+ * 0.02 ms per cycle at 4 k unknowns, 0.15 ms at 12 k, against 2.6 ms for the sparse solves at 16 k -- lower n_max to trade time for memory.  Above: a sparse Cholesky factorisation P A P^T = L L^T -- what the
  * reference's Eigen::SimplicialLDLT does -- computed on the host during smg_precompute (nested-dissection order), with the two
  * triangular solves on the device (one launch each, rows wait for the rows they read; deterministic).  So mg_precompute's nVCoarsest
  * may be anything the reference accepts, down to a 1-level call on the whole mesh, in O(n log n) memory.  Not available with the sparse

@@ -5,7 +5,7 @@
 // dense product (smg_device.hip: launch_spd_inverse, k_sym_gemv_*): 8 n^2 bytes.  Above, the reference's own method: a sparse Cholesky
 // factorisation  P A P^T = L L^T  -- nested-dissection ordering by breadth-first bisection, up-looking numeric factorisation, both on the
 // host as part of the precompute (the reference factors on the host, too) -- and the two triangular solves on the device, each ONE launch:
-// one wavefront per row in dependency order, a row waits for the rows it reads through per-row flags in HBM (bounded spins; rows only wait
+// one wavefront per row in dependency order, a row waits for the rows it reads by polling their values in HBM (bounded spins; rows only wait
 // for rows of lower launch index, which the dispatcher has started before them), products summed in a fixed order: deterministic.
 // Memory: 2 x 12 bytes per entry of L (rows for the forward solve, columns for the backward one): O(n log n) on meshes.
 #pragma once

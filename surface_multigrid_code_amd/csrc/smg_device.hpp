@@ -148,8 +148,7 @@ struct SparseCholDev {
     const int *rptr = nullptr, *rcol = nullptr;      // strict lower triangle by rows
     const int *cptr = nullptr, *crow = nullptr;      // ... and by columns
     const double *rval = nullptr, *cval = nullptr, *diag = nullptr;
-    double* work = nullptr;                          // n
-    int* flags = nullptr;                            // 2 n
+    double* work = nullptr;                          // 2 n: the forward solve's z, the backward solve's x
     int* err = nullptr;                              // raised when a wait gave up
 };
 // u[:, c] += (L L^T)^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)

@@ -187,7 +187,7 @@ struct smg_hierarchy {
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
     smg::SparseChol chol;
-    smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_flags, c_err;
+    smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;
     smg::SparseCholDev c_view;
     bool f32_valid = false;

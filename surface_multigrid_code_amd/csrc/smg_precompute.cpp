@@ -412,12 +412,12 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
     const SparseChol& F = h->chol;
     HIPCHK(h->c_perm.upload(F.perm)); HIPCHK(h->c_rptr.upload(F.rptr)); HIPCHK(h->c_rcol.upload(F.rcol)); HIPCHK(h->c_cptr.upload(F.cptr));
     HIPCHK(h->c_crow.upload(F.crow)); HIPCHK(h->c_rval.upload(F.rval)); HIPCHK(h->c_cval.upload(F.cval)); HIPCHK(h->c_diag.upload(F.diag));
-    HIPCHK(h->c_work.ensure((size_t)F.n)); HIPCHK(h->c_flags.ensure((size_t)2 * F.n));
+    HIPCHK(h->c_work.ensure((size_t)2 * F.n));
     HIPCHK(h->c_err.ensure(1));
     HIPCHK(hipMemset(h->c_err.p, 0, sizeof(int)));
     SparseCholDev& V = h->c_view;
     V.n = F.n; V.perm = h->c_perm.p; V.rptr = h->c_rptr.p; V.rcol = h->c_rcol.p; V.cptr = h->c_cptr.p; V.crow = h->c_crow.p;
-    V.rval = h->c_rval.p; V.cval = h->c_cval.p; V.diag = h->c_diag.p; V.work = h->c_work.p; V.flags = h->c_flags.p; V.err = h->c_err.p;
+    V.rval = h->c_rval.p; V.cval = h->c_cval.p; V.diag = h->c_diag.p; V.work = h->c_work.p; V.err = h->c_err.p;
     h->coarse_sparse = true;
     h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release();
     tm.lap("device: sparse coarse factor uploaded");
