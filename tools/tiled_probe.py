@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""us per relax(2) call per level (graph replay), C3.  usage: tools/tiled_probe.py"""
+"""us per relax(2) call per level (graph replay), C3.  usage: tools/tiled_probe.py [columns]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
@@ -7,4 +7,5 @@ import surface_multigrid_code_amd as smg
 from surface_multigrid_code_amd import mesh
 mg, A, Mb, Vf, Ff, label, _ = B.build_workload("C3", smg, mesh)
 mg.precompute(A)
-print(" ".join("L%d %.2f" % (lv, mg.bench_relax(lv, 1, 2, 200)) for lv in range(mg.n_levels - 1)), "| env", {k: v for k, v in os.environ.items() if k.startswith("SMG_")})
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+print(" ".join("L%d %.2f" % (lv, mg.bench_relax(lv, K, 2, 200)) for lv in range(mg.n_levels - 1)), "| k", K, "env", {k: v for k, v in os.environ.items() if k.startswith("SMG_")})
