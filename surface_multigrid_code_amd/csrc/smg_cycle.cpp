@@ -26,14 +26,14 @@ using namespace smg;
 // ------------------------------------------------------------------------------------------------ V-cycle
 
 // ---- overlapped tiling of the Gauss-Seidel sweeps of the latency-bound levels (smg_tiled.hpp): relax(sweeps) as ONE launch ----------
-// Which levels: scalar fp64 hierarchies, one column, Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
+// Which levels: scalar fp64 hierarchies, up to 7 columns (groups of 3 per launch; 8 and more take the wide colour kernels), Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
 // 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 12 entries per row.
 // SMG_TILED=0 switches it off (A/B knob; the results are bit-identical either way).
 static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
 {
     static const int on = env_int("SMG_TILED", 1);
     static const int max_rows = env_int("SMG_TILED_MAX_ROWS", 100000), min_rows = env_int("SMG_TILED_MIN_ROWS", 2048);
-    if (!on || h->bs != 1 || k != 1 || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || sweeps > 3) return false;
+    if (!on || h->bs != 1 || k < 1 || k > 7 || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || sweeps > 3) return false;
     if (level_kind(h, lv) != LV_GS) return false;
     const int n = h->lv[lv].n;
     return n >= min_rows && n <= max_rows;
@@ -43,7 +43,8 @@ static const TiledDev* tiled_plan(const smg_hierarchy* h, int lv, int k, int swe
 {
     if (!tiled_wanted(h, lv, k, sweeps)) return nullptr;
     const TiledBuf& B = h->lv[lv].tiled[sweeps];
-    return B.view.n_tiles > 0 ? &B.view : nullptr;
+    // k columns go through the tiles in groups of up to 3, whose iterates share the workgroup's 64 KB of LDS
+    return B.view.n_tiles > 0 && (size_t)B.view.max_ext * std::min(k, 3) * sizeof(double) <= 64 * 1024 ? &B.view : nullptr;
 }
 static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
 {

@@ -14,15 +14,15 @@ namespace smg {
 
 constexpr int TILED_NT = TILED_THREADS;   // most threads of a tile's workgroup (the plan says how many: TiledDev::threads)
 
-// x -> y (x != y).  ld: columns of the row-major blocks (the launch handles one column; pointers are offset to it).
-// Thread t owns row t of every colour's panel (the plan guarantees m_c <= TILED_NT): the matrix rows are loaded ONCE, all requests
+// x -> y (x != y).  ld: columns of the row-major blocks; the launch handles KB adjacent columns (pointers are offset to the first).
+// Thread t owns row t of every colour's panel (the plan guarantees m_c <= threads): the matrix rows are loaded ONCE, all requests
 // in flight together, and stay in registers for all sweeps -- after the prologue the phases touch nothing but LDS.
-template <int NC, int W>
+template <int NC, int W, int KB>
 __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ hdr, const int* __restrict__ ext_rows, const int* __restrict__ pcol,
                                                        const double* __restrict__ pval, const int* __restrict__ prow, const double* __restrict__ b,
                                                        const double* __restrict__ x, double* __restrict__ y, int ld, int nc, int sweeps, const int* done, int dbg_phases)
 {
-    extern __shared__ double xs[];
+    extern __shared__ double xs[];      // the extended tile's iterate: n_ext x KB, row-major like the global blocks
     __shared__ int Hs[TILED_HDR];
     const int tid = threadIdx.x;
     if (tid < TILED_HDR) Hs[tid] = hdr[(size_t)blockIdx.x * TILED_HDR + tid];
@@ -30,12 +30,17 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
     __syncthreads();
     const int ext_off = Hs[0], n_ext = Hs[1], w = Hs[2];
     const int P = sweeps * nc;
-    for (int i = tid; i < n_ext; i += (int)blockDim.x) xs[i] = x[(size_t)ext_rows[ext_off + i] * ld];
+    for (int i = tid; i < n_ext; i += (int)blockDim.x) {
+        double g[KB];
+        gather_kb<KB, double>(x + (size_t)ext_rows[ext_off + i] * ld, true, g);
+#pragma unroll
+        for (int q = 0; q < KB; q++) xs[i * KB + q] = g[q];
+    }
     int cR[NC][W], gR[NC];
-    double vR[NC][W], bR[NC], dR[NC];
+    double vR[NC][W], bR[NC][KB], dR[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        gR[c] = -1; bR[c] = 0.0;
+        gR[c] = -1;
 #pragma unroll
         for (int j = 0; j < W; j++) { cR[c][j] = -1; vR[c][j] = 0.0; }
         if (c < nc) {
@@ -50,10 +55,10 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
         }
     }
 #pragma unroll
-    for (int c = 0; c < NC; c++) if (gR[c] >= 0) bR[c] = b[(size_t)gR[c] * ld];
+    for (int c = 0; c < NC; c++) gather_kb<KB, double>(b + (size_t)(gR[c] >= 0 ? gR[c] : 0) * ld, gR[c] >= 0, bR[c]);
     // Branch-free phases: the diagonal leaves the row (its slot keeps a zero that multiplies the row's own, finite, value) and padding
     // slots point at the row itself with a zero -- a sum that starts at +0 is not changed by adding +-0 (it never holds -0), so the bits
-    // are those of the sum that skips these slots, and the phase loop is W straight-line LDS reads and multiply-adds.
+    // are those of the sum that skips these slots, and the phase loop is W straight-line LDS reads and multiply-adds per column.
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int lrow = (c < nc ? Hs[4 + c * TILED_CSTRIDE + 3] : 0) + tid;
@@ -73,13 +78,18 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
                 const int* C = Hs + 4 + c * TILED_CSTRIDE;
                 const int lrow = C[3] + tid, cnt = C[4 + (P - p)];
                 if (tid < cnt) {
-                    double xv[W];
+                    double acc[KB];
 #pragma unroll
-                    for (int j = 0; j < W; j++) xv[j] = xs[cR[c][j]];
-                    double acc = 0.0;
+                    for (int q = 0; q < KB; q++) acc[q] = 0.0;
 #pragma unroll
-                    for (int j = 0; j < W; j++) acc += vR[c][j] * xv[j];
-                    xs[lrow] = (bR[c] - acc) / dR[c];      // rows of one colour never read each other: no hazard inside a phase
+                    for (int j = 0; j < W; j++) {
+                        const double v = vR[c][j];
+                        const int at = cR[c][j] * KB;
+#pragma unroll
+                        for (int q = 0; q < KB; q++) acc[q] += v * xs[at + q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < KB; q++) xs[lrow * KB + q] = (bR[c][q] - acc[q]) / dR[c];      // rows of one colour never read each other
                 }
                 __syncthreads();
             }
@@ -90,28 +100,37 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
         for (int c = 0; c < NC; c++)
             if (c < nc) {
                 const int* C = Hs + 4 + c * TILED_CSTRIDE;
-                if (tid < C[4]) y[(size_t)gR[c] * ld] = xs[C[3] + tid];      // the owned rows lead the colour's panel
+                if (tid < C[4]) {      // the owned rows lead the colour's panel
+#pragma unroll
+                    for (int q = 0; q < KB; q++) y[(size_t)gR[c] * ld + q] = xs[(C[3] + tid) * KB + q];
+                }
             }
     }
 }
 
 template <int NC, int W>
-static void launch_tiled_one(const TiledDev& Tl, const double* x, const double* b, double* y, int k, const int* done, hipStream_t st)
+static void launch_tiled_one(const TiledDev& Tl, const double* x, const double* b, double* y, int ld, int kb, const int* done, hipStream_t st)
 {
-    const size_t lds = (size_t)Tl.max_ext * sizeof(double);
+    const size_t lds = (size_t)Tl.max_ext * kb * sizeof(double);
     static const int dbg = getenv("SMG_DEBUG_TILED_PHASES") ? atoi(getenv("SMG_DEBUG_TILED_PHASES")) : 1 << 20;   // timing probe (wrong results)
-    hipLaunchKernelGGL((k_tiled_gs<NC, W>), dim3(Tl.n_tiles), dim3(Tl.threads), lds, st, Tl.hdr, Tl.ext_rows, Tl.pcol, Tl.pval, Tl.prow, b, x, y, k, Tl.nc, Tl.sweeps, done, dbg);
+#define SMG_TILED_LAUNCH(KB) hipLaunchKernelGGL((k_tiled_gs<NC, W, KB>), dim3(Tl.n_tiles), dim3(Tl.threads), lds, st, Tl.hdr, Tl.ext_rows, Tl.pcol, Tl.pval, Tl.prow, b, x, y, ld, Tl.nc, Tl.sweeps, done, dbg)
+    if (kb == 1) SMG_TILED_LAUNCH(1);
+    else if (kb == 2) SMG_TILED_LAUNCH(2);
+    else SMG_TILED_LAUNCH(3);
+#undef SMG_TILED_LAUNCH
 }
 
+// columns go through in groups of up to 3 (the mean-curvature-flow callers' k = 3 is one launch)
 hipError_t launch_tiled_gs(const TiledDev& Tl, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st)
 {
-    if (Tl.n_tiles <= 0) return hipErrorInvalidValue;
+    if (Tl.n_tiles <= 0 || k < 1 || (size_t)Tl.max_ext * (k < 3 ? k : 3) * sizeof(double) > 64 * 1024) return hipErrorInvalidValue;
     const int* done = ctrl ? &ctrl->done : never_done();
-    for (int c = 0; c < k; c++) {
+    for (int c = 0; c < k; c += 3) {
+        const int kb = k - c < 3 ? k - c : 3;
         const bool w8 = Tl.w_max <= 8;
-        if (Tl.nc <= 3) { if (w8) launch_tiled_one<3, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<3, 12>(Tl, x + c, b + c, y + c, k, done, st); }
-        else if (Tl.nc == 4) { if (w8) launch_tiled_one<4, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<4, 12>(Tl, x + c, b + c, y + c, k, done, st); }
-        else { if (w8) launch_tiled_one<5, 8>(Tl, x + c, b + c, y + c, k, done, st); else launch_tiled_one<5, 12>(Tl, x + c, b + c, y + c, k, done, st); }
+        if (Tl.nc <= 3) { if (w8) launch_tiled_one<3, 8>(Tl, x + c, b + c, y + c, k, kb, done, st); else launch_tiled_one<3, 12>(Tl, x + c, b + c, y + c, k, kb, done, st); }
+        else if (Tl.nc == 4) { if (w8) launch_tiled_one<4, 8>(Tl, x + c, b + c, y + c, k, kb, done, st); else launch_tiled_one<4, 12>(Tl, x + c, b + c, y + c, k, kb, done, st); }
+        else { if (w8) launch_tiled_one<5, 8>(Tl, x + c, b + c, y + c, k, kb, done, st); else launch_tiled_one<5, 12>(Tl, x + c, b + c, y + c, k, kb, done, st); }
     }
     return hipGetLastError();
 }

@@ -667,7 +667,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import numpy as np
 import surface_multigrid_code_amd as smg
 from problems import subdiv_problem
-for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2)):
+for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2), ("poisson", 5)):     # the tiles take columns in groups of up to 3: 1, 3, 2, 3 + 2
     p = subdiv_problem(kind=kind, k=k, n_sub=3)
     mg = smg.Hierarchy.from_prolongs(p["Ps"])
     mg.precompute(p["A"], p["known"])
@@ -699,7 +699,7 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
         r = subprocess.run([sys.executable, "-c", _SHORTCUT_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("mcf", "poisson"))]
-        assert len(lines) == 3, r.stdout
+        assert len(lines) == 4, r.stdout
         outs.append(lines)
     assert all(int(ln.split()[2]) >= 4 for ln in outs[0])   # deep enough for the fused restriction to be in play
     assert outs[0] == outs[1]

@@ -25,6 +25,7 @@ for seed in range(seed0, seed0 + ncases):
     A = (Mb - float(rng.uniform(0.001, 0.1)) * Lc).tocsr(); A.sort_indices()
     n = A.shape[0]
     known = rng.choice(n, int(rng.integers(1, 20)), replace=False).astype(np.int32) if rng.integers(0, 2) else None
+    k = int(rng.choice([1, 1, 2, 3, 4, 5, 7]))     # the tiles take up to 7 columns, in groups of 3
     try:
         mg.precompute(A, known)
         tiled = 0
@@ -32,26 +33,26 @@ for seed in range(seed0, seed0 + ncases):
             m, perm = mg.rows(lv), mg.perm(lv)
             Ai = mg.matrix(lv, "A", internal=True); Pi = mg.matrix(lv + 1, "P", internal=True)
             oi = OracleMG([Pi]); oi.precompute(Ai)
-            x = rng.uniform(-1, 1, (m, 1)); b = rng.uniform(-1, 1, (m, 1))
+            x = rng.uniform(-1, 1, (m, k)); b = rng.uniform(-1, 1, (m, k))
             assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), "A level %d" % lv
             for sw in (1, 2, 3):
                 assert np.array_equal(mg.relax(lv, b, x, sw)[perm], oi.relax(0, b[perm], x[perm], sw)), "relax(%d) level %d" % (sw, lv)
             assert np.array_equal(mg.restrict(lv, x)[mg.perm(lv + 1)], oi.restrict(0, x[perm])), "restrict level %d" % lv
-            xc = rng.uniform(-1, 1, (mg.rows(lv + 1), 1))
+            xc = rng.uniform(-1, 1, (mg.rows(lv + 1), k))
             assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[mg.perm(lv + 1)])), "prolong level %d" % lv
             if 2048 <= m <= 100000: tiled += 1
         # a whole solve against the reference algorithm in the caller's numbering
         Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
         o = OracleMG(Ps); o.precompute(A, known)
-        rhs = Mb @ rng.uniform(-1, 1, (n, 1)); z0 = np.zeros((n, 1))
-        kv = rng.uniform(-1, 1, (len(known), 1)) if known is not None else None
+        rhs = Mb @ rng.uniform(-1, 1, (n, k)); z0 = np.zeros((n, k))
+        kv = rng.uniform(-1, 1, (len(known), k)) if known is not None else None
         a = mg.solve(rhs, z0, kv, smg.SolveOpts(tol=1e-10, max_iter=200)); r = o.solve(rhs, z0, kv, tol=1e-10, max_iter=200)
         rel = np.linalg.norm(a[1] - r[1]) / np.linalg.norm(r[1])
         # (the device sweeps run in the colour-major numbering, the oracle lexicographically: iteration counts agree to a few, more on
         #  slowly converging anisotropic cases; the bar of tests/test_gpu_parity.py)
         assert a[0] == r[0] and abs(len(a[2]) - len(r[2])) <= max(3, len(r[2]) // 4) and (not a[0] or rel <= 1e-6), \
             "solve: converged %s/%s, %d/%d iterations, last residual %.2e/%.2e, rel diff %.2e" % (a[0], r[0], len(a[2]), len(r[2]), a[2][-1], r[2][-1], rel)
-        print("seed %d ok: torus %dx%d x%d -> %d rows, %d levels, %d tiled, known %s, %d cycles" % (seed, nu, nv, n_sub, n, mg.n_levels, tiled, None if known is None else len(known), len(a[2]) - 1))
+        print("seed %d ok: torus %dx%d x%d -> %d rows x %d columns, %d levels, %d tiled, known %s, %d cycles" % (seed, nu, nv, n_sub, n, k, mg.n_levels, tiled, None if known is None else len(known), len(a[2]) - 1))
     except AssertionError as e:
         bad += 1
         print("seed %d FAILED: %s (torus %dx%d x%d, %d rows)" % (seed, e, nu, nv, n_sub, n))
