@@ -42,7 +42,8 @@ struct DevBuf {
         return e;
     }
     hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count); }
-    hipError_t upload(const std::vector<T>& v)
+    template <class Alloc>
+    hipError_t upload(const std::vector<T, Alloc>& v)
     {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
@@ -178,6 +179,8 @@ struct smg_hierarchy {
     smg::DevBuf<int> d_lhs_src, d_auk_src, d_diag_idx;
     smg::DevBuf<long long> d_dense_pos;
     smg::DevBuf<double> d_Afull;
+    // the caller's arrays of A on the device, sent beside the host half of a first precompute (transient: consumed or dropped by its device half)
+    struct EarlyUpload { smg::DevBuf<int> ptr, col; smg::DevBuf<double> val; bool valid = false; } early0;
     // ---- coarse solver: stands in for Eigen::SimplicialLDLT (factorisation pre-inverted on the device) ----
     int nc = 0, nc_pad = 0;
     smg::DevBuf<double> d_Ainv;

@@ -2,6 +2,7 @@
 #include "smg_order.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -14,14 +15,15 @@
 
 namespace smg {
 
-std::vector<int> rcm_order(const Csr& A)
+std::vector<int> rcm_order(const Csr& A) { return rcm_order_arrays(A.nr, A.ptr.data(), A.col.data()); }
+
+std::vector<int> rcm_order_arrays(int n, const int* Aptr, const int* Acol)
 {
-    int n = A.nr;
     std::vector<int> order;
     order.reserve(n);
     std::vector<char> seen(n, 0);
     std::vector<int> deg(n);
-    for (int i = 0; i < n; i++) deg[i] = A.ptr[i + 1] - A.ptr[i];
+    for (int i = 0; i < n; i++) deg[i] = Aptr[i + 1] - Aptr[i];
     // component seeds in ascending degree (cheap stand-in for a pseudo-peripheral search)
     // (a counting sort: the same sequence a stable sort by degree gives, without its 1 M-element merge passes)
     std::vector<int> seeds(n);
@@ -45,10 +47,13 @@ std::vector<int> rcm_order(const Csr& A)
             order.push_back(start);
             seen[start] = 1;
             while (head < order.size()) {
+                // the queue is known a few vertices ahead: ask for their rows now (the search is a chain of cache misses otherwise)
+                if (head + 8 < order.size()) __builtin_prefetch(&Aptr[order[head + 8]]);
+                if (head + 4 < order.size()) __builtin_prefetch(&Acol[Aptr[order[head + 4]]]);
                 int v = order[head++];
                 nb.clear();
-                for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) {
-                    int w = A.col[p];
+                for (int p = Aptr[v]; p < Aptr[v + 1]; p++) {
+                    int w = Acol[p];
                     if (w != v && !seen[w]) { seen[w] = 1; nb.push_back(w); }
                 }
                 // (the first round only looks for a far vertex: any breadth-first order ends in the last level)
@@ -425,19 +430,25 @@ bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, cons
     if (P.nr != A.nr || (int)coarse_color.size() != P.nc) return false;
     for (int c : coarse_color) if (c < 0 || c > 3) return false;
     out.assign(P.nr, -1);
-    for (int i = 0; i < P.nr; i++) {
-        const int b = P.ptr[i], e = P.ptr[i + 1];
-        if (e - b == 1 && P.val[b] == 1.0) out[i] = 0;
-        else if (e - b == 2 && P.val[b] == 0.5 && P.val[b + 1] == 0.5) {
-            const int x = coarse_color[P.col[b]] ^ coarse_color[P.col[b + 1]];
-            if (x == 0) return false;
-            out[i] = x;
-        } else return false;
-    }
-    for (int i = 0; i < A.nr; i++)
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
-            if (A.col[p] != i && out[A.col[p]] == out[i]) return false;
-    return true;
+    std::atomic<int> bad{0};
+    parallel_for(P.nr, 1 << 15, [&](long r0, long r1) {
+        for (long i = r0; i < r1; i++) {
+            const int b = P.ptr[i], e = P.ptr[i + 1];
+            if (e - b == 1 && P.val[b] == 1.0) out[i] = 0;
+            else if (e - b == 2 && P.val[b] == 0.5 && P.val[b + 1] == 0.5) {
+                const int x = coarse_color[P.col[b]] ^ coarse_color[P.col[b + 1]];
+                if (x == 0) { bad.store(1, std::memory_order_relaxed); return; }
+                out[i] = x;
+            } else { bad.store(1, std::memory_order_relaxed); return; }
+        }
+    });
+    if (bad.load()) return false;
+    parallel_for(A.nr, 1 << 15, [&](long r0, long r1) {
+        for (long i = r0; i < r1 && !bad.load(std::memory_order_relaxed); i++)
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+                if (A.col[p] != i && out[A.col[p]] == out[i]) { bad.store(1, std::memory_order_relaxed); break; }
+    });
+    return bad.load() == 0;
 }
 
 Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors, const std::vector<int>* rcm_in)
@@ -460,16 +471,18 @@ Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_c
     }
     // rows bucketed by nnz: inside each sigma-row window of a colour, longest rows first (stable)
     if (sigma > 1) {
+        std::vector<std::pair<int, int>> win;      // the windows are independent
         for (int c = 0; c < ncol; c++)
-            for (int b = o.color_ptr[c]; b < o.color_ptr[c + 1]; b += sigma) {
-                int e = std::min(b + sigma, o.color_ptr[c + 1]);
-                std::stable_sort(o.perm.begin() + b, o.perm.begin() + e, [&](int x, int y) {
+            for (int b = o.color_ptr[c]; b < o.color_ptr[c + 1]; b += sigma) win.emplace_back(b, std::min(b + sigma, o.color_ptr[c + 1]));
+        parallel_for((long)win.size(), 64, [&](long w0, long w1) {
+            for (long w = w0; w < w1; w++)
+                std::stable_sort(o.perm.begin() + win[(size_t)w].first, o.perm.begin() + win[(size_t)w].second, [&](int x, int y) {
                     return (A.ptr[x + 1] - A.ptr[x]) > (A.ptr[y + 1] - A.ptr[y]);
                 });
-            }
+        });
     }
     o.iperm.resize(n);
-    for (int i = 0; i < n; i++) o.iperm[o.perm[i]] = i;
+    parallel_for(n, 1 << 16, [&](long a, long b) { for (long i = a; i < b; i++) o.iperm[(size_t)o.perm[(size_t)i]] = (int)i; });
     if (n == 0) o.color_ptr = {0, 0};
     return o;
 }

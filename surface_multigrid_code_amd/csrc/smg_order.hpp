@@ -24,6 +24,7 @@ struct Ordering {
 };
 
 std::vector<int> rcm_order(const Csr& A);                    // returns new -> old
+std::vector<int> rcm_order_arrays(int n, const int* ptr, const int* col);   // the same on raw CSR arrays (rows sorted)
 // Locality order of a fine level induced by its coarse level: fine vertex i goes where its parent -- the column of the largest
 // weight in row i of P (fine x coarse) -- sits in the coarse order (coarse_rank: old -> position), children of one parent
 // together.  O(nnz(P)), against a sequential breadth-first search over the fine matrix for RCM.

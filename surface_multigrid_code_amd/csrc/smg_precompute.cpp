@@ -6,11 +6,14 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <numeric>
@@ -24,22 +27,47 @@ using namespace smg;
 
 // ------------------------------------------------------------------------------------------------ precompute
 // A == A^T, bit for bit?  (row-parallel: every entry looks its mirror image up by bisection; no transpose is materialised)
-static bool bit_symmetric(const Csr& A)
+static bool bit_symmetric_arrays(int nr, int nc, const int* Aptr, const int* Acol, const double* Aval)
 {
-    if (A.nr != A.nc) return false;
+    if (nr != nc) return false;
     std::atomic<int> any{0};
-    parallel_for(A.nr, 4096, [&](long r0, long r1) {
+    parallel_for(nr, 4096, [&](long r0, long r1) {
         for (long i = r0; i < r1 && !any.load(std::memory_order_relaxed); i++)
-            for (int p = A.ptr[(size_t)i]; p < A.ptr[(size_t)i + 1]; p++) {
-                const int j = A.col[(size_t)p];
-                const int* b = A.col.data() + A.ptr[(size_t)j];
-                const int* e = A.col.data() + A.ptr[(size_t)j + 1];
+            for (int p = Aptr[(size_t)i]; p < Aptr[(size_t)i + 1]; p++) {
+                const int j = Acol[(size_t)p];
+                const int* b = Acol + Aptr[(size_t)j];
+                const int* e = Acol + Aptr[(size_t)j + 1];
                 const int* q = std::lower_bound(b, e, (int)i);
-                if (q == e || *q != (int)i || std::memcmp(&A.val[(size_t)(q - A.col.data())], &A.val[(size_t)p], sizeof(double)) != 0) { any.store(1); break; }
+                if (q == e || *q != (int)i || std::memcmp(&Aval[(size_t)(q - Acol)], &Aval[(size_t)p], sizeof(double)) != 0) { any.store(1); break; }
             }
     });
     return any.load() == 0;
 }
+static bool bit_symmetric(const Csr& A) { return bit_symmetric_arrays(A.nr, A.nc, A.ptr.data(), A.col.data(), A.val.data()); }
+// key of a level's numbering: FNV-1a over (rows, smoothed?, block size, ptr, col)
+static uint64_t pattern_key_arrays(int nr, bool smoothed, int bs, const int* ptr, const int* col)
+{
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
+    const int hdr[3] = {nr, smoothed ? 1 : 0, bs};
+    mix(hdr, 3); mix(ptr, (size_t)nr + 1); mix(col, (size_t)ptr[nr]);
+    return key;
+}
+// Work on level 0 that needs nothing but the caller's arrays, started by smg_precompute before anything else when they ARE level 0's
+// matrix (canonical rows, no constraints, scalar numbering): the locality order -- the longest sequential piece of the whole precompute
+// (a Cuthill-McKee search over all rows).
+static bool use_rcm_order()
+{
+    static const bool v = [] { const char* e = std::getenv("SMG_ORDER"); return !(e && std::string(e) == "induced"); }();
+    return v;
+}
+struct Early0 {
+    std::thread rcm_t;
+    bool rcm_started = false;
+    std::vector<int> rcm;      // empty after the join: the level's pattern is the one its present numbering was built on
+    double rcm_ms = 0.0;
+    ~Early0() { if (rcm_t.joinable()) rcm_t.join(); }
+};
 // The panels of a big level's A can be filled on the device straight from the caller's arrays and the permutation (launch_sell_fill):
 // the host then skips the permuted copy and the transposition test of 7 M entries, and ships 85 MB instead of 145 MB of padded
 // panels (C3 level 0: ~ 100 ms of the first precompute).  Conditions: scalar path, a level that is smoothed, at least
@@ -57,7 +85,7 @@ static bool device_fill_rows(const smg_hierarchy* h, int n_rows)
 // SELL image of B(i, j) = M(rperm[i], cperm[j]) (ciperm = the inverse of cperm) built on the device from M's arrays: layout from the
 // row lengths on the host, panels by launch_sell_fill.  Called from the precompute's worker threads (own stream).
 static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector<int>& rperm, const std::vector<int>& ciperm, const std::vector<int>* breaks,
-                                   bool region)
+                                   bool region, const smg_hierarchy::EarlyUpload* sent = nullptr)
 {
     std::vector<int> row_len((size_t)M.nr);
     for (int r = 0; r < M.nr; r++) { const int o = rperm[(size_t)r]; row_len[(size_t)r] = M.ptr[(size_t)o + 1] - M.ptr[(size_t)o]; }
@@ -65,14 +93,17 @@ static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector
     hipError_t e = dst.upload(S);
     DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
     DevBuf<double> d_val;
-    if (e == hipSuccess) e = d_ptr.upload(M.ptr);
-    if (e == hipSuccess) e = d_col.upload(M.col);
-    if (e == hipSuccess) e = d_val.upload(M.val);
+    const bool have = sent && sent->valid && sent->ptr.n == M.ptr.size() && sent->col.n == M.col.size();     // M's arrays are on the device already
+    if (!have) {
+        if (e == hipSuccess) e = d_ptr.upload(M.ptr);
+        if (e == hipSuccess) e = d_col.upload(M.col);
+        if (e == hipSuccess) e = d_val.upload(M.val);
+    }
     if (e == hipSuccess) e = d_perm.upload(rperm);
     if (e == hipSuccess) e = d_iperm.upload(ciperm);
     hipStream_t st2 = nullptr;      // own stream: the other tasks' uploads go on beside it
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = launch_sell_fill(d_ptr.p, d_col.p, d_val.p, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2);
+    if (e == hipSuccess) e = launch_sell_fill(have ? sent->ptr.p : d_ptr.p, have ? sent->col.p : d_col.p, have ? sent->val.p : d_val.p, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2);
     if (e == hipSuccess) e = hipStreamSynchronize(st2);
     if (st2) (void)hipStreamDestroy(st2);
     return e;
@@ -98,8 +129,25 @@ int smg::ensure_A_int(smg_hierarchy* h, int lv)
     return SMG_OK;
 }
 
+// Where the two halves of a first precompute meet.  The host half posts what has become final -- the coarsest matrix, then the
+// numbering of every level, coarse to fine -- and the device half (the calling thread) builds a level's images as soon as its numbering and
+// that of the next coarser level exist, while the host half is still working on the finer ones.
+struct Handoff {
+    std::mutex m;
+    std::condition_variable cv;
+    bool coarse_ready = false, host_over = false;
+    std::vector<char> level_ready;
+    explicit Handoff(int L) : level_ready((size_t)L, 0) {}
+    void post_coarse() { { std::lock_guard<std::mutex> g(m); coarse_ready = true; } cv.notify_all(); }
+    void post_level(int lv) { { std::lock_guard<std::mutex> g(m); level_ready[(size_t)lv] = 1; } cv.notify_all(); }
+    void post_over() { { std::lock_guard<std::mutex> g(m); host_over = true; } cv.notify_all(); }
+    // false: the host half ended without getting there
+    bool wait_coarse() { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return coarse_ready || host_over; }); return coarse_ready; }
+    bool wait_level(int lv) { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return level_ready[(size_t)lv] || host_over; }); return level_ready[(size_t)lv] != 0; }
+};
+
 // Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
-static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known)
+static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_known, Early0& e0, Handoff& hand)
 {
     const int n = A.nr;
     const int L = h->n_levels;
@@ -108,7 +156,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     h->known.clear(); h->unknown.clear();
     for (int lv = 1; lv < L; lv++) {
         if (h->lv[lv].P_full.empty()) return fail(SMG_ERR_INVALID, "level %d has no prolongation (smg_level_set_prolong)", lv);
-        h->lv[lv].P = h->lv[lv].P_full;  // always restart from P_full (see smg.h)
+        h->lv[lv].P = copy_of(h->lv[lv].P_full);  // always restart from P_full (see smg.h)
     }
     if (L > 1 && h->lv[1].P_full.nr != n)
         return fail(SMG_ERR_INVALID, "A is %d x %d but P_1 has %d rows", n, n, h->lv[1].P_full.nr);
@@ -116,16 +164,10 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     StageTimer tm;
     if (!h->has_known) {
         // reference src/min_quad_with_fixed_mg.cpp:17-22
-        h->lhs_src.resize(A.nnz());
-        std::iota(h->lhs_src.begin(), h->lhs_src.end(), 0);
+        h->lhs_src.clear();      // (identity: written out when the value-only path first needs it, build_recipes)
         h->auk_src.clear();
         h->lv[0].A = std::move(A);
         h->Auk = Csr();
-        {
-            std::vector<std::function<void()>> tasks;
-            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });
-            parallel_tasks(tasks);
-        }
     } else {
         // unknown = setdiff(0..n-1, known), ascending (:155-158); known keeps the caller's order (:178)
         std::vector<char> isk(n, 0);
@@ -153,13 +195,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 } else break;                                                    // :216-219
             }
         }
-        {
-            std::vector<std::function<void()>> tasks;
-            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });  // :226
-            parallel_tasks(tasks);
-        }
     }
-    tm.lap("host: slices / transposes of P");
+    tm.lap("host: constraint slices");
     // ---- block (3-DOF) variant?  (smg_bsr3.hpp)  Every prolongation must be Pv (x) I_3 (mg_precompute_block builds them so), no
     // constraints (they break the Kronecker structure; 06_example_balloon_sim has none), and -- unless the caller insists -- the
     // 3 x 3 blocks of A must be at least half full (a system like kron(S, I_3) is three scalar problems: the scalar kernels with
@@ -174,11 +211,6 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
             const double fill = (double)h->lv[0].A.nnz() / (9.0 * (double)std::max<long>(pat[0].nnz(), 1));
             if (h->block_mode == 3 || fill >= 0.5) h->bs = 3;
         }
-        if (h->bs == 3) {
-            std::vector<std::function<void()>> tasks;
-            for (int lv = 1; lv < L; lv++) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); });
-            parallel_tasks(tasks);
-        }
         tm.lap("host: block structure (P = Pv (x) I_3, block pattern of A_0)");
     }
     if (h->block_mode == 3 && h->bs != 3)
@@ -188,30 +220,40 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     if (!blk) for (int lv = 0; lv < L; lv++) { h->lv[lv].Pv = Csr(); h->lv[lv].PTv = Csr(); h->lv[lv].vord = Ordering(); }
     auto graph = [&](int lv) -> const Csr& { return blk ? pat[lv] : h->lv[lv].A; };                 // what a level's numbering is built on
     auto order_of = [&](int lv) -> Ordering& { return blk ? h->lv[lv].vord : h->lv[lv].ord; };      // ... and where it goes
-    // The locality order of the finest level is the longest sequential piece of the whole precompute (a Cuthill-McKee search over
-    // all rows) and needs nothing but A_0's pattern: it starts now, on its own thread, beside the Galerkin products.
     auto pattern_key = [&](int lv) {
         const Csr& M = h->lv[lv].A;
-        uint64_t key = 1469598103934665603ull;  // FNV-1a over (n, ptr, col)
-        auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
-        const int hdr[3] = {M.nr, lv < L - 1 ? 1 : 0, h->bs};
-        mix(hdr, 3); mix(M.ptr.data(), M.ptr.size()); mix(M.col.data(), M.col.size());
-        return key;
+        return pattern_key_arrays(M.nr, lv < L - 1, h->bs, M.ptr.data(), M.col.data());
     };
-    static const bool use_rcm = [] { const char* v = std::getenv("SMG_ORDER"); return !(v && std::string(v) == "induced"); }();
-    std::vector<int> rcm0;
-    std::thread rcm0_thread;
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } rcm0_joiner{rcm0_thread};
+    const bool use_rcm = use_rcm_order();
+    struct E0Join { Early0& e; ~E0Join() { if (e.rcm_t.joinable()) e.rcm_t.join(); } } e0_join{e0};   // (it may read this frame)
+    // Level 0's locality order (Early0) runs on a thread of its own, beside the Galerkin products: started by smg_precompute on the
+    // caller's arrays where it could, else here.
+    if (e0.rcm_started && (blk || h->has_known)) {       // (cannot happen: the caller starts them only for scalar, unconstrained systems)
+        if (e0.rcm_t.joinable()) e0.rcm_t.join();
+        e0.rcm_started = false; e0.rcm.clear();
+    }
     uint64_t key0 = 0;
     if (L >= 3 && use_rcm && host_threads() > 1) {
         key0 = pattern_key(0);
         const Level& L0 = h->lv[0];
-        if (!(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) rcm0_thread = std::thread([&] {
-            const auto t0 = std::chrono::steady_clock::now();
-            rcm0 = rcm_order(graph(0));
-            if (tm.on) std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        });
+        if (!e0.rcm_started && !(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) {
+            e0.rcm_started = true;
+            e0.rcm_t = std::thread([&] {
+                const auto t0 = std::chrono::steady_clock::now();
+                e0.rcm = rcm_order(graph(0));
+                e0.rcm_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+        }
     }
+    {
+        std::vector<std::function<void()>> tasks;
+        for (int lv = 1; lv < L; lv++) {
+            tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });      // :226
+            if (blk) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); });
+        }
+        parallel_tasks(tasks);
+    }
+    tm.lap("host: transposes of P");
     // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
     for (int lv = 1; lv < L; lv++) {
         Level& Lv = h->lv[lv];
@@ -246,12 +288,13 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 if (h->lv[lv].A_diag[i] == 0.0) return fail(SMG_ERR_INVALID, "level %d: zero or missing diagonal at row %d", lv, i);
     }
     tm.lap("host: shift, diagonals");
+    hand.post_coarse();
     // ---- device numbering (still host work): colour-major ordering of every smoothed level and the operators
     // expressed in it.  The coarsest level is only ever hit by the dense solve and keeps the caller's numbering.
     // coarse to fine, so that a subdivision level can inherit a 4-colouring from its parent; the RCM orders (the expensive,
     // sequential part of an ordering) of all levels that need one are computed concurrently first
     std::vector<uint64_t> keys(L);
-    std::vector<char> need(L, 0);
+    std::vector<char> need(L, 0), fresh_early(L, 0);     // fresh_early: numbered anew ahead of the level loop below
     {
         std::vector<std::function<void()>> tasks;
         for (int lv = 0; lv < L; lv++) tasks.push_back([&, lv] {
@@ -282,12 +325,11 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 (void)Lv;
                 if (tm.on) std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring from scratch %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 Lv.ord_key = keys[L - 2];
-                need[L - 2] = 0;
+                need[L - 2] = 0; fresh_early[(size_t)L - 2] = 1;
             });
-            const bool early0 = rcm0_thread.joinable();
+            const bool early0 = e0.rcm_started;
             for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(graph(lv)); });
-            parallel_tasks(tasks);
-            if (early0) { rcm0_thread.join(); rcm[0] = std::move(rcm0); }
+            parallel_tasks(tasks);      // (level 0's search, on its own thread since the start, is waited for when level 0's turn comes)
         } else {
             std::vector<int> rank;
             for (int lv = L - 2; lv >= 0; lv--) {
@@ -301,24 +343,30 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     tm.lap("host:   locality orders (RCM) + coarsest colouring");
     for (int lv = L - 1; lv >= 0; lv--) {
         Level& Lv = h->lv[lv];
-        if (!need[lv]) continue;
-        if (lv == L - 1) { Lv.ord = identity_ordering(Lv.n); if (blk) Lv.vord = identity_ordering(Lv.n / 3); }
-        else {
-            std::vector<int> inherited;
-            const Level& Lc = h->lv[lv + 1];
-            const Ordering& Oc = order_of(lv + 1);
-            const bool ok = (lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
-                            subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited);
-            if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
-            order_of(lv) = make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
-            if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
+        bool fresh = fresh_early[(size_t)lv] != 0;
+        if (need[lv]) {
+            fresh = true;
+            if (lv == L - 1) { Lv.ord = identity_ordering(Lv.n); if (blk) Lv.vord = identity_ordering(Lv.n / 3); }
+            else {
+                if (lv == 0 && use_rcm && e0.rcm_started) {
+                    if (e0.rcm_t.joinable()) e0.rcm_t.join();
+                    if (tm.on) { std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", e0.rcm_ms); tm.lap("host:   waiting for level 0's locality order"); }
+                    if ((int)e0.rcm.size() != graph(0).nr) e0.rcm = rcm_order(graph(0));     // (the early thread found the pattern unchanged, the key says otherwise: cannot happen)
+                    rcm[0] = std::move(e0.rcm);
+                }
+                std::vector<int> inherited;
+                const Level& Lc = h->lv[lv + 1];
+                const Ordering& Oc = order_of(lv + 1);
+                const bool ok = (lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
+                                subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited);
+                if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
+                order_of(lv) = make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
+                if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
+            }
+            Lv.ord_key = keys[lv];
         }
-        Lv.ord_key = keys[lv];
-    }
-    if (blk)   // the DOF numbering a vertex numbering induces: DOF 3v+d of vertex v, colours = vertex colours
-        for (int lv = 0; lv < L - 1; lv++) {
-            Level& Lv = h->lv[lv];
-            if (!need[lv] && (int)Lv.ord.perm.size() == Lv.n) continue;
+        if (blk && lv < L - 1 && (fresh || (int)Lv.ord.perm.size() != Lv.n)) {
+            // the DOF numbering a vertex numbering induces: DOF 3v+d of vertex v, colours = vertex colours
             const Ordering& O = Lv.vord;
             const int nv = (int)O.perm.size();
             Lv.ord = Ordering();
@@ -331,40 +379,9 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 }
             for (int c : O.color_ptr) Lv.ord.color_ptr.push_back(3 * c);
         }
-    tm.lap("host: orderings + colourings");
-    {
-        std::vector<std::function<void()>> tasks;
-        for (int lv = 0; lv < L; lv++) {
-            tasks.push_back([h, lv, L] {
-                Level& Lv = h->lv[lv];
-                Lv.device_filled = false;
-                if (lv < L - 1 && device_fill_candidate(h, lv) && (Lv.A_bit_symmetric = bit_symmetric(Lv.A))) {
-                    Lv.A_int = Csr(); Lv.A_int_src.clear();      // built on demand (ensure_A_int): the device fills the panels from A itself
-                    Lv.device_filled = true;
-                }
-                else if (lv < L - 1) Lv.A_int = permute(Lv.A, Lv.ord.perm, Lv.ord.perm, &Lv.A_int_src);
-                else { Lv.A_int = Lv.A; Lv.A_int_src.resize(Lv.A.nnz()); std::iota(Lv.A_int_src.begin(), Lv.A_int_src.end(), 0); }
-            });
-            if (lv >= 1) {
-                // (the transfer operators of a big level are filled on the device as well: their permuted host copies are built on demand)
-                tasks.push_back([h, lv] {
-                    Level& Lv = h->lv[lv];
-                    Lv.P_device_filled = device_fill_rows(h, Lv.P.nr);
-                    if (Lv.P_device_filled) Lv.P_int = Csr(); else Lv.P_int = permute(Lv.P, h->lv[lv - 1].ord.perm, Lv.ord.perm);
-                });
-                tasks.push_back([h, lv] {
-                    Level& Lv = h->lv[lv];
-                    static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
-                    bool ok = device_fill_rows(h, Lv.PT.nr);
-                    if (ok && long_min > 0) for (int r = 0; r < Lv.PT.nr && ok; r++) if (Lv.PT.ptr[(size_t)r + 1] - Lv.PT.ptr[(size_t)r] >= long_min) ok = false;   // long rows leave the panels: host path
-                    Lv.PT_device_filled = ok;
-                    if (ok) Lv.PT_int = Csr(); else Lv.PT_int = permute(Lv.PT, Lv.ord.perm, h->lv[lv - 1].ord.perm);
-                });
-            }
-        }
-        parallel_tasks(tasks);
+        hand.post_level(lv);     // the device half takes it from here (level_images)
     }
-    tm.lap("host: permuted operators");
+    tm.lap("host: orderings + colourings");
     return SMG_OK;
 }
 
@@ -424,208 +441,246 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
     return SMG_OK;
 }
 
-// Device half: renumber every level colour-major, build the SELL images, invert the coarsest matrix.
-static int precompute_device(smg_hierarchy* h)
+// ---- device half: the images of every level in the colour-major numbering, the coarse factorisation ----------------------------------
+// Runs on the calling thread beside the host half (Handoff): device_begin, coarse_images once the coarsest matrix is final, level_images
+// for every smoothed level as its numbering arrives (coarse to fine), finish_images.
+static int device_begin(smg_hierarchy* h)
+{
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    drop_tiled(h);
+    for (Level& Lv : h->lv) {
+        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release(); Lv.d.release();
+        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release(); Lv.d32.release();
+    }
+    h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
+    return SMG_OK;
+}
+
+// run the tasks; with SMG_TIMING their durations are listed
+static void run_image_tasks(const char* what, int lv, std::vector<std::function<void()>>& tasks)
+{
+    static const bool on = env_int("SMG_TIMING", 0) != 0;
+    if (!on) { parallel_tasks(tasks); return; }
+    std::vector<double> ms(tasks.size(), 0.0);
+    std::vector<std::function<void()>> timed;
+    for (size_t i = 0; i < tasks.size(); i++)
+        timed.push_back([&, i] {
+            const auto t0 = std::chrono::steady_clock::now();
+            tasks[i]();
+            ms[i] = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+    const auto t0 = std::chrono::steady_clock::now();
+    parallel_tasks(timed);
+    std::fprintf(stderr, "[smg timing] device:   level %d %s: %.1f ms, tasks", lv, what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    for (double v : ms) std::fprintf(stderr, " %.1f", v);
+    std::fprintf(stderr, "\n");
+}
+
+// The coarsest level: only ever hit by coarseSolve, keeps the caller's numbering.  Dense inverse on the device (stands in for
+// solver.compute(Ac), :47-48 / :253-254) up to smg_hierarchy_set_coarse_dense_max unknowns; beyond, the reference's own method: sparse
+// Cholesky (smg_coarse.hpp).
+static int coarse_images(smg_hierarchy* h)
+{
+    const int L = h->n_levels;
+    Level& Lc = h->lv[L - 1];
+    Lc.device_filled = false;
+    Lc.A_int = Lc.A;
+    Lc.A_int_src.resize((size_t)Lc.A.nnz());
+    std::iota(Lc.A_int_src.begin(), Lc.A_int_src.end(), 0);
+    if (L == 1) {
+        // a single level goes straight to coarseSolve (src/mg_VCycle.cpp:28-33); the outer loop still needs A_0 for its residual
+        Sell S = build_sell(Lc.A_int, nullptr, SELL_C, false);
+        HIPCHK(Lc.dA.upload(S));
+    }
+    if (Lc.n > h->coarse_dense_max) {
+        h->nc = Lc.n; h->nc_pad = Lc.n;
+        return coarse_factor_sparse(h, Lc.A, false);
+    }
+    h->coarse_sparse = false;
+    const int nc = Lc.n;
+    const int np = ((nc + 63) / 64) * 64;
+    h->nc = nc; h->nc_pad = np;
+    // dense image on the device: the few entries travel, not n^2 zeros
+    std::vector<long long> pos((size_t)Lc.A.nnz());
+    for (int i = 0; i < nc; i++)
+        for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) pos[(size_t)p] = (long long)i * np + Lc.A.col[p];
+    DevBuf<long long> d_pos;
+    DevBuf<double> d_val;
+    HIPCHK(d_pos.upload(pos));
+    HIPCHK(d_val.upload(Lc.A.val));
+    HIPCHK(h->d_Ainv.ensure((size_t)np * np));
+    HIPCHK(launch_dense_from_csr(h->d_Ainv.p, np, nc, d_val.p, d_pos.p, (int)Lc.A.nnz(), h->stream));
+    if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(h->d_sympart.ensure((size_t)(np / 64) * (np / 64) * 64)); else h->d_sympart.release();
+    DevBuf<double> work;
+    HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
+    HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMG_OK;
+}
+
+// Level lv < L - 1, once its numbering and that of level lv + 1 are final: A_lv (and A_lv^T where the two differ in any bit) and the
+// transfer operators between the two levels, P_{lv+1} and PT_{lv+1}, expressed in the device numbering and stored as SELL images.
+// sym0: level 0 only -- 1 / 0: A_0 == A_0^T was already decided (on the device, from the arrays sent ahead), -1: not.
+static int level_images(smg_hierarchy* h, int lv, int sym0)
 {
     const int L = h->n_levels;
     const int sellC = SELL_C;
     const bool region = env_int("SMG_REGION_ORDER", 1) != 0;   // A/B knob: region-major launch order
     const bool blk = h->bs == 3;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    drop_graphs(h);
-    drop_tiled(h);
-    for (int lv = 0; lv < L; lv++) {
-        Level& Lv = h->lv[lv];
-        Lv.b.release(); Lv.u.release(); Lv.r.release(); Lv.t.release(); Lv.d.release();
-        Lv.b32.release(); Lv.u32.release(); Lv.r32.release(); Lv.t32.release(); Lv.d32.release();
-    }
-    h->kcap = 0; h->kcap32 = 0; h->f32_valid = false;
-    StageTimer tm;
-    // all SELL images concurrently on host threads, each uploaded by the task that built it (pageable-memory copies are bound by
-    // the host-side staging copy, so they overlap with the other tasks' work and with each other)
-    std::vector<int> bad(L, 0);
+    const int lp = lv + 1;                                    // the level whose P / PT connect the two
+    Level& Lw = h->lv[lv];
+    Level& Lp = h->lv[lp];
+    // ---- host: the operators in the device numbering (or the decision that the device fills the panels from the caller-order arrays)
     {
         std::vector<std::function<void()>> tasks;
-        std::vector<hipError_t> errs;
-        errs.reserve((size_t)4 * L);
-        if (L == 1) {
-            // a single level goes straight to coarseSolve (src/mg_VCycle.cpp:28-33); the outer loop still needs A_0 for its residual
-            errs.push_back(hipSuccess);
-            hipError_t* eA = &errs.back();
-            tasks.push_back([&, eA] {
-                DeviceScope ds(h->device);
-                Sell S = build_sell(h->lv[0].A_int, nullptr, sellC, false);
-                *eA = h->lv[0].dA.upload(S);
-            });
+        tasks.push_back([h, lv, sym0, &Lw] {
+            Lw.device_filled = false;
+            if (device_fill_candidate(h, lv) && (Lw.A_bit_symmetric = (lv == 0 && sym0 >= 0) ? sym0 == 1 : bit_symmetric(Lw.A))) {
+                Lw.A_int = Csr(); Lw.A_int_src.clear();      // built on demand (ensure_A_int): the device fills the panels from A itself
+                Lw.device_filled = true;
+            } else Lw.A_int = permute(Lw.A, Lw.ord.perm, Lw.ord.perm, &Lw.A_int_src);
+        });
+        // (the transfer operators of a big level are filled on the device as well: their permuted host copies are built on demand)
+        tasks.push_back([h, &Lw, &Lp] {
+            Lp.P_device_filled = device_fill_rows(h, Lp.P.nr);
+            if (Lp.P_device_filled) Lp.P_int = Csr(); else Lp.P_int = permute(Lp.P, Lw.ord.perm, Lp.ord.perm);
+        });
+        tasks.push_back([h, &Lw, &Lp] {
+            static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+            bool ok = device_fill_rows(h, Lp.PT.nr);
+            if (ok && long_min > 0) for (int r = 0; r < Lp.PT.nr && ok; r++) if (Lp.PT.ptr[(size_t)r + 1] - Lp.PT.ptr[(size_t)r] >= long_min) ok = false;   // long rows leave the panels: host path
+            Lp.PT_device_filled = ok;
+            if (ok) Lp.PT_int = Csr(); else Lp.PT_int = permute(Lp.PT, Lp.ord.perm, Lw.ord.perm);
+        });
+        run_image_tasks("operators in the device numbering", lv, tasks);
+    }
+    // ---- device: the SELL images, concurrently on host threads, each uploaded by the task that built it (pageable-memory copies are
+    // bound by the host-side staging copy, so they overlap with the other tasks' work and with each other)
+    int bad = 0;
+    hipError_t eA = hipSuccess, eT = hipSuccess, eP = hipSuccess, eQ = hipSuccess;
+    std::vector<std::function<void()>> tasks;
+    tasks.push_back([&] {
+        DeviceScope ds(h->device);   // worker threads start on device 0
+        if (blk) {
+            Lw.dA = SellBuf();
+            Bsr3Sell S = build_bsr3(Lw.A_int, &Lw.vord.color_ptr, region);
+            eA = Lw.bA.upload(S);
+            return;
         }
-        for (int lv = 0; lv < L; lv++) {
-            if (lv < L - 1) {
-                errs.push_back(hipSuccess);
-                hipError_t* eA = &errs.back();
-                tasks.push_back([&, lv, eA] {
-                    DeviceScope ds(h->device);   // worker threads start on device 0
-                    if (blk) {
-                        h->lv[lv].dA = SellBuf();
-                        Bsr3Sell S = build_bsr3(h->lv[lv].A_int, &h->lv[lv].vord.color_ptr, region);
-                        *eA = h->lv[lv].bA.upload(S);
-                        return;
-                    }
-                    h->lv[lv].bA = Bsr3Buf();
-                    Level& Lw = h->lv[lv];
-                    if (Lw.device_filled) {
-                        // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device
-                        *eA = device_fill_sell(Lw.dA, Lw.A, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region);
-                        return;
-                    }
-                    Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
-                    *eA = Lw.dA.upload(S);
-                });
-                // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
-                // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
-                // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
-                errs.push_back(hipSuccess);
-                hipError_t* eT = &errs.back();
-                tasks.push_back([&, lv, eT] {
-                    DeviceScope ds(h->device);
-                    Level& Lw = h->lv[lv];
-                    if (Lw.device_filled) { Lw.gs_on_transpose = false; Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf(); return; }   // A == A^T was checked on the host half
-                    Csr AT = transpose(Lw.A_int);
-                    Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
-                    Lw.dAT = SellBuf();
-                    Lw.bAT = Bsr3Buf();
-                    if (Lw.gs_on_transpose) {
-                        if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad[lv] = 1; return; }
-                        if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false); *eT = Lw.bAT.upload(S); }
-                        else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false); *eT = Lw.dAT.upload(S); }
-                    }
-                });
-            }
-            if (lv >= 1) {
-                errs.push_back(hipSuccess);
-                hipError_t* eP = &errs.back();
-                // P and PT are launched whole: with their rows cut at the colour boundaries of the level they belong to, the slices get
-                // the same region-major launch order as A, and the workgroups an XCD receives (a contiguous piece of that order) read
-                // their gathers from one region of the mesh instead of from all over it (restriction at C3: 54 MB of HBM traffic per
-                // launch for 33 MB of algorithmic bytes before)
-                static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
-                tasks.push_back([&, lv, eP] {
-                    DeviceScope ds(h->device);
-                    // block hierarchies: the device applies the VERTEX-level factor of P (x) I_3 to 3 k columns (smg_bsr3.hpp)
-                    const Ordering& Of = blk ? h->lv[lv - 1].vord : h->lv[lv - 1].ord;
-                    const bool cut = tr_region && region && Of.color_ptr.size() > 2;
-                    if (!blk && h->lv[lv].P_device_filled) {
-                        *eP = device_fill_sell(h->lv[lv].dP, h->lv[lv].P, Of.perm, h->lv[lv].ord.iperm, cut ? &Of.color_ptr : nullptr, cut);
-                        return;
-                    }
-                    Csr Pvi;
-                    if (blk) Pvi = permute(h->lv[lv].Pv, Of.perm, h->lv[lv].vord.perm);
-                    Sell S = build_sell(blk ? Pvi : h->lv[lv].P_int, cut ? &Of.color_ptr : nullptr, sellC, cut);
-                    *eP = h->lv[lv].dP.upload(S);
-                });
-                errs.push_back(hipSuccess);
-                hipError_t* eQ = &errs.back();
-                tasks.push_back([&, lv, eQ] {
-                    DeviceScope ds(h->device);
-                    const Ordering& Oc = blk ? h->lv[lv].vord : h->lv[lv].ord;
-                    const bool cut = tr_region && region && lv < L - 1 && Oc.color_ptr.size() > 2;
-                    // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
-                    // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
-                    // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
-                    static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
-                    if (!blk && h->lv[lv].PT_device_filled) {
-                        *eQ = device_fill_sell(h->lv[lv].dPT, h->lv[lv].PT, Oc.perm, h->lv[lv - 1].ord.iperm, cut ? &Oc.color_ptr : nullptr, cut);
-                        if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long({}, {0}, {}, {});
-                        return;
-                    }
-                    Csr PTvi;
-                    if (blk) PTvi = permute(h->lv[lv].PTv, Oc.perm, h->lv[lv - 1].vord.perm);
-                    const Csr& M = blk ? PTvi : h->lv[lv].PT_int;
-                    std::vector<int> lrow, lptr{0}, lcol;
-                    std::vector<double> lval;
-                    if (long_min > 0)
-                        for (int r = 0; r < M.nr; r++)
-                            if (M.ptr[r + 1] - M.ptr[r] >= long_min) {
-                                lrow.push_back(r);
-                                lcol.insert(lcol.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]);
-                                lval.insert(lval.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]);
-                                lptr.push_back((int)lcol.size());
-                            }
-                    if (lrow.empty()) {
-                        Sell S = build_sell(M, cut ? &Oc.color_ptr : nullptr, sellC, cut);
-                        *eQ = h->lv[lv].dPT.upload(S);
-                        if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
-                        return;
-                    }
-                    Csr Ms;     // M with the long rows emptied
-                    Ms.nr = M.nr; Ms.nc = M.nc; Ms.ptr.assign((size_t)M.nr + 1, 0);
-                    {
-                        size_t li = 0;
-                        for (int r = 0; r < M.nr; r++) {
-                            const bool is_long = li < lrow.size() && lrow[li] == r;
-                            if (is_long) li++;
-                            else { Ms.col.insert(Ms.col.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]); Ms.val.insert(Ms.val.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]); }
-                            Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
-                        }
-                    }
-                    Sell S = build_sell(Ms, cut ? &Oc.color_ptr : nullptr, sellC, cut);
-                    *eQ = h->lv[lv].dPT.upload(S);
-                    if (*eQ == hipSuccess) *eQ = h->lv[lv].dPT.upload_long(lrow, lptr, lcol, lval);
-                });
+        Lw.bA = Bsr3Buf();
+        if (Lw.device_filled) {
+            // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device
+            eA = device_fill_sell(Lw.dA, Lw.A, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region, lv == 0 && !h->has_known ? &h->early0 : nullptr);
+            return;
+        }
+        Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
+        eA = Lw.dA.upload(S);
+    });
+    // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
+    // "legal" because A is symmetric).  Galerkin products are symmetric only up to rounding, so the sweep
+    // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
+    tasks.push_back([&] {
+        DeviceScope ds(h->device);
+        if (Lw.device_filled) { Lw.gs_on_transpose = false; Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf(); return; }   // A == A^T was checked above
+        Csr AT = transpose(Lw.A_int);
+        Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
+        Lw.dAT = SellBuf();
+        Lw.bAT = Bsr3Buf();
+        if (Lw.gs_on_transpose) {
+            if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad = 1; return; }
+            if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false); eT = Lw.bAT.upload(S); }
+            else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false); eT = Lw.dAT.upload(S); }
+        }
+    });
+    // P and PT are launched whole: with their rows cut at the colour boundaries of the level they belong to, the slices get
+    // the same region-major launch order as A, and the workgroups an XCD receives (a contiguous piece of that order) read
+    // their gathers from one region of the mesh instead of from all over it (restriction at C3: 54 MB of HBM traffic per
+    // launch for 33 MB of algorithmic bytes before)
+    static const bool tr_region = env_int("SMG_TRANSFER_REGION_ORDER", 1) != 0;
+    tasks.push_back([&] {
+        DeviceScope ds(h->device);
+        // block hierarchies: the device applies the VERTEX-level factor of P (x) I_3 to 3 k columns (smg_bsr3.hpp)
+        const Ordering& Of = blk ? Lw.vord : Lw.ord;
+        const bool cut = tr_region && region && Of.color_ptr.size() > 2;
+        if (!blk && Lp.P_device_filled) {
+            eP = device_fill_sell(Lp.dP, Lp.P, Of.perm, Lp.ord.iperm, cut ? &Of.color_ptr : nullptr, cut);
+            return;
+        }
+        Csr Pvi;
+        if (blk) Pvi = permute(Lp.Pv, Of.perm, Lp.vord.perm);
+        Sell S = build_sell(blk ? Pvi : Lp.P_int, cut ? &Of.color_ptr : nullptr, sellC, cut);
+        eP = Lp.dP.upload(S);
+    });
+    tasks.push_back([&] {
+        DeviceScope ds(h->device);
+        const Ordering& Oc = blk ? Lp.vord : Lp.ord;
+        const bool cut = tr_region && region && lp < L - 1 && Oc.color_ptr.size() > 2;
+        // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
+        // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
+        // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
+        static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+        if (!blk && Lp.PT_device_filled) {
+            eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut);
+            if (eQ == hipSuccess) eQ = Lp.dPT.upload_long({}, {0}, {}, {});
+            return;
+        }
+        Csr PTvi;
+        if (blk) PTvi = permute(Lp.PTv, Oc.perm, Lw.vord.perm);
+        const Csr& M = blk ? PTvi : Lp.PT_int;
+        std::vector<int> lrow, lptr{0}, lcol;
+        std::vector<double> lval;
+        if (long_min > 0)
+            for (int r = 0; r < M.nr; r++)
+                if (M.ptr[r + 1] - M.ptr[r] >= long_min) {
+                    lrow.push_back(r);
+                    lcol.insert(lcol.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]);
+                    lval.insert(lval.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]);
+                    lptr.push_back((int)lcol.size());
+                }
+        if (lrow.empty()) {
+            Sell S = build_sell(M, cut ? &Oc.color_ptr : nullptr, sellC, cut);
+            eQ = Lp.dPT.upload(S);
+            if (eQ == hipSuccess) eQ = Lp.dPT.upload_long(lrow, lptr, lcol, lval);
+            return;
+        }
+        Csr Ms;     // M with the long rows emptied
+        Ms.nr = M.nr; Ms.nc = M.nc; Ms.ptr.assign((size_t)M.nr + 1, 0);
+        {
+            size_t li = 0;
+            for (int r = 0; r < M.nr; r++) {
+                const bool is_long = li < lrow.size() && lrow[li] == r;
+                if (is_long) li++;
+                else { Ms.col.insert(Ms.col.end(), M.col.begin() + M.ptr[r], M.col.begin() + M.ptr[r + 1]); Ms.val.insert(Ms.val.end(), M.val.begin() + M.ptr[r], M.val.begin() + M.ptr[r + 1]); }
+                Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
             }
         }
-        parallel_tasks(tasks);
-        for (int lv = 0; lv < L; lv++)
-            if (bad[lv]) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
-        for (hipError_t e : errs) HIPCHK(e);
+        Sell S = build_sell(Ms, cut ? &Oc.color_ptr : nullptr, sellC, cut);
+        eQ = Lp.dPT.upload(S);
+        if (eQ == hipSuccess) eQ = Lp.dPT.upload_long(lrow, lptr, lcol, lval);
+    });
+    run_image_tasks("images", lv, tasks);
+    if (bad) return fail(SMG_ERR_INVALID, "level %d matrix is not structurally symmetric", lv);
+    HIPCHK(eA); HIPCHK(eT); HIPCHK(eP); HIPCHK(eQ);
+    return SMG_OK;
+}
+
+// level-0 index maps; the spectral bounds are computed when a Chebyshev smoother first asks for them (ensure_spectral_bounds)
+static int finish_images(smg_hierarchy* h)
+{
+    const Level& L0 = h->lv[0];
+    std::vector<int> map0((size_t)L0.n);
+    for (int i = 0; i < L0.n; i++) map0[(size_t)i] = h->has_known ? h->unknown[(size_t)L0.ord.perm[(size_t)i]] : L0.ord.perm[(size_t)i];
+    HIPCHK(h->d_map0.upload(map0));
+    HIPCHK(h->d_perm0.upload(L0.ord.perm));
+    if (h->has_known) {
+        HIPCHK(h->d_unknown.upload(h->unknown));
+        HIPCHK(h->d_known.upload(h->known));
+        HIPCHK(h->d_auk_ptr.upload(h->Auk.ptr));
+        HIPCHK(h->d_auk_col.upload(h->Auk.col));
+        HIPCHK(h->d_auk_val.upload(h->Auk.val));
     }
-    tm.lap("device: SELL images built and uploaded");
-    // level-0 index maps
-    {
-        const Level& L0 = h->lv[0];
-        std::vector<int> map0(L0.n);
-        for (int i = 0; i < L0.n; i++) map0[i] = h->has_known ? h->unknown[L0.ord.perm[i]] : L0.ord.perm[i];
-        HIPCHK(h->d_map0.upload(map0));
-        HIPCHK(h->d_perm0.upload(L0.ord.perm));
-        if (h->has_known) {
-            HIPCHK(h->d_unknown.upload(h->unknown));
-            HIPCHK(h->d_known.upload(h->known));
-            HIPCHK(h->d_auk_ptr.upload(h->Auk.ptr));
-            HIPCHK(h->d_auk_col.upload(h->Auk.col));
-            HIPCHK(h->d_auk_val.upload(h->Auk.val));
-        }
-    }
-    tm.lap("device: index maps");
-    // coarsest level: dense inverse on the device (stands in for solver.compute(Ac), :47-48 / :253-254) up to SMG_COARSE_DENSE_MAX
-    // unknowns; beyond, the reference's own method: sparse Cholesky (smg_coarse.hpp)
-    if (h->lv[L - 1].n > h->coarse_dense_max) {
-        const Level& Lc = h->lv[L - 1];
-        h->nc = Lc.n; h->nc_pad = Lc.n;
-        int rc = coarse_factor_sparse(h, Lc.A, false);
-        if (rc) return rc;
-    } else {
-        h->coarse_sparse = false;
-        const Level& Lc = h->lv[L - 1];
-        const int nc = Lc.n;
-        const int np = ((nc + 63) / 64) * 64;
-        h->nc = nc; h->nc_pad = np;
-        // dense image on the device: the few entries travel, not n^2 zeros
-        std::vector<long long> pos(Lc.A.nnz());
-        for (int i = 0; i < nc; i++)
-            for (int p = Lc.A.ptr[i]; p < Lc.A.ptr[i + 1]; p++) pos[p] = (long long)i * np + Lc.A.col[p];
-        DevBuf<long long> d_pos;
-        DevBuf<double> d_val;
-        HIPCHK(d_pos.upload(pos));
-        HIPCHK(d_val.upload(Lc.A.val));
-        HIPCHK(h->d_Ainv.ensure((size_t)np * np));
-        HIPCHK(launch_dense_from_csr(h->d_Ainv.p, np, nc, d_val.p, d_pos.p, (int)Lc.A.nnz(), h->stream));
-        if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(h->d_sympart.ensure((size_t)(np / 64) * (np / 64) * 64)); else h->d_sympart.release();
-        DevBuf<double> work;
-        HIPCHK(work.alloc((size_t)2 * np * 64 + 2 * 64 * 64));
-        HIPCHK(launch_spd_inverse(h->d_Ainv.p, np, work.p, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    tm.lap("device: coarse factorisation");
-    h->lam_valid = false;   // the Gershgorin bounds are computed when a Chebyshev smoother first asks for them (ensure_spectral_bounds)
+    h->lam_valid = false;
     return SMG_OK;
 }
 
@@ -757,6 +812,10 @@ static int build_recipes(smg_hierarchy* h)
             }
         if (!h->coarse_sparse) HIPCHK(h->d_dense_pos.upload(pos));
         HIPCHK(h->d_diag_idx.upload(dg));
+    }
+    if (!h->has_known && h->lhs_src.size() != (size_t)h->lv[0].A.nnz()) {
+        h->lhs_src.resize((size_t)h->lv[0].A.nnz());
+        std::iota(h->lhs_src.begin(), h->lhs_src.end(), 0);
     }
     HIPCHK(h->d_lhs_src.upload(h->lhs_src));
     if (h->has_known) HIPCHK(h->d_auk_src.upload(h->auk_src));
@@ -935,19 +994,97 @@ static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const
     h->precomputed = false;
     h->recipes_built = false;
     h->host_stale = false;
-    Csr A = csr_from_arrays(n, n, rowptr, col, val);
-    h->input_canonical = (A.nnz() == (long)rowptr[n]) && std::equal(A.col.begin(), A.col.end(), col);
-    tmv.lap("precompute: input copy (sorted, duplicates summed)");
-    int rc = precompute_host(h, std::move(A), known, n_known);
+    // Two halves side by side.  The host half (the reference's sparse algebra, numberings; no device call in it) runs on a thread of its own;
+    // this thread meanwhile brings the device up -- in a process that has not used HIP yet that alone is ~ 0.1 s of runtime
+    // initialisation, then the stream, the library's code object -- and, when the caller's arrays are what level 0's panels will be
+    // filled from (canonical rows, no constraints, a level big enough for launch_sell_fill), sends them ahead.
+    const bool canonical = rowptr[0] == 0 && rows_strictly_ascending(n, rowptr, col);
+    h->input_canonical = canonical;
+    h->early0 = smg_hierarchy::EarlyUpload();
+    Early0 e0;
+    {
+        const int L = h->n_levels;
+        static const int early_host = env_int("SMG_EARLY_HOST", 1);
+        bool maybe_block = h->block_mode != 0 && n_known == 0 && L >= 2 && n % 3 == 0;
+        if (maybe_block) { Csr tmp; maybe_block = kron3_factor(h->lv[1].P_full, tmp); }      // (a scalar prolongation fails this within a row or two)
+        if (early_host && canonical && n_known == 0 && !maybe_block && host_threads() > 1) {
+            if (L >= 3 && use_rcm_order()) {
+                e0.rcm_started = true;
+                e0.rcm_t = std::thread([&e0, h, n, rowptr, col] {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const uint64_t k0 = pattern_key_arrays(n, true, 1, rowptr, col);
+                    if (!(k0 == h->lv[0].ord_key && (int)h->lv[0].ord.perm.size() == n)) e0.rcm = rcm_order_arrays(n, rowptr, col);
+                    e0.rcm_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                });
+            }
+        }
+    }
+    int host_rc = SMG_OK;
+    std::string host_err;
+    std::exception_ptr host_exc;
+    const int L = h->n_levels;
+    Handoff hand(L);
+    std::thread host_half([&] {
+        struct Over { Handoff& hd; ~Over() { hd.post_over(); } } over{hand};     // whatever happens, the other half stops waiting
+        try {
+            StageTimer tmh;
+            Csr A = csr_from_arrays(n, n, rowptr, col, val);
+            tmh.lap("precompute: input copy (sorted, duplicates summed)");
+            host_rc = precompute_host(h, std::move(A), known, n_known, e0, hand);
+            if (host_rc != SMG_OK) host_err = smg_last_error();
+            tmh.lap("precompute: host half");
+        } catch (...) { host_exc = std::current_exception(); }      // rethrown on the calling thread (smg_precompute's guard reports it)
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } host_joiner{host_half};
+    struct DropEarly { smg_hierarchy* h; ~DropEarly() { h->early0 = smg_hierarchy::EarlyUpload(); } } drop_early{h};
+    int rc = ensure_device(h);
+    int sym0 = -1;
+    if (rc == SMG_OK) {
+        DeviceScope dsc(h->device);
+        hipError_t e = warm_device_code(h->stream);
+        static const int fill_on = env_int("SMG_DEVICE_FILL", 1), fill_min = env_int("SMG_DEVICE_FILL_MIN", 200000), early_on = env_int("SMG_EARLY_UPLOAD", 1);
+        if (e == hipSuccess && early_on && fill_on && canonical && n_known == 0 && L > 1 && n >= fill_min && h->block_mode != 3) {
+            if (e == hipSuccess) e = h->early0.ptr.alloc((size_t)n + 1);
+            if (e == hipSuccess) e = h->early0.col.alloc((size_t)rowptr[n]);
+            if (e == hipSuccess) e = h->early0.val.alloc((size_t)rowptr[n]);
+            if (e == hipSuccess) e = hipMemcpy(h->early0.ptr.p, rowptr, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(h->early0.col.p, col, (size_t)rowptr[n] * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(h->early0.val.p, val, (size_t)rowptr[n] * sizeof(double), hipMemcpyHostToDevice);
+            h->early0.valid = e == hipSuccess;
+            // ... and with the arrays there, A == A^T bit for bit (what lets the device fill level 0's panels by itself) is one short launch
+            DevBuf<int> d_differs;
+            int differs = 0;
+            if (e == hipSuccess) e = d_differs.alloc(1);
+            if (e == hipSuccess) e = launch_bit_symmetric(n, h->early0.ptr.p, h->early0.col.p, h->early0.val.p, d_differs.p, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&differs, d_differs.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) sym0 = differs ? 0 : 1;
+        }
+        if (e != hipSuccess) rc = fail(SMG_ERR_HIP, "device bring-up: %s", hipGetErrorString(e));
+        if (rc == SMG_OK) rc = device_begin(h);
+        tmv.lap("precompute: device / stream / code object / early upload (beside the host half)");
+        // the images, as the host half hands the levels over
+        if (rc == SMG_OK && hand.wait_coarse()) {
+            rc = coarse_images(h);
+            tmv.lap("precompute: coarse factorisation (beside the host half)");
+            for (int lv = L - 2; lv >= 0 && rc == SMG_OK; lv--) {
+                if (lv == L - 2 && !hand.wait_level(L - 1)) break;
+                if (!hand.wait_level(lv)) break;
+                rc = level_images(h, lv, lv == 0 ? sym0 : -1);
+            }
+        }
+    }
+    host_half.join();
+    if (host_exc) std::rethrow_exception(host_exc);
+    if (host_rc != SMG_OK) return fail(host_rc, "%s", host_err.c_str());
     if (rc != SMG_OK) return rc;
-    tmv.lap("precompute: host half");
-    rc = ensure_device(h);
-    if (rc != SMG_OK) return rc;
-    tmv.lap("precompute: device / stream");
-    DeviceScope dsc(h->device);
-    rc = precompute_device(h);
-    if (rc != SMG_OK) return rc;
-    tmv.lap("precompute: device half");
+    tmv.lap("precompute: images of all levels (the finest after the host half)");
+    {
+        DeviceScope dsc(h->device);
+        rc = finish_images(h);
+        if (rc != SMG_OK) return rc;
+    }
+    tmv.lap("precompute: index maps");
     h->pre_key = key;
     h->precomputed = true;
     return SMG_OK;

@@ -6,15 +6,32 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace smg {
 
+// The arrays of a Csr: std::vector with an allocator whose resize(n) leaves new elements UNINITIALISED.  The big ones (tens of MB at a
+// million rows) are always filled right after they are sized, by several threads: with the usual value-initialisation one thread would
+// first touch -- page-fault in -- all of it, which costs more than the fill (input copy of C3: 20 ms of 23).  resize(n, v) / assign(n, v)
+// still initialise.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) noexcept {}
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T> using raw_vector = std::vector<T, NoInitAlloc<T>>;
+
 struct Csr {
     int nr = 0, nc = 0;
-    std::vector<int> ptr;     // nr + 1
-    std::vector<int> col;     // nnz, ascending inside a row
-    std::vector<double> val;  // nnz
+    raw_vector<int> ptr;     // nr + 1
+    raw_vector<int> col;     // nnz, ascending inside a row
+    raw_vector<double> val;  // nnz
     long nnz() const { return ptr.empty() ? 0 : (long)ptr.back(); }
     bool empty() const { return nr == 0 && nc == 0; }
 };
@@ -22,9 +39,11 @@ struct Csr {
 // Build from raw arrays; sorts every row by column and sums duplicate (row,col) pairs
 // (Eigen setFromTriplets semantics).  Explicit zeros are kept.
 Csr csr_from_arrays(int nr, int nc, const int* ptr, const int* col, const double* val);
+bool rows_strictly_ascending(int nr, const int* ptr, const int* col);   // every row sorted, no duplicates: the arrays are canonical already
 // Interpret (ptr,idx,val) as compressed *columns* of an nr x nc matrix and return its CSR.
 Csr csr_from_csc_arrays(int nr, int nc, const int* colptr, const int* rowidx, const double* val);
 
+Csr copy_of(const Csr& A);   // a copy made by several threads
 Csr transpose(const Csr& A, std::vector<int>* src = nullptr);  // src[e]: index in A.val of output entry e
 
 // C = A * B.  Row i of C accumulates  A(i,k) * B(k,:)  over the stored k of row i in ascending order;
