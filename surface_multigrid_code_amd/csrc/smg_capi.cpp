@@ -227,6 +227,7 @@ extern "C" void smg_hierarchy_destroy(smg_hierarchy* h)
     for (auto& r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    for (hipStream_t a : h->aux) if (a) (void)hipStreamDestroy(a);
     delete h;
 }
 

@@ -1560,9 +1560,11 @@ hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double
 // column is its rank among the row's new column numbers (rows have a handful of entries: the quadratic count is cheaper than a sort and
 // needs no scratch).  The panels must hold col = -1, val = 0 on entry.  Entry order inside a row: ascending new column, the order of the
 // host's permute() + build_sell(): the very same image.
+// transposed: the image of A^T for a structurally symmetric A -- same slots (row o of A^T has the pattern of row o of A), the value of
+// slot (o, j) is A(j, o), found by bisection in row j.
 __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
                                                    const int* __restrict__ perm, const int* __restrict__ iperm, const int* __restrict__ slice_row,
-                                                   const int* __restrict__ slice_off, int stride, int n_slices, int* s_col, double* s_val)
+                                                   const int* __restrict__ slice_off, int stride, int n_slices, int transposed, int* s_col, double* s_val)
 {
     const int lane = threadIdx.x & 63, s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (s >= n_slices) return;
@@ -1572,20 +1574,28 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ ptr, 
     const int p0 = ptr[old], p1 = ptr[old + 1];
     const size_t base = (size_t)(stride ? s * stride : slice_off[s]) * 64 + lane;
     for (int p = p0; p < p1; p++) {
-        const int c = iperm[col[p]];
+        const int j = col[p];
+        const int c = iperm[j];
         int rank = 0;
         for (int q = p0; q < p1; q++) rank += iperm[col[q]] < c ? 1 : 0;
+        int from = p;
+        if (transposed) {
+            int lo = ptr[j], hi = ptr[j + 1];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < old) lo = mid + 1; else hi = mid; }
+            from = lo;      // (the caller has checked that A(j, old) is stored: launch_bit_symmetric)
+        }
         s_col[base + (size_t)rank * 64] = c;
-        s_val[base + (size_t)rank * 64] = val[p];
+        s_val[base + (size_t)rank * 64] = val[from];
     }
 }
-hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st)
+hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st,
+                            bool transposed)
 {
     hipError_t e = hipMemsetAsync(const_cast<int*>(S.col), 0xFF, padded * sizeof(int), st);       // col = -1
     if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(S.val), 0, padded * sizeof(double), st);
     if (e != hipSuccess || S.n_slices <= 0) return e;
     hipLaunchKernelGGL(k_sell_fill, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, val, perm, iperm, S.slice_row, S.slice_off, S.stride, S.n_slices,
-                       const_cast<int*>(S.col), const_cast<double*>(S.val));
+                       transposed ? 1 : 0, const_cast<int*>(S.col), const_cast<double*>(S.val));
     return hipGetLastError();
 }
 
@@ -1598,18 +1608,22 @@ hipError_t warm_device_code(hipStream_t st)
     return hipGetLastError();
 }
 
-// A == A^T bit for bit?  One thread per row: every entry looks its mirror image up by bisection.  *differs is set when not.
+// A == A^T?  One thread per row: every entry looks its mirror image up by bisection.  *differs: bit 0 set when some value differs from its
+// mirror image in any bit, bit 1 when some entry has no mirror image at all (A is not structurally symmetric).
 __global__ __launch_bounds__(256) void k_bit_symmetric(int n, const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val, int* differs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    int d = 0;
     for (int p = ptr[i]; p < ptr[i + 1]; p++) {
         const int j = col[p];
-        if (j < 0 || j >= n) { *differs = 1; return; }
+        if (j < 0 || j >= n) { d |= 2; continue; }
         int lo = ptr[j], hi = ptr[j + 1];
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < i) lo = mid + 1; else hi = mid; }
-        if (lo >= ptr[j + 1] || col[lo] != i || __double_as_longlong(val[lo]) != __double_as_longlong(val[p])) { *differs = 1; return; }
+        if (lo >= ptr[j + 1] || col[lo] != i) d |= 2;
+        else if (__double_as_longlong(val[lo]) != __double_as_longlong(val[p])) d |= 1;
     }
+    if (d) atomicOr(differs, d);
 }
 hipError_t launch_bit_symmetric(int n, const int* ptr, const int* col, const double* val, int* differs, hipStream_t st)
 {

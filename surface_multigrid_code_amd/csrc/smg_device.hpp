@@ -187,10 +187,13 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st);
 // out[e] = sum_t coef[t] * src[idx[t]]  (numeric Galerkin stage with a fixed recipe, smg_sparse.hpp)
 hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double* coef, const double* src, double* out, hipStream_t st);
 // SELL panels of A(perm, perm) from A's CSR arrays (caller numbering, on the device): S.col / S.val (padded slots) are cleared and filled
-hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st);
+// transposed: the image of A(perm, perm)^T instead -- A structurally symmetric (launch_bit_symmetric), values looked up by bisection
+hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st,
+                            bool transposed = false);
 // one empty launch: makes the runtime load this library's main code object now rather than inside the first real launch
 hipError_t warm_device_code(hipStream_t st);
-// square CSR matrix (rows sorted) on the device: *differs = 1 unless A == A^T bit for bit (the host's bit_symmetric, smg_precompute.cpp)
+// square CSR matrix (rows sorted) on the device: *differs = 0 when A == A^T bit for bit; bit 0: some value differs from its mirror image,
+// bit 1: some entry has none (A is not structurally symmetric)
 hipError_t launch_bit_symmetric(int n, const int* ptr, const int* col, const double* val, int* differs, hipStream_t st);
 // dst[i] = map[i] >= 0 ? src[map[i]] : 0   (refresh of SELL value panels / LHS and Auk slices)
 hipError_t launch_gather_vals(double* dst, const double* src, const int* map, size_t n, hipStream_t st);

@@ -203,6 +203,7 @@ struct smg_hierarchy {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false, user_stream = false;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // the precompute's image fills run side by side on these (creating a stream costs milliseconds: made once)
     smg::DevBuf<smg::Ctrl> d_ctrl;
     smg::Ctrl host_ctrl;            // staging of the control block smg_solve_begin uploads (must outlive the asynchronous copy)
     smg::DevBuf<double> d_rhis;     // residual history (Ctrl::r_his points here), at least max_iter entries

@@ -466,8 +466,23 @@ Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_c
     for (int c = 0; c < ncol; c++) o.color_ptr[c + 1] += o.color_ptr[c];
     o.perm.resize(n);
     {
-        std::vector<int> next(o.color_ptr.begin(), o.color_ptr.end() - 1);
-        for (int t = 0; t < n; t++) { int v = rcm[t]; o.perm[next[color[v]]++] = v; }
+        // a stable partition of the RCM sequence by colour; big levels: chunks of the sequence counted, then placed, side by side
+        const int chunks = n >= (1 << 17) ? std::min(16, host_threads()) : 1;
+        std::vector<std::vector<int>> cnt((size_t)chunks, std::vector<int>((size_t)ncol, 0));
+        auto t0 = [&](int c) { return (int)((long)n * c / chunks); };
+        parallel_for(chunks, 1, [&](long c0, long c1) {
+            for (long c = c0; c < c1; c++) for (int t = t0((int)c); t < t0((int)c + 1); t++) cnt[(size_t)c][(size_t)color[rcm[t]]]++;
+        });
+        for (int k = 0; k < ncol; k++) {
+            int run = o.color_ptr[k];
+            for (int c = 0; c < chunks; c++) { const int m = cnt[(size_t)c][(size_t)k]; cnt[(size_t)c][(size_t)k] = run; run += m; }
+        }
+        parallel_for(chunks, 1, [&](long c0, long c1) {
+            for (long c = c0; c < c1; c++) {
+                std::vector<int>& next = cnt[(size_t)c];
+                for (int t = t0((int)c); t < t0((int)c + 1); t++) { const int v = rcm[t]; o.perm[next[(size_t)color[v]]++] = v; }
+            }
+        });
     }
     // rows bucketed by nnz: inside each sigma-row window of a colour, longest rows first (stable)
     if (sigma > 1) {

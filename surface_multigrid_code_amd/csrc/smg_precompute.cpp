@@ -26,24 +26,6 @@
 using namespace smg;
 
 // ------------------------------------------------------------------------------------------------ precompute
-// A == A^T, bit for bit?  (row-parallel: every entry looks its mirror image up by bisection; no transpose is materialised)
-static bool bit_symmetric_arrays(int nr, int nc, const int* Aptr, const int* Acol, const double* Aval)
-{
-    if (nr != nc) return false;
-    std::atomic<int> any{0};
-    parallel_for(nr, 4096, [&](long r0, long r1) {
-        for (long i = r0; i < r1 && !any.load(std::memory_order_relaxed); i++)
-            for (int p = Aptr[(size_t)i]; p < Aptr[(size_t)i + 1]; p++) {
-                const int j = Acol[(size_t)p];
-                const int* b = Acol + Aptr[(size_t)j];
-                const int* e = Acol + Aptr[(size_t)j + 1];
-                const int* q = std::lower_bound(b, e, (int)i);
-                if (q == e || *q != (int)i || std::memcmp(&Aval[(size_t)(q - Acol)], &Aval[(size_t)p], sizeof(double)) != 0) { any.store(1); break; }
-            }
-    });
-    return any.load() == 0;
-}
-static bool bit_symmetric(const Csr& A) { return bit_symmetric_arrays(A.nr, A.nc, A.ptr.data(), A.col.data(), A.val.data()); }
 // key of a level's numbering: FNV-1a over (rows, smoothed?, block size, ptr, col)
 static uint64_t pattern_key_arrays(int nr, bool smoothed, int bs, const int* ptr, const int* col)
 {
@@ -82,31 +64,64 @@ static bool device_fill_rows(const smg_hierarchy* h, int n_rows)
     static const int on = env_int("SMG_DEVICE_FILL", 1), min_rows = env_int("SMG_DEVICE_FILL_MIN", 200000);
     return on && h->bs == 1 && n_rows >= min_rows;
 }
-// SELL image of B(i, j) = M(rperm[i], cperm[j]) (ciperm = the inverse of cperm) built on the device from M's arrays: layout from the
-// row lengths on the host, panels by launch_sell_fill.  Called from the precompute's worker threads (own stream).
-static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector<int>& rperm, const std::vector<int>& ciperm, const std::vector<int>* breaks,
-                                   bool region, const smg_hierarchy::EarlyUpload* sent = nullptr)
-{
-    std::vector<int> row_len((size_t)M.nr);
-    for (int r = 0; r < M.nr; r++) { const int o = rperm[(size_t)r]; row_len[(size_t)r] = M.ptr[(size_t)o + 1] - M.ptr[(size_t)o]; }
-    Sell S = sell_layout(row_len, M.nc, M.nnz(), breaks, SELL_C, region);
-    hipError_t e = dst.upload(S);
-    DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
+// A matrix's CSR arrays on the device (caller numbering), for the fills below; `sent`: they are there already (smg_hierarchy::EarlyUpload).
+struct DeviceCsr {
+    DevBuf<int> d_ptr, d_col;
     DevBuf<double> d_val;
-    const bool have = sent && sent->valid && sent->ptr.n == M.ptr.size() && sent->col.n == M.col.size();     // M's arrays are on the device already
-    if (!have) {
-        if (e == hipSuccess) e = d_ptr.upload(M.ptr);
+    const int* ptr = nullptr;
+    const int* col = nullptr;
+    const double* val = nullptr;
+    hipError_t put(const Csr& M, const smg_hierarchy::EarlyUpload* sent)
+    {
+        if (sent && sent->valid && sent->ptr.n == M.ptr.size() && sent->col.n == M.col.size()) { ptr = sent->ptr.p; col = sent->col.p; val = sent->val.p; return hipSuccess; }
+        hipError_t e = d_ptr.upload(M.ptr);
         if (e == hipSuccess) e = d_col.upload(M.col);
         if (e == hipSuccess) e = d_val.upload(M.val);
+        ptr = d_ptr.p; col = d_col.p; val = d_val.p;
+        return e;
     }
+};
+// SELL image of B(i, j) = M(rperm[i], cperm[j]) (ciperm = the inverse of cperm) -- or of B^T when `transposed` (M square, structurally
+// symmetric, rperm == cperm) -- built on the device from M's arrays: layout from the row lengths on the host, panels by launch_sell_fill.
+// Called from the precompute's worker threads (own stream).
+static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const DeviceCsr& D, const std::vector<int>& rperm, const std::vector<int>& ciperm,
+                                   const std::vector<int>* breaks, bool region, hipStream_t st2, bool transposed = false)
+{
+    static const bool tm_on = env_int("SMG_TIMING", 0) >= 2;
+    auto t_last = std::chrono::steady_clock::now();
+    std::string log;
+    auto lap = [&](const char* what) {
+        if (!tm_on) return;
+        const auto t = std::chrono::steady_clock::now();
+        char b[64]; std::snprintf(b, sizeof b, " %s %.1f", what, 1e3 * std::chrono::duration<double>(t - t_last).count());
+        log += b; t_last = t;
+    };
+    std::vector<int> row_len((size_t)M.nr);
+    parallel_for(M.nr, 1 << 16, [&](long r0, long r1) {
+        for (long r = r0; r < r1; r++) { const int o = rperm[(size_t)r]; row_len[(size_t)r] = M.ptr[(size_t)o + 1] - M.ptr[(size_t)o]; }
+    });
+    lap("row_len");
+    Sell S = sell_layout(row_len, M.nc, M.nnz(), breaks, SELL_C, region);
+    lap("layout");
+    hipError_t e = dst.upload(S);
+    lap("panels");
+    DevBuf<int> d_perm, d_iperm;
     if (e == hipSuccess) e = d_perm.upload(rperm);
     if (e == hipSuccess) e = d_iperm.upload(ciperm);
-    hipStream_t st2 = nullptr;      // own stream: the other tasks' uploads go on beside it
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = launch_sell_fill(have ? sent->ptr.p : d_ptr.p, have ? sent->col.p : d_col.p, have ? sent->val.p : d_val.p, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2);
+    lap("perms");
+    // (st2: one of the handle's auxiliary streams -- the other tasks' uploads and fills go on beside this one)
+    if (e == hipSuccess) e = launch_sell_fill(D.ptr, D.col, D.val, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2, transposed);
     if (e == hipSuccess) e = hipStreamSynchronize(st2);
-    if (st2) (void)hipStreamDestroy(st2);
+    lap("fill");
+    if (tm_on) std::fprintf(stderr, "[smg timing] device:     fill of %d x %d (ms):%s\n", M.nr, M.nc, log.c_str());
     return e;
+}
+static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector<int>& rperm, const std::vector<int>& ciperm, const std::vector<int>* breaks, bool region,
+                                   hipStream_t st2)
+{
+    DeviceCsr D;
+    hipError_t e = D.put(M, nullptr);
+    return e == hipSuccess ? device_fill_sell(dst, M, D, rperm, ciperm, breaks, region, st2) : e;
 }
 int smg::ensure_P_int(smg_hierarchy* h, int lv)
 {
@@ -254,6 +269,11 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         parallel_tasks(tasks);
     }
     tm.lap("host: transposes of P");
+    std::thread cl_thread;
+    struct ClJoin { std::thread& t; ~ClJoin() { if (t.joinable()) t.join(); } } cl_join{cl_thread};     // (it reads this frame)
+    bool cl_started = false, cl_fresh = false;
+    uint64_t cl_key = 0;
+    double cl_ms = 0.0;
     // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
     for (int lv = 1; lv < L; lv++) {
         Level& Lv = h->lv[lv];
@@ -262,6 +282,23 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
             return fail(SMG_ERR_INVALID, "P_%d has %d rows but level %d has %d unknowns", lv, Lv.P.nr, lv - 1, h->lv[lv - 1].A.nr);
         Csr tmp = spgemm(Lv.PT, h->lv[lv - 1].A);
         Lv.A = spgemm(tmp, Lv.P);
+        // The coarsest smoothed level is coloured from scratch, every finer one waits for its colours (they are inherited, coarse to
+        // fine), and the search takes longer than all that is left to do here: it starts the moment that level's matrix exists.
+        if (lv == L - 2 && L >= 3 && !blk && use_rcm && host_threads() > 1) {
+            cl_started = true;
+            cl_thread = std::thread([&, lv] {
+                Level& Lw = h->lv[lv];
+                const auto t0 = std::chrono::steady_clock::now();
+                cl_key = pattern_key(lv);
+                if (!(cl_key == Lw.ord_key && (int)Lw.ord.perm.size() == Lw.A.nr)) {
+                    const std::vector<int> r = rcm_order(Lw.A);
+                    Lw.ord = make_ordering(Lw.A, 512, nullptr, &r);
+                    Lw.ord_key = cl_key;
+                    cl_fresh = true;
+                }
+                cl_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+        }
     }
     tm.lap("host: Galerkin products");
     if (blk) {
@@ -298,6 +335,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     {
         std::vector<std::function<void()>> tasks;
         for (int lv = 0; lv < L; lv++) tasks.push_back([&, lv] {
+            if (cl_started && lv == L - 2) return;      // (being numbered right now)
             Level& Lv = h->lv[lv];
             const uint64_t key = (lv == 0 && key0) ? key0 : pattern_key(lv);
             keys[lv] = key;
@@ -310,6 +348,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     // order induced by its parent level through P -- O(nnz) instead of a sequential search over a million rows; measured at C3:
     // 0.1 s less setup, sweeps 1-3 % slower.
     tm.lap("host:   pattern hashes");
+    if (cl_started) { keys[(size_t)L - 2] = 0; need[(size_t)L - 2] = 0; }      // (numbered on its own thread: joined below, after the other levels' searches)
     std::vector<std::vector<int>> rcm(L);
     const bool any_need = std::any_of(need.begin(), need.end(), [](char c) { return c != 0; });
     if (any_need) {
@@ -341,6 +380,11 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         }
     }
     tm.lap("host:   locality orders (RCM) + coarsest colouring");
+    if (cl_started) {
+        cl_thread.join();
+        keys[(size_t)L - 2] = cl_key; fresh_early[(size_t)L - 2] = cl_fresh ? 1 : 0;
+        if (tm.on) { std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring, own thread %.1f ms)\n", cl_ms); tm.lap("host:   waiting for the coarsest smoothed level's colours"); }
+    }
     for (int lv = L - 1; lv >= 0; lv--) {
         Level& Lv = h->lv[lv];
         bool fresh = fresh_early[(size_t)lv] != 0;
@@ -534,9 +578,9 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
     // ---- host: the operators in the device numbering (or the decision that the device fills the panels from the caller-order arrays)
     {
         std::vector<std::function<void()>> tasks;
-        tasks.push_back([h, lv, sym0, &Lw] {
+        tasks.push_back([h, lv, &Lw] {
             Lw.device_filled = false;
-            if (device_fill_candidate(h, lv) && (Lw.A_bit_symmetric = (lv == 0 && sym0 >= 0) ? sym0 == 1 : bit_symmetric(Lw.A))) {
+            if (device_fill_candidate(h, lv)) {
                 Lw.A_int = Csr(); Lw.A_int_src.clear();      // built on demand (ensure_A_int): the device fills the panels from A itself
                 Lw.device_filled = true;
             } else Lw.A_int = permute(Lw.A, Lw.ord.perm, Lw.ord.perm, &Lw.A_int_src);
@@ -570,8 +614,25 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         }
         Lw.bA = Bsr3Buf();
         if (Lw.device_filled) {
-            // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device
-            eA = device_fill_sell(Lw.dA, Lw.A, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region, lv == 0 && !h->has_known ? &h->early0 : nullptr);
+            // layout from the row lengths; the caller's arrays and the permutation travel, the panels are written on the device.  The sweep
+            // streams A^T where the two differ in any bit (see below): decided on the device as well, and that image, too, is filled there.
+            DeviceCsr D;
+            eA = D.put(Lw.A, lv == 0 && !h->has_known ? &h->early0 : nullptr);
+            int differs = sym0 == 1 ? 0 : -1;      // (known to be symmetric / to be found out: which of the two ways it is not matters)
+            if (eA == hipSuccess && differs < 0) {
+                DevBuf<int> d_differs;
+                eA = d_differs.alloc(1);
+                if (eA == hipSuccess) eA = launch_bit_symmetric(Lw.A.nr, D.ptr, D.col, D.val, d_differs.p, h->aux[0]);
+                if (eA == hipSuccess) eA = hipMemcpyAsync(&differs, d_differs.p, sizeof(int), hipMemcpyDeviceToHost, h->aux[0]);
+                if (eA == hipSuccess) eA = hipStreamSynchronize(h->aux[0]);
+            }
+            if (eA != hipSuccess) return;
+            if (Lw.A.nr != Lw.A.nc || (differs & 2)) { bad = 1; return; }
+            Lw.A_bit_symmetric = differs == 0;
+            Lw.gs_on_transpose = differs != 0;
+            Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf();
+            eA = device_fill_sell(Lw.dA, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region, h->aux[0]);
+            if (eA == hipSuccess && Lw.gs_on_transpose) eT = device_fill_sell(Lw.dAT, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, false, h->aux[0], true);
             return;
         }
         Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
@@ -582,7 +643,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
     // streams A^T wherever the two differ in any bit; the SpMV / residual keep the true rows.
     tasks.push_back([&] {
         DeviceScope ds(h->device);
-        if (Lw.device_filled) { Lw.gs_on_transpose = false; Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf(); return; }   // A == A^T was checked above
+        if (Lw.device_filled) return;      // (the task above decides, and fills that image as well)
         Csr AT = transpose(Lw.A_int);
         Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
         Lw.dAT = SellBuf();
@@ -604,7 +665,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         const Ordering& Of = blk ? Lw.vord : Lw.ord;
         const bool cut = tr_region && region && Of.color_ptr.size() > 2;
         if (!blk && Lp.P_device_filled) {
-            eP = device_fill_sell(Lp.dP, Lp.P, Of.perm, Lp.ord.iperm, cut ? &Of.color_ptr : nullptr, cut);
+            eP = device_fill_sell(Lp.dP, Lp.P, Of.perm, Lp.ord.iperm, cut ? &Of.color_ptr : nullptr, cut, h->aux[1]);
             return;
         }
         Csr Pvi;
@@ -621,7 +682,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
         static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
         if (!blk && Lp.PT_device_filled) {
-            eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut);
+            eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut, h->aux[2]);
             if (eQ == hipSuccess) eQ = Lp.dPT.upload_long({}, {0}, {}, {});
             return;
         }
@@ -1042,6 +1103,7 @@ static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const
     if (rc == SMG_OK) {
         DeviceScope dsc(h->device);
         hipError_t e = warm_device_code(h->stream);
+        for (hipStream_t& a : h->aux) if (!a && e == hipSuccess) e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
         static const int fill_on = env_int("SMG_DEVICE_FILL", 1), fill_min = env_int("SMG_DEVICE_FILL_MIN", 200000), early_on = env_int("SMG_EARLY_UPLOAD", 1);
         if (e == hipSuccess && early_on && fill_on && canonical && n_known == 0 && L > 1 && n >= fill_min && h->block_mode != 3) {
             if (e == hipSuccess) e = h->early0.ptr.alloc((size_t)n + 1);
@@ -1058,7 +1120,7 @@ static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const
             if (e == hipSuccess) e = launch_bit_symmetric(n, h->early0.ptr.p, h->early0.col.p, h->early0.val.p, d_differs.p, h->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(&differs, d_differs.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e == hipSuccess) sym0 = differs ? 0 : 1;
+            if (e == hipSuccess) sym0 = differs == 0 ? 1 : 0;
         }
         if (e != hipSuccess) rc = fail(SMG_ERR_HIP, "device bring-up: %s", hipGetErrorString(e));
         if (rc == SMG_OK) rc = device_begin(h);

@@ -279,9 +279,24 @@ Csr spgemm(const Csr& A, const Csr& B)
         std::vector<int> key(64, -1);
         std::vector<double> acc(64, 0.0);
         std::vector<uint64_t> used;      // (column << 32) | slot
+        {
+            // room for every product of the chunk (an upper bound of its entries; pages that stay unused are never touched): no regrowth
+            long all = 0;
+            for (long i = r0; i < r1; i++)
+                for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) all += B.ptr[(size_t)A.col[pa] + 1] - B.ptr[A.col[pa]];
+            ch.col.reserve((size_t)all); ch.val.reserve((size_t)all);
+        }
         for (long i = r0; i < r1; i++) {
+            // (the rows of B a row of A asks for lie all over B: request them before they are needed -- the row pointers of the next
+            //  row's, the entries of this row's -- or the product is one cache miss after the other)
+            if (i + 1 < r1) for (int pa = A.ptr[i + 1]; pa < A.ptr[i + 2]; pa++) __builtin_prefetch(&B.ptr[A.col[pa]]);
             long upper = 0;
-            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) upper += B.ptr[(size_t)A.col[pa] + 1] - B.ptr[A.col[pa]];
+            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+                const int b0 = B.ptr[A.col[pa]], b1 = B.ptr[(size_t)A.col[pa] + 1];
+                upper += b1 - b0;
+                __builtin_prefetch(&B.col[b0]); __builtin_prefetch(&B.val[b0]);
+                if (b1 - b0 > 8) { __builtin_prefetch(&B.col[b0] + 16); __builtin_prefetch(&B.val[b0] + 8); }
+            }
             int lg = 4;
             while ((1L << lg) < 2 * upper) lg++;
             const uint32_t cap = 1u << lg, mask = cap - 1;
@@ -403,9 +418,11 @@ void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, R
 std::vector<double> diagonal(const Csr& A)
 {
     std::vector<double> d(A.nr, 0.0);
-    for (int i = 0; i < A.nr; i++)
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
-            if (A.col[p] == i) d[i] = A.val[p];
+    parallel_for(A.nr, 1 << 16, [&](long r0, long r1) {
+        for (long i = r0; i < r1; i++)
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+                if (A.col[p] == i) d[i] = A.val[p];
+    });
     return d;
 }
 

@@ -4,6 +4,7 @@
 // (column-major, int32) that mg_data carries (reference src/mg_data.h:13-19).  For the symmetric system
 // matrices CSR == CSC; P and PT are both kept explicitly, as the reference does.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <functional>
 #include <memory>
