@@ -80,7 +80,7 @@ Csr kron3(const Csr& P)
     return B;
 }
 
-Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order)
+Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order, bool with_entry)
 {
     constexpr int C = 64;
     Bsr3Sell S;
@@ -108,12 +108,19 @@ Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool re
     S.slice_off.assign((size_t)S.n_slices + 1, 0);
     for (int s = 0; s < S.n_slices; s++) S.slice_off[(size_t)s + 1] = S.slice_off[(size_t)s] + S.slice_w[(size_t)s];
     const size_t cols = (size_t)C * (size_t)S.slice_off.back();
-    S.col.assign(cols, -1);
-    S.val.assign(cols * 9, 0.0);
-    S.entry.assign(cols * 9, -1);
+    // (sized without initialisation: every slice clears and fills its own part, so the hundreds of MB are first touched by many threads)
+    S.col.resize(cols);
+    S.val.resize(cols * 9);
+    if (with_entry) S.entry.resize(cols * 9);
     parallel_for(S.n_slices, 256, [&](long s0, long s1) {
         for (long s = s0; s < s1; s++) {
             const size_t off = (size_t)S.slice_off[(size_t)s];
+            {
+                const size_t c0 = off * C, c1 = (size_t)S.slice_off[(size_t)s + 1] * C;
+                std::fill(S.col.begin() + c0, S.col.begin() + c1, -1);
+                std::fill(S.val.begin() + c0 * 9, S.val.begin() + c1 * 9, 0.0);
+                if (with_entry) std::fill(S.entry.begin() + c0 * 9, S.entry.begin() + c1 * 9, -1);
+            }
             for (int r = S.slice_row[(size_t)s]; r < S.slice_row[(size_t)s + 1]; r++) {
                 const int lane = r - S.slice_row[(size_t)s];
                 const int g0 = G.ptr[(size_t)r], gw = G.ptr[(size_t)r + 1] - g0;
@@ -125,7 +132,7 @@ Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool re
                         while (G.col[(size_t)g0 + j] != J) j++;
                         const size_t at = ((off + (size_t)j) * 9 + (size_t)(3 * d + e)) * C + lane;
                         S.val[at] = A.val[p];
-                        S.entry[at] = p;
+                        if (with_entry) S.entry[at] = p;
                     }
                 }
             }

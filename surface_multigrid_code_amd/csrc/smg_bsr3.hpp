@@ -28,9 +28,9 @@ struct Bsr3Sell {
     std::vector<int> slice_row;        // n_slices + 1 (vertex offsets)
     std::vector<int> slice_off;        // n_slices + 1, in panel columns
     std::vector<int> slice_w;          // n_slices
-    std::vector<int> col;              // 64 * slice_off.back()
-    std::vector<double> val;           // 9 * 64 * slice_off.back():  val[((off + j) * 9 + e) * 64 + lane]
-    std::vector<int> entry;            // like val: index of the scalar CSR entry the slot holds, -1 = explicit zero / padding
+    raw_vector<int> col;               // 64 * slice_off.back()
+    raw_vector<double> val;            // 9 * 64 * slice_off.back():  val[((off + j) * 9 + e) * 64 + lane]
+    raw_vector<int> entry;             // like val: index of the scalar CSR entry the slot holds, -1 = explicit zero / padding (empty unless asked for)
     std::vector<int> color_slice_ptr;  // n_colors + 1 slice offsets
     std::vector<int> region_order;     // launch order of whole-matrix kernels (see Sell::region_order), or empty
     long nnz_scalar = 0;               // stored entries of the scalar matrix
@@ -39,7 +39,8 @@ struct Bsr3Sell {
 
 // A: 3 n_v x 3 n_v, rows / columns numbered 3 v + d in the INTERNAL vertex numbering, entries ascending inside a row.
 // vertex_breaks: optional ascending vertex offsets (the vertex colouring's colour_ptr) at which a new slice starts.
-Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order);
+// with_entry: also fill Bsr3Sell::entry (what the value-only recipes are built from; a third of the image's bytes)
+Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order, bool with_entry = true);
 
 // n_v x n_v pattern of the 3 x 3 blocks of A (values 1.0); *n_blocks receives their number.  A.nr must be a multiple of 3.
 Csr block_pattern3(const Csr& A);

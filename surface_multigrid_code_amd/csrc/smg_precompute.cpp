@@ -26,6 +26,24 @@
 using namespace smg;
 
 // ------------------------------------------------------------------------------------------------ precompute
+// A == A^T, bit for bit?  (row-parallel: every entry looks its mirror image up by bisection; no transpose is materialised.  The levels whose
+// panels the device fills are tested there, launch_bit_symmetric.)
+static bool bit_symmetric(const Csr& A)
+{
+    if (A.nr != A.nc) return false;
+    std::atomic<int> any{0};
+    parallel_for(A.nr, 4096, [&](long r0, long r1) {
+        for (long i = r0; i < r1 && !any.load(std::memory_order_relaxed); i++)
+            for (int p = A.ptr[(size_t)i]; p < A.ptr[(size_t)i + 1]; p++) {
+                const int j = A.col[(size_t)p];
+                const int* b = A.col.data() + A.ptr[(size_t)j];
+                const int* e = A.col.data() + A.ptr[(size_t)j + 1];
+                const int* q = std::lower_bound(b, e, (int)i);
+                if (q == e || *q != (int)i || std::memcmp(&A.val[(size_t)(q - A.col.data())], &A.val[(size_t)p], sizeof(double)) != 0) { any.store(1); break; }
+            }
+    });
+    return any.load() == 0;
+}
 // key of a level's numbering: FNV-1a over (rows, smoothed?, block size, ptr, col)
 static uint64_t pattern_key_arrays(int nr, bool smoothed, int bs, const int* ptr, const int* col)
 {
@@ -608,7 +626,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         DeviceScope ds(h->device);   // worker threads start on device 0
         if (blk) {
             Lw.dA = SellBuf();
-            Bsr3Sell S = build_bsr3(Lw.A_int, &Lw.vord.color_ptr, region);
+            Bsr3Sell S = build_bsr3(Lw.A_int, &Lw.vord.color_ptr, region, false);
             eA = Lw.bA.upload(S);
             return;
         }
@@ -644,13 +662,15 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
     tasks.push_back([&] {
         DeviceScope ds(h->device);
         if (Lw.device_filled) return;      // (the task above decides, and fills that image as well)
-        Csr AT = transpose(Lw.A_int);
-        Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
         Lw.dAT = SellBuf();
         Lw.bAT = Bsr3Buf();
+        // big matrices: the symmetric ones (a caller's level 0, as a rule) are recognised without transposing tens of millions of entries
+        if (Lw.A_int.nnz() >= (1L << 22) && bit_symmetric(Lw.A_int)) { Lw.gs_on_transpose = false; return; }
+        Csr AT = transpose(Lw.A_int);
+        Lw.gs_on_transpose = !(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col && AT.val == Lw.A_int.val);
         if (Lw.gs_on_transpose) {
             if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad = 1; return; }
-            if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false); eT = Lw.bAT.upload(S); }
+            if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false, false); eT = Lw.bAT.upload(S); }
             else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false); eT = Lw.dAT.upload(S); }
         }
     });
