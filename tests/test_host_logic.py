@@ -79,6 +79,33 @@ def test_precompute_host_half_is_bit_identical_to_oracle(smg_mod, oracle_mod, ki
     assert np.allclose(mg.Adiag(Lc) - unshifted, 1e-12, atol=1e-13)
 
 
+def test_precompute_host_half_with_many_threads_on_a_bigger_system_is_bit_identical(smg_mod, oracle_mod):
+    """The host half at a size where its multi-threaded paths are the ones that run -- SpGEMM by row chunks with per-row hash tables, the
+    chunked transposition (>= 200 k entries), the parallel copies into arrays that were sized without initialisation, the hand-over to
+    the device half (which ends with 'no device' here) -- against the single-threaded oracle, bit for bit: 163 k unknowns, with constraints."""
+    smg = smg_mod
+    p = subdiv_problem(kind="poisson", k=1, n_sub=3)
+    assert p["A"].shape[0] > 150000 and p["Ps"][0].nnz >= 200000 and p["known"] is not None
+    mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"])
+    orc = oracle_mod.OracleMG(p["Ps"])
+    orc.precompute(p["A"], p["known"])
+    for l in range(mg.n_levels):
+        A, Ao = mg.matrix(l, "A"), orc.level_A(l).tocsr()
+        Ao.sort_indices()
+        assert np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices) and np.array_equal(A.data, Ao.data), l
+        assert np.array_equal(mg.Adiag(l), orc.level_Adiag(l))
+        if l >= 1:
+            for which, ref in (("P", orc.level_P(l)), ("PT", orc.level_PT(l))):
+                Mx, Rx = mg.matrix(l, which), ref.tocsr()
+                Rx.sort_indices()
+                assert np.array_equal(Mx.indptr, Rx.indptr) and np.array_equal(Mx.indices, Rx.indices) and np.array_equal(Mx.data, Rx.data), (l, which)
+    assert np.array_equal(mg.unknown(), orc.unknown())
+    # the numbering the host half hands over: a permutation, colour classes independent
+    for l in range(mg.n_levels - 1):
+        perm = mg.perm(l)
+        assert np.array_equal(np.sort(perm), np.arange(len(perm)))
+
+
 def test_constraint_cascade_drops_empty_columns(smg_mod, oracle_mod):
     """Pin whole coarse 1-rings so that coarse columns become empty and the drop cascade (.cpp:190-220) fires."""
     smg = smg_mod
