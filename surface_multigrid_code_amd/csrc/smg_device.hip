@@ -1599,6 +1599,29 @@ hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, c
     return hipGetLastError();
 }
 
+// Where the diagonal of every row sits in the value array of a filled square image (SellBuf::diag_slot, what the host computes for the
+// images it builds itself): slot[r] = index, or -1; *first_missing = the smallest row without a stored diagonal (n_rows if none).
+__global__ __launch_bounds__(256) void k_sell_diag_slots(const int* __restrict__ slice_row, const int* __restrict__ slice_off, const int* __restrict__ slice_w, int stride,
+                                                         int n_slices, const int* __restrict__ s_col, int* __restrict__ slot, int* first_missing)
+{
+    const int lane = threadIdx.x & 63, s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const int row0 = slice_row[s], nrow = slice_row[s + 1] - row0;
+    if (lane >= nrow) return;
+    const int r = row0 + lane, w = slice_w[s];
+    const size_t base = (size_t)(stride ? s * stride : slice_off[s]) * 64 + lane;
+    int at = -1;
+    for (int j = 0; j < w; j++) if (s_col[base + (size_t)j * 64] == r) { at = (int)(base + (size_t)j * 64); break; }
+    slot[r] = at;
+    if (at < 0) atomicMin(first_missing, r);
+}
+hipError_t launch_sell_diag_slots(const SellDev& S, int* slot, int* first_missing, hipStream_t st)
+{
+    if (S.n_slices <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sell_diag_slots, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, S.slice_row, S.slice_off, S.slice_w, S.stride, S.n_slices, S.col, slot, first_missing);
+    return hipGetLastError();
+}
+
 // An empty launch: the runtime loads a translation unit's code object when one of its kernels is first launched (tens of ms for this
 // file); the first precompute asks for that while its host half is still running.
 __global__ void k_nothing() {}

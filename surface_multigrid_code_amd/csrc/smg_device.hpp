@@ -190,6 +190,9 @@ hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double
 // transposed: the image of A(perm, perm)^T instead -- A structurally symmetric (launch_bit_symmetric), values looked up by bisection
 hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st,
                             bool transposed = false);
+// slot[r] = index of a_rr in the value array of the filled square image S (-1: not stored); *first_missing (preset to n_rows by the caller) =
+// the smallest row without one
+hipError_t launch_sell_diag_slots(const SellDev& S, int* slot, int* first_missing, hipStream_t st);
 // one empty launch: makes the runtime load this library's main code object now rather than inside the first real launch
 hipError_t warm_device_code(hipStream_t st);
 // square CSR matrix (rows sorted) on the device: *differs = 0 when A == A^T bit for bit; bit 0: some value differs from its mirror image,

@@ -129,7 +129,28 @@ static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const DeviceCsr& 
     lap("perms");
     // (st2: one of the handle's auxiliary streams -- the other tasks' uploads and fills go on beside this one)
     if (e == hipSuccess) e = launch_sell_fill(D.ptr, D.col, D.val, d_perm.p, d_iperm.p, dst.view, (size_t)dst.padded, st2, transposed);
+    // coloured square images: where each row's diagonal sits (SellBuf::diag_slot / n_first / n_all: what lets the restriction launch of the
+    // finer level produce this level's first colour, as SellBuf::upload works out for the images built on the host)
+    dst.n_first = 0; dst.n_all = 0;
+    const bool want_slots = M.nr == M.nc && S.color_slice_ptr.size() >= 2 && M.nr > 0;
+    DevBuf<int> d_missing;
+    int first_missing = M.nr;
+    if (e == hipSuccess && want_slots) {
+        e = dst.diag_slot.alloc((size_t)M.nr);
+        if (e == hipSuccess) e = d_missing.alloc(1);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_missing.p, &first_missing, sizeof(int), hipMemcpyHostToDevice, st2);
+        if (e == hipSuccess) e = launch_sell_diag_slots(dst.view, dst.diag_slot.p, d_missing.p, st2);
+        if (e == hipSuccess) e = hipMemcpyAsync(&first_missing, d_missing.p, sizeof(int), hipMemcpyDeviceToHost, st2);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st2);
+    if (e == hipSuccess && want_slots) {
+        const int s1 = S.color_slice_ptr.size() >= 3 ? S.color_slice_ptr[1] : S.n_slices;
+        const int nf = S.slice_row[(size_t)s1];
+        if (first_missing >= nf) {
+            if (S.color_slice_ptr.size() >= 3) dst.n_first = nf;
+            if (first_missing == M.nr) dst.n_all = M.nr;
+        } else dst.diag_slot.release();
+    }
     lap("fill");
     if (tm_on) std::fprintf(stderr, "[smg timing] device:     fill of %d x %d (ms):%s\n", M.nr, M.nc, log.c_str());
     return e;
