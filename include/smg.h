@@ -327,6 +327,10 @@ int smg_level_get_colors(const smg_hierarchy *h, int lv, int *n_colors, int *col
 int smg_level_get_Adiag(const smg_hierarchy *h, int lv, double *diag);          /* mg[lv].A_diag, caller numbering */
 int smg_get_unknown(const smg_hierarchy *h, int *n_unknown, int *unknown /* or NULL */);
 int smg_level_sell_stats(const smg_hierarchy *h, int lv, int which, long *stored, long *padded, int *n_slices);
+/* Rows of the first colour of level lv's Gauss-Seidel image whose diagonal slots the device knows (scalar hierarchies): > 0 means the
+ * restriction launch of level lv - 1 can produce the first colour of this level's first sweep itself (one launch less per visit);
+ * 0: not available (uncoloured / coarsest level, a row of the first colour without a stored diagonal). */
+int smg_level_first_colour_rows(const smg_hierarchy *h, int lv);
 /* algorithmic bytes of one y = A_lv x with k columns: 12 nnz + 4 (n+1) + 16 n k  (SURVEY.md section 8d); on a block hierarchy
  * 76 per 3 x 3 block (72 of values + 4 of block column) + 4 (n/3 + 1) + 16 n k */
 long smg_level_spmv_bytes(const smg_hierarchy *h, int lv, int k);

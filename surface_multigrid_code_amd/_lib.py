@@ -93,6 +93,7 @@ def load():
         "smg_level_get_Adiag": (i, [vp, i, dp]),
         "smg_get_unknown": (i, [vp, ip, ip]),
         "smg_level_sell_stats": (i, [vp, i, i, lp, lp, ip]),
+        "smg_level_first_colour_rows": (i, [vp, i]),
         "smg_debug_check_tiling_plan": (i, [vp, i, i, i, ip, ip, dp, dp]),
         "smg_debug_check_sparse_cholesky": (i, [i, ip, ip, dp, lp, ip, dp]),
         "smg_hierarchy_set_coarse_dense_max": (i, [vp, i]),

@@ -282,6 +282,10 @@ class Hierarchy:
                                          C.byref(ns)), "smg_level_sell_stats")
         return {"stored": st.value, "padded": pd.value, "n_slices": ns.value}
 
+    def first_colour_rows(self, lv):
+        """rows of level lv's first colour the restriction launch of level lv - 1 can update itself (0: not available)"""
+        return self.L.smg_level_first_colour_rows(self.h, lv)
+
     # ---- coarsest-level solver
     def set_coarse_dense_max(self, n_max):
         """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""

@@ -490,6 +490,13 @@ extern "C" int smg_level_sell_stats(const smg_hierarchy* h, int lv, int which, l
     return SMG_OK;
 }
 
+extern "C" int smg_level_first_colour_rows(const smg_hierarchy* h, int lv)
+{
+    if (!h || lv < 0 || lv >= h->n_levels) return fail(SMG_ERR_INVALID, "smg_level_first_colour_rows: bad level");
+    const Level& Lv = h->lv[lv];
+    return (Lv.gs_on_transpose ? Lv.dAT : Lv.dA).n_first;
+}
+
 extern "C" long smg_level_spmv_bytes(const smg_hierarchy* h, int lv, int k)
 {
     if (!h || lv < 0 || lv >= h->n_levels) return -1;

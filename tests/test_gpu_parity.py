@@ -677,7 +677,8 @@ for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2), ("poisson", 5)):     # t
     v = mg.vcycle(B, u)
     conv, z, rh = mg.solve(p["RHS"], p["z0"], p["known_val"], smg.SolveOpts(tol=1e-9, max_iter=30))
     print(kind, k, mg.n_levels, hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest(),
-          hashlib.sha256(np.ascontiguousarray(z).tobytes()).hexdigest(), len(rh))
+          hashlib.sha256(np.ascontiguousarray(z).tobytes()).hexdigest(), len(rh),
+          "first_colour_rows=" + ",".join(str(mg.first_colour_rows(l)) for l in range(1, mg.n_levels - 1)))
 """
 
 
@@ -702,6 +703,9 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
         assert len(lines) == 4, r.stdout
         outs.append(lines)
     assert all(int(ln.split()[2]) >= 4 for ln in outs[0])   # deep enough for the fused restriction to be in play
+    # ... and it IS in play on every coarse smoothed level, whether the host or the device filled its image (the device works the diagonal
+    # slots out itself, k_sell_diag_slots): same numbers of first-colour rows both ways, none of them zero
+    assert all(all(int(x) > 0 for x in ln.split("first_colour_rows=")[1].split(",")) for ln in outs[0])
     assert outs[0] == outs[1]
 
 
