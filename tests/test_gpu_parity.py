@@ -757,6 +757,60 @@ def test_allreduce_on_the_solve_stream(smg):
     assert r.returncode == 0 and "RCCL_STREAM_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+_NONSYM_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, scipy.sparse as sp
+import surface_multigrid_code_amd as smg
+from problems import subdiv_problem
+from oracle import oracle as oracle_mod
+oracle_mod.build()
+p = subdiv_problem(kind="mcf", k=1, n_sub=2)
+A = p["A"].tocsr().copy(); A.sort_indices()
+n = A.shape[0]
+# (1) values that differ from their mirror images in the last bits, pattern symmetric: the sweep must stream A^T (reference relax() walks
+#     COLUMN i, src/mg_VCycle.cpp:149-155), on level 0 too -- whose A^T image the device now fills itself
+rng = np.random.default_rng(5)
+A1 = A.copy(); A1.data = A1.data * (1.0 + 1e-13 * rng.integers(-3, 4, A1.nnz))
+mg = smg.Hierarchy.from_prolongs(p["Ps"]); mg.precompute(A1)
+for lv in range(mg.n_levels - 1):
+    Ai = mg.matrix(lv, "A", internal=True); Pi = mg.matrix(lv + 1, "P", internal=True)
+    oi = oracle_mod.OracleMG([Pi]); oi.precompute(Ai)
+    perm = mg.perm(lv)
+    x = rng.uniform(-1, 1, (mg.rows(lv), 2)); b = rng.uniform(-1, 1, (mg.rows(lv), 2))
+    assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), lv
+    assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2)), lv
+o = oracle_mod.OracleMG(p["Ps"]); o.precompute(A1)
+a = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-9, max_iter=40)); r = o.solve(p["RHS"], p["z0"], None, tol=1e-9, max_iter=40)
+assert a[0] and r[0] and abs(len(a[2]) - len(r[2])) <= 2 and np.linalg.norm(a[1] - r[1]) <= 1e-7 * np.linalg.norm(r[1])
+print("VALUES_OK")
+# (2) an entry without a mirror image: refused, with the level named
+A2 = A.tolil(); i = 10; j = [c for c in A.indices[A.indptr[i]:A.indptr[i + 1]] if c != i][0]; A2[j, i] = 0.0
+A2 = A2.tocsr(); A2.eliminate_zeros(); A2.sort_indices()
+assert A2.nnz == A.nnz - 1
+try:
+    smg.Hierarchy.from_prolongs(p["Ps"]).precompute(A2)
+    print("ACCEPTED")
+except smg.SmgError as e:
+    print("REFUSED", e.code, str(e))
+"""
+
+
+def test_a_level_0_matrix_that_is_not_bit_symmetric_on_the_device_fill_path(smg):
+    """Level 0 filled on the device (SMG_DEVICE_FILL_MIN lowered to reach it on a test-sized mesh; the default path with the host-built
+    images as the control): a matrix whose values differ from their mirror images in the last bits gets its A^T image (k_sell_fill,
+    transposed) and the sweeps are the oracle's bit for bit; one whose pattern is not symmetric is refused."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fill_min in ("100", "100000000"):
+        env = dict(os.environ, SMG_DEVICE_FILL_MIN=fill_min)
+        r = subprocess.run([sys.executable, "-c", _NONSYM_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert "VALUES_OK" in r.stdout
+        refused = [ln for ln in r.stdout.splitlines() if ln.startswith("REFUSED")]
+        assert refused and "-1" in refused[0].split()[1] and "symmetric" in refused[0], r.stdout
+
+
 _LONGROW_CHILD = r"""
 import hashlib, os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
