@@ -1562,9 +1562,12 @@ hipError_t launch_recipe(int n_out, const int* ptr, const int* idx, const double
 // host's permute() + build_sell(): the very same image.
 // transposed: the image of A^T for a structurally symmetric A -- same slots (row o of A^T has the pattern of row o of A), the value of
 // slot (o, j) is A(j, o), found by bisection in row j.
+// MAP: instead of the image, write for every slot the index of the CSR entry it holds (s_map, preset to -1): what the value-only
+// re-precompute gathers the panels' new values through (launch_gather_vals).
+template <bool MAP>
 __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
                                                    const int* __restrict__ perm, const int* __restrict__ iperm, const int* __restrict__ slice_row,
-                                                   const int* __restrict__ slice_off, int stride, int n_slices, int transposed, int* s_col, double* s_val)
+                                                   const int* __restrict__ slice_off, int stride, int n_slices, int transposed, int* s_col, double* s_val, int* s_map)
 {
     const int lane = threadIdx.x & 63, s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (s >= n_slices) return;
@@ -1584,8 +1587,11 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ ptr, 
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < old) lo = mid + 1; else hi = mid; }
             from = lo;      // (the caller has checked that A(j, old) is stored: launch_bit_symmetric)
         }
-        s_col[base + (size_t)rank * 64] = c;
-        s_val[base + (size_t)rank * 64] = val[from];
+        if (MAP) s_map[base + (size_t)rank * 64] = from;
+        else {
+            s_col[base + (size_t)rank * 64] = c;
+            s_val[base + (size_t)rank * 64] = val[from];
+        }
     }
 }
 hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, const int* perm, const int* iperm, const SellDev& S, size_t padded, hipStream_t st,
@@ -1594,8 +1600,16 @@ hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, c
     hipError_t e = hipMemsetAsync(const_cast<int*>(S.col), 0xFF, padded * sizeof(int), st);       // col = -1
     if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(S.val), 0, padded * sizeof(double), st);
     if (e != hipSuccess || S.n_slices <= 0) return e;
-    hipLaunchKernelGGL(k_sell_fill, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, val, perm, iperm, S.slice_row, S.slice_off, S.stride, S.n_slices,
-                       transposed ? 1 : 0, const_cast<int*>(S.col), const_cast<double*>(S.val));
+    hipLaunchKernelGGL(k_sell_fill<false>, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, val, perm, iperm, S.slice_row, S.slice_off, S.stride, S.n_slices,
+                       transposed ? 1 : 0, const_cast<int*>(S.col), const_cast<double*>(S.val), (int*)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_sell_fill_map(const int* ptr, const int* col, const int* perm, const int* iperm, const SellDev& S, size_t padded, bool transposed, int* map, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(map, 0xFF, padded * sizeof(int), st);       // -1: padding
+    if (e != hipSuccess || S.n_slices <= 0) return e;
+    hipLaunchKernelGGL(k_sell_fill<true>, dim3((S.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, (const double*)nullptr, perm, iperm, S.slice_row, S.slice_off, S.stride,
+                       S.n_slices, transposed ? 1 : 0, (int*)nullptr, (double*)nullptr, map);
     return hipGetLastError();
 }
 

@@ -195,6 +195,9 @@ hipError_t launch_sell_fill(const int* ptr, const int* col, const double* val, c
 hipError_t launch_sell_diag_slots(const SellDev& S, int* slot, int* first_missing, hipStream_t st);
 // one empty launch: makes the runtime load this library's main code object now rather than inside the first real launch
 hipError_t warm_device_code(hipStream_t st);
+// map[slot] = index of the CSR entry slot holds in the image launch_sell_fill(..., transposed) builds (-1: padding): the gather map of
+// the value-only re-precompute, for an image of that layout however it was built
+hipError_t launch_sell_fill_map(const int* ptr, const int* col, const int* perm, const int* iperm, const SellDev& S, size_t padded, bool transposed, int* map, hipStream_t st);
 // square CSR matrix (rows sorted) on the device: *differs = 0 when A == A^T bit for bit; bit 0: some value differs from its mirror image,
 // bit 1: some entry has none (A is not structurally symmetric)
 hipError_t launch_bit_symmetric(int n, const int* ptr, const int* col, const double* val, int* differs, hipStream_t st);

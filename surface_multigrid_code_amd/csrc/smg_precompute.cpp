@@ -833,7 +833,8 @@ static int build_recipes(smg_hierarchy* h)
     const int L = h->n_levels;
     const int sellC = SELL_C;
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int lv = 0; lv < L; lv++) { int rc = ensure_A_int(h, lv); if (rc) return rc; }
+    if (h->bs == 3) for (int lv = 0; lv < L; lv++) { int rc = ensure_A_int(h, lv); if (rc) return rc; }     // (the block maps are built on the host)
+    for (hipStream_t& a : h->aux) if (!a) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     drop_graphs(h);  // the GS launches move to the A^T images on every level
     drop_tiled(h);   // ... and so do the overlapped-tiling plans (rebuilt on demand)
     // all levels concurrently (maps of the SELL slots; the two numeric Galerkin stages as recipes); every task uploads what it built
@@ -850,6 +851,27 @@ static int build_recipes(smg_hierarchy* h)
                 // values are bit-symmetric cannot be known in advance)
                 Level& Lv = h->lv[lv];
                 hipError_t& er = errs[2 * lv];
+                if (h->bs != 3) {
+                    // Scalar images: the maps are written on the device, by the kernel that can also fill the image (k_sell_fill<MAP>: the slot
+                    // an entry lands in is its rank among the row's new column numbers, whoever built the image) -- no permuted copy, no
+                    // transposition, no second SELL build on the host.  (The pattern was found symmetric when the images were made.)
+                    up(er, Lv.d_Aval.upload(Lv.A.val));
+                    DevBuf<int> d_ptr, d_col, d_perm, d_iperm;
+                    up(er, d_ptr.upload(Lv.A.ptr)); up(er, d_col.upload(Lv.A.col)); up(er, d_perm.upload(Lv.ord.perm)); up(er, d_iperm.upload(Lv.ord.iperm));
+                    hipStream_t st2 = h->aux[lv % 3];
+                    up(er, Lv.mapA.alloc((size_t)Lv.dA.padded));
+                    if (er == hipSuccess) up(er, launch_sell_fill_map(d_ptr.p, d_col.p, d_perm.p, d_iperm.p, Lv.dA.view, (size_t)Lv.dA.padded, false, Lv.mapA.p, st2));
+                    if (!Lv.gs_on_transpose && er == hipSuccess) {      // (values: whatever A holds now -- refreshed through the map right after)
+                        DeviceCsr D;
+                        D.ptr = d_ptr.p; D.col = d_col.p; D.val = Lv.d_Aval.p;
+                        up(er, device_fill_sell(Lv.dAT, Lv.A, D, Lv.ord.perm, Lv.ord.iperm, &Lv.ord.color_ptr, false, st2, true));
+                        Lv.gs_on_transpose = true;
+                    }
+                    up(er, Lv.mapAT.alloc((size_t)Lv.dAT.padded));
+                    if (er == hipSuccess) up(er, launch_sell_fill_map(d_ptr.p, d_col.p, d_perm.p, d_iperm.p, Lv.dAT.view, (size_t)Lv.dAT.padded, true, Lv.mapAT.p, st2));
+                    if (er == hipSuccess) up(er, hipStreamSynchronize(st2));
+                    return;
+                }
                 std::vector<int> m;
                 std::vector<int> tsrc;
                 Csr AT = transpose(Lv.A_int, &tsrc);
@@ -884,7 +906,7 @@ static int build_recipes(smg_hierarchy* h)
                 DeviceScope ds(h->device);
                 Level& Lv = h->lv[lv];
                 hipError_t& er = errs[2 * lv + 1];
-                up(er, Lv.d_Aval.upload(Lv.A.val));
+                if (h->bs == 3 || lv == L - 1) up(er, Lv.d_Aval.upload(Lv.A.val));      // (scalar smoothed levels: the task above)
                 if (lv == 0) return;
                 const Csr& Af = h->lv[lv - 1].A;
                 Csr T = spgemm(Lv.PT, Af);

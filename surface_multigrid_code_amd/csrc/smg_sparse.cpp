@@ -388,31 +388,39 @@ Csr permute(const Csr& A, const std::vector<int>& rperm, const std::vector<int>&
 
 void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, Recipe& R)
 {
-    // position of column j inside row i of C
-    std::vector<int> pos(C.nc, -1);
-    R.ptr.assign(C.nnz() + 1, 0);
-    for (int i = 0; i < A.nr; i++) {
-        for (int e = C.ptr[i]; e < C.ptr[i + 1]; e++) pos[C.col[e]] = e;
-        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
-            const int k = A.col[pa];
-            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) R.ptr[pos[B.col[pb]] + 1]++;
-        }
-    }
-    for (long e = 0; e < C.nnz(); e++) R.ptr[e + 1] += R.ptr[e];
-    R.idx.resize(R.ptr[C.nnz()]);
-    R.coef.resize(R.ptr[C.nnz()]);
-    std::vector<int> next(R.ptr.begin(), R.ptr.end() - 1);
-    for (int i = 0; i < A.nr; i++) {
-        for (int e = C.ptr[i]; e < C.ptr[i + 1]; e++) pos[C.col[e]] = e;
-        for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {  // ascending k: the accumulation order of spgemm()
-            const int k = A.col[pa];
-            for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
-                const int t = next[pos[B.col[pb]]]++;
-                if (coef_from_A) { R.coef[t] = A.val[pa]; R.idx[t] = pb; }
-                else { R.coef[t] = B.val[pb]; R.idx[t] = pa; }
+    // Rows in parallel: the terms of an output entry all come from its own row of A.  Where a column of B lands inside row i of C is
+    // found by bisection (rows of C are sorted and short).
+    auto entry_of = [&](long i, int j) {
+        const int* b = C.col.data() + C.ptr[i];
+        const int* e = C.col.data() + C.ptr[i + 1];
+        return (long)(std::lower_bound(b, e, j) - C.col.data());
+    };
+    R.ptr.assign((size_t)C.nnz() + 1, 0);
+    parallel_for(A.nr, 2048, [&](long r0, long r1) {
+        for (long i = r0; i < r1; i++)
+            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {
+                const int k = A.col[pa];
+                for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) R.ptr[(size_t)entry_of(i, B.col[pb]) + 1]++;
+            }
+    });
+    for (long e = 0; e < C.nnz(); e++) R.ptr[(size_t)e + 1] += R.ptr[(size_t)e];
+    R.idx.resize((size_t)R.ptr[(size_t)C.nnz()]);
+    R.coef.resize((size_t)R.ptr[(size_t)C.nnz()]);
+    parallel_for(A.nr, 2048, [&](long r0, long r1) {
+        std::vector<int> next;      // write cursors of the entries of the row at hand
+        for (long i = r0; i < r1; i++) {
+            const long e0 = C.ptr[i];
+            next.assign(R.ptr.begin() + e0, R.ptr.begin() + C.ptr[i + 1]);
+            for (int pa = A.ptr[i]; pa < A.ptr[i + 1]; pa++) {  // ascending k: the accumulation order of spgemm()
+                const int k = A.col[pa];
+                for (int pb = B.ptr[k]; pb < B.ptr[k + 1]; pb++) {
+                    const int t = next[(size_t)(entry_of(i, B.col[pb]) - e0)]++;
+                    if (coef_from_A) { R.coef[(size_t)t] = A.val[pa]; R.idx[(size_t)t] = pb; }
+                    else { R.coef[(size_t)t] = B.val[pb]; R.idx[(size_t)t] = pa; }
+                }
             }
         }
-    }
+    });
 }
 
 std::vector<double> diagonal(const Csr& A)

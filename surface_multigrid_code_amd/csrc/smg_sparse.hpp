@@ -66,8 +66,9 @@ std::vector<double> diagonal(const Csr& A);
 // values of the variable factor reproduces spgemm bit for bit.  coef_from_A: A is the constant factor (its values are
 // baked into coef, idx points into B.val); otherwise B is constant and idx points into A.val.
 struct Recipe {
-    std::vector<int> ptr, idx;
-    std::vector<double> coef;
+    std::vector<int> ptr;
+    raw_vector<int> idx;
+    raw_vector<double> coef;
 };
 void spgemm_recipe(const Csr& A, const Csr& B, bool coef_from_A, const Csr& C, Recipe& R);
 

@@ -1,29 +1,20 @@
 #!/usr/bin/env python3
-"""Time a full smg_precompute against the value-only (device) re-precompute on one workload."""
+"""The time-stepping callers' precompute (05_example_mean_curvature_flow/main.cpp:74: a new matrix with the same sparsity every step), C3:
+first call (full), second (the value-only path builds its recipes once), then the steady state; host arrays in, and values already in HBM."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, scipy.sparse as sp
+import numpy as np
+import torch
+torch.zeros(1, device="cuda")
 import bench as B
 import surface_multigrid_code_amd as smg
 from surface_multigrid_code_amd import mesh
-wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
-mg, A, Mb, Vf, Ff, label, _ = B.build_workload(wl, smg, mesh)
-t = time.time(); mg.precompute(A); t_full = time.time() - t
-A2 = (A + 0.1 * sp.diags(A.diagonal())).tocsr(); A2.sort_indices()
-t = time.time(); mg.precompute(A2); t_first = time.time() - t     # builds the recipes
-ts = []
-for i in range(5):
-    A3 = (A + (0.2 + 0.1 * i) * sp.diags(A.diagonal())).tocsr(); A3.sort_indices()
-    ptr, col, val = A3.indptr.astype(np.int32), A3.indices.astype(np.int32), A3.data
-    t = time.time(); mg.precompute(A3); ts.append(time.time() - t)
+mg, A, Mb, Vf, Ff, label, _ = B.build_workload("C3", smg, mesh)
 print(label)
-print("full precompute %.3f s | first value-only (recipe build) %.3f s | value-only steady %.1f ms (min %.1f)" % (t_full, t_first, 1e3 * np.median(ts), 1e3 * min(ts)))
-# values already in HBM: no H2D copy
-import torch
-dev = torch.device("cuda", 0)
-vals = torch.from_numpy(A3.data).to(dev)
-torch.cuda.synchronize()
-ts = []
-for i in range(5):
-    t = time.time(); mg.precompute_values_device(vals.data_ptr()); ts.append(time.time() - t)
-print("value-only from HBM (smg_precompute_values_device): %.1f ms (min %.1f)" % (1e3 * np.median(ts), 1e3 * min(ts)))
+for i in range(6):
+    A2 = A.copy(); A2.data = A.data * (1.0 + 0.01 * i)
+    t0 = time.time(); mg.precompute(A2); torch.cuda.synchronize(); print("precompute call %d: %.2f ms" % (i + 1, 1e3 * (time.time() - t0)))
+d = torch.from_numpy(A.data).cuda()
+for i in range(4):
+    torch.cuda.synchronize(); t0 = time.time(); mg.precompute_values_device(d.data_ptr()); torch.cuda.synchronize()
+    print("values already on the device, call %d: %.2f ms" % (i + 1, 1e3 * (time.time() - t0)))
