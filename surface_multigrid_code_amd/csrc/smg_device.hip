@@ -277,13 +277,35 @@ __global__ __launch_bounds__(256) void k_sell_wide(const int* a_col, const T* a_
             int cc[U][R];
             T vv[U][R], xv[U][R];
             T xo[MODE == SELL_GS_HEAD ? U : 1][R];
+            constexpr int NL = G == 1 ? 1 : (U * RW + 63) / 64;     // coalesced loads of the batch's entries (G > 1), one entry per lane:
+            int cL[NL];                                              // entry e = t * RW + (row inside the wave's RW rows)
+            T vL[NL];
+            if constexpr (G > 1) {
+#pragma unroll
+                for (int q = 0; q < NL; q++) {
+                    const int e = q * 64 + lane, tt = e / RW, rr = e % RW;
+                    const bool in2 = e < U * RW && (j0 + tt) < w;
+                    cL[q] = in2 ? cp[(size_t)(j0 + tt) * 64 + sub * RW + rr] : -1;
+                    vL[q] = in2 ? vp[(size_t)(j0 + tt) * 64 + sub * RW + rr] : (T)0;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < U; t++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool in = (j0 + t) < w;  // wave-uniform
-                    cc[t][r] = in ? cp[(size_t)(j0 + t) * 64 + rl[r]] : -1;
-                    vv[t][r] = in ? vp[(size_t)(j0 + t) * 64 + rl[r]] : (T)0;
+                    (void)in;
+                    if constexpr (G == 1) {        // the row is the same for all lanes: the compiler fetches the entry through the scalar cache
+                        cc[t][r] = in ? cp[(size_t)(j0 + t) * 64 + rl[r]] : -1;
+                        vv[t][r] = in ? vp[(size_t)(j0 + t) * 64 + rl[r]] : (T)0;
+                    } else {
+                        // G rows per wave-instruction: as a load of its own every slot would have the 64 lanes ask for G distinct words, and
+                        // these two loads per slot -- not the gathers -- bound the launch.  The batch's U x RW entries are fetched by
+                        // coalesced loads (one entry per lane) above and handed to the lanes of their rows through the LDS crossbar.
+                        const int src = t * RW + r * G + g;
+                        cc[t][r] = __shfl(cL[(t * RW + r * G) / 64], src & 63, 64);
+                        vv[t][r] = __shfl(vL[(t * RW + r * G) / 64], src & 63, 64);
+                    }
                 }
 #pragma unroll
             for (int t = 0; t < U; t++)
