@@ -105,6 +105,42 @@ def build_sanitized(verbose=False):
     return ASAN_LIB
 
 
+# ---- ThreadSanitizer lane: the host translation units through g++ -fsanitize=thread, linked with tests/tsan_precompute_driver.cpp into an
+# executable (python itself would drown the report in noise) that runs the threaded host half of a first smg_precompute.
+TSAN_EXE = os.path.join(LIBDIR, "tsan_precompute_driver")
+
+
+def build_tsan(verbose=False):
+    build(verbose=verbose)                                   # the device objects come from the regular build
+    objdir = os.path.join(LIBDIR, "obj_tsan")
+    os.makedirs(objdir, exist_ok=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    driver = os.path.join(root, "tests", "tsan_precompute_driver.cpp")
+    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-fsanitize=thread", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+             "-I" + os.path.join(root, "include"), "-w"]
+    host = [s for s in SOURCES if s.endswith(".cpp")]
+    objs, procs = [os.path.join(LIBDIR, "obj", os.path.splitext(s)[0] + ".o") for s in SOURCES if s.endswith(".hip")], []
+    newest_hdr = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    for s in host:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr, os.path.getmtime(os.path.abspath(__file__))):
+            continue
+        cmd = ["g++"] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("thread-sanitized build failed: " + " ".join(cmd))
+    if procs or not os.path.exists(TSAN_EXE) or os.path.getmtime(TSAN_EXE) < max(os.path.getmtime(driver), os.path.getmtime(objs[0])):
+        cmd = ["g++"] + flags + [driver] + objs + ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", TSAN_EXE]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return TSAN_EXE
+
+
 def sanitizer_env(base=None):
     """Environment for a python child that loads libsmg_asan.so."""
     env = dict(base if base is not None else os.environ)

@@ -38,3 +38,17 @@ def test_host_logic_and_abi_under_asan_ubsan():
 def test_host_fuzz_under_asan_ubsan():
     out = _run(["tools/fuzz_host.py", "10", "0"], 1500)
     assert "FUZZ_HOST OK" in out
+
+
+def test_threaded_host_half_of_the_precompute_under_tsan():
+    """ThreadSanitizer over the host half of a first smg_precompute (its own thread beside the caller's, the early locality-order and colouring
+    threads, the persistent pool, the hand-over object): tests/tsan_precompute_driver.cpp, three rounds on a 77 k-row, 4-level system.
+    Without a device the call ends with SMG_ERR_NO_DEVICE after the host half has run -- which is what this lane is about."""
+    from surface_multigrid_code_amd import build as smg_build
+    exe = smg_build.build_tsan()
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0", SMG_HOST_THREADS="6",
+               HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")     # (on a box with a GPU: keep the runtime's own threads out of the report)
+    r = subprocess.run([exe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert "ThreadSanitizer" not in out, out[-6000:]
+    assert out.count("precompute rc = ") == 3 and r.returncode == 0, out[-3000:]
