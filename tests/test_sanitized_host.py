@@ -50,5 +50,14 @@ def test_threaded_host_half_of_the_precompute_under_tsan():
                HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")     # (on a box with a GPU: keep the runtime's own threads out of the report)
     r = subprocess.run([exe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
+    if "unexpected memory mapping" in out:       # kernels with more address-space randomisation than this libtsan knows: run without it
+        import shutil
+        import pytest
+        if not shutil.which("setarch"):
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel and setarch is not available")
+        r = subprocess.run(["setarch", os.uname().machine, "-R", exe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        out = r.stdout + r.stderr
+        if "unexpected memory mapping" in out:
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
     assert "ThreadSanitizer" not in out, out[-6000:]
     assert out.count("precompute rc = ") == 3 and r.returncode == 0, out[-3000:]
