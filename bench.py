@@ -64,6 +64,11 @@ def build_workload(name, smg, mesh):
         mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 5, n_extra_levels=0)
         Vf = mesh.normalize_unit_area(_onto_torus(Vf), Ff)
         label = "C5: torus (R=1, r=0.4) 64x64 x5 midpoint subdivision re-projected onto the torus, 4194304 verts, 6 levels, M_bary+0.01(-L), fp64"
+    elif name == "C6":       # (not a BASELINE config: four times C5, far beyond every cache -- tools/level_times.py C6)
+        V, F = mesh.torus(64, 64)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 6, n_extra_levels=0)
+        Vf = mesh.normalize_unit_area(_onto_torus(Vf), Ff)
+        label = "C6: torus (R=1, r=0.4) 64x64 x6 midpoint subdivision re-projected onto the torus, 16777216 verts, 7 levels, M_bary+0.01(-L), fp64"
     elif name == "small":
         V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
         V = mesh.normalize_unit_area(V, F)
