@@ -80,15 +80,14 @@ Csr kron3(const Csr& P)
     return B;
 }
 
-Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order, bool with_entry)
+Bsr3Sell bsr3_layout(const std::vector<int>& row_len, const std::vector<int>* vertex_breaks, bool region_order, long nnz_scalar, long n_blocks)
 {
     constexpr int C = 64;
     Bsr3Sell S;
-    const int nv = A.nr / 3;
+    const int nv = (int)row_len.size();
     S.n_vert = nv;
-    S.nnz_scalar = A.nnz();
-    const Csr G = block_pattern3(A);
-    S.n_blocks = G.nnz();
+    S.nnz_scalar = nnz_scalar;
+    S.n_blocks = n_blocks;
     std::vector<int> breaks;
     if (vertex_breaks) breaks = *vertex_breaks; else breaks = {0, nv};
     S.slice_row.push_back(0);
@@ -97,7 +96,7 @@ Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool re
         for (int r0 = breaks[c]; r0 < breaks[c + 1]; r0 += C) {
             const int r1 = std::min(r0 + C, breaks[c + 1]);
             int w = 0;
-            for (int r = r0; r < r1; r++) w = std::max(w, G.ptr[(size_t)r + 1] - G.ptr[(size_t)r]);
+            for (int r = r0; r < r1; r++) w = std::max(w, row_len[(size_t)r]);
             S.slice_row.push_back(r1);
             S.slice_w.push_back(w);
             S.w_max = std::max(S.w_max, w);
@@ -107,6 +106,27 @@ Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool re
     S.n_slices = (int)S.slice_row.size() - 1;
     S.slice_off.assign((size_t)S.n_slices + 1, 0);
     for (int s = 0; s < S.n_slices; s++) S.slice_off[(size_t)s + 1] = S.slice_off[(size_t)s] + S.slice_w[(size_t)s];
+    if (region_order && S.color_slice_ptr.size() > 2) {
+        std::vector<std::pair<double, int>> key((size_t)S.n_slices);
+        for (size_t c = 0; c + 1 < S.color_slice_ptr.size(); c++) {
+            const int b = S.color_slice_ptr[c], e = S.color_slice_ptr[c + 1];
+            for (int s = b; s < e; s++) key[(size_t)s] = {(s - b + 0.5) / (double)(e - b), s};
+        }
+        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
+        S.region_order.resize((size_t)S.n_slices);
+        for (int i = 0; i < S.n_slices; i++) S.region_order[(size_t)i] = key[(size_t)i].second;
+    }
+    return S;
+}
+
+Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order, bool with_entry)
+{
+    constexpr int C = 64;
+    const int nv = A.nr / 3;
+    const Csr G = block_pattern3(A);
+    std::vector<int> row_len((size_t)nv);
+    for (int r = 0; r < nv; r++) row_len[(size_t)r] = G.ptr[(size_t)r + 1] - G.ptr[(size_t)r];
+    Bsr3Sell S = bsr3_layout(row_len, vertex_breaks, region_order, A.nnz(), G.nnz());
     const size_t cols = (size_t)C * (size_t)S.slice_off.back();
     // (sized without initialisation: every slice clears and fills its own part, so the hundreds of MB are first touched by many threads)
     S.col.resize(cols);
@@ -138,16 +158,6 @@ Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool re
             }
         }
     });
-    if (region_order && S.color_slice_ptr.size() > 2) {
-        std::vector<std::pair<double, int>> key((size_t)S.n_slices);
-        for (size_t c = 0; c + 1 < S.color_slice_ptr.size(); c++) {
-            const int b = S.color_slice_ptr[c], e = S.color_slice_ptr[c + 1];
-            for (int s = b; s < e; s++) key[(size_t)s] = {(s - b + 0.5) / (double)(e - b), s};
-        }
-        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
-        S.region_order.resize((size_t)S.n_slices);
-        for (int i = 0; i < S.n_slices; i++) S.region_order[(size_t)i] = key[(size_t)i].second;
-    }
     return S;
 }
 

@@ -42,6 +42,10 @@ struct Bsr3Sell {
 // with_entry: also fill Bsr3Sell::entry (what the value-only recipes are built from; a third of the image's bytes)
 Bsr3Sell build_bsr3(const Csr& A, const std::vector<int>* vertex_breaks, bool region_order, bool with_entry = true);
 
+// The layout alone (slices, widths, offsets, colour / region tables) from the block-row lengths in the internal vertex numbering: col / val / entry stay
+// empty -- the device fills the panels (launch_bsr3_fill).
+Bsr3Sell bsr3_layout(const std::vector<int>& block_row_len, const std::vector<int>* vertex_breaks, bool region_order, long nnz_scalar, long n_blocks);
+
 // n_v x n_v pattern of the 3 x 3 blocks of A (values 1.0); *n_blocks receives their number.  A.nr must be a multiple of 3.
 Csr block_pattern3(const Csr& A);
 

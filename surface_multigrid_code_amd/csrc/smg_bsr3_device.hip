@@ -203,6 +203,56 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
 
 int bsr3_blocks(int n_slices) { return (n_slices + 3) / 4; }
 
+// The block image of B = A(perm3, perm3) -- perm3 the DOF numbering a vertex numbering `perm` (new -> old) induces -- or of B^T (A
+// structurally symmetric), written on the device from A's scalar CSR arrays in the caller's numbering (Bsr3Buf of a layout made on the
+// host from the block-row lengths): one lane per vertex.  A block's panel column is the rank of its new vertex index among the block row's
+// (gptr / gcol: the n_v x n_v pattern of the blocks, caller numbering) -- block columns ascend, the host's build_bsr3 order: the same image.
+// The panels must hold col = -1, val = 0 on entry.
+__global__ __launch_bounds__(256) void k_bsr3_fill(const int* __restrict__ ptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                   const int* __restrict__ gptr, const int* __restrict__ gcol, const int* __restrict__ perm,
+                                                   const int* __restrict__ iperm, const int* __restrict__ slice_row, const int* __restrict__ slice_off,
+                                                   int n_slices, int transposed, int* b_col, double* b_val)
+{
+    const int lane = threadIdx.x & 63, s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const int row0 = slice_row[s], nrow = slice_row[s + 1] - row0;
+    if (lane >= nrow) return;
+    const int v = perm[row0 + lane];
+    const int g0 = gptr[v], g1 = gptr[v + 1];
+    const size_t off = (size_t)slice_off[s];
+    for (int q = g0; q < g1; q++) {        // the block columns of the row, each at its rank
+        const int Jn = iperm[gcol[q]];
+        int rank = 0;
+        for (int t = g0; t < g1; t++) rank += iperm[gcol[t]] < Jn ? 1 : 0;
+        b_col[(off + (size_t)rank) * 64 + lane] = Jn;
+    }
+    for (int d = 0; d < 3; d++)
+        for (int p = ptr[3 * v + d]; p < ptr[3 * v + d + 1]; p++) {
+            const int c = col[p], Jo = c / 3, e = c - 3 * Jo;
+            const int Jn = iperm[Jo];
+            int rank = 0;
+            for (int t = g0; t < g1; t++) rank += iperm[gcol[t]] < Jn ? 1 : 0;
+            int from = p;
+            if (transposed) {              // B^T(3v+d, 3J+e) = A(3J+e, 3v+d), found by bisection (the caller has checked that it is stored)
+                const int want = 3 * v + d;
+                int lo = ptr[c], hi = ptr[c + 1];
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < want) lo = mid + 1; else hi = mid; }
+                from = lo;
+            }
+            b_val[((off + (size_t)rank) * 9 + (size_t)(3 * d + e)) * 64 + lane] = val[from];
+        }
+}
+hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, const int* gptr, const int* gcol, const int* perm, const int* iperm, const Bsr3Dev& B,
+                            size_t panel_cols, bool transposed, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(const_cast<int*>(B.col), 0xFF, panel_cols * 64 * sizeof(int), st);       // -1
+    if (e == hipSuccess) e = hipMemsetAsync(const_cast<double*>(B.val), 0, panel_cols * 64 * 9 * sizeof(double), st);
+    if (e != hipSuccess || B.n_slices <= 0) return e;
+    hipLaunchKernelGGL(k_bsr3_fill, dim3((B.n_slices + 3) / 4), dim3(256), 0, st, ptr, col, val, gptr, gcol, perm, iperm, B.slice_row, B.slice_off, B.n_slices,
+                       transposed ? 1 : 0, const_cast<int*>(B.col), const_cast<double*>(B.val));
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_bsr3_mode(const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
                                    double* partials, int* n_blocks, hipStream_t st, double omega, double c1, double* dvec)

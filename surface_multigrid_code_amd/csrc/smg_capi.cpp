@@ -170,14 +170,21 @@ hipError_t Bsr3Buf::upload(const Bsr3Sell& S)
     if ((e = slice_row.upload(S.slice_row)) != hipSuccess) return e;
     if ((e = slice_off.upload(S.slice_off)) != hipSuccess) return e;
     if ((e = slice_w.upload(S.slice_w)) != hipSuccess) return e;
-    if ((e = col.upload(S.col)) != hipSuccess) return e;
-    if ((e = val.upload(S.val)) != hipSuccess) return e;
+    const size_t slots = (size_t)64 * (size_t)(S.slice_off.empty() ? 0 : S.slice_off.back());
+    const bool layout_only = S.col.empty() && slots > 0;       // bsr3_layout(): the panels are filled on the device (launch_bsr3_fill)
+    if (layout_only) {
+        if ((e = col.alloc(slots)) != hipSuccess) return e;
+        if ((e = val.alloc(slots * 9)) != hipSuccess) return e;
+    } else {
+        if ((e = col.upload(S.col)) != hipSuccess) return e;
+        if ((e = val.upload(S.val)) != hipSuccess) return e;
+    }
     if ((e = order.upload(S.region_order)) != hipSuccess) return e;
     view.n_vert = S.n_vert; view.n_slices = S.n_slices; view.w_max = S.w_max;
     view.slice_row = slice_row.p; view.slice_off = slice_off.p; view.slice_w = slice_w.p; view.col = col.p; view.val = val.p;
     view.order = S.region_order.empty() ? nullptr : order.p;
     color_slice_ptr = S.color_slice_ptr;
-    stored = S.nnz_scalar; blocks = S.n_blocks; padded = (long)S.val.size();
+    stored = S.nnz_scalar; blocks = S.n_blocks; padded = (long)(slots * 9);
     return hipSuccess;
 }
 

@@ -127,6 +127,11 @@ hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, 
                        double* partials, int* n_blocks, hipStream_t st, double omega = 1.0, double c1 = 0.0, double* dvec = nullptr);
 hipError_t launch_bsr3_gershgorin(const Bsr3Dev& A, double* out, hipStream_t st);
 int bsr3_blocks(int n_slices);
+// the image B (laid out on the host, Bsr3Buf::upload of a layout; panel_cols = its panel columns) filled on the device from the scalar CSR arrays of A
+// in the caller's numbering, the pattern of its blocks (gptr / gcol) and the vertex numbering (perm new -> old, iperm): B = A(perm3, perm3), or its
+// transpose (A structurally symmetric)
+hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, const int* gptr, const int* gcol, const int* perm, const int* iperm, const Bsr3Dev& B,
+                            size_t panel_cols, bool transposed, hipStream_t st);
 
 // ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------
 struct TiledDev {

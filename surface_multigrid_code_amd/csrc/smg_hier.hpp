@@ -111,6 +111,7 @@ struct Level {
     bool gs_on_transpose = false;  // the reference's GS walks COLUMN i of A (src/mg_VCycle.cpp:149-155)
     bool P_device_filled = false, PT_device_filled = false;   // likewise dP / dPT (P_int / PT_int on demand: ensure_P_int)
     bool device_filled = false;    // dA was filled on the device from A and the permutation: A_int is built on demand (ensure_A_int)
+    Csr vpat;               // block hierarchies: the n_v x n_v pattern of the 3 x 3 blocks of A (caller's vertex numbering; values unused)
     bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----

@@ -75,7 +75,7 @@ struct Early0 {
 static bool device_fill_candidate(const smg_hierarchy* h, int lv)
 {
     static const int on = env_int("SMG_DEVICE_FILL", 1), min_rows = env_int("SMG_DEVICE_FILL_MIN", 200000);
-    return on && h->bs == 1 && lv < h->n_levels - 1 && h->lv[lv].A.nr >= min_rows;
+    return on && lv < h->n_levels - 1 && h->lv[lv].A.nr >= min_rows;       // (block hierarchies too: launch_bsr3_fill)
 }
 static bool device_fill_rows(const smg_hierarchy* h, int n_rows)
 {
@@ -256,13 +256,13 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     // 3 x 3 blocks of A must be at least half full (a system like kron(S, I_3) is three scalar problems: the scalar kernels with
     // k = 3 columns serve it better).
     h->bs = 1;
-    std::vector<Csr> pat(L);      // bs == 3: the n_v x n_v pattern of the blocks of A_l, the graph the numbering is built on
+    for (int lv = 0; lv < L; lv++) h->lv[lv].vpat = Csr();     // bs == 3: the n_v x n_v pattern of the blocks of A_l (Level::vpat), the graph the numbering is built on
     if (h->block_mode != 0 && !h->has_known && L >= 2 && n % 3 == 0) {
         bool ok = true;
         for (int lv = 1; lv < L && ok; lv++) ok = kron3_factor(h->lv[lv].P, h->lv[lv].Pv);
         if (ok) {
-            pat[0] = block_pattern3(h->lv[0].A);
-            const double fill = (double)h->lv[0].A.nnz() / (9.0 * (double)std::max<long>(pat[0].nnz(), 1));
+            h->lv[0].vpat = block_pattern3(h->lv[0].A);
+            const double fill = (double)h->lv[0].A.nnz() / (9.0 * (double)std::max<long>(h->lv[0].vpat.nnz(), 1));
             if (h->block_mode == 3 || fill >= 0.5) h->bs = 3;
         }
         tm.lap("host: block structure (P = Pv (x) I_3, block pattern of A_0)");
@@ -272,7 +272,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                     h->has_known ? "constraints are given" : (n % 3 || L < 2) ? "the system is not a multi-level 3-DOF system" : "a prolongation is not of the form Pv (x) I_3");
     const bool blk = h->bs == 3;
     if (!blk) for (int lv = 0; lv < L; lv++) { h->lv[lv].Pv = Csr(); h->lv[lv].PTv = Csr(); h->lv[lv].vord = Ordering(); }
-    auto graph = [&](int lv) -> const Csr& { return blk ? pat[lv] : h->lv[lv].A; };                 // what a level's numbering is built on
+    if (!blk) h->lv[0].vpat = Csr();
+    auto graph = [&](int lv) -> const Csr& { return blk ? h->lv[lv].vpat : h->lv[lv].A; };                 // what a level's numbering is built on
     auto order_of = [&](int lv) -> Ordering& { return blk ? h->lv[lv].vord : h->lv[lv].ord; };      // ... and where it goes
     auto pattern_key = [&](int lv) {
         const Csr& M = h->lv[lv].A;
@@ -342,7 +343,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     tm.lap("host: Galerkin products");
     if (blk) {
         std::vector<std::function<void()>> tasks;
-        for (int lv = 1; lv < L - 1; lv++) tasks.push_back([&, lv] { pat[lv] = block_pattern3(h->lv[lv].A); });
+        for (int lv = 1; lv < L - 1; lv++) tasks.push_back([&, lv] { h->lv[lv].vpat = block_pattern3(h->lv[lv].A); });
         parallel_tasks(tasks);
         tm.lap("host: block patterns of the Galerkin levels");
     }
@@ -645,6 +646,44 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
     std::vector<std::function<void()>> tasks;
     tasks.push_back([&] {
         DeviceScope ds(h->device);   // worker threads start on device 0
+        if (blk && Lw.device_filled) {
+            // the block image from the scalar arrays in the caller's numbering, the pattern of the blocks and the vertex numbering: layout on the
+            // host (block-row lengths), panels on the device -- and, as for the scalar images, A == A^T decided there and the A^T image too
+            Lw.dA = SellBuf();
+            DeviceCsr D;
+            eA = D.put(Lw.A, lv == 0 && !h->has_known ? &h->early0 : nullptr);
+            int differs = sym0 == 1 ? 0 : -1;
+            DevBuf<int> d_differs, d_gptr, d_gcol, d_perm, d_iperm;
+            if (eA == hipSuccess && differs < 0) {
+                eA = d_differs.alloc(1);
+                if (eA == hipSuccess) eA = launch_bit_symmetric(Lw.A.nr, D.ptr, D.col, D.val, d_differs.p, h->aux[0]);
+                if (eA == hipSuccess) eA = hipMemcpyAsync(&differs, d_differs.p, sizeof(int), hipMemcpyDeviceToHost, h->aux[0]);
+                if (eA == hipSuccess) eA = hipStreamSynchronize(h->aux[0]);
+            }
+            if (eA != hipSuccess) return;
+            if (Lw.A.nr != Lw.A.nc || (differs & 2)) { bad = 1; return; }
+            Lw.A_bit_symmetric = differs == 0;
+            Lw.gs_on_transpose = differs != 0;
+            Lw.bAT = Bsr3Buf(); Lw.dAT = SellBuf();
+            const Csr& G = Lw.vpat;
+            const std::vector<int>& vp = Lw.vord.perm;
+            std::vector<int> row_len(vp.size());
+            parallel_for((long)vp.size(), 1 << 16, [&](long r0, long r1) { for (long r = r0; r < r1; r++) row_len[(size_t)r] = G.ptr[(size_t)vp[(size_t)r] + 1] - G.ptr[(size_t)vp[(size_t)r]]; });
+            if (eA == hipSuccess) eA = d_gptr.upload(G.ptr);
+            if (eA == hipSuccess) eA = d_gcol.upload(G.col);
+            if (eA == hipSuccess) eA = d_perm.upload(vp);
+            if (eA == hipSuccess) eA = d_iperm.upload(Lw.vord.iperm);
+            const Bsr3Sell S = bsr3_layout(row_len, &Lw.vord.color_ptr, region, Lw.A.nnz(), G.nnz());
+            if (eA == hipSuccess) eA = Lw.bA.upload(S);
+            if (eA == hipSuccess) eA = launch_bsr3_fill(D.ptr, D.col, D.val, d_gptr.p, d_gcol.p, d_perm.p, d_iperm.p, Lw.bA.view, (size_t)S.slice_off.back(), false, h->aux[0]);
+            if (eA == hipSuccess && Lw.gs_on_transpose) {
+                const Bsr3Sell ST = bsr3_layout(row_len, &Lw.vord.color_ptr, false, Lw.A.nnz(), G.nnz());
+                eT = Lw.bAT.upload(ST);
+                if (eT == hipSuccess) eT = launch_bsr3_fill(D.ptr, D.col, D.val, d_gptr.p, d_gcol.p, d_perm.p, d_iperm.p, Lw.bAT.view, (size_t)ST.slice_off.back(), true, h->aux[0]);
+            }
+            if (eA == hipSuccess) eA = hipStreamSynchronize(h->aux[0]);
+            return;
+        }
         if (blk) {
             Lw.dA = SellBuf();
             Bsr3Sell S = build_bsr3(Lw.A_int, &Lw.vord.color_ptr, region, false);

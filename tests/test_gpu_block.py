@@ -202,3 +202,18 @@ def test_block_mode_refusals(smg):
     with pytest.raises(smg.SmgError):
         mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=10, precision="mixed"))
     assert mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=60))[0]      # the handle is still usable
+
+
+def test_block_images_filled_on_the_device_pass_the_same_tests():
+    """Levels of at least SMG_DEVICE_FILL_MIN rows (default 200 000: none of the meshes above) get their block images written on the device
+    (launch_bsr3_fill: panels from the scalar arrays in the caller's numbering, the A^T image of a level that is not bit-symmetric as well)
+    instead of built on the host.  With the threshold lowered every level of these tests takes that path, and everything above must hold
+    unchanged -- the kernels bit for bit against the oracle, the value-only re-precompute, the solves."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMG_DEVICE_FILL_MIN="200")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", "not filled_on_the_device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
