@@ -3,6 +3,7 @@
 #include "smg_bsr3.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <utility>
 
 namespace smg {
@@ -40,27 +41,34 @@ bool kron3_factor(const Csr& P, Csr& Pv)
 {
     if (P.nr % 3 || P.nc % 3) return false;
     const int nr = P.nr / 3;
-    for (int r = 0; r < nr; r++) {
-        const int p0 = P.ptr[3 * r], n = P.ptr[3 * r + 1] - p0;
-        for (int d = 0; d < 3; d++) {
-            const int pd = P.ptr[3 * r + d];
-            if (P.ptr[3 * r + d + 1] - pd != n) return false;
-            for (int t = 0; t < n; t++) {
-                if (P.col[pd + t] % 3 != d || P.col[pd + t] / 3 != P.col[p0 + t] / 3) return false;
-                // the three copies must be the same BITS (the device applies one of them to all three components)
-                if (!(P.val[pd + t] == P.val[p0 + t]) && !(P.val[pd + t] != P.val[pd + t] && P.val[p0 + t] != P.val[p0 + t])) return false;
+    std::atomic<int> bad{0};
+    parallel_for(nr, 1 << 15, [&](long r0, long r1) {
+        for (long r = r0; r < r1 && !bad.load(std::memory_order_relaxed); r++) {
+            const int p0 = P.ptr[3 * r], n = P.ptr[3 * r + 1] - p0;
+            for (int d = 0; d < 3; d++) {
+                const int pd = P.ptr[3 * r + d];
+                if (P.ptr[3 * r + d + 1] - pd != n) { bad.store(1, std::memory_order_relaxed); return; }
+                for (int t = 0; t < n; t++) {
+                    if (P.col[pd + t] % 3 != d || P.col[pd + t] / 3 != P.col[p0 + t] / 3) { bad.store(1, std::memory_order_relaxed); return; }
+                    // the three copies must be the same BITS (the device applies one of them to all three components)
+                    if (!(P.val[pd + t] == P.val[p0 + t]) && !(P.val[pd + t] != P.val[pd + t] && P.val[p0 + t] != P.val[p0 + t])) { bad.store(1, std::memory_order_relaxed); return; }
+                }
             }
         }
-    }
+    });
+    if (bad.load()) return false;
     Pv = Csr();
     Pv.nr = nr; Pv.nc = P.nc / 3;
     Pv.ptr.resize((size_t)nr + 1);
-    Pv.col.reserve((size_t)(P.nnz() / 3)); Pv.val.reserve((size_t)(P.nnz() / 3));
     Pv.ptr[0] = 0;
-    for (int r = 0; r < nr; r++) {
-        for (int p = P.ptr[3 * r]; p < P.ptr[3 * r + 1]; p++) { Pv.col.push_back(P.col[p] / 3); Pv.val.push_back(P.val[p]); }
-        Pv.ptr[(size_t)r + 1] = (int)Pv.col.size();
-    }
+    for (int r = 0; r < nr; r++) Pv.ptr[(size_t)r + 1] = Pv.ptr[(size_t)r] + (P.ptr[3 * (size_t)r + 1] - P.ptr[3 * (size_t)r]);
+    Pv.col.resize((size_t)Pv.ptr[(size_t)nr]); Pv.val.resize((size_t)Pv.ptr[(size_t)nr]);
+    parallel_for(nr, 1 << 15, [&](long r0, long r1) {
+        for (long r = r0; r < r1; r++) {
+            int o = Pv.ptr[(size_t)r];
+            for (int p = P.ptr[3 * r]; p < P.ptr[3 * r + 1]; p++, o++) { Pv.col[(size_t)o] = P.col[p] / 3; Pv.val[(size_t)o] = P.val[p]; }
+        }
+    });
     return true;
 }
 
