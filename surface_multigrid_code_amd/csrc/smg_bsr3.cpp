@@ -78,13 +78,17 @@ Csr kron3(const Csr& P)
     B.nr = 3 * P.nr; B.nc = 3 * P.nc;
     B.ptr.resize((size_t)B.nr + 1);
     B.col.resize((size_t)3 * P.nnz()); B.val.resize((size_t)3 * P.nnz());
-    int q = 0;
-    for (int r = 0; r < P.nr; r++)
-        for (int d = 0; d < 3; d++) {   // row 3r+d holds P(r,c) at column 3c+d  (reference src/get_prolong.cpp:108-110)
-            B.ptr[(size_t)3 * r + d] = q;
-            for (int p = P.ptr[r]; p < P.ptr[r + 1]; p++) { B.col[q] = 3 * P.col[p] + d; B.val[q] = P.val[p]; q++; }
+    parallel_for(P.nr, 1 << 15, [&](long r0, long r1) {
+        for (long r = r0; r < r1; r++) {
+            const int len = P.ptr[r + 1] - P.ptr[r];
+            for (int d = 0; d < 3; d++) {   // row 3r+d holds P(r,c) at column 3c+d  (reference src/get_prolong.cpp:108-110)
+                int q = 3 * P.ptr[r] + d * len;
+                B.ptr[(size_t)3 * r + d] = q;
+                for (int p = P.ptr[r]; p < P.ptr[r + 1]; p++, q++) { B.col[(size_t)q] = 3 * P.col[p] + d; B.val[(size_t)q] = P.val[p]; }
+            }
         }
-    B.ptr[(size_t)B.nr] = q;
+    });
+    B.ptr[(size_t)B.nr] = (int)(3 * P.nnz());
     return B;
 }
 

@@ -303,8 +303,9 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     {
         std::vector<std::function<void()>> tasks;
         for (int lv = 1; lv < L; lv++) {
-            tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });      // :226
-            if (blk) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); });
+            // (block hierarchies: P = Pv (x) I_3, so PT = PTv (x) I_3 -- the same entries in the same order as the transposition of three times as many)
+            if (blk) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); h->lv[lv].PT = kron3(h->lv[lv].PTv); });
+            else tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });      // :226
         }
         parallel_tasks(tasks);
     }
