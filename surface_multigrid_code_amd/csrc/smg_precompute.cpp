@@ -44,13 +44,38 @@ static bool bit_symmetric(const Csr& A)
     });
     return any.load() == 0;
 }
-// key of a level's numbering: FNV-1a over (rows, smoothed?, block size, ptr, col)
+// FNV-1a over an int array, hashed in fixed blocks of 64 Ki entries -- the blocks concurrently on the host threads, the block hashes chained in
+// order: the value does not depend on the number of threads (a time step's re-precompute hashes the 8 M pattern entries of a 1 M-vertex mesh
+// before anything else: 6.5 ms as one sequential chain; the 63 M of the block benchmark: 54 ms)
+static uint64_t fnv_mix(uint64_t key, const int* p, size_t cnt)
+{
+    constexpr size_t B = 65536;
+    const size_t nblk = (cnt + B - 1) / B;
+    if (nblk <= 1) {
+        for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; }
+        return key;
+    }
+    std::vector<uint64_t> part(nblk);
+    parallel_for((long)nblk, 4, [&](long b0, long b1) {
+        for (long b = b0; b < b1; b++) {
+            uint64_t k = 1469598103934665603ull;
+            const size_t e = std::min(cnt, (size_t)(b + 1) * B);
+            for (size_t i = (size_t)b * B; i < e; i++) { k ^= (uint32_t)p[i]; k *= 1099511628211ull; }
+            part[b] = k;
+        }
+    });
+    for (size_t b = 0; b < nblk; b++) { key ^= part[b]; key *= 1099511628211ull; }
+    return key;
+}
+
+// key of a level's numbering: (rows, smoothed?, block size, ptr, col)
 static uint64_t pattern_key_arrays(int nr, bool smoothed, int bs, const int* ptr, const int* col)
 {
     uint64_t key = 1469598103934665603ull;
-    auto mix = [&](const int* p, size_t cnt) { for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; } };
     const int hdr[3] = {nr, smoothed ? 1 : 0, bs};
-    mix(hdr, 3); mix(ptr, (size_t)nr + 1); mix(col, (size_t)ptr[nr]);
+    key = fnv_mix(key, hdr, 3);
+    key = fnv_mix(key, ptr, (size_t)nr + 1);
+    key = fnv_mix(key, col, (size_t)ptr[nr]);
     return key;
 }
 // Work on level 0 that needs nothing but the caller's arrays, started by smg_precompute before anything else when they ARE level 0's
@@ -290,6 +315,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     uint64_t key0 = 0;
     if (L >= 3 && use_rcm && host_threads() > 1) {
         key0 = pattern_key(0);
+        tm.lap("host:   pattern hash of level 0");
         const Level& L0 = h->lv[0];
         if (!e0.rcm_started && !(key0 == L0.ord_key && (int)L0.ord.perm.size() == L0.A.nr)) {
             e0.rcm_started = true;
@@ -304,7 +330,14 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         std::vector<std::function<void()>> tasks;
         for (int lv = 1; lv < L; lv++) {
             // (block hierarchies: P = Pv (x) I_3, so PT = PTv (x) I_3 -- the same entries in the same order as the transposition of three times as many)
-            if (blk) tasks.push_back([h, lv] { h->lv[lv].PTv = transpose(h->lv[lv].Pv); h->lv[lv].PT = kron3(h->lv[lv].PTv); });
+            if (blk) tasks.push_back([h, lv, &tm] {
+                const auto t0 = std::chrono::steady_clock::now();
+                h->lv[lv].PTv = transpose(h->lv[lv].Pv);
+                const auto t1 = std::chrono::steady_clock::now();
+                h->lv[lv].PT = kron3(h->lv[lv].PTv);
+                if (tm.on) std::fprintf(stderr, "[smg timing] host:   (level %d: PTv %.1f ms, PT = PTv (x) I_3 %.1f ms)\n", lv, 1e3 * std::chrono::duration<double>(t1 - t0).count(),
+                                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+            });
             else tasks.push_back([h, lv] { h->lv[lv].PT = transpose(h->lv[lv].P); });      // :226
         }
         parallel_tasks(tasks);
@@ -832,30 +865,6 @@ static int finish_images(smg_hierarchy* h)
 // sliced P, Galerkin patterns, colouring, SELL layout, graphs) is unchanged and the numeric work moves to the GPU:
 // slice gathers, two fixed-recipe SpGEMM stages per level (bit-identical to the host spgemm), SELL value refresh and
 // the dense coarse inverse.
-
-static uint64_t fnv_mix(uint64_t key, const int* p, size_t cnt)
-{
-    // hashed in fixed blocks of 64 Ki entries, the blocks concurrently on the host threads, the block hashes chained in order:
-    // the value does not depend on the number of threads (a time step's re-precompute hashes the 8 M pattern entries of a
-    // 1 M-vertex mesh before anything else: 6.5 ms as one sequential chain)
-    constexpr size_t B = 65536;
-    const size_t nblk = (cnt + B - 1) / B;
-    if (nblk <= 1) {
-        for (size_t i = 0; i < cnt; i++) { key ^= (uint32_t)p[i]; key *= 1099511628211ull; }
-        return key;
-    }
-    std::vector<uint64_t> part(nblk);
-    parallel_for((long)nblk, 4, [&](long b0, long b1) {
-        for (long b = b0; b < b1; b++) {
-            uint64_t k = 1469598103934665603ull;
-            const size_t e = std::min(cnt, (size_t)(b + 1) * B);
-            for (size_t i = (size_t)b * B; i < e; i++) { k ^= (uint32_t)p[i]; k *= 1099511628211ull; }
-            part[b] = k;
-        }
-    });
-    for (size_t b = 0; b < nblk; b++) { key ^= part[b]; key *= 1099511628211ull; }
-    return key;
-}
 
 static uint64_t precompute_key(const smg_hierarchy* h, int n, const int* rowptr, const int* col, const int* known, int n_known)
 {
