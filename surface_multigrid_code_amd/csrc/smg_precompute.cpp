@@ -394,9 +394,15 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         h->lv[lv].A_diag = diagonal(h->lv[lv].A);
         h->lv[lv].n = h->lv[lv].A.nr;
         // relax() divides by A_diag (src/mg_VCycle.cpp:157): a missing or zero diagonal would give Inf/NaN there
-        if (lv < L - 1)
-            for (int i = 0; i < h->lv[lv].n; i++)
-                if (h->lv[lv].A_diag[i] == 0.0) return fail(SMG_ERR_INVALID, "level %d: zero or missing diagonal at row %d", lv, i);
+        if (lv < L - 1) {
+            std::atomic<int> first_bad{h->lv[lv].n};
+            const std::vector<double>& dg = h->lv[lv].A_diag;
+            parallel_for(h->lv[lv].n, 1 << 16, [&](long a, long b) {
+                for (long i = a; i < b; i++)
+                    if (dg[(size_t)i] == 0.0) { int cur = first_bad.load(); while ((int)i < cur && !first_bad.compare_exchange_weak(cur, (int)i)) {} break; }
+            });
+            if (first_bad.load() < h->lv[lv].n) return fail(SMG_ERR_INVALID, "level %d: zero or missing diagonal at row %d", lv, first_bad.load());
+        }
     }
     tm.lap("host: shift, diagonals");
     hand.post_coarse();
