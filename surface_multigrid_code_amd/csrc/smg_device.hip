@@ -1398,6 +1398,137 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double* M, int n)
     }
 }
 
+// The same update with the operands shared: a workgroup owns a 2 x 2 block of tiles (the lower triangle of it on the diagonal).  A tile costs
+// three 32 KB loads as its own workgroup -- its old values, 64 rows of the column panel, a 64-column slab of the row panel -- and at 4.6 - 4.7 TB/s
+// of such loads the update is bound by re-reading the panels, not by the matrix cores (a third busy).  Here the 128-column slab is staged in LDS once
+// for the block and a tile row's column-panel operand is loaded once for its two tiles: 64 KB per tile instead of 96.
+// Workgroup 0 (while a next pivot block exists) is the look-ahead: it updates that block alone and inverts it, as in k_gj_update.
+constexpr int GJ_P2 = 2 * GJ_NB + 1;      // pitch of the 128-column slab
+__global__ __launch_bounds__(256) void k_gj_update2(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp,
+                                                     double* dinv_next)
+{
+    __shared__ double lds[GJ_NB * GJ_P2];
+    const int K = kb * GJ_NB;
+    const int nb = n / 64, nxt = kb + 1;
+    const bool have_la = nxt < nb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 4, lc = lane & 15;
+    if (have_la && blockIdx.x == 0) {
+        // ---- look-ahead: tile (nxt, nxt), then its inverse (a | Rb | Cb carved out of the slab's space)
+        double (*a)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(lds);
+        double (*Rb)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(lds + GJ_NB * (GJ_NB + 1));
+        double (*Cb)[17] = reinterpret_cast<double (*)[17]>(lds + GJ_NB * (GJ_NB + 1) + 16 * (GJ_NB + 1));
+        const int i0 = nxt * 64, j0 = nxt * 64;
+        double* mp = M + (size_t)(i0 + 16 * wave + lr) * n + j0 + lc;
+        v4f64 old[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) old[c][r] = mp[(size_t)(4 * r) * n + 16 * c];
+        double av[GJ_NB / 4];
+        const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
+#pragma unroll
+        for (int s = 0; s < GJ_NB / 4; s++) av[s] = ap[4 * s];
+        {
+            double br[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) { const int x = threadIdx.x + 256 * e; br[e] = rowp[(size_t)(x >> 6) * n + j0 + (x & 63)]; }
+#pragma unroll
+            for (int e = 0; e < 16; e++) { const int x = threadIdx.x + 256 * e; a[x >> 6][x & 63] = br[e]; }
+        }
+        __syncthreads();
+        v4f64 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < GJ_NB / 4; s++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], a[4 * s + lr][16 * c + lc], acc[c], 0, 0, 0);
+        }
+        __syncthreads();   // every wave is done with the slab before the results overwrite it
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double v = old[c][r] - acc[c][r];
+                mp[(size_t)(4 * r) * n + 16 * c] = v;
+                a[16 * wave + lr + 4 * r][16 * c + lc] = v;
+            }
+        __syncthreads();
+        gj_invert64(a, Rb, Cb);
+        for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 256) dinv_next[e] = a[e / GJ_NB][e % GJ_NB];
+        return;
+    }
+    // ---- a 2 x 2 block of tiles: (BY, BX), BX <= BY, enumerated row by row
+    const int idx = (int)blockIdx.x - (have_la ? 1 : 0);
+    int BY = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    BY -= (BY * (BY + 1) / 2 > idx);
+    BY += ((BY + 1) * (BY + 2) / 2 <= idx);
+    const int BX = idx - BY * (BY + 1) / 2;
+    const int jb = 2 * BX * 64;                                  // first column of the block
+    const int ncolt = min(2, nb - 2 * BX);                       // tile columns that exist
+    // the row panel's slab for the block's columns: once, through LDS
+    {
+        double br[32];
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            const int x = threadIdx.x + 256 * e, r = x >> 7, c = x & 127;
+            br[e] = c < 64 * ncolt ? rowp[(size_t)r * n + jb + c] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 32; e++) { const int x = threadIdx.x + 256 * e; lds[(x >> 7) * GJ_P2 + (x & 127)] = br[e]; }
+    }
+    __syncthreads();
+    for (int ti = 0; ti < 2; ti++) {
+        const int by = 2 * BY + ti;
+        if (by >= nb) break;
+        const int i0 = by * 64;
+        if (by == kb) {   // the pivot rows take the scaled row panel
+            for (int tj = 0; tj < ncolt; tj++) {
+                const int bx = 2 * BX + tj;
+                if (bx > by) break;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int i = i0 + 16 * wave + lr + 4 * r, j = bx * 64 + 16 * c + lc;
+                        M[(size_t)i * n + j] = rowp[(size_t)(i - K) * n + j];
+                    }
+            }
+            continue;
+        }
+        // this wave's 16 rows of the column panel: once for the tile row
+        double av[GJ_NB / 4];
+        const double* ap = colp + (size_t)(i0 + 16 * wave + lc) * GJ_NB + lr;
+#pragma unroll
+        for (int s = 0; s < GJ_NB / 4; s++) av[s] = ap[4 * s];
+        for (int tj = 0; tj < ncolt; tj++) {
+            const int bx = 2 * BX + tj;
+            if (bx > by) break;
+            if (have_la && by == nxt && bx == nxt) continue;      // the look-ahead workgroup's tile
+            const bool jpiv = bx == kb;
+            double* mp = M + (size_t)(i0 + 16 * wave + lr) * n + bx * 64 + lc;
+            v4f64 old[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) old[c][r] = jpiv ? 0.0 : mp[(size_t)(4 * r) * n + 16 * c];
+            v4f64 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < GJ_NB / 4; s++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], lds[(4 * s + lr) * GJ_P2 + 64 * tj + 16 * c + lc], acc[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mp[(size_t)(4 * r) * n + 16 * c] = old[c][r] - acc[c][r];
+        }
+    }
+}
+
 hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
@@ -1409,7 +1540,12 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
     hipLaunchKernelGGL(k_gj_diag, dim3(1), dim3(256), 0, st, M, n, 0, dinv[0]);   // only the first pivot block; the others: look-ahead
     for (int kb = 0; kb < nt; kb++) {
         hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv[kb & 1], rowp, colp);
-        hipLaunchKernelGGL(k_gj_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
+        static const int blocks2 = getenv("SMG_GJ_2X2") ? atoi(getenv("SMG_GJ_2X2")) : 1;     // A/B knob: 2 x 2 tiles per workgroup
+        if (blocks2) {
+            const int nt2 = (nt + 1) / 2;
+            hipLaunchKernelGGL(k_gj_update2, dim3(nt2 * (nt2 + 1) / 2 + (kb + 1 < nt ? 1 : 0)), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
+        } else
+            hipLaunchKernelGGL(k_gj_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
     }
     if (nt > 1) hipLaunchKernelGGL(k_mirror_lower, dim3(nt * (nt - 1) / 2), dim3(256), 0, st, M, n);
     return hipGetLastError();
