@@ -1398,12 +1398,21 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double* M, int n)
     }
 }
 
-// The same update with the operands shared: a workgroup owns a 2 x 2 block of tiles (the lower triangle of it on the diagonal).  A tile costs
+// The same update with the operands shared: a workgroup owns a block of GJ_R x 2 tiles (what of it lies in the lower triangle).  A tile costs
 // three 32 KB loads as its own workgroup -- its old values, 64 rows of the column panel, a 64-column slab of the row panel -- and at 4.6 - 4.7 TB/s
 // of such loads the update is bound by re-reading the panels, not by the matrix cores (a third busy).  Here the 128-column slab is staged in LDS once
 // for the block and a tile row's column-panel operand is loaded once for its two tiles: 64 KB per tile instead of 96.
 // Workgroup 0 (while a next pivot block exists) is the look-ahead: it updates that block alone and inverts it, as in k_gj_update.
 constexpr int GJ_P2 = 2 * GJ_NB + 1;      // pitch of the 128-column slab
+// GJ_R tile rows x 2 tile columns per workgroup: 2 for matrices of a few thousand rows (4: too few workgroups there, 3.2 -> 3.6 ms at 3 952), 4 from
+// 8 192 rows on (55.4 -> 53.7 ms at 11 856)
+static int gj_update2_blocks(int nt, int R)
+{
+    int w = 0;
+    for (int BY = 0; R * BY < nt; BY++) { const int last = R * BY + R - 1 < nt - 1 ? R * BY + R - 1 : nt - 1; w += last / 2 + 1; }
+    return w;
+}
+template <int GJ_R>
 __global__ __launch_bounds__(256) void k_gj_update2(double* M, int n, int kb, const double* __restrict__ rowp, const double* __restrict__ colp,
                                                      double* dinv_next)
 {
@@ -1459,12 +1468,10 @@ __global__ __launch_bounds__(256) void k_gj_update2(double* M, int n, int kb, co
         for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 256) dinv_next[e] = a[e / GJ_NB][e % GJ_NB];
         return;
     }
-    // ---- a 2 x 2 block of tiles: (BY, BX), BX <= BY, enumerated row by row
+    // ---- a block of GJ_R x 2 tiles: block row BY holds the block columns BX with 2 BX <= GJ_R BY + GJ_R - 1, enumerated row by row
     const int idx = (int)blockIdx.x - (have_la ? 1 : 0);
-    int BY = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    BY -= (BY * (BY + 1) / 2 > idx);
-    BY += ((BY + 1) * (BY + 2) / 2 <= idx);
-    const int BX = idx - BY * (BY + 1) / 2;
+    int BY = 0, BX = idx;
+    for (;; BY++) { const int cols = (GJ_R * BY + GJ_R - 1) / 2 + 1; if (BX < cols) break; BX -= cols; }      // (<= 64 rounds)
     const int jb = 2 * BX * 64;                                  // first column of the block
     const int ncolt = min(2, nb - 2 * BX);                       // tile columns that exist
     // the row panel's slab for the block's columns: once, through LDS
@@ -1479,8 +1486,8 @@ __global__ __launch_bounds__(256) void k_gj_update2(double* M, int n, int kb, co
         for (int e = 0; e < 32; e++) { const int x = threadIdx.x + 256 * e; lds[(x >> 7) * GJ_P2 + (x & 127)] = br[e]; }
     }
     __syncthreads();
-    for (int ti = 0; ti < 2; ti++) {
-        const int by = 2 * BY + ti;
+    for (int ti = 0; ti < GJ_R; ti++) {
+        const int by = GJ_R * BY + ti;
         if (by >= nb) break;
         const int i0 = by * 64;
         if (by == kb) {   // the pivot rows take the scaled row panel
@@ -1542,8 +1549,8 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
         hipLaunchKernelGGL(k_gj_panels, dim3(n / GJ_H), dim3(256), 0, st, M, n, kb, dinv[kb & 1], rowp, colp);
         static const int blocks2 = getenv("SMG_GJ_2X2") ? atoi(getenv("SMG_GJ_2X2")) : 1;     // A/B knob: 2 x 2 tiles per workgroup
         if (blocks2) {
-            const int nt2 = (nt + 1) / 2;
-            hipLaunchKernelGGL(k_gj_update2, dim3(nt2 * (nt2 + 1) / 2 + (kb + 1 < nt ? 1 : 0)), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
+            if (nt >= 128) hipLaunchKernelGGL(k_gj_update2<4>, dim3(gj_update2_blocks(nt, 4) + (kb + 1 < nt ? 1 : 0)), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
+            else hipLaunchKernelGGL(k_gj_update2<2>, dim3(gj_update2_blocks(nt, 2) + (kb + 1 < nt ? 1 : 0)), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
         } else
             hipLaunchKernelGGL(k_gj_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, M, n, kb, rowp, colp, dinv[(kb + 1) & 1]);
     }

@@ -85,3 +85,32 @@ def test_one_and_two_level_calls_on_a_15k_mesh(smg, oracle_mod):
     assert r_dense[0] and r_sparse[0] and len(r_dense[2]) == len(r_sparse[2])
     assert np.linalg.norm(r_dense[1] - r_sparse[1]) <= 1e-9 * np.linalg.norm(r_dense[1])
     assert np.linalg.norm(r_sparse[1] - xref) <= 1e-7 * np.linalg.norm(xref)
+
+
+def test_dense_inverse_of_a_coarsest_level_beyond_8192_unknowns(smg, oracle_mod):
+    """The dense range reaches 16 384 unknowns; from 8 192 on the Gauss-Jordan update runs with 4 x 2 tiles per workgroup (k_gj_update2<4>,
+    2 x 2 below).  A 1-level call on a torus of 10 000 vertices -- the direct solve IS the inverse applied to the right-hand side -- against the
+    oracle's LDL^T (and scipy), one and three columns; then a value-only re-precompute (the device inverts again) with scaled values."""
+    import scipy.sparse.linalg as sla
+    V, F = M.torus(100, 100)
+    V = M.normalize_unit_area(V, F)
+    n = V.shape[0]
+    A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+    rng = np.random.default_rng(17)
+    mg = smg.Hierarchy(1)
+    mg.precompute(A)
+    cs = mg.coarse_solver()
+    assert cs["kind"] == "dense_inverse" and n >= 8192
+    for k in (1, 3):
+        rhs, z0 = rng.uniform(-1, 1, (n, k)), np.zeros((n, k))
+        a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=5))
+        o1 = oracle_mod.OracleMG([]); o1.precompute(A)
+        b = o1.solve(rhs, z0, tol=1e-9, max_iter=5)
+        assert a[0] and len(a[2]) == len(b[2]) == 2
+        assert np.linalg.norm(a[1] - b[1]) <= 1e-10 * np.linalg.norm(b[1])
+        assert np.linalg.norm(a[1] - sla.spsolve(A.tocsc(), rhs).reshape(n, k)) <= 1e-6 * np.linalg.norm(b[1])
+    A2 = A.copy(); A2.data = A.data * 1.25
+    mg.precompute(A2)                                  # same pattern: the value-only path, inverse recomputed on the device
+    rhs, z0 = rng.uniform(-1, 1, (n, 1)), np.zeros((n, 1))
+    a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=5))
+    assert a[0] and np.linalg.norm(A2 @ a[1] - rhs) <= 1e-9 * np.linalg.norm(rhs)
