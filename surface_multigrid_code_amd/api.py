@@ -286,6 +286,24 @@ class Hierarchy:
         """rows of level lv's first colour the restriction launch of level lv - 1 can update itself (0: not available)"""
         return self.L.smg_level_first_colour_rows(self.h, lv)
 
+    # ---- block-sequential Gauss-Seidel for solves with a multiple of 64 columns
+    def set_block_gs(self, min_rows):
+        """levels of at least min_rows rows sweep block-sequentially when k % 64 == 0 (< 0: never)"""
+        _chk(self.L.smg_hierarchy_set_block_gs(self.h, int(min_rows)), "smg_hierarchy_set_block_gs")
+
+    def block_gs_order(self, lv, k):
+        """None when level lv does not sweep block-sequentially for k columns, else a dict: rows (position -> internal row), blk_ptr,
+        color_ptr, rim, ring_hits"""
+        nb, nc = C.c_int(), C.c_int()
+        rc = self.L.smg_level_get_block_gs_order(self.h, lv, int(k), C.byref(nb), C.byref(nc), None, None, None, None)
+        if rc < 0:
+            _chk(rc, "smg_level_get_block_gs_order")
+        if rc == 0:
+            return None
+        cp, bp, rows, st = np.zeros(nc.value + 1, np.int32), np.zeros(nb.value + 1, np.int32), np.zeros(self.rows(lv), np.int32), np.zeros(2)
+        _chk(min(self.L.smg_level_get_block_gs_order(self.h, lv, int(k), None, None, _ip(cp), _ip(bp), _ip(rows), _dp(st)), 0), "smg_level_get_block_gs_order")
+        return {"rows": rows, "blk_ptr": bp, "color_ptr": cp, "rim": st[0], "ring_hits": st[1]}
+
     # ---- coarsest-level solver
     def set_coarse_dense_max(self, n_max):
         """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""

@@ -95,16 +95,67 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
 }
 int smg::refresh_tiled_values(smg_hierarchy* h)
 {
-    for (int lv = 0; lv < h->n_levels - 1; lv++)
+    for (int lv = 0; lv < h->n_levels - 1; lv++) {
         for (int s = 1; s <= 3; s++) {
             TiledBuf& B = h->lv[lv].tiled[s];
             if (B.view.n_tiles > 0) HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
         }
+        BgsBuf& Q = h->lv[lv].bgs;
+        if (Q.view.n_blocks > 0) HIPCHK(launch_gather_vals(Q.eval.p, h->lv[lv].d_Aval.p, Q.map.p, Q.eval.n, h->stream));
+    }
     return SMG_OK;
 }
 void smg::drop_tiled(smg_hierarchy* h)
 {
-    for (auto& Lv : h->lv) for (auto& B : Lv.tiled) B = TiledBuf();
+    for (auto& Lv : h->lv) { for (auto& B : Lv.tiled) B = TiledBuf(); Lv.bgs = BgsBuf(); }
+}
+
+// ---- block-sequential Gauss-Seidel for solves with a multiple of 64 columns (smg_bgs.hpp): one launch per BLOCK colour -----------------
+// Which levels: scalar fp64 hierarchies, Gauss-Seidel, k % 64 == 0, at least bgs_min_rows rows (smg_hierarchy_set_block_gs; default
+// 100 000, SMG_BGS_MIN_ROWS; SMG_BGS=0 switches it off).  Below, a sweep is a few launches of a few microseconds: nothing to win.
+static bool bgs_wanted(const smg_hierarchy* h, int lv, int k)
+{
+    static const int on = env_int("SMG_BGS", 1);
+    if (!on || h->bs != 1 || h->precision != 0 || k < 64 || k % 64 != 0 || lv < 0 || lv >= h->n_levels - 1 || h->bgs_min_rows < 0) return false;
+    if (level_kind(h, lv) != LV_GS) return false;
+    return h->lv[lv].n >= h->bgs_min_rows;
+}
+static const BgsBuf* bgs_plan(const smg_hierarchy* h, int lv, int k)
+{
+    if (!bgs_wanted(h, lv, k)) return nullptr;
+    const BgsBuf& B = h->lv[lv].bgs;
+    return B.view.n_blocks > 0 ? &B : nullptr;
+}
+static int ensure_bgs(smg_hierarchy* h, int lv)
+{
+    Level& Lv = h->lv[lv];
+    BgsBuf& B = Lv.bgs;
+    if (B.tried) return SMG_OK;
+    B.tried = true;
+    static const int rows_env = env_int("SMG_BGS_ROWS", 64);
+    std::vector<int> tsrc;
+    Csr AT;
+    { int rc = ensure_A_int(h, lv); if (rc) return rc; }
+    if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
+    const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
+    BgsPlan P = build_bgs(G, std::max(rows_env, 8));
+    if (P.empty()) return SMG_OK;
+    std::vector<int> map(P.eentry.size());
+    for (size_t i = 0; i < map.size(); i++) {
+        const int e = P.eentry[i];
+        map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
+    }
+    HIPCHK(B.blk_ptr.upload(P.blk_ptr)); HIPCHK(B.rows.upload(P.rows)); HIPCHK(B.row_bat.upload(P.row_bat)); HIPCHK(B.ecol.upload(P.ecol));
+    HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map));
+    B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors;
+    B.view.blk_ptr = B.blk_ptr.p; B.view.rows = B.rows.p; B.view.row_bat = B.row_bat.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
+    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.rim = P.rim; B.ring_hits = P.ring_hits;
+    // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
+    if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
+    if (env_int("SMG_DEBUG_BGS", 0))
+        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, rim %.3f rows gathered per row beyond the iterate, %.1f %% of the in-block earlier neighbours from the ring\n",
+                     lv, Lv.n, P.n_blocks, P.n_colors, P.rim, 100.0 * P.ring_hits);
+    return SMG_OK;
 }
 
 // plans + second iterate for relax(sa) / relax(sb) wherever they are wanted (host work and uploads: never inside a graph capture)
@@ -113,6 +164,7 @@ static int prepare_tiled(smg_hierarchy* h, int k, int sa, int sb)
     for (int lv = 0; lv < h->n_levels - 1; lv++) {
         Level& Lv = h->lv[lv];
         for (int sw : {sa, sb}) if (tiled_wanted(h, lv, k, sw)) { int rc = ensure_tiled(h, lv, sw); if (rc) return rc; }
+        if (bgs_wanted(h, lv, k) && !Lv.bgs.tried) { drop_graphs(h); int rc = ensure_bgs(h, lv); if (rc) return rc; }
         if ((tiled_plan(h, lv, k, sa) || tiled_plan(h, lv, k, sb)) && Lv.t.n < (size_t)Lv.n * std::max(h->kcap, 1)) {
             drop_graphs(h);
             HIPCHK(Lv.t.alloc((size_t)Lv.n * std::max(h->kcap, 1)));
@@ -352,6 +404,14 @@ static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int ite
 {
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
+    if (std::is_same<T, double>::value && first == FIRST_NONE) {
+        if (const BgsBuf* Q = bgs_plan(h, lv, k)) {      // many columns: one launch per block colour (smg_bgs.hpp)
+            for (int it = 0; it < iters; it++)
+                for (size_t c = 0; c + 1 < Q->color_ptr.size(); c++)
+                    HIPCHK(launch_bgs(Q->view, Q->color_ptr[c], Q->color_ptr[c + 1], (const double*)b, (double*)u, k, ctrl, h->stream));
+            return SMG_OK;
+        }
+    }
     const std::vector<int>& cs = colour_slices(h, Lv);
     for (int it = first == FIRST_SWEEP ? 1 : 0; it < iters; it++)
         for (size_t c = (it == 0 && first == FIRST_LAUNCH) ? 1 : 0; c + 1 < cs.size(); c++) {
@@ -461,7 +521,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     const bool jac_c = kind_c != LV_GS;
     // (block hierarchies: the first launch of a coarse sweep is not a plain division -- row 3v+1 of the first colour already reads 3v)
     const bool tiled_c = level_kind(h, lv + 1) == LV_GS && pre > 0 && tiled_for<T>(h, Lc, lv + 1, k, pre) != nullptr;   // the coarse level runs all its phases itself
-    const bool fuse = h->bs == 1 && !tiled_c && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    const bool fuse = h->bs == 1 && !tiled_c && !(std::is_same<T, double>::value && bgs_plan(h, lv + 1, k)) && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
     const int kt = k * h->bs;   // block hierarchies: dP / dPT hold the vertex-level factor of P (x) I_3, applied to 3 k columns
     {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
@@ -540,12 +600,13 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
 // second accumulator that repeats SELL_RESID_SS's additions (SELL_*_HEAD in smg_device.hpp) -- and the cycle starts with FIRST_SWEEP.
 // fp64 cycles only (the mixed mode's residual IS the right-hand side of its fp32 cycle); Gauss-Seidel needs a second sweep to come back
 // into u; a level 0 that smooths on A^T (non-symmetric storage) forms other sums than the residual.
-static bool head_fusable(smg_hierarchy* h)
+static bool head_fusable(smg_hierarchy* h, int k)
 {
     static const int on = env_int("SMG_FUSE_HEAD", 1);
     if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on || h->bs != 1) return false;
     Level& L0 = h->lv[0];
     if (L0.gs_on_transpose) return false;
+    if (bgs_plan(h, 0, k)) return false;   // block-sequential sweeps run in place; their head is the residual launch
     const int kind = level_kind(h, 0);
     return kind == LV_GS ? h->pre >= 2 : h->pre >= 1;
 }
@@ -773,7 +834,7 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     if (memspace == SMG_HOST) HIPCHK(hipStreamSynchronize(h->stream));  // the caller's host blocks may change after this call
-    h->head_fuse = head_fusable(h);   // latched: both halves of every iteration of this solve follow it
+    h->head_fuse = head_fusable(h, k);   // latched: both halves of every iteration of this solve follow it
     h->iters_enqueued = 0;
     h->in_solve = true;
     return SMG_OK;
@@ -1066,6 +1127,31 @@ extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int po
     *us_per_cycle = 1e3 * ms / reps;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(g);
     return SMG_OK;
+}
+
+extern "C" int smg_hierarchy_set_block_gs(smg_hierarchy* h, int min_rows)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_block_gs: null handle");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_block_gs called during a split-phase solve");
+    if (min_rows != h->bgs_min_rows) { h->bgs_min_rows = min_rows; if (h->stream) drop_graphs(h); }
+    return SMG_OK;
+}
+extern "C" int smg_level_get_block_gs_order(smg_hierarchy* h, int lv, int k, int* n_blocks, int* n_colors, int* color_ptr, int* blk_ptr, int* rows, double* stats)
+{
+    int rc = check_ready(h, "smg_level_get_block_gs_order");
+    if (rc) return rc;
+    if (lv < 0 || lv >= h->n_levels || k < 1) return fail(SMG_ERR_INVALID, "smg_level_get_block_gs_order: bad level / k");
+    if (!bgs_wanted(h, lv, k)) return 0;
+    if (!h->lv[lv].bgs.tried) { drop_graphs(h); if ((rc = ensure_bgs(h, lv))) return rc; }
+    const BgsBuf* Q = bgs_plan(h, lv, k);
+    if (!Q) return 0;
+    if (n_blocks) *n_blocks = Q->view.n_blocks;
+    if (n_colors) *n_colors = Q->view.n_colors;
+    if (color_ptr) std::copy(Q->color_ptr.begin(), Q->color_ptr.end(), color_ptr);
+    if (blk_ptr) HIPCHK(hipMemcpy(blk_ptr, Q->blk_ptr.p, ((size_t)Q->view.n_blocks + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (rows) std::copy(Q->host_rows.begin(), Q->host_rows.end(), rows);
+    if (stats) { stats[0] = Q->rim; stats[1] = Q->ring_hits; }
+    return 1;
 }
 
 extern "C" int smg_bench_relax(smg_hierarchy* h, int lv, int k, int sweeps, int reps, double* us_per_call)

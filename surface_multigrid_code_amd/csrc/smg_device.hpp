@@ -133,6 +133,18 @@ int bsr3_blocks(int n_slices);
 hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, const int* gptr, const int* gcol, const int* perm, const int* iperm, const Bsr3Dev& B,
                             size_t panel_cols, bool transposed, hipStream_t st);
 
+// ---- Gauss-Seidel sweep for blocks of 64 right-hand-side columns: block-sequential order (smg_bgs.hpp plan, smg_bgs_device.hip kernel) ----
+struct BgsDev {
+    int n_blocks = 0, n_colors = 0;
+    const int* blk_ptr = nullptr;     // n_blocks + 1 positions
+    const int* rows = nullptr;        // position -> row
+    const int* row_bat = nullptr;     // position -> first batch (n + 1)
+    const int* ecol = nullptr;        // batches x 8 entry codes
+    const double* eval = nullptr;
+};
+// the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 64)
+hipError_t launch_bgs(const BgsDev& P, int b_begin, int b_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+
 // ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------
 struct TiledDev {
     int n_tiles = 0, nc = 0, P = 0, sweeps = 0, max_ext = 0, w_max = 0, threads = 512;

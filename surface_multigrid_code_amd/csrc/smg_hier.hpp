@@ -16,6 +16,7 @@
 #include "smg_order.hpp"
 #include "smg_sparse.hpp"
 #include "smg_tiled.hpp"
+#include "smg_bgs.hpp"
 
 namespace smg {
 
@@ -48,6 +49,15 @@ struct DevBuf {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    // upload that keeps the allocation (and with it every pointer captured in a hipGraph) when the size is unchanged; *moved is set
+    // when the buffer had to be reallocated -- the caller then owes a drop_graphs()
+    template <class Alloc>
+    hipError_t upload_in_place(const std::vector<T, Alloc>& v, bool* moved)
+    {
+        if (p && v.size() == n) return v.empty() ? hipSuccess : hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        *moved = true;
+        return upload(v);
     }
 };
 
@@ -85,6 +95,16 @@ struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
     bool tried = false;      // a plan was attempted for this (level, sweeps): empty view = the level does not qualify
 };
 
+struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a level (smg_bgs.hpp)
+    DevBuf<int> blk_ptr, rows, row_bat, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
+    DevBuf<double> eval;
+    BgsDev view;
+    std::vector<int> color_ptr;      // blocks of colour c
+    std::vector<int> host_rows;      // the bgs order (position -> internal row): introspection, tests
+    double rim = 0.0, ring_hits = 0.0;
+    bool tried = false;
+};
+
 // one element of std::vector<mg_data> (reference src/mg_data.h:11-27)
 struct Level {
     // ---- host, caller numbering: the mg_data fields ----
@@ -114,6 +134,7 @@ struct Level {
     Csr vpat;               // block hierarchies: the n_v x n_v pattern of the 3 x 3 blocks of A (caller's vertex numbering; values unused)
     bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
+    BgsBuf bgs;             // block-sequential Gauss-Seidel plan for solves with a multiple of 64 columns (built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
     std::vector<int> A_int_src;   // A_int entry -> index into A.val
     DevBuf<double> d_Aval;        // values of A in the caller's CSR order: the canonical device copy
@@ -190,6 +211,7 @@ struct smg_hierarchy {
     // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
+    int bgs_min_rows = 100000;      // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 64 == 0 (< 0: never)
     smg::SparseChol chol;
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;

@@ -551,11 +551,18 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
         return fail(SMG_ERR_INVALID, "coarsest matrix (%d unknowns) is not positive definite: sparse Cholesky met a non-positive pivot", Ac.nr);
     tm.lap("host: sparse Cholesky of the coarsest matrix");
     const SparseChol& F = h->chol;
-    HIPCHK(h->c_perm.upload(F.perm)); HIPCHK(h->c_rptr.upload(F.rptr)); HIPCHK(h->c_rcol.upload(F.rcol)); HIPCHK(h->c_cptr.upload(F.cptr));
-    HIPCHK(h->c_crow.upload(F.crow)); HIPCHK(h->c_rval.upload(F.rval)); HIPCHK(h->c_cval.upload(F.cval)); HIPCHK(h->c_diag.upload(F.diag));
+    // The captured graphs hold SparseCholDev BY VALUE (kernel arguments): a value-only refactorisation writes into the buffers they point at;
+    // whatever has to be reallocated (first factorisation, another pattern) invalidates them.  The solve stream may still be reading the old factor.
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool moved = !h->coarse_sparse;
+    const double *work0 = h->c_work.p; const int* err0 = h->c_err.p;
+    HIPCHK(h->c_perm.upload_in_place(F.perm, &moved)); HIPCHK(h->c_rptr.upload_in_place(F.rptr, &moved)); HIPCHK(h->c_rcol.upload_in_place(F.rcol, &moved));
+    HIPCHK(h->c_cptr.upload_in_place(F.cptr, &moved)); HIPCHK(h->c_crow.upload_in_place(F.crow, &moved)); HIPCHK(h->c_rval.upload_in_place(F.rval, &moved));
+    HIPCHK(h->c_cval.upload_in_place(F.cval, &moved)); HIPCHK(h->c_diag.upload_in_place(F.diag, &moved));
     HIPCHK(h->c_work.ensure((size_t)2 * F.n));
     HIPCHK(h->c_err.ensure(1));
     HIPCHK(hipMemset(h->c_err.p, 0, sizeof(int)));
+    if (moved || h->c_work.p != work0 || h->c_err.p != err0) drop_graphs(h);
     SparseCholDev& V = h->c_view;
     V.n = F.n; V.perm = h->c_perm.p; V.rptr = h->c_rptr.p; V.rcol = h->c_rcol.p; V.cptr = h->c_cptr.p; V.crow = h->c_crow.p;
     V.rval = h->c_rval.p; V.cval = h->c_cval.p; V.diag = h->c_diag.p; V.work = h->c_work.p; V.err = h->c_err.p;

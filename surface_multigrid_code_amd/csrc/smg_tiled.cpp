@@ -1,5 +1,6 @@
 // smg_tiled.cpp -- host side of the overlapped tiling of the Gauss-Seidel sweeps (smg_tiled.hpp): tiles, halo rings, tile-local panels.
 #include "smg_tiled.hpp"
+#include "smg_bgs.hpp"
 
 #include <algorithm>
 #include <array>
@@ -23,7 +24,7 @@ struct TileData {
 // elongated part is cut across its long axis, so the parts come out roundish: the halo of P rings around a tile of N rows then has
 // ~ P * sqrt(N) rows, not ~ P * N / band width as for a range of the locality order, which is a thin band of the mesh).
 // Returns the tile of every row; *n_tiles receives their number.  O(n log(n / tile_rows)).
-static std::vector<int> partition_tiles(const Csr& G, int tile_rows, int* n_tiles)
+std::vector<int> partition_tiles(const Csr& G, int tile_rows, int* n_tiles)
 {
     const int n = G.nr;
     std::vector<int> part((size_t)n, 0), order((size_t)n), dist((size_t)n, -1), queue;

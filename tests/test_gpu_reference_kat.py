@@ -1,0 +1,60 @@
+"""GPU lane (-m gpu) twin of the one reference-pinned known-answer test ("next" #3).
+
+(i)  libsmg's mg_precompute reproduces, ON THE GPU BOX, the 5 316 points the reference checks in as 08_subdiv_remesh/output_s0/_s1/_s2.obj
+     (reference 08_subdiv_remesh/main.cpp:123-166; fixture tests/golden/bunny_remesh_500.npz made from /root/reference by
+     tests/golden/make_remesh_golden.py -- data, not source);
+(ii) a 03_mg_solver-style Poisson solve (reference 03_mg_solver/main.cpp:44-75: A = -cotmatrix, longest boundary loop pinned to 0,
+     B = M_voronoi 1) runs through the HIP path ON THAT VERY HIERARCHY -- the one object in this repository whose construction is pinned by
+     reference outputs -- and is held against the oracle: the kernels bit for bit in the device numbering, the solution to 1e-8.
+The solve-path oracle itself stays unpinned (no Eigen in the image: DESIGN.md section 5); what this test adds to GPUTEST is that the
+prolongation the solve runs on is the reference's own, to 8e-14."""
+import numpy as np
+import pytest
+
+from kat_remesh import check_subdiv_remesh_kat
+from test_gpu_parity import oracle_on_device_numbering, smg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_pinned_hierarchy_reproduced_on_the_gpu_box_and_solved_on(smg, oracle_mod):
+    from oracle import mesh_np as M
+    mg, V, F = check_subdiv_remesh_kat(smg)             # (i): asserts the 261 / 1020 / 4035 reference points and the coarse triangulation
+    assert mg.n_levels == 2 and mg.rows(1) == 261
+    # (ii) the 03-style system on the same mesh (bunny.obj has a boundary: its longest loop is pinned)
+    n = V.shape[0]
+    A = (-M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+    b = M.boundary_loop(F)
+    B = M.massmatrix(V, F, "voronoi") @ np.ones(n)
+    B[b] = 0.0
+    data = smg.min_quad_with_fixed_mg_precompute(A, b, mg)
+    assert data.n == n and len(data.unknown) == n - len(b)
+    Ps = [mg.matrix(1, "P_full")]
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A, b)
+    # the reduced prolongation the device runs with is the oracle's slice of the reference-pinned P_full (min_quad_with_fixed_mg.cpp:185-215)
+    assert abs(mg.matrix(1, "P") - orc.level_P(1)).max() == 0
+    assert abs(mg.matrix(1, "A") - orc.level_A(1)).max() <= 1e-12 * abs(orc.level_A(1)).max()     # Galerkin product: summation order only
+    # kernels, bit for bit, in the device numbering of level 0 (A x, Gauss-Seidel, restriction, prolongation)
+    rng = np.random.default_rng(11)
+    nu, nc = mg.rows(0), mg.rows(1)
+    perm, permc = mg.perm(0), mg.perm(1)
+    oi = oracle_on_device_numbering(oracle_mod, mg, 0)
+    x, rhs, xc = rng.uniform(-1, 1, (nu, 1)), rng.uniform(-1, 1, (nu, 1)), rng.uniform(-1, 1, (nc, 1))
+    assert np.array_equal(mg.A(0, x)[perm], oi.A(0, x[perm]))
+    assert np.array_equal(mg.relax(0, rhs, x, 2)[perm], oi.relax(0, rhs[perm], x[perm], 2))
+    assert np.array_equal(mg.restrict(0, x)[permc], oi.restrict(0, x[perm]))
+    assert np.array_equal(mg.prolong(0, xc)[perm], oi.prolong(0, xc[permc]))
+    # the reference's defaults (tol 1e-3, maxIter 20; min_quad_with_fixed_mg.h:79-113): same verdict, same cycle count to +-2
+    z0, bval = np.zeros(n), np.zeros(len(b))
+    conv, z, rh = smg.min_quad_with_fixed_mg_solve(data, B, bval, z0, mg)
+    conv2, z2, rh2 = orc.solve(B, z0, bval, tol=1e-3, max_iter=20)
+    assert conv == conv2 and abs(len(rh) - len(rh2)) <= 2
+    assert abs(rh[0] - rh2[0]) <= 1e-12 * rh2[0]                                      # residual before the first cycle: no smoother order in it
+    # tight solve: the 9 353 -> 261 hierarchy coarsens 36-fold in one step, so it converges slowly -- on both sides alike
+    o = smg.SolveOpts(tol=1e-9, max_iter=2000)
+    conv, z, rh = mg.solve(B, z0, bval, o)
+    conv2, z2, rh2 = orc.solve(B, z0, bval, tol=1e-9, max_iter=2000)
+    assert conv and conv2 and abs(len(rh) - len(rh2)) <= max(2, len(rh2) // 10)
+    assert np.linalg.norm(z - z2) <= 1e-8 * np.linalg.norm(z2)
+    assert np.array_equal(z[b], bval)
