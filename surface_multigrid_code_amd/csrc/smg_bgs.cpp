@@ -106,17 +106,32 @@ BgsPlan build_bgs(const Csr& G, int block_rows)
             }
         }
     });
-    // batches per row
-    R.row_bat.assign((size_t)n + 1, 0);
-    for (int t = 0; t < n; t++) {
-        const int i = R.rows[(size_t)t];
-        const int w = G.ptr[(size_t)i + 1] - G.ptr[(size_t)i];
-        R.row_bat[(size_t)t + 1] = R.row_bat[(size_t)t] + std::max(1, (w + BGS_BATCH - 1) / BGS_BATCH);
+    // batches per row: the same for all rows of a block; chunks of 64 entry slots
+    R.hdr.assign((size_t)nb * 4, 0);
+    std::vector<int> first_chunk((size_t)nb + 1, 0);
+    {
+        int prow_off = 0;
+        for (int q = 0; q < nb; q++) {
+            int wmax = 1;
+            for (int t = R.blk_ptr[(size_t)q]; t < R.blk_ptr[(size_t)q + 1]; t++) {
+                const int i = R.rows[(size_t)t];
+                wmax = std::max(wmax, G.ptr[(size_t)i + 1] - G.ptr[(size_t)i]);
+            }
+            const int per_row = (wmax + BGS_BATCH - 1) / BGS_BATCH;
+            if (per_row > BGS_MAX_BATCHES) return BgsPlan();
+            const int m = R.blk_ptr[(size_t)q + 1] - R.blk_ptr[(size_t)q], rows_per_chunk = 8 / per_row;
+            const int chunks = (m + rows_per_chunk - 1) / rows_per_chunk;
+            R.hdr[(size_t)q * 4 + 0] = prow_off; R.hdr[(size_t)q * 4 + 1] = m;
+            R.hdr[(size_t)q * 4 + 2] = first_chunk[(size_t)q]; R.hdr[(size_t)q * 4 + 3] = per_row;
+            first_chunk[(size_t)q + 1] = first_chunk[(size_t)q] + chunks;
+            prow_off += chunks * rows_per_chunk;
+        }
+        R.prow.assign((size_t)prow_off, 0);
+        const size_t slots = (size_t)first_chunk[(size_t)nb] * 64;
+        R.ecol.assign(slots, BGS_PAD);
+        R.eval.assign(slots, 0.0);
+        R.eentry.assign(slots, -1);
     }
-    const size_t slots = (size_t)R.row_bat[(size_t)n] * BGS_BATCH;
-    R.ecol.assign(slots, BGS_PAD);
-    R.eval.assign(slots, 0.0);
-    R.eentry.assign(slots, -1);
     std::vector<long> rim_cnt((size_t)nb, 0), in_early((size_t)nb, 0), in_ring((size_t)nb, 0);
     std::vector<char> no_diag((size_t)nb, 0);
     parallel_for(nb, 32, [&](long q0, long q1) {
@@ -130,7 +145,9 @@ BgsPlan build_bgs(const Csr& G, int block_rows)
                 ent.clear();
                 for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) ent.emplace_back(pos[(size_t)G.col[(size_t)p]], p);
                 std::sort(ent.begin(), ent.end());
-                size_t s = (size_t)R.row_bat[(size_t)t] * BGS_BATCH;
+                const int per_row = R.hdr[(size_t)q * 4 + 3];
+                size_t s = (size_t)R.hdr[(size_t)q * 4 + 2] * 64 + (size_t)(t - base) * per_row * BGS_BATCH;
+                R.prow[(size_t)R.hdr[(size_t)q * 4 + 0] + (t - base)] = i;
                 bool diag = false;
                 for (const auto& e : ent) {
                     const int pj = e.first, j = G.col[(size_t)e.second];
@@ -148,6 +165,19 @@ BgsPlan build_bgs(const Csr& G, int block_rows)
                     s++;
                 }
                 if (!diag) no_diag[(size_t)q] = 1;
+            }
+            {   // copies of the last row up to a whole chunk
+                const int per_row = R.hdr[(size_t)q * 4 + 3], m = end - base, rows_per_chunk = 8 / per_row;
+                const int padded = (m + rows_per_chunk - 1) / rows_per_chunk * rows_per_chunk;
+                const size_t e0 = (size_t)R.hdr[(size_t)q * 4 + 2] * 64, w = (size_t)per_row * BGS_BATCH;
+                for (int t = m; t < padded; t++) {
+                    R.prow[(size_t)R.hdr[(size_t)q * 4 + 0] + t] = R.rows[(size_t)end - 1];
+                    for (size_t z = 0; z < w; z++) {
+                        R.ecol[e0 + (size_t)t * w + z] = R.ecol[e0 + (size_t)(m - 1) * w + z];
+                        R.eval[e0 + (size_t)t * w + z] = R.eval[e0 + (size_t)(m - 1) * w + z];
+                        R.eentry[e0 + (size_t)t * w + z] = R.eentry[e0 + (size_t)(m - 1) * w + z];
+                    }
+                }
             }
             std::sort(foreign.begin(), foreign.end());
             rim_cnt[(size_t)q] = (long)(std::unique(foreign.begin(), foreign.end()) - foreign.begin());

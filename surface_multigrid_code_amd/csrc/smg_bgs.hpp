@@ -26,6 +26,7 @@ namespace smg {
 
 constexpr int BGS_RING = 16;          // new values of the last BGS_RING rows of a block live in LDS
 constexpr int BGS_BATCH = 8;          // entries per batch (a row holds a whole number of batches)
+constexpr int BGS_MAX_BATCHES = 2;    // per row: levels with rows of more than 16 entries keep the multi-colour launches
 constexpr int BGS_PAD = -1;           // entry column codes below 0: padding,
 constexpr int BGS_DIAG = -2;          //   the row's diagonal,
 constexpr int BGS_RING0 = -3;         //   ring slot s as BGS_RING0 - s
@@ -35,8 +36,13 @@ struct BgsPlan {
     std::vector<int> color_ptr;       // blocks of colour c: [color_ptr[c], color_ptr[c + 1])
     std::vector<int> blk_ptr;         // rows of block b: positions [blk_ptr[b], blk_ptr[b + 1]) of `rows`
     std::vector<int> rows;            // position in the bgs order -> row (internal numbering)
-    std::vector<int> row_bat;         // position -> first batch of the row's entries; n + 1 values
-    std::vector<int> ecol;            // batches * BGS_BATCH entry codes: >= 0 row to gather, else BGS_*
+    // ---- what the kernel reads.  A wavefront takes its block in CHUNKS of 64 entry slots = 8 rows of one batch (4 rows of two: every
+    // row of a block holds the same number of batches, so a row's entries are found from its position alone); a block whose row count is
+    // no multiple of that is padded with copies of its LAST row -- updating a row again with unchanged neighbours reproduces its value,
+    // so the copies are harmless and the walk needs no tail code.
+    std::vector<int> hdr;             // per block 4 ints: offset into prow, rows of the block (without copies), first chunk, batches per row
+    std::vector<int> prow;            // rows of the blocks, padded per block to whole chunks
+    std::vector<int> ecol;            // chunks * 64 entry codes: >= 0 row to gather, else BGS_*
     std::vector<double> eval;
     std::vector<int> eentry;          // like eval: index of the entry of G the slot holds (-1: padding) -- value refresh
     double rim = 0.0;                 // (distinct (block, foreign row) pairs) / n: what a sweep gathers beyond the iterate itself
@@ -45,7 +51,7 @@ struct BgsPlan {
 };
 
 // G: the matrix the smoother streams (A, or A^T where A is not bit-symmetric), internal numbering, structurally symmetric, diagonal stored.
-// Returns an empty plan when a row has no stored diagonal.
+// Returns an empty plan when a row has no stored diagonal or more than BGS_MAX_BATCHES * BGS_BATCH entries.
 BgsPlan build_bgs(const Csr& G, int block_rows = 64);
 
 // compact parts of <= tile_rows rows (smg_tiled.cpp)

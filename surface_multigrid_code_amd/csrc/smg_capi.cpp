@@ -224,7 +224,7 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     h->n_levels = n_levels;
     h->lv.resize(n_levels);
     h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 16384);
-    h->bgs_min_rows = env_int("SMG_BGS_MIN_ROWS", 100000);
+    h->bgs_min_rows = env_int("SMG_BGS_MIN_ROWS", -1);
     return h;
 }
 

@@ -145,11 +145,11 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
         const int e = P.eentry[i];
         map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
     }
-    HIPCHK(B.blk_ptr.upload(P.blk_ptr)); HIPCHK(B.rows.upload(P.rows)); HIPCHK(B.row_bat.upload(P.row_bat)); HIPCHK(B.ecol.upload(P.ecol));
+    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.rows.upload(P.prow)); HIPCHK(B.ecol.upload(P.ecol));
     HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map));
     B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors;
-    B.view.blk_ptr = B.blk_ptr.p; B.view.rows = B.rows.p; B.view.row_bat = B.row_bat.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
-    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.rim = P.rim; B.ring_hits = P.ring_hits;
+    B.view.hdr = B.hdr.p; B.view.prow = B.rows.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
+    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_blk_ptr = P.blk_ptr; B.rim = P.rim; B.ring_hits = P.ring_hits;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
     if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
     if (env_int("SMG_DEBUG_BGS", 0))
@@ -1148,7 +1148,7 @@ extern "C" int smg_level_get_block_gs_order(smg_hierarchy* h, int lv, int k, int
     if (n_blocks) *n_blocks = Q->view.n_blocks;
     if (n_colors) *n_colors = Q->view.n_colors;
     if (color_ptr) std::copy(Q->color_ptr.begin(), Q->color_ptr.end(), color_ptr);
-    if (blk_ptr) HIPCHK(hipMemcpy(blk_ptr, Q->blk_ptr.p, ((size_t)Q->view.n_blocks + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (blk_ptr) std::copy(Q->host_blk_ptr.begin(), Q->host_blk_ptr.end(), blk_ptr);
     if (rows) std::copy(Q->host_rows.begin(), Q->host_rows.end(), rows);
     if (stats) { stats[0] = Q->rim; stats[1] = Q->ring_hits; }
     return 1;

@@ -136,10 +136,9 @@ hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, c
 // ---- Gauss-Seidel sweep for blocks of 64 right-hand-side columns: block-sequential order (smg_bgs.hpp plan, smg_bgs_device.hip kernel) ----
 struct BgsDev {
     int n_blocks = 0, n_colors = 0;
-    const int* blk_ptr = nullptr;     // n_blocks + 1 positions
-    const int* rows = nullptr;        // position -> row
-    const int* row_bat = nullptr;     // position -> first batch (n + 1)
-    const int* ecol = nullptr;        // batches x 8 entry codes
+    const int* hdr = nullptr;         // per block: offset into prow, rows, first chunk, batches per row
+    const int* prow = nullptr;        // rows of the blocks, padded per block to whole chunks
+    const int* ecol = nullptr;        // chunks x 64 entry codes
     const double* eval = nullptr;
 };
 // the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 64)

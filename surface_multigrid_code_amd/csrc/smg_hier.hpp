@@ -96,11 +96,11 @@ struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
 };
 
 struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a level (smg_bgs.hpp)
-    DevBuf<int> blk_ptr, rows, row_bat, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
+    DevBuf<int> hdr, rows, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
     DevBuf<double> eval;
     BgsDev view;
     std::vector<int> color_ptr;      // blocks of colour c
-    std::vector<int> host_rows;      // the bgs order (position -> internal row): introspection, tests
+    std::vector<int> host_rows, host_blk_ptr;      // the bgs order (position -> internal row), positions per block: introspection, tests
     double rim = 0.0, ring_hits = 0.0;
     bool tried = false;
 };
@@ -211,7 +211,7 @@ struct smg_hierarchy {
     // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
-    int bgs_min_rows = 100000;      // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 64 == 0 (< 0: never)
+    int bgs_min_rows = -1;          // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 64 == 0 (< 0: never, the default)
     smg::SparseChol chol;
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;
