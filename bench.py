@@ -83,6 +83,25 @@ def build_workload(name, smg, mesh):
     return mg, A, Mb, Vf, Ff, label, time.time() - t0
 
 
+def precompute_known_s(smg, mesh, mg, Vf, Ff, n_pins=346):
+    """First smg_precompute WITH constraints on a fresh handle over the same prolongations: the Poisson system -L with 346 pinned vertices
+    (BASELINE config C2's count on the C3 mesh; reference src/min_quad_with_fixed_mg.cpp:137-257: setdiff, slices, column-drop cascade,
+    Galerkin products).  Seconds, HIP already up."""
+    try:
+        Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+        m2 = smg.Hierarchy.from_prolongs(Ps)
+        A = (-mesh.cotmatrix(Vf, Ff)).tocsr()
+        A.sort_indices()
+        known = np.sort(np.random.default_rng(0).choice(A.shape[0], n_pins, replace=False)).astype(np.int32)
+        t0 = time.time()
+        m2.precompute(A, known)
+        dt = time.time() - t0
+        del m2
+        return dt
+    except Exception as e:   # informational: never lose the bench line over it
+        return {"error": repr(e)}
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources: profiles/traffic.json carries the hash of the sources its PMC passes ran on
     (tools/make_traffic.py); a committed traffic figure is only reported while it still describes the kernels that are timed."""
@@ -176,6 +195,25 @@ def cpu_allcore(mg, A, rhs, budget_s=6.0):
             "ms_per_cycle": best[1], "r_his_head": best[3]}
 
 
+def median_us(torch, stream, fn, reps, repeats=5, warm=10):
+    """us per call of fn (launches on `stream`): median of `repeats` HIP-event-timed loops of `reps` calls -- one stalled loop (a clock ramp, a
+    host hiccup between eager launches) must not become the reported figure (a single 200-launch loop once gave 274 us for a
+    122 us kernel)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(max(1, repeats)):
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t.append(1e3 * e0.elapsed_time(e1) / reps)
+    return float(np.median(t)), [float(v) for v in t]
+
+
 def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
     """The same two kernels at a working set the 256 MiB Infinity Cache cannot hold (BASELINE config C5: torus, 4 194 304 vertices,
     matrix 352 MB): the fine-level y = A x and one Gauss-Seidel sweep, HIP events on the launch stream.  This is the HBM number;
@@ -191,18 +229,8 @@ def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
     u = torch.zeros_like(x)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def timed(fn, r):
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(r):
-            fn()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        return 1e3 * e0.elapsed_time(e1) / r
-    spmv_us = timed(lambda: mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr()), reps)
-    gs_us = timed(lambda: mg.raw_relax(0, b.data_ptr(), u.data_ptr(), 1, 1), reps // 2)
+    spmv_us, spmv_all = median_us(torch, stream, lambda: mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr()), reps // 2, 5)
+    gs_us, gs_all = median_us(torch, stream, lambda: mg.raw_relax(0, b.data_ptr(), u.data_ptr(), 1, 1), reps // 4, 5)
     cyc_us = mg.bench_vcycle(0, 1, 2, 2, 30)
     spmv_bytes = mg.spmv_bytes(0, 1)
     gs_bytes = 12 * A.nnz + 4 * (n + 1) + 24 * n
@@ -216,7 +244,7 @@ def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
     try:
         x32 = x.float()
         y32 = torch.empty_like(x32)
-        us32 = timed(lambda: mg.raw_spmv_f32(0, x32.data_ptr(), y32.data_ptr()), reps)
+        us32, _ = median_us(torch, stream, lambda: mg.raw_spmv_f32(0, x32.data_ptr(), y32.data_ptr()), reps // 2, 5)
         b32 = 8 * A.nnz + 4 * (n + 1) + 8 * n
         mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
         torch.cuda.synchronize()
@@ -249,6 +277,7 @@ def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
         f32 = {"error": repr(e)}
     return {"workload": label, "f32": f32, "kernel": "k_sell<SELL_AX,1> (fine-level y = A x)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "frac_of_sustainable": gbs / HBM_SUSTAINABLE_GBS, "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
+            "us_per_launch_repeats": spmv_all, "timing": "median of 5 HIP-event-timed loops",
             "working_set_bytes": int(ws), "infinity_cache_resident": bool(ws < INFINITY_CACHE_BYTES),
             "traffic_committed_pmc": traffic, "traffic_source": traffic_note,
             "gs_sweep": {"us_per_sweep": gs_us, "bytes_per_sweep": int(gs_bytes), "achieved": gs_bytes / (gs_us * 1e-6) / 1e9,
@@ -347,6 +376,14 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
     return {"workload": "C3 mesh (1 011 330 verts, 5 levels), k = 64 RHS columns M g_j, column-sharded", "k": K64, "columns_per_gpu": kl, "n_gpus": world,
             "scaling": "strong", "smoother": "gs", "loop": "smg_solve_sharded (C++ loop, %s)" % ("no reduction at N = 1" if world == 1 else "RCCL closure on the solve stream" if stream_ar is not None else "host closure"),
             "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms if ms else None, "column_cycles_per_s": K64 * 1e3 / ms if ms else None,
+            # algorithmic bytes of one outer iteration with the columns THIS GPU owns (smg_vcycle_bytes: a sweep charged one read of the iterate).
+            # NB the multi-colour sweep of the wide kernels cannot move that little: each of the 4 colour launches streams the other three
+            # colours' iterate (512 B per row at 64 columns: beyond every cache), 5.4 n k 8 B per sweep measured against 3 n k 8 algorithmic
+            # (profiles/r04_pmc_summary_C3_k64.json: 698 MB per level-0 colour launch at 5.2 TB/s, the memory's rate) -- so `frac` here is
+            # bounded by ~0.45, not 1
+            "bytes_per_step": int(mg.vcycle_bytes(kl, 2, 2)) if kl else None,
+            "gbs": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9) if (kl and ms) else None,
+            "frac": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kl and ms) else None,
             "solve": {"tol": tol, "converged": bool(conv), "cycles": len(rh) - 1, "wall_ms": 1e3 * wall, "same_history_on_all_ranks": same,
                       "final_residual": float(rh[-1]) if len(rh) else None}}
 
@@ -676,31 +713,14 @@ def main():
         # ---- roofline of the fine-level SpMV kernel (k_sell<SELL_AX,1> on A_0), HIP events on the launch stream
         x = torch.from_numpy(rng.uniform(-1.0, 1.0, n)).to(dev)
         y = torch.empty_like(x)
-        for _ in range(20):
-            mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         R = args.spmv_reps
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(R):
-            mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        spmv_us = 1e3 * e0.elapsed_time(e1) / R
+        spmv_us, spmv_all = median_us(torch, stream, lambda: mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr()), max(R // 5, 50), 5, warm=20)
         spmv_bytes = mg.spmv_bytes(0, 1)
         spmv_gbs = spmv_bytes / (spmv_us * 1e-6) / 1e9
         # ---- one full Gauss-Seidel sweep on level 0 (all colours), same byte model + b read
         bvec = torch.from_numpy(rhs_h).to(dev)
         u = torch.zeros_like(bvec)
-        for _ in range(5):
-            mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1)
-        torch.cuda.synchronize()
-        e0.record(stream)
-        for _ in range(100):
-            mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        gs_us = 1e3 * e0.elapsed_time(e1) / 100
+        gs_us, gs_all = median_us(torch, stream, lambda: mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1), 40, 5, warm=5)
         nnz0 = A.nnz
         gs_bytes = 12 * nnz0 + 4 * (n + 1) + 24 * n
         # ---- per-scope timing of the V-cycle (profc mirror; eager launches with hipEvents)
@@ -724,7 +744,9 @@ def main():
             # the reference's cycle -- V(2,2), Gauss-Seidel on every level (src/mg_VCycle.cpp) -- whatever --smoother timed
             "reference_cycle": {"v_cycles_per_s": ref["v_cycles_per_s"], "ms_per_step": ref["ms_per_step"], "cycles_to_1e-10": ref["cycles_to_tol"],
                                 "bytes_per_step": ref["bytes_per_step"], "frac_of_hbm_peak": ref["frac_of_hbm_peak"]} if ref else None,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak",
+            "scaling_note": "top-level value: one right-hand-side column per GPU, hierarchy replicated (fixed work per GPU as N grows); the c3_k64_sharded / c4_k64_sharded legs split a FIXED 64-column job over the ranks and say 'strong' themselves",
+            "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f64 outer loop + f32 V-cycle (mixed)", "data": "synthetic",
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
@@ -744,7 +766,8 @@ def main():
                          # the committed PMC figure of this kernel at this grid (rocprofv3 cannot run inside the benchmark): fabric-side
                          # requests, which do not tell Infinity-Cache hits from HBM reads
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us,
+                         "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us, "us_per_launch_repeats": spmv_all,
+                         "timing": "median of 5 HIP-event-timed loops on the launch stream",
                          "sell_padding": st["padded"] / max(st["stored"], 1) - 1.0,
                          # what the launch streams (SELL slots incl. padding + x + y): below 256 MiB the matrix survives in the
                          # Infinity Cache between back-to-back launches, so `achieved` may exceed what HBM alone sustains (~6.3 TB/s);
@@ -764,7 +787,7 @@ def main():
             "cycles_to_tol": smoothers["timed"]["cycles_to_tol"] if smoothers else None,
             "profc": {k: {"count": v[0], "ms_total": v[1]} for k, v in prof.items()},
             "residual_history_head": [float(v) for v in r_his[:6]],
-            "setup_s": {"mesh_hierarchy_host": t_host, "precompute": t_pre,
+            "setup_s": {"mesh_hierarchy_host": t_host, "precompute": t_pre, "precompute_known": precompute_known_s(smg, mesh, mg, Vf, Ff) if args.workload == "C3" else None,
                         "precompute_note": "first (pattern-changing) smg_precompute of the process, HIP runtime already initialised; libsmg's own code object is loaded inside it"},
             # memory budget: everything libsmg holds in HBM for this workload (operators in SELL incl. the fixed panel pitch, A^T images of the
             # Galerkin levels, dense coarse inverse, work vectors, graphs' buffers) against the algorithmic size of the hierarchy

@@ -58,33 +58,25 @@ def measure(smg, torch, A, Ps, mode, smoother="gs", reps=200):
     mg.solve_end(z.data_ptr(), n, max_iter=1024)
     ms = ea.elapsed_time(eb) / reps
     # fine-level y = A x and one Gauss-Seidel sweep
+    import bench as B
     x = torch.from_numpy(rng.uniform(-1.0, 1.0, n)).to(dev)
     y = torch.empty_like(x)
-    for _ in range(10):
-        mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
-    ea.record(stream)
-    for _ in range(200):
-        mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr())
-    eb.record(stream)
-    torch.cuda.synchronize()
-    spmv_us = 1e3 * ea.elapsed_time(eb) / 200
+    spmv_us, spmv_all = B.median_us(torch, stream, lambda: mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr()), 60, 5)
     u = torch.zeros_like(x)
     mg.set_smoother("gs")
-    for _ in range(5):
-        mg.raw_relax(0, rhs.data_ptr(), u.data_ptr(), 1, 1)
-    ea.record(stream)
-    for _ in range(100):
-        mg.raw_relax(0, rhs.data_ptr(), u.data_ptr(), 1, 1)
-    eb.record(stream)
-    torch.cuda.synchronize()
-    gs_us = 1e3 * ea.elapsed_time(eb) / 100
+    gs_us, gs_all = B.median_us(torch, stream, lambda: mg.raw_relax(0, rhs.data_ptr(), u.data_ptr(), 1, 1), 30, 5, warm=5)
     byt = mg.vcycle_bytes(1, 2, 2)
     sb = mg.spmv_bytes(0, 1)
     out = {"mode": mode, "block_size": mg.block_size(), "smoother": smoother, "dofs": n, "levels": mg.n_levels,
            "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)], "ms_per_iteration": ms, "cycles_to_1e-10": len(rh) - 1,
            "converged": bool(conv), "time_to_tol_ms": (len(rh) - 1) * ms, "bytes_per_iteration": int(byt), "gbs": byt / (ms * 1e-3) / 1e9,
            "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e9 / 8000.0, "spmv_us": spmv_us, "spmv_bytes": int(sb), "spmv_gbs": sb / (spmv_us * 1e-6) / 1e9,
-           "gs_sweep_us": gs_us, "gs_sweep_gbs": (sb + 8 * n) / (gs_us * 1e-6) / 1e9, "precompute_s": t_pre, "final_residual": float(rh[-1])}
+           "gs_sweep_us": gs_us, "gs_sweep_gbs": (sb + 8 * n) / (gs_us * 1e-6) / 1e9, "precompute_s": t_pre, "final_residual": float(rh[-1]),
+           "spmv_us_repeats": spmv_all, "gs_sweep_us_repeats": gs_all, "timing": "median of 5 HIP-event-timed loops",
+           # roofline of the fine-level y = A x of this path: k_bsr3<SELL_AX> on 3 x 3 blocks (76 B per block) / k_sell on scalar entries
+           "roofline": {"kernel": "k_bsr3<SELL_AX> (fine-level y = A x, 3 x 3 blocks)" if mg.block_size() == 3 else "k_sell<SELL_AX,1>", "bound": "hbm",
+                        "bytes_per_launch": int(sb), "us_per_launch": spmv_us, "achieved": sb / (spmv_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": sb / (spmv_us * 1e-6) / 1e9 / 8000.0}}
     if mg.block_size() == 3:
         out["block_stats"] = mg.block_stats(0)
     del mg
