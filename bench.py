@@ -608,6 +608,28 @@ def main():
             stream_ar = sar
         elif rank == 0:
             print("bench: direct RCCL all-reduce unavailable (%s), using torch.distributed" % sar.err, file=sys.stderr)
+    # ---- multi-GPU pre-flight (N > 1 over RCCL): every rank on a device of its own and a communicator that really has N ranks -- or no line.
+    # (A run whose ranks silently share a GPU, or whose collective fell back to something else, would print a plausible but meaningless
+    # scaling point.)  SMG_BENCH_BACKEND=gloo / SMG_BENCH_ALLOW_SHARED=1: the CPU-side exercise of the N > 1 code path on fewer GPUs.
+    preflight = None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(dev)
+        ident = "%s|%s|%s|%s" % (os.uname().nodename, getattr(pr, "uuid", ""), getattr(pr, "pci_bus_id", ""), getattr(pr, "pci_device_id", ""))
+        if ident.count("|") == 3 and ident.split("|")[1:] == ["", "", ""]:
+            ident = "%s|index %d" % (os.uname().nodename, local_rank % ndev)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        comm_ranks = stream_ar.n_ranks() if stream_ar is not None else dist.get_world_size()
+        preflight = {"rccl_comm_ranks": int(comm_ranks), "distinct_devices": len(set(idents)), "devices": idents, "backend": dist.get_backend(),
+                     "allreduce": "RCCL communicator of libsmg's own (ncclCommCount)" if stream_ar is not None else "torch.distributed process group"}
+        shared_ok = os.environ.get("SMG_BENCH_BACKEND", "nccl") != "nccl" or os.environ.get("SMG_BENCH_ALLOW_SHARED") == "1"
+        if (preflight["rccl_comm_ranks"] != world or preflight["distinct_devices"] != world) and not shared_ok:
+            if rank == 0:
+                print("bench: multi-GPU pre-flight FAILED: --gpus %d needs %d RCCL ranks on %d distinct devices, found %s"
+                      % (world, world, world, json.dumps(preflight)), file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     W, K = args.warmup, args.steps
     # tol = 0: the loop never converges, every step is a full outer iteration (residual + norm + break test + V(2,2) cycle) that
     # stores its results.  The device-side residual history holds 1024 entries (= the largest max_iter), and launches after the
@@ -738,7 +760,7 @@ def main():
         out = {
             "metric": "V-cycles/sec + fine-level SpMV GB/s (% HBM peak), 1M-vert mesh fp64",
             "value": world * K / dt, "unit": "V-cycles/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step,
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_step, "multi_gpu_preflight": preflight,
             "timing": {"repeats": NREP, "what": "each repeat = --steps outer iterations between barrier + synchronize, HIP events on the solve stream, max over ranks; ms_per_step / value = the median repeat",
                        "ms_per_step_min": min(rep_ms) / K, "ms_per_step_median": float(np.median(rep_ms)) / K, "ms_per_step_max": max(rep_ms) / K},
             # the reference's cycle -- V(2,2), Gauss-Seidel on every level (src/mg_VCycle.cpp) -- whatever --smoother timed

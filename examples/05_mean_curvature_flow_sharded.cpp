@@ -10,9 +10,17 @@
 //
 //   launch (N processes, one per GPU):   RANK=g WORLD_SIZE=N SMG_NCCL_ID_FILE=/tmp/smg_id ./05_mean_curvature_flow_sharded mesh.smgm [steps] [k]
 //   single process:                      ./05_mean_curvature_flow_sharded mesh.smgm [steps] [k]
+//   ranks SHARING a GPU (RCCL refuses that; the GPU test suite has one device): SMG_HOST_COMM_FILE=/tmp/smg_comm instead of SMG_NCCL_ID_FILE --
+//   the same closure slot then holds a host reduction through a memory-mapped file (the sums cross the host: what dist.HostReduce does
+//   for the Python callers), so smg_solve_sharded's loop runs with world size > 1 from C++ on one device.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +38,63 @@ static int rccl_reduce(double* d, int count, void* hip_stream, void* ctx)
     Reducer* r = (Reducer*)ctx;
     r->calls++;
     return ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, r->comm, (hipStream_t)hip_stream) == ncclSuccess ? 0 : 1;
+}
+
+// ---- host communicator for ranks that share a device: a memory-mapped file, a generation barrier, sums in rank order (the same bits on every rank)
+struct HostComm {
+    static constexpr int MAXR = 16, SLOT = 64;
+    static constexpr size_t BCAST = (size_t)1 << 20;                    // doubles
+    struct Shared { std::atomic<int> count, gen; double slot[MAXR][SLOT]; double bcast[BCAST]; };
+    Shared* sh = nullptr;
+    int rank = 0, world = 1;
+    long calls = 0;
+    bool open(const char* path, int r, int w)
+    {
+        rank = r; world = w;
+        if (w > MAXR) return false;
+        const int fd = ::open(path, O_RDWR | O_CREAT, 0600);
+        if (fd < 0) return false;
+        if (ftruncate(fd, (off_t)sizeof(Shared)) != 0) { ::close(fd); return false; }     // a fresh file is all zeros: count = gen = 0
+        void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        sh = (Shared*)p;
+        return true;
+    }
+    void barrier()
+    {
+        const int g = sh->gen.load(std::memory_order_acquire);
+        if (sh->count.fetch_add(1, std::memory_order_acq_rel) + 1 == world) { sh->count.store(0, std::memory_order_relaxed); sh->gen.fetch_add(1, std::memory_order_acq_rel); }
+        else while (sh->gen.load(std::memory_order_acquire) == g) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    bool allreduce(double* v, int count)
+    {
+        if (count > SLOT) return false;
+        for (int i = 0; i < count; i++) sh->slot[rank][i] = v[i];
+        barrier();
+        for (int i = 0; i < count; i++) { double t = 0.0; for (int r = 0; r < world; r++) t += sh->slot[r][i]; v[i] = t; }
+        barrier();
+        return true;
+    }
+    bool broadcast(double* buf, size_t n, int owner)
+    {
+        if (n > BCAST) return false;
+        if (rank == owner) std::memcpy(sh->bcast, buf, n * sizeof(double));
+        barrier();
+        if (rank != owner) std::memcpy(buf, sh->bcast, n * sizeof(double));
+        barrier();
+        return true;
+    }
+};
+// smg_reduce_fn through the host: wait for the solve stream, sum on the host, put the result back (dist.HostReduce's C++ twin)
+static int host_reduce(double* d, int count, void* hip_stream, void* ctx)
+{
+    HostComm* c = (HostComm*)ctx;
+    c->calls++;
+    double v[HostComm::SLOT];
+    if (count > HostComm::SLOT || hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) return 1;
+    if (hipMemcpy(v, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess || !c->allreduce(v, count)) return 1;
+    return hipMemcpy(d, v, (size_t)count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
 }
 
 // the unique id travels through a file: rank 0 writes it (to a temporary name, then renames), the others wait for it
@@ -67,10 +132,16 @@ int main(int argc, char* argv[])
 
     ncclUniqueId id;
     const char* id_file = std::getenv("SMG_NCCL_ID_FILE");
-    if (world > 1) { if (!id_file || !exchange_id(id, rank, id_file)) { std::fprintf(stderr, "rank %d: no unique id (SMG_NCCL_ID_FILE)\n", rank); return 1; } }
-    else if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+    const char* host_file = std::getenv("SMG_HOST_COMM_FILE");
+    HostComm hc;
     Reducer red{nullptr, 0};
-    if (ncclCommInitRank(&red.comm, world, id, rank) != ncclSuccess) { std::fprintf(stderr, "rank %d: ncclCommInitRank failed\n", rank); return 1; }
+    if (host_file) {
+        if (!hc.open(host_file, rank, world)) { std::fprintf(stderr, "rank %d: cannot map %s\n", rank, host_file); return 1; }
+    } else {
+        if (world > 1) { if (!id_file || !exchange_id(id, rank, id_file)) { std::fprintf(stderr, "rank %d: no unique id (SMG_NCCL_ID_FILE)\n", rank); return 1; } }
+        else if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+        if (ncclCommInitRank(&red.comm, world, id, rank) != ncclSuccess) { std::fprintf(stderr, "rank %d: ncclCommInitRank failed\n", rank); return 1; }
+    }
 
     double* Vp = nullptr; int* Fp = nullptr; int nV = 0, nF = 0;
     if (smg_mesh_read(path, &Vp, &nV, &Fp, &nF) != SMG_OK) { std::fprintf(stderr, "%s\n", smg_last_error()); return 1; }
@@ -98,8 +169,8 @@ int main(int argc, char* argv[])
     std::vector<double> Urow((size_t)nV * 3), M(nV);
     min_quad_with_fixed_mg_data solverData;
     smgCoarseSolver coarseSolver;
-    coarseSolver.reduce = rccl_reduce;                            // <- the whole multi-GPU hook
-    coarseSolver.reduce_ctx = &red;
+    coarseSolver.reduce = host_file ? host_reduce : rccl_reduce;  // <- the whole multi-GPU hook
+    coarseSolver.reduce_ctx = host_file ? (void*)&hc : (void*)&red;
     for (int s = 0; s < steps; s++) {
         for (int i = 0; i < nV; i++) for (int c = 0; c < 3; c++) Urow[3 * (size_t)i + c] = U(i, c);
         smg_mesh_massmatrix(Urow.data(), nV, Fp, nF, /*voronoi=*/0, M.data());
@@ -121,10 +192,13 @@ int main(int argc, char* argv[])
         for (int c = 0; c < 3; c++) {
             const int owner = (int)(((long)(c + 1) * world - 1) / k);                 // the rank whose range holds column c
             if (owner == rank) for (int i = 0; i < nV; i++) buf[(size_t)i] = Zl(i, c - lo);
-            (void)hipMemcpy(dbuf, buf.data(), (size_t)nV * sizeof(double), hipMemcpyHostToDevice);
-            if (ncclBroadcast(dbuf, dbuf, (size_t)nV, ncclDouble, owner, red.comm, nullptr) != ncclSuccess) return 1;
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(buf.data(), dbuf, (size_t)nV * sizeof(double), hipMemcpyDeviceToHost);
+            if (host_file) { if (!hc.broadcast(buf.data(), (size_t)nV, owner)) return 1; }
+            else {
+                (void)hipMemcpy(dbuf, buf.data(), (size_t)nV * sizeof(double), hipMemcpyHostToDevice);
+                if (ncclBroadcast(dbuf, dbuf, (size_t)nV, ncclDouble, owner, red.comm, nullptr) != ncclSuccess) return 1;
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(buf.data(), dbuf, (size_t)nV * sizeof(double), hipMemcpyDeviceToHost);
+            }
             for (int i = 0; i < nV; i++) U(i, c) = buf[(size_t)i];
         }
         (void)hipFree(dbuf);
@@ -137,8 +211,8 @@ int main(int argc, char* argv[])
                         (int)rHis.size(), rHis.empty() ? 0.0 : rHis.back(), s2);
         if (!ok) return 2;
     }
-    if (rank == 0) std::printf("reductions issued by rank 0: %ld\n", red.calls);
-    ncclCommDestroy(red.comm);
+    if (rank == 0) std::printf("reductions issued by rank 0: %ld (%s)\n", host_file ? hc.calls : red.calls, host_file ? "host closure" : "RCCL closure");
+    if (!host_file) ncclCommDestroy(red.comm);
     smg_free(Vp); smg_free(Fp);
     return 0;
 }

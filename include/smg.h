@@ -174,7 +174,10 @@ int smg_mg_precompute_block(const double *V, int nV, const int *F, int nF, float
  * per kernel in the device numbering (smg_level_get_matrix(..., internal = 1) is the scalar matrix in it).
  * mode: -1 (default) decide at smg_precompute: structure present AND the blocks of A at least half full (kron(S, I_3) is better
  * served as three right-hand sides of a scalar problem); 0 never; 3 required (smg_precompute fails when the structure is absent).
- * Not available on block hierarchies: constraints (`known` selects the scalar path), the mixed-precision cycle. */
+ * Constraints: pinned VERTICES (all three DOFs 3v, 3v+1, 3v+2 in `known`) keep the structure -- the reference's slices and column drops
+ * (src/min_quad_with_fixed_mg.cpp:137-257) are formed on the scalar matrices and factor as Pv' (x) I_3 again -- and stay on the block
+ * kernels; constraints on single degrees of freedom select the scalar path (mode 3: smg_precompute fails and says so).
+ * Not available on block hierarchies: the mixed-precision cycle. */
 int smg_hierarchy_set_block_mode(smg_hierarchy *h, int mode);
 int smg_hierarchy_block_size(const smg_hierarchy *h);   /* 1 or 3: what the last smg_precompute decided */
 /* block image of A_lv (lv < n_levels - 1, block hierarchies only): stored 3 x 3 blocks, allocated block slots (SELL padding
@@ -361,6 +364,10 @@ long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);
  * *n_tiles = 0: the level does not qualify for tiling (too many colours, rows wider than 12 entries). */
 int smg_debug_check_tiling_plan(smg_hierarchy *h, int lv, int sweeps, int tile_rows, int *n_tiles, int *max_ext_rows, double *redundancy,
                                 double *max_abs_diff);
+/* Test hook: raises the stall flag of the sparse triangular solves on the device, as a wait that gave up would (csrc/smg_coarse_device.hip).
+ * The next solve's waits then give up at once, its coarse corrections are NaN, and the next synchronising entry point returns SMG_ERR_HIP
+ * and clears the flag.  Fails unless the handle holds a sparse coarse factorisation. */
+int smg_debug_raise_coarse_stall(smg_hierarchy *h);
 /* Sparse Cholesky of the coarse solver (csrc/smg_coarse.hpp) on an SPD matrix given in CSR (both triangles): nested-dissection order,
  * factorisation, and the relative residual |b - A x| / |b| of a host solve with the factor for a deterministic right-hand side.
  * Returns SMG_ERR_INVALID when a pivot is not positive. */

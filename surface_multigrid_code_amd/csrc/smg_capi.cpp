@@ -583,6 +583,15 @@ extern "C" int smg_debug_check_tiling_plan(smg_hierarchy* h, int lv, int sweeps,
     });
 }
 
+extern "C" int smg_debug_raise_coarse_stall(smg_hierarchy* h)
+{
+    if (!h || !h->coarse_sparse || !h->c_err.p) return fail(SMG_ERR_INVALID, "smg_debug_raise_coarse_stall: no sparse coarse factorisation on this handle");
+    const int one = 1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->c_err.p, &one, sizeof(int), hipMemcpyHostToDevice));
+    return SMG_OK;
+}
+
 extern "C" int smg_debug_check_sparse_cholesky(int n, const int* rowptr, const int* col, const double* val, long* factor_entries, int* dependency_depth,
                                                double* rel_residual)
 {

@@ -214,6 +214,14 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.d.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
         }
     }
+    if (h->coarse_sparse) {      // the triangular solves take up to 64 columns per pass: 2 n doubles of scratch per column of a pass
+        const size_t need = (size_t)2 * h->chol.n * sparse_coarse_work_cols(std::max(h->kcap, 1));
+        if (h->c_work.n < need) {
+            drop_graphs(h);          // the captured launches hold the scratch pointer
+            HIPCHK(h->c_work.alloc(need));
+            h->c_view.work = h->c_work.p;
+        }
+    }
     int rc = prepare_tiled(h, k, h->pre, h->post);
     if (rc) return rc;
     return ensure_spectral_bounds(h);
@@ -753,6 +761,19 @@ static int enqueue_outer_iteration(smg_hierarchy* h)
 }
 
 // ------------------------------------------------------------------------------------------------ solve
+// The sparse triangular solves raise c_err when a wait gave up (smg_coarse_device.hip): the values they then wrote are NaN.  Every entry point
+// that has just synchronised with work that may contain such a solve reads the flag, clears it (it is sticky on the device: later waits give
+// up at once while it is set) and fails with SMG_ERR_HIP.  The stream is idle when this runs.
+static int coarse_stall_check(smg_hierarchy* h)
+{
+    if (!h->coarse_sparse || !h->c_err.p) return SMG_OK;
+    int cerr = 0;
+    HIPCHK(hipMemcpy(&cerr, h->c_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (!cerr) return SMG_OK;
+    (void)hipMemset(h->c_err.p, 0, sizeof(int));
+    return fail(SMG_ERR_HIP, "the triangular solves of the sparse coarse factorisation stalled (results are NaN)");
+}
+
 int smg::check_ready(const smg_hierarchy* h, const char* who)
 {
     if (!h) return fail(SMG_ERR_INVALID, "%s: null handle", who);
@@ -968,11 +989,7 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
         for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, his[i]);  // :111
         if (cnt) std::printf("residual norm: %g\n", his[cnt - 1]);                                    // :127
     }
-    if (h->coarse_sparse) {
-        int cerr = 0;
-        HIPCHK(hipMemcpy(&cerr, h->c_err.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (cerr) { (void)hipMemset(h->c_err.p, 0, sizeof(int)); return fail(SMG_ERR_HIP, "the triangular solves of the sparse coarse factorisation stalled"); }
-    }
+    { int rc = coarse_stall_check(h); if (rc) return rc; }
     if (hc.status != 0) return fail(SMG_ERR_NONFINITE, "non-finite residual at iteration %d", cnt - 1);
     return SMG_OK;
 }
@@ -1126,7 +1143,7 @@ extern "C" int smg_bench_vcycle(smg_hierarchy* h, int lv, int k, int pre, int po
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *us_per_cycle = 1e3 * ms / reps;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipGraphExecDestroy(g);
-    return SMG_OK;
+    return coarse_stall_check(h);
 }
 
 extern "C" int smg_hierarchy_set_block_gs(smg_hierarchy* h, int min_rows)
@@ -1185,7 +1202,7 @@ extern "C" int smg_synchronize(smg_hierarchy* h)
     if (!h || h->device < 0) return fail(SMG_ERR_INVALID, "smg_synchronize: no device");
     DeviceScope dsc(h->device);
     HIPCHK(hipStreamSynchronize(h->stream));
-    return SMG_OK;
+    return coarse_stall_check(h);
 }
 
 // ------------------------------------------------------------------------------------------------ V-cycle pieces (host blocks)
@@ -1214,7 +1231,7 @@ static int get_block(smg_hierarchy* h, int lv, const double* src, int k, double*
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < Lv.n; i++)
         for (int c = 0; c < k; c++) dst[(size_t)Lv.ord.perm[i] + (size_t)c * Lv.n] = tmp[(size_t)i * k + c];
-    return SMG_OK;
+    return coarse_stall_check(h);      // (the pieces' results leave through here: a stalled coarse solve must not pass for a result)
 }
 
 static int piece_prolog(smg_hierarchy* h, int lv, int k, const char* who, bool need_coarser)

@@ -164,11 +164,12 @@ struct SparseCholDev {
     const int *rptr = nullptr, *rcol = nullptr;      // strict lower triangle by rows
     const int *cptr = nullptr, *crow = nullptr;      // ... and by columns
     const double *rval = nullptr, *cval = nullptr, *diag = nullptr;
-    double* work = nullptr;                          // 2 n: the forward solve's z, the backward solve's x
+    double* work = nullptr;                          // 2 n KC (KC = columns per pass, sparse_coarse_work_cols): the forward solve's z, the backward solve's x
     int* err = nullptr;                              // raised when a wait gave up
 };
 // u[:, c] += (L L^T)^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)
 hipError_t launch_sparse_coarse_solve(const SparseCholDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+int sparse_coarse_work_cols(int k);   // F.work must hold 2 n sparse_coarse_work_cols(k) doubles for a solve with k columns
 
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs

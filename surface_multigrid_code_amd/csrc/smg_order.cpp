@@ -390,12 +390,20 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     if (nbest > 32 || A.nnz() > 64L * A.nr) return best;
     const std::vector<int> fallback = best;
     lap("greedy", nbest);
-    if (dsatur_color(A, cur) <= nbest) best = cur;
-    compact_colors(best);
-    nbest = count_colors(best);
-    lap("dsatur", nbest);
+    // Big graphs of high degree (the scalar image of a 3-DOF system: 21 neighbours per row, 3 M rows) get first-fit plus one round of
+    // iterated greedy only: DSATUR and the class-dissolving searches are sequential, cost seconds there (13 s + 3 s at 3 M rows -- of the
+    // 18 s that first precompute took in round 3) and found nothing iterated greedy had not (15 colours either way).  Mesh levels
+    // (7 per row) and the small, wide Galerkin levels of decimated hierarchies, where a colour less is a launch less per sweep, keep
+    // the full treatment.
+    const bool heavy = A.nr > 100000 && A.nnz() > 12L * A.nr;
+    if (!heavy) {
+        if (dsatur_color(A, cur) <= nbest) best = cur;
+        compact_colors(best);
+        nbest = count_colors(best);
+        lap("dsatur", nbest);
+    }
     // two rounds of iterated greedy (Culberson): revisit class by class, can only lower the count
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < (heavy ? 1 : 2); it++) {
         const int nc = count_colors(best);
         std::vector<std::vector<int>> cls(nc);
         for (int t = 0; t < A.nr; t++) cls[best[rcm[t]]].push_back(rcm[t]);
@@ -406,6 +414,7 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     }
     nbest = count_colors(best);
     lap("iterated greedy", nbest);
+    if (heavy) return coloring_is_valid(A, best) ? best : fallback;
     // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle, 4 with an odd wheel)
     const int floor_colors = (nbest > 3 && has_odd_wheel(A)) ? 4 : 3;
     for (int guard = 0; guard < 6 && nbest > floor_colors; guard++) {

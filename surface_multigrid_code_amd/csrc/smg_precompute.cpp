@@ -276,13 +276,21 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         }
     }
     tm.lap("host: constraint slices");
-    // ---- block (3-DOF) variant?  (smg_bsr3.hpp)  Every prolongation must be Pv (x) I_3 (mg_precompute_block builds them so), no
-    // constraints (they break the Kronecker structure; 06_example_balloon_sim has none), and -- unless the caller insists -- the
-    // 3 x 3 blocks of A must be at least half full (a system like kron(S, I_3) is three scalar problems: the scalar kernels with
-    // k = 3 columns serve it better).
+    // ---- block (3-DOF) variant?  (smg_bsr3.hpp)  Every prolongation must be Pv (x) I_3 (mg_precompute_block builds them so) and --
+    // unless the caller insists -- the 3 x 3 blocks of A must be at least half full (a system like kron(S, I_3) is three scalar
+    // problems: the scalar kernels with k = 3 columns serve it better).  Constraints keep the structure when they are VERTEX-wise --
+    // all three degrees of freedom of a pinned vertex known, which is what pinning a vertex means: `unknown` then consists of whole
+    // triples, A(unknown, unknown) is a block matrix again, P_full(unknown, :) = Pv(unknown vertices, :) (x) I_3, and the column-drop
+    // cascade (:190-219) removes the three columns of a coarse vertex together (they hold the same entries) -- so the reference's
+    // slicing, run on the scalar matrices above as always, hands the block path operators it can factor like any others.  Constraints
+    // on single degrees of freedom break the structure: scalar path (the factoring below fails).
     h->bs = 1;
     for (int lv = 0; lv < L; lv++) h->lv[lv].vpat = Csr();     // bs == 3: the n_v x n_v pattern of the blocks of A_l (Level::vpat), the graph the numbering is built on
-    if (h->block_mode != 0 && !h->has_known && L >= 2 && n % 3 == 0) {
+    bool triples = h->lv[0].A.nr % 3 == 0 && n % 3 == 0;
+    if (triples && h->has_known)
+        for (size_t u = 0; u < h->unknown.size() && triples; u += 3)
+            triples = h->unknown[u] % 3 == 0 && h->unknown[u + 1] == h->unknown[u] + 1 && h->unknown[u + 2] == h->unknown[u] + 2;
+    if (h->block_mode != 0 && triples && L >= 2) {
         bool ok = true;
         for (int lv = 1; lv < L && ok; lv++) ok = kron3_factor(h->lv[lv].P, h->lv[lv].Pv);
         if (ok) {
@@ -294,7 +302,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     }
     if (h->block_mode == 3 && h->bs != 3)
         return fail(SMG_ERR_INVALID, "smg_precompute: block mode was required (smg_hierarchy_set_block_mode) but %s",
-                    h->has_known ? "constraints are given" : (n % 3 || L < 2) ? "the system is not a multi-level 3-DOF system" : "a prolongation is not of the form Pv (x) I_3");
+                    !triples ? (h->has_known ? "the constraints do not cover whole vertices (all three degrees of freedom of each pinned vertex)" : "the system is not a 3-DOF system")
+                             : L < 2 ? "the hierarchy has one level" : "a prolongation is not of the form Pv (x) I_3");
     const bool blk = h->bs == 3;
     if (!blk) for (int lv = 0; lv < L; lv++) { h->lv[lv].Pv = Csr(); h->lv[lv].PTv = Csr(); h->lv[lv].vord = Ordering(); }
     if (!blk) h->lv[0].vpat = Csr();

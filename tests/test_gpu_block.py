@@ -217,3 +217,79 @@ def test_block_images_filled_on_the_device_pass_the_same_tests():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", "not filled_on_the_device"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_block_hierarchy_with_pinned_vertices_stays_on_the_block_kernels(smg, oracle_mod, k):
+    """VERDICT r03 missing #4: the reference treats the 3-DOF system like any other matrix, constraints included
+    (src/min_quad_with_fixed_mg.cpp:137-257 on src/get_prolong.cpp:59-115 hierarchies).  Pinned VERTICES (all three DOFs known) keep the
+    3 x 3 structure: A(unknown, unknown), P_full(unknown, :) and the column-drop cascade are formed on the scalar matrices exactly as the
+    reference forms them (the oracle does the same), and the block kernels run on the result -- bit for bit the oracle on the scalar
+    matrices in the device numbering; the solve agrees with the oracle's, the pinned values come back untouched."""
+    V, F = M.read_smgm("ogre_sim.smgm")
+    V = M.normalize_unit_area(V, F)
+    rng = np.random.default_rng(21)
+    A = elastic_like_system(V, F, rng, mass=0.0)                      # no mass term: the pins are what makes the system definite
+    nv = V.shape[0]
+    pins = np.sort(rng.choice(nv, 37, replace=False))
+    known = (3 * pins[:, None] + np.arange(3)[None, :]).ravel().astype(np.int32)
+    mg = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    mg.set_block_mode("block")                                        # required: a silent scalar fallback would fail here
+    mg.precompute(A, known)
+    assert mg.block_size() == 3 and mg.rows(0) == 3 * (nv - len(pins))
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(A, known)
+    for lv in range(mg.n_levels):
+        assert mg.rows(lv) == orc.rows(lv)
+    for lv in range(1, mg.n_levels):
+        assert abs(mg.matrix(lv, "P") - orc.level_P(lv)).max() == 0       # the reference's slices and column drops, entry for entry
+    for lv in range(mg.n_levels - 1):
+        n, nc = mg.rows(lv), mg.rows(lv + 1)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        x, b, xc = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (nc, k))
+        assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm]))
+        assert np.array_equal(mg.relax(lv, b, x, 2)[perm], oi.relax(0, b[perm], x[perm], 2))
+        assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm]))
+        assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc]))
+    n = A.shape[0]
+    RHS, z0 = rng.uniform(-1, 1, (n, k)), np.zeros((n, k))
+    kv = rng.uniform(-1, 1, (len(known), k))
+    o = smg.SolveOpts(tol=1e-9, max_iter=200)
+    conv, z, rh = mg.solve(RHS, z0, kv, o)
+    conv2, z2, rh2 = orc.solve(RHS, z0, kv, tol=1e-9, max_iter=200)
+    assert conv and conv2 and abs(len(rh) - len(rh2)) <= max(2, len(rh2) // 10)
+    assert abs(rh[0] - rh2[0]) <= 1e-12 * rh2[0]
+    assert np.linalg.norm(z - z2) <= 1e-7 * np.linalg.norm(z2)
+    assert np.array_equal(z[known], kv)
+    # value-only re-precompute (a new matrix on the same pattern and pins: the 06 caller's inner loop) stays on the block path
+    A2 = A.copy(); A2.data = A.data * 1.5
+    mg.precompute(A2, known); orc.precompute(A2, known)
+    assert mg.block_size() == 3
+    conv, z, rh = mg.solve(RHS, z0, kv, o)
+    conv2, z2, rh2 = orc.solve(RHS, z0, kv, tol=1e-9, max_iter=200)
+    assert conv and conv2 and np.linalg.norm(z - z2) <= 1e-7 * np.linalg.norm(z2)
+
+
+def test_constraints_on_single_degrees_of_freedom_take_the_scalar_path(smg, oracle_mod):
+    """Per-DOF constraints break the Kronecker structure of P_full(unknown, :): auto mode falls back to the scalar kernels (same answers),
+    required block mode refuses with a message that says why."""
+    V, F = M.read_smgm("ogre_sim.smgm")
+    V = M.normalize_unit_area(V, F)
+    rng = np.random.default_rng(22)
+    A = elastic_like_system(V, F, rng, mass=5.0)
+    known = np.sort(rng.choice(A.shape[0], 30, replace=False)).astype(np.int32)
+    mg = smg.mg_precompute_block(V, F, 0.25, 100, 1)
+    Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels)]
+    mg.precompute(A, known)
+    assert mg.block_size() == 1
+    orc = oracle_mod.OracleMG(Ps); orc.precompute(A, known)
+    n = A.shape[0]
+    RHS, z0, kv = rng.uniform(-1, 1, (n, 1)), np.zeros((n, 1)), rng.uniform(-1, 1, (len(known), 1))
+    a = mg.solve(RHS, z0, kv, smg.SolveOpts(tol=1e-9, max_iter=100))
+    b = orc.solve(RHS, z0, kv, tol=1e-9, max_iter=100)
+    assert a[0] and b[0] and np.linalg.norm(a[1] - b[1]) <= 1e-7 * np.linalg.norm(b[1])
+    mg.set_block_mode("block")
+    with pytest.raises(smg.SmgError, match="whole vertices"):
+        mg.precompute(A, known)

@@ -14,7 +14,7 @@ from test_gpu_parity import smg  # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 3, 8, 64])
 def test_sparse_coarse_solver_on_small_hierarchies_matches_the_dense_one(smg, oracle_mod, k):
     """The sparse factorisation forced onto an ordinary hierarchy (coarsest level of a few thousand unknowns): coarse_solve agrees with
     the oracle's LDL^T to 1e-11, the solve takes the iterations of the dense-inverse handle and returns the same solution to 1e-9."""
@@ -38,8 +38,13 @@ def test_sparse_coarse_solver_on_small_hierarchies_matches_the_dense_one(smg, or
     assert a[0] and b[0] and len(a[2]) == len(b[2])
     assert np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
     # value-only re-precompute: the factorisation is redone from the new values (same ordering)
+    # (the refactorisation must not move the factor the captured graphs point at -- some foreign allocations in between, so that
+    #  a free + malloc of the factor buffers would not get the old addresses back)
+    import torch
+    foreign = [torch.empty(int(cs["factor_entries"]) + 17 * q, dtype=torch.float64, device="cuda") for q in range(4)]
     A2 = (p["A"] + 0.25 * sp.diags(p["A"].diagonal())).tocsr(); A2.sort_indices()
     mg.precompute(A2); dense.precompute(A2)
+    del foreign
     a, b = mg.solve(p["RHS"], p["z0"], None, o), dense.solve(p["RHS"], p["z0"], None, o)
     assert a[0] and len(a[2]) == len(b[2]) and np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
     with pytest.raises(smg.SmgError):
@@ -114,3 +119,59 @@ def test_dense_inverse_of_a_coarsest_level_beyond_8192_unknowns(smg, oracle_mod)
     rhs, z0 = rng.uniform(-1, 1, (n, 1)), np.zeros((n, 1))
     a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=5))
     assert a[0] and np.linalg.norm(A2 @ a[1] - rhs) <= 1e-9 * np.linalg.norm(rhs)
+
+
+def test_a_stalled_triangular_solve_surfaces_as_an_error_code_not_as_a_result(smg, oracle_mod):
+    """ADVICE r03 / VERDICT r03 weak #13: a wait of the sparse triangular solves that gives up raises a flag on the device.  With the flag
+    raised (test hook) the next coarse solve's waits give up at once: its values are NaN and EVERY synchronising entry point -- the piece
+    call itself, not only smg_solve_end -- returns SMG_ERR_HIP and clears the flag; the call after that is sound again."""
+    p = subdiv_problem(kind="mcf", k=8, n_sub=2)
+    mg = smg.Hierarchy.from_prolongs(p["Ps"])
+    mg.set_coarse_dense_max(0)
+    mg.precompute(p["A"])
+    nc = mg.rows(mg.n_levels - 1)
+    rng = np.random.default_rng(4)
+    B, u = rng.uniform(-1, 1, (nc, 8)), np.zeros((nc, 8))
+    good = mg.coarse_solve(B, u)
+    assert np.isfinite(good).all()
+    L = smg._lib.load()
+    assert L.smg_debug_raise_coarse_stall(mg.h) == 0
+    with pytest.raises(smg.SmgError, match="stalled"):
+        mg.coarse_solve(B, u)
+    assert np.array_equal(mg.coarse_solve(B, u), good)                                   # flag cleared, same bits as before
+    assert L.smg_debug_raise_coarse_stall(mg.h) == 0
+    with pytest.raises(smg.SmgError, match="stalled"):
+        mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-10, max_iter=10))
+    a = mg.solve(p["RHS"], p["z0"], None, smg.SolveOpts(tol=1e-10, max_iter=40))
+    assert a[0] and np.isfinite(a[1]).all()
+    dense = smg.Hierarchy.from_prolongs(p["Ps"]); dense.precompute(p["A"])
+    assert L.smg_debug_raise_coarse_stall(dense.h) != 0                                  # no sparse factor on that handle
+
+
+def test_many_columns_cost_the_sparse_triangular_solves_little_more_than_one(smg, oracle_mod):
+    """the columns of a block of <= 16 in ONE pair of launches (a lane carries one running sum per column).  15 804
+    unknowns, 1-level call: 8 columns within 3.2 x the time of one (round 3: 8 x; measured 2.5 x -- the solves are bound by the number of
+    cache-bypassing requests, so columns are cheaper, not free), 64 (four passes of 16) within 24 x (round 3: 64 x; measured 18 x);
+    values as the oracle's LDL^T, and a column's bits do not depend on how many columns travel with it."""
+    import time
+    V, F = M.read_smgm("bunny_15K_init.smgm")
+    V = M.normalize_unit_area(V, F)
+    n = V.shape[0]
+    A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+    mg = smg.Hierarchy(1)
+    mg.set_coarse_dense_max(8192)
+    mg.precompute(A)
+    assert mg.coarse_solver()["kind"] == "sparse_cholesky"
+    o1 = oracle_mod.OracleMG([]); o1.precompute(A)
+    rng = np.random.default_rng(6)
+    t = {}
+    for k in (1, 8, 64):
+        B = rng.uniform(-1, 1, (n, k))
+        got = mg.coarse_solve(B, np.zeros((n, k)))
+        ref = o1.coarse_solve(B, np.zeros((n, k)))
+        assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
+        t[k] = min(mg.bench_vcycle(0, k, 2, 2, 5) for _ in range(3))                 # a 1-level "cycle" is the coarse solve (us)
+    print("sparse triangular solves at %d unknowns: %.0f us (k = 1), %.0f us (k = 8), %.0f us (k = 64)" % (n, t[1], t[8], t[64]))
+    assert t[8] <= 3.2 * t[1] and t[64] <= 24.0 * t[1], t
+    B = rng.uniform(-1, 1, (n, 8))
+    assert np.array_equal(mg.coarse_solve(B, np.zeros((n, 8)))[:, :1], mg.coarse_solve(B[:, :1].copy(), np.zeros((n, 1))))

@@ -153,7 +153,7 @@ def test_cpp_sharded_mean_curvature_flow_example(smg_mod):
     out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "meshes", "ogre_sim.smgm"), "2", "8"], env=env, text=True, timeout=600)
     steps = re.findall(r"step (\d+): 8 columns on 1 rank\(s\) \(this rank: 8\), converged (\d) in (\d+) iterations, last residual ([0-9.eE+-]+), \|U\|\^2 = ([0-9.eE+-]+)", out)
     assert len(steps) == 2 and all(st[1] == "1" for st in steps), out[-2000:]
-    calls = int(re.search(r"reductions issued by rank 0: (\d+)", out).group(1))
+    calls = int(re.search(r"reductions issued by rank 0: (\d+) \(RCCL closure\)", out).group(1))
     assert calls >= sum(int(st[2]) for st in steps)
     # step 0 through the python mirror: same hierarchy, same matrix, the same 8 columns in one fused solve
     V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
@@ -171,6 +171,50 @@ def test_cpp_sharded_mean_curvature_flow_example(smg_mod):
     conv, z, rh = mg.solve(Mb @ Z0, Z0, None, smg.SolveOpts(tol=5e-7, max_iter=20))
     assert conv and len(rh) == int(steps[0][2])
     assert abs(float(steps[0][3]) - rh[-1]) <= 1e-5 * rh[-1]      # printed with %.6e
+
+
+def test_cpp_sharded_example_with_two_ranks_on_one_gpu(smg_mod, tmp_path):
+    """smg_solve_sharded's loop driven from C++ with WORLD SIZE 2: two processes of examples/05_mean_curvature_flow_sharded on
+    this one GPU, the reduction closure going through the host (SMG_HOST_COMM_FILE: RCCL refuses ranks that share a device).  Both ranks
+    must stop after the same iterations as the single-rank run (the break test sees the same Frobenius norm over ALL columns, reference
+    src/min_quad_with_fixed_mg.cpp:110 -- up to the order of the partial sums), and the mesh after two flow steps must agree to 1e-12."""
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers")
+    exe = os.path.join(ROOT, "examples", "05_mean_curvature_flow_sharded")
+    src = os.path.join(ROOT, "examples", "05_mean_curvature_flow_sharded.cpp")
+    libdir = os.path.join(ROOT, "surface_multigrid_code_amd", "lib")
+    if _stale(exe, [src]):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O2", src, "-I/opt/rocm/include", "-L" + libdir, "-lsmg", "-L/opt/rocm/lib", "-lrccl",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    base = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SMG_NCCL_ID_FILE", "SMG_HOST_COMM_FILE"):
+        base.pop(k, None)
+    mesh_file = os.path.join(ROOT, "tests", "golden", "meshes", "ogre_sim.smgm")
+    pat = r"step (\d+): 8 columns on (\d) rank\(s\) \(this rank: (\d)\), converged (\d) in (\d+) iterations, last residual ([0-9.eE+-]+), \|U\|\^2 = ([0-9.eE+-]+)"
+    one = subprocess.check_output([exe, mesh_file, "2", "8"], env=dict(base, SMG_HOST_COMM_FILE=str(tmp_path / "comm1")), text=True, timeout=600)
+    s1 = re.findall(pat, one)
+    assert len(s1) == 2 and all(st[1] == "1" and st[3] == "1" for st in s1) and "host closure" in one, one[-2000:]
+    comm = str(tmp_path / "comm2")
+    procs = [subprocess.Popen([exe, mesh_file, "2", "8"], env=dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", SMG_HOST_COMM_FILE=comm),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    assert all(rc == 0 for rc, _, _ in outs), [(rc, o[-500:], e[-500:]) for rc, o, e in outs]
+    s2 = re.findall(pat, outs[0][1])
+    assert len(s2) == 2 and all(st[1] == "2" and st[2] == "4" and st[3] == "1" for st in s2), outs[0][1][-2000:]
+    for a, b in zip(s1, s2):
+        assert a[4] == b[4], (a, b)                                                     # same iteration count per step
+        assert abs(float(a[5]) - float(b[5])) <= 1e-5 * float(a[5])                     # printed with %.6e
+        assert abs(float(a[6]) - float(b[6])) <= 1e-12 * float(a[6])                    # the mesh after the step
+    calls = int(re.search(r"reductions issued by rank 0: (\d+) \(host closure\)", outs[0][1]).group(1))
+    assert calls >= sum(int(st[4]) for st in s2)
 
 
 def test_eigen_adapter_against_real_eigen():

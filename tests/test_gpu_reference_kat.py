@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def test_reference_pinned_hierarchy_reproduced_on_the_gpu_box_and_solved_on(smg, oracle_mod):
     from oracle import mesh_np as M
     mg, V, F = check_subdiv_remesh_kat(smg)             # (i): asserts the 261 / 1020 / 4035 reference points and the coarse triangulation
-    assert mg.n_levels == 2 and mg.rows(1) == 261
+    assert mg.n_levels == 2 and mg.matrix(1, "P_full").shape == (V.shape[0], 261)
     # (ii) the 03-style system on the same mesh (bunny.obj has a boundary: its longest loop is pinned)
     n = V.shape[0]
     A = (-M.cotmatrix(V, F)).tocsr(); A.sort_indices()
