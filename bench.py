@@ -403,6 +403,125 @@ def block3_leg(smg, mesh, torch, with_scalar=True):
     return out
 
 
+def multi_mesh_leg(smg, mesh, torch, dev, counts=(1, 2, 4, 8), steps=300, repeats=3):
+    """BASELINE north_star: 'independent RHS columns / independent meshes shard' -- independent meshes on ONE GPU.  A mesh the size of
+    ogre.obj (19 985 vertices, the reference's 03 / 05 example mesh) is pure launch latency (16 workgroups per colour launch on 256 CUs), so
+    M independent solves -- M handles, each with its own stream (handles are thread-safe across handles), driven by M host threads -- should
+    overlap.  Reported: aggregate V-cycles/s (outer iterations of the reference's Gauss-Seidel V(2,2) cycle, graph-replayed) for M handles
+    at once, wall clock from a common start until every stream has drained, median of `repeats`; and what one handle holds in HBM."""
+    import threading
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    mg0 = smg.mg_precompute(V, F, 0.25, 500, 1)
+    Ps = [mg0.matrix(l, "P_full") for l in range(1, mg0.n_levels)]
+    Mb = mesh.massmatrix(V, F, "barycentric")
+    A = (Mb - 0.01 * mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    L = smg._lib.load()
+    live0 = int(L.smg_device_bytes_live())
+    M = max(counts)
+    handles, vecs = [], []
+    for i in range(M):
+        h = smg.Hierarchy.from_prolongs(Ps)
+        h.precompute(A)
+        rhs = torch.from_numpy(Mb @ np.random.default_rng(300 + i).uniform(-1.0, 1.0, n)).to(dev)
+        z0 = torch.zeros(n, dtype=torch.float64, device=dev)
+        handles.append(h)
+        vecs.append((rhs, z0, torch.empty_like(z0)))
+    torch.cuda.synchronize()
+    HIS = 4096
+    res = {}
+    for m in counts:
+        times = []
+        for rep_i in range(repeats + 1):          # the first round warms (graph capture per handle)
+            for i in range(m):
+                handles[i].solve_begin(vecs[i][0].data_ptr(), n, vecs[i][1].data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs"))
+                handles[i].outer_iterations(10)
+                handles[i].synchronize()
+            bar = threading.Barrier(m + 1)
+            errs = []
+
+            def work(i):
+                try:
+                    bar.wait()
+                    handles[i].outer_iterations(steps)
+                    handles[i].synchronize()
+                except Exception as e:     # noqa: BLE001
+                    errs.append(repr(e))
+            th = [threading.Thread(target=work, args=(i,)) for i in range(m)]
+            for t in th:
+                t.start()
+            bar.wait()
+            t0 = time.perf_counter()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            for i in range(m):
+                handles[i].solve_end(vecs[i][2].data_ptr(), n, max_iter=HIS)
+            if errs:
+                return {"error": errs[0]}
+            if rep_i > 0:
+                times.append(dt)
+        dt = float(np.median(times))
+        res[str(m)] = {"handles": m, "v_cycles_per_s_aggregate": m * steps / dt, "ms_per_cycle_per_handle": 1e3 * dt / steps, "wall_ms": [1e3 * t for t in times]}
+    live1 = int(L.smg_device_bytes_live())
+    base = res[str(counts[0])]["v_cycles_per_s_aggregate"]
+    del handles, vecs
+    # ---- the same M meshes as ONE block-diagonal system in ONE handle (disjoint union: P_l = diag(P_l^i), A = diag(A^i)): every launch
+    # serves all M meshes, so the launch latency is shared instead of multiplied.  Hierarchy with nVCoarsest = 100 (the coarsest level of the
+    # union is inverted densely as a whole: small coarsest levels keep that cheap); M = 1 on the same hierarchy is the baseline.
+    union = {}
+    try:
+        import scipy.sparse as sp
+        mgu0 = smg.mg_precompute(V, F, 0.25, 100, 1)
+        Pu = [mgu0.matrix(l, "P_full") for l in range(1, mgu0.n_levels)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream(dev)
+        for m in counts:
+            Psm = [sp.block_diag([P] * m, format="csr") for P in Pu] if m > 1 else Pu
+            Am = sp.block_diag([A] * m, format="csr") if m > 1 else A
+            for X in Psm:
+                X.sort_indices()
+            Am.sort_indices()
+            hu = smg.Hierarchy.from_prolongs(Psm)
+            hu.precompute(Am)
+            hu.set_stream(st.cuda_stream)
+            nn = Am.shape[0]
+            rhs = torch.from_numpy(np.concatenate([Mb @ np.random.default_rng(300 + i).uniform(-1.0, 1.0, n) for i in range(m)])).to(dev)
+            z0 = torch.zeros(nn, dtype=torch.float64, device=dev)
+            zz = torch.empty_like(z0)
+            hu.solve_begin(rhs.data_ptr(), nn, z0.data_ptr(), nn, 1, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs"))
+            hu.outer_iterations(20)
+            ts = []
+            for _ in range(repeats):
+                torch.cuda.synchronize()
+                e0.record(st)
+                hu.outer_iterations(steps)
+                e1.record(st)
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / steps)
+            hu.solve_end(zz.data_ptr(), nn, max_iter=HIS)
+            ms = float(np.median(ts))
+            union[str(m)] = {"meshes": m, "ms_per_iteration": ms, "v_cycles_per_s_aggregate": m * 1e3 / ms, "levels": hu.n_levels,
+                             "colors": [len(hu.colors(l)) - 1 for l in range(hu.n_levels - 1)], "coarsest_rows": hu.rows(hu.n_levels - 1)}
+            del hu, rhs, z0, zz
+        union["speedup_at_%d" % max(counts)] = union[str(max(counts))]["v_cycles_per_s_aggregate"] / union[str(counts[0])]["v_cycles_per_s_aggregate"]
+    except Exception as e:     # noqa: BLE001
+        union = {"error": repr(e)}
+    out = {"workload": "ogre.obj (19 985 verts, %d levels from smg_mg_precompute), M_bary + 0.01(-L), one RHS column per mesh, Gauss-Seidel V(2,2)" % mg0.n_levels,
+           "what": "M independent handles (own streams) driven by M host threads at once; wall clock until all streams drained; median of %d" % repeats,
+           "by_handles": res, "speedup_at_%d" % max(counts): res[str(max(counts))]["v_cycles_per_s_aggregate"] / base,
+           "by_handles_note": "two handles overlap (1.9 x); beyond, the aggregate FALLS: an outer iteration is one hipGraphLaunch of ~80 kernel nodes and the runtime "
+                              "enqueues them at 2.3 - 3.3 us per node under a process-wide lock, so M threads submit no faster than one (M = 8: 2.5 ms per cycle and handle "
+                              "= 8 x 80 x 3.3 us of host enqueue + the cross-queue signals); GPU_MAX_HW_QUEUES = 8 / 16 make it worse (profiles/r04_multi_mesh.txt). "
+                              "Independent meshes on one GPU belong in ONE handle: union_in_one_handle",
+           "union_in_one_handle": union,
+           "device_bytes_per_handle": (live1 - live0) // M,
+           "hierarchy_algorithmic_bytes": int(sum(12 * mg0.matrix(l, "P_full").nnz for l in range(1, mg0.n_levels)) * 2 + 12 * A.nnz)}
+    return out
+
+
 def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, smoother_kw, steps=200, warmup=20):
     """BASELINE config C4: mean-curvature-flow system on ogre.obj (05_example_mean_curvature_flow/main.cpp:57-76), k = 64 right-hand
     sides, column-sharded over the ranks: rank g owns columns [g k / N, (g+1) k / N), the hierarchy is
@@ -533,6 +652,7 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the out-of-cache roofline leg (C5, 4.19 M vertices)")
+    ap.add_argument("--no-multi-mesh", action="store_true", help="skip the leg with M independent ogre.obj-size solves on one GPU")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (ogre.obj, k = 64, column-sharded) leg")
     ap.add_argument("--no-block3", action="store_true", help="skip the block (3-DOF) leg (C3 mesh, kron(S, C3) system)")
     ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
@@ -855,6 +975,13 @@ def main():
             torch.cuda.set_stream(stream)
         except Exception as e:
             out["block3_c3"] = {"error": repr(e)}
+    # ---- independent meshes on one GPU (north_star: "independent RHS columns / independent meshes shard"), rank 0 at N = 1 only
+    if rank == 0 and world == 1 and not args.no_multi_mesh:
+        try:
+            out["multi_mesh"] = multi_mesh_leg(smg, mesh, torch, dev)
+            torch.cuda.set_stream(stream)
+        except Exception as e:
+            out["multi_mesh"] = {"error": repr(e)}
     # ---- BASELINE config C4: k = 64 columns sharded over the ranks (strong scaling; N = 1 is the curve's first point)
     if not args.no_c4:
         try:
