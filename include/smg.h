@@ -191,18 +191,18 @@ int smg_level_get_block_image(const smg_hierarchy *h, int lv, int *n_slices, int
                               int *col, double *val);
 /* relax() with MANY right-hand sides (reference k > 1 branch, src/mg_VCycle.cpp:161-177: k independent lexicographic sweeps).
  * With k a multiple of 64 the lanes of a wavefront run across the columns and a wavefront handles one row at a time, so on levels of at
- * least min_rows rows (default 100 000, or SMG_BGS_MIN_ROWS; < 0: never; SMG_BGS=0: never) a sweep runs BLOCK-sequentially: the level is
- * cut into compact blocks of <= 64 rows, blocks are coloured, one launch per block colour, and a wavefront walks its block row by row
- * with the freshly updated neighbours coming out of LDS.  That is the reference's lexicographic sweep on the numbering (block colour,
- * block, position in the block) -- per kernel bit for bit what the oracle computes on that numbering, smg_level_get_block_gs_order --
- * and moves ~3.7 instead of ~5.4 n k 8 bytes per sweep (the multi-colour order re-reads the iterate once per colour).  It is a
- * different, equally valid Gauss-Seidel order than the multi-colour one used for k < 64 and k % 64 != 0: iterates of the two paths
- * differ, converged solutions agree to the tolerance.  Changing min_rows takes effect at the next solve. */
+ * least min_rows rows (default: never; SMG_BGS_MIN_ROWS; < 0: never; SMG_BGS=0: never) a sweep can run BLOCK-wise: the level is cut into
+ * compact blocks of <= 64 rows, blocks are coloured, one launch per block colour, a workgroup keeps its block's 64 x 64 iterate values in
+ * LDS and updates the block's rows vertex colour by vertex colour.  That is the reference's lexicographic sweep on the numbering (block
+ * colour, block, vertex colour, row) -- per kernel bit for bit what the oracle computes on that numbering, smg_level_get_block_gs_order --
+ * and reads the iterate ~1.65 times per sweep instead of 3 (the multi-colour order re-reads it once per colour).  It is a different,
+ * equally valid Gauss-Seidel order than the multi-colour one used for k < 64 and k % 64 != 0: iterates of the two paths differ, converged
+ * solutions agree to the tolerance.  Changing min_rows takes effect at the next solve. */
 int smg_hierarchy_set_block_gs(smg_hierarchy *h, int min_rows);
 /* The block-sequential order of level lv as a solve with k columns would use it (after smg_precompute; builds the plan): *n_blocks,
  * *n_colors, color_ptr[n_colors + 1] (blocks per block colour), blk_ptr[n_blocks + 1] (positions per block), rows[n] (position -> row
- * in the INTERNAL numbering, smg_level_get_perm), stats[2] = {rows gathered per row beyond the iterate itself, share of the in-block
- * earlier neighbours served from LDS}.  Any pointer may be NULL.  Returns 1 when level lv sweeps block-sequentially for this k, 0 when
+ * in the INTERNAL numbering, smg_level_get_perm), stats[2] = {rows gathered per row beyond the iterate itself, share of the walk's row
+ * slots that hold a row of their own (the rest repeat one)}.  Any pointer may be NULL.  Returns 1 when level lv sweeps block-sequentially for this k, 0 when
  * it does not (nothing is written then), < 0 on error. */
 int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks, int *n_colors, int *color_ptr, int *blk_ptr, int *rows, double *stats);
 /* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).

@@ -293,7 +293,7 @@ class Hierarchy:
 
     def block_gs_order(self, lv, k):
         """None when level lv does not sweep block-sequentially for k columns, else a dict: rows (position -> internal row), blk_ptr,
-        color_ptr, rim, ring_hits"""
+        color_ptr, rim, fill"""
         nb, nc = C.c_int(), C.c_int()
         rc = self.L.smg_level_get_block_gs_order(self.h, lv, int(k), C.byref(nb), C.byref(nc), None, None, None, None)
         if rc < 0:
@@ -302,7 +302,7 @@ class Hierarchy:
             return None
         cp, bp, rows, st = np.zeros(nc.value + 1, np.int32), np.zeros(nb.value + 1, np.int32), np.zeros(self.rows(lv), np.int32), np.zeros(2)
         _chk(min(self.L.smg_level_get_block_gs_order(self.h, lv, int(k), None, None, _ip(cp), _ip(bp), _ip(rows), _dp(st)), 0), "smg_level_get_block_gs_order")
-        return {"rows": rows, "blk_ptr": bp, "color_ptr": cp, "rim": st[0], "ring_hits": st[1]}
+        return {"rows": rows, "blk_ptr": bp, "color_ptr": cp, "rim": st[0], "fill": st[1]}
 
     # ---- coarsest-level solver
     def set_coarse_dense_max(self, n_max):

@@ -7,11 +7,11 @@
 
 namespace smg {
 
-BgsPlan build_bgs(const Csr& G, int block_rows)
+BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
 {
     BgsPlan R;
     const int n = G.nr;
-    if (n == 0 || block_rows < 2) return R;
+    if (n == 0 || block_rows < 2 || block_rows > BGS_ROWS || vcp.size() < 2 || vcp.back() != n) return R;
     int nb = 0;
     const std::vector<int> part = partition_tiles(G, block_rows, &nb);
     // members of every block (ascending row)
@@ -63,120 +63,97 @@ BgsPlan build_bgs(const Csr& G, int block_rows)
     for (int c = 0; c < ncol; c++) R.color_ptr[(size_t)c + 1] += R.color_ptr[(size_t)c];
     R.blk_ptr.assign((size_t)nb + 1, 0);
     for (int q = 0; q < nb; q++) R.blk_ptr[(size_t)q + 1] = R.blk_ptr[(size_t)q] + (mptr[(size_t)blocks[(size_t)q] + 1] - mptr[(size_t)blocks[(size_t)q]]);
-    // order inside a block: breadth-first from a far end of the block (fronts of a roundish block of 60 rows are <= ~10 rows wide, so
-    // the earlier neighbours of a row sit within the last two fronts: the ring)
+    // order inside a block: vertex colour by vertex colour, ascending row inside a colour (the numbering is colour-major: ascending row
+    // IS colour-major) -- `members` is ascending already
     R.rows.assign((size_t)n, 0);
     std::vector<int> pos((size_t)n, 0);          // row -> position in the bgs order
-    parallel_for(nb, 32, [&](long q0, long q1) {
-        std::vector<int> queue, local;
-        std::vector<int> seen;
-        for (long q = q0; q < q1; q++) {
-            const int b = blocks[(size_t)q], m0 = mptr[(size_t)b], m1 = mptr[(size_t)b + 1], cnt = m1 - m0;
-            // local index of a member by binary search in the (ascending) member list
-            auto loc = [&](int row) { return (int)(std::lower_bound(members.begin() + m0, members.begin() + m1, row) - (members.begin() + m0)); };
-            auto bfs = [&](int root_local) {
-                queue.clear();
-                seen.assign((size_t)cnt, 0);
-                int next_root = root_local, scan = 0;
-                size_t head = 0;
-                while ((int)queue.size() < cnt) {
-                    if (head == queue.size()) {           // start, or another component of the block
-                        while (next_root < 0 || seen[(size_t)next_root]) next_root = scan++;
-                        seen[(size_t)next_root] = 1;
-                        queue.push_back(next_root);
-                        next_root = -1;
-                    }
-                    const int v = members[(size_t)m0 + queue[head++]];
-                    for (int p = G.ptr[(size_t)v]; p < G.ptr[(size_t)v + 1]; p++) {
-                        const int w = G.col[(size_t)p];
-                        if (part[(size_t)w] != b) continue;
-                        const int lw = loc(w);
-                        if (!seen[(size_t)lw]) { seen[(size_t)lw] = 1; queue.push_back(lw); }
-                    }
-                }
-                return queue.back();
-            };
-            const int far = bfs(0);
-            bfs(far);
-            const int base = R.blk_ptr[(size_t)q];
-            for (int t = 0; t < cnt; t++) {
-                const int row = members[(size_t)m0 + queue[(size_t)t]];
-                R.rows[(size_t)base + t] = row;
-                pos[(size_t)row] = base + t;
-            }
-        }
-    });
-    // batches per row: the same for all rows of a block; chunks of 64 entry slots
-    R.hdr.assign((size_t)nb * 4, 0);
-    std::vector<int> first_chunk((size_t)nb + 1, 0);
-    {
-        int prow_off = 0;
-        for (int q = 0; q < nb; q++) {
-            int wmax = 1;
-            for (int t = R.blk_ptr[(size_t)q]; t < R.blk_ptr[(size_t)q + 1]; t++) {
-                const int i = R.rows[(size_t)t];
-                wmax = std::max(wmax, G.ptr[(size_t)i + 1] - G.ptr[(size_t)i]);
-            }
-            const int per_row = (wmax + BGS_BATCH - 1) / BGS_BATCH;
-            if (per_row > BGS_MAX_BATCHES) return BgsPlan();
-            const int m = R.blk_ptr[(size_t)q + 1] - R.blk_ptr[(size_t)q], rows_per_chunk = 8 / per_row;
-            const int chunks = (m + rows_per_chunk - 1) / rows_per_chunk;
-            R.hdr[(size_t)q * 4 + 0] = prow_off; R.hdr[(size_t)q * 4 + 1] = m;
-            R.hdr[(size_t)q * 4 + 2] = first_chunk[(size_t)q]; R.hdr[(size_t)q * 4 + 3] = per_row;
-            first_chunk[(size_t)q + 1] = first_chunk[(size_t)q] + chunks;
-            prow_off += chunks * rows_per_chunk;
-        }
-        R.prow.assign((size_t)prow_off, 0);
-        const size_t slots = (size_t)first_chunk[(size_t)nb] * 64;
-        R.ecol.assign(slots, BGS_PAD);
-        R.eval.assign(slots, 0.0);
-        R.eentry.assign(slots, -1);
+    for (int q = 0; q < nb; q++) {
+        const int b = blocks[(size_t)q], m0 = mptr[(size_t)b], cnt = mptr[(size_t)b + 1] - m0, base = R.blk_ptr[(size_t)q];
+        for (int t = 0; t < cnt; t++) { R.rows[(size_t)base + t] = members[(size_t)m0 + t]; pos[(size_t)members[(size_t)m0 + t]] = base + t; }
     }
-    std::vector<long> rim_cnt((size_t)nb, 0), in_early((size_t)nb, 0), in_ring((size_t)nb, 0);
+    auto vcolour = [&](int row) { return (int)(std::upper_bound(vcp.begin(), vcp.end(), row) - vcp.begin()) - 1; };
+    // per block: phases = the vertex colours present, rows of a phase dealt round-robin to the waves; batches per row
+    struct Blk { int nph = 0, nb = 1; std::vector<int> ph_ptr; };      // ph_ptr: positions (relative to the block) where the phases start
+    std::vector<Blk> info((size_t)nb);
+    int lp = 1;
+    bool bad = false;
+    for (int q = 0; q < nb; q++) {
+        Blk& I = info[(size_t)q];
+        const int base = R.blk_ptr[(size_t)q], m = R.blk_ptr[(size_t)q + 1] - base;
+        if (m > BGS_ROWS) { bad = true; break; }
+        int wmax = 1, last = -1;
+        for (int t = 0; t < m; t++) {
+            const int i = R.rows[(size_t)base + t], c = vcolour(i);
+            if (c != last) { I.ph_ptr.push_back(t); last = c; }
+            wmax = std::max(wmax, G.ptr[(size_t)i + 1] - G.ptr[(size_t)i]);
+        }
+        I.ph_ptr.push_back(m);
+        I.nph = (int)I.ph_ptr.size() - 1;
+        I.nb = (wmax + BGS_BATCH - 1) / BGS_BATCH;
+        if (I.nb > BGS_MAX_BATCHES) { bad = true; break; }
+        for (int p = 0; p < I.nph; p++) lp = std::max(lp, (I.ph_ptr[(size_t)p + 1] - I.ph_ptr[(size_t)p] + BGS_WAVES - 1) / BGS_WAVES);
+    }
+    if (bad || lp > BGS_LP_MAX) return BgsPlan();
+    lp = std::max(lp, 4);
+    if (lp == 7) lp = 8;      // (the kernel is instantiated for 4, 5, 6 and 8 row slots)
+    R.lp = lp;
+    R.hdr.assign((size_t)nb * BGS_HDR, 0);
+    R.brow.assign((size_t)nb * BGS_ROWS, 0);
+    std::vector<long> unit0((size_t)nb + 1, 0), ent0((size_t)nb + 1, 0);
+    for (int q = 0; q < nb; q++) {
+        const Blk& I = info[(size_t)q];
+        unit0[(size_t)q + 1] = unit0[(size_t)q] + (long)I.nph * BGS_WAVES;
+        ent0[(size_t)q + 1] = ent0[(size_t)q] + (long)I.nph * BGS_WAVES * 64 * I.nb;
+        R.hdr[(size_t)q * BGS_HDR + 0] = (int)unit0[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 1] = I.nph;
+        R.hdr[(size_t)q * BGS_HDR + 2] = R.blk_ptr[(size_t)q + 1] - R.blk_ptr[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 3] = I.nb;
+        R.hdr[(size_t)q * BGS_HDR + 4] = (int)ent0[(size_t)q];
+    }
+    if (ent0[(size_t)nb] > 0x7fffffffl) return BgsPlan();
+    R.urow.assign((size_t)unit0[(size_t)nb] * 16, 0);
+    R.ecol.assign((size_t)ent0[(size_t)nb], BGS_PAD);
+    R.eval.assign((size_t)ent0[(size_t)nb], 0.0);
+    R.eentry.assign((size_t)ent0[(size_t)nb], -1);
+    std::vector<long> rim_cnt((size_t)nb, 0);
     std::vector<char> no_diag((size_t)nb, 0);
     parallel_for(nb, 32, [&](long q0, long q1) {
         std::vector<std::pair<int, int>> ent;     // (position of the column, entry of G)
         std::vector<int> foreign;
         for (long q = q0; q < q1; q++) {
             foreign.clear();
-            const int base = R.blk_ptr[(size_t)q], end = R.blk_ptr[(size_t)q + 1];
-            for (int t = base; t < end; t++) {
-                const int i = R.rows[(size_t)t];
-                ent.clear();
-                for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) ent.emplace_back(pos[(size_t)G.col[(size_t)p]], p);
-                std::sort(ent.begin(), ent.end());
-                const int per_row = R.hdr[(size_t)q * 4 + 3];
-                size_t s = (size_t)R.hdr[(size_t)q * 4 + 2] * 64 + (size_t)(t - base) * per_row * BGS_BATCH;
-                R.prow[(size_t)R.hdr[(size_t)q * 4 + 0] + (t - base)] = i;
-                bool diag = false;
-                for (const auto& e : ent) {
-                    const int pj = e.first, j = G.col[(size_t)e.second];
-                    int code;
-                    if (j == i) { code = BGS_DIAG; diag = true; }
-                    else if (pj >= base && pj < t) {           // earlier row of this block
-                        in_early[(size_t)q]++;
-                        if (t - pj <= BGS_RING) { code = BGS_RING0 - ((pj - base) % BGS_RING); in_ring[(size_t)q]++; }
-                        else code = j;
-                    } else {
-                        code = j;
-                        if (pj < base || pj >= end) foreign.push_back(j);
+            const Blk& I = info[(size_t)q];
+            const int base = R.blk_ptr[(size_t)q], end = R.blk_ptr[(size_t)q + 1], m = end - base;
+            for (int l = 0; l < BGS_ROWS; l++) R.brow[(size_t)q * BGS_ROWS + l] = R.rows[(size_t)base + (l < m ? l : 0)];
+            const size_t S = (size_t)I.nb * BGS_BATCH;
+            for (int p = 0; p < I.nph; p++) {
+                const int t0 = I.ph_ptr[(size_t)p], cnt = I.ph_ptr[(size_t)p + 1] - t0;
+                for (int w = 0; w < BGS_WAVES; w++) {
+                    const size_t u = (size_t)unit0[(size_t)q] + (size_t)p * BGS_WAVES + w;
+                    const size_t e0 = (size_t)ent0[(size_t)q] + ((size_t)p * BGS_WAVES + w) * 64 * I.nb;
+                    for (int r = 0; r < lp; r++) {
+                        // the wave's r-th row of the phase: local w + 4 r; beyond the phase's rows: one of its rows again
+                        int t = w + BGS_WAVES * r;
+                        const bool repeat = t >= cnt;
+                        if (repeat) t = t % cnt;
+                        const int loc = t0 + t, i = R.rows[(size_t)base + loc];
+                        R.urow[u * 16 + r] = i;
+                        R.urow[u * 16 + 8 + r] = loc;
+                        ent.clear();
+                        for (int pp = G.ptr[(size_t)i]; pp < G.ptr[(size_t)i + 1]; pp++) ent.emplace_back(pos[(size_t)G.col[(size_t)pp]], pp);
+                        std::sort(ent.begin(), ent.end());
+                        size_t s = e0 + (size_t)r * S;
+                        bool diag = false;
+                        for (const auto& e : ent) {
+                            const int pj = e.first, j = G.col[(size_t)e.second];
+                            int code;
+                            if (j == i) { code = BGS_DIAG; diag = true; }
+                            else if (pj >= base && pj < end) code = BGS_LOCAL0 - (pj - base);
+                            else { code = j; if (!repeat) foreign.push_back(j); }
+                            R.ecol[s] = code; R.eval[s] = G.val[(size_t)e.second]; R.eentry[s] = e.second;
+                            s++;
+                        }
+                        if (!diag) no_diag[(size_t)q] = 1;
                     }
-                    R.ecol[s] = code; R.eval[s] = G.val[(size_t)e.second]; R.eentry[s] = e.second;
-                    s++;
-                }
-                if (!diag) no_diag[(size_t)q] = 1;
-            }
-            {   // copies of the last row up to a whole chunk
-                const int per_row = R.hdr[(size_t)q * 4 + 3], m = end - base, rows_per_chunk = 8 / per_row;
-                const int padded = (m + rows_per_chunk - 1) / rows_per_chunk * rows_per_chunk;
-                const size_t e0 = (size_t)R.hdr[(size_t)q * 4 + 2] * 64, w = (size_t)per_row * BGS_BATCH;
-                for (int t = m; t < padded; t++) {
-                    R.prow[(size_t)R.hdr[(size_t)q * 4 + 0] + t] = R.rows[(size_t)end - 1];
-                    for (size_t z = 0; z < w; z++) {
-                        R.ecol[e0 + (size_t)t * w + z] = R.ecol[e0 + (size_t)(m - 1) * w + z];
-                        R.eval[e0 + (size_t)t * w + z] = R.eval[e0 + (size_t)(m - 1) * w + z];
-                        R.eentry[e0 + (size_t)t * w + z] = R.eentry[e0 + (size_t)(m - 1) * w + z];
-                    }
+                    for (int r = lp; r < 8; r++) { R.urow[u * 16 + r] = R.urow[u * 16]; R.urow[u * 16 + 8 + r] = R.urow[u * 16 + 8]; }
                 }
             }
             std::sort(foreign.begin(), foreign.end());
@@ -184,11 +161,11 @@ BgsPlan build_bgs(const Csr& G, int block_rows)
         }
     });
     for (char c : no_diag) if (c) return BgsPlan();
-    long rim = 0, early = 0, ring = 0;
-    for (int q = 0; q < nb; q++) { rim += rim_cnt[(size_t)q]; early += in_early[(size_t)q]; ring += in_ring[(size_t)q]; }
+    long rim = 0;
+    for (int q = 0; q < nb; q++) rim += rim_cnt[(size_t)q];
     R.n = n; R.n_blocks = nb; R.n_colors = ncol;
     R.rim = (double)rim / n;
-    R.ring_hits = early ? (double)ring / (double)early : 1.0;
+    R.fill = (double)n / ((double)unit0[(size_t)nb] * lp);
     return R;
 }
 

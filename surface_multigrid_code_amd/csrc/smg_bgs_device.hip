@@ -1,14 +1,13 @@
-// smg_bgs_device.hip -- block-sequential Gauss-Seidel sweep for blocks of 64 right-hand-side columns (plan: smg_bgs.hpp / smg_bgs.cpp).
+// smg_bgs_device.hip -- block Gauss-Seidel sweep for blocks of 64 right-hand-side columns (plan: smg_bgs.hpp / smg_bgs.cpp).
 //
-// One wavefront = one block of <= 64 rows of the level, walked row by row; one lane = one of 64 columns.  Everything about a row is
-// wave-uniform: its entries arrive through the scalar cache (a row's batch of 8 codes + 8 values is 96 contiguous bytes), the choice
-// "ring / gather / diagonal" is a scalar branch, a gather is one 512-byte segment of the row-major n x k block.
-// Memory order: the wave's own stores to u and its later gathers from u are ordered by the program (same lane, same address); rows of
-// other blocks read by this launch belong to other block colours and are not written by it.
-// Bound: HBM.  Per row and 64-column block 512 B of b, 512 B of u written, and the gathers: the row's own old value (read by the earlier
-// rows of its block: once from HBM, again from L2) plus the block's rim.  Arithmetic per row is ~8 dependent multiply-adds and a division,
-// ~0.15 us; with 16-20 waves per CU that is an order of magnitude above what the memory delivers.
+// One workgroup (4 waves) = one block of <= 64 rows of the level; one lane = one of 64 columns; the block's 64 x 64 iterate lives in LDS.
+// Everything about a row is wave-uniform: its entry codes and values are picked out of the lanes of a coalesced metadata load
+// (v_readlane, constant lane) into scalar registers; a gather is one 512-byte segment of the row-major n x k block.
+// Bound: HBM.  Per row and 64-column block: 512 B of the iterate read once (the block's own rows, in bulk at the start), 512 B of b,
+// 512 B written, and the block's rim gathered (~0.65 rows per row).
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "smg_bgs.hpp"
 #include "smg_device.hpp"
@@ -16,116 +15,112 @@
 
 namespace smg {
 
-// The walk of one block.  D: rows whose gathers are in flight (the requests of row r + D go out when row r has been stored; D <= BGS_RING,
-// see smg_bgs.hpp); NB: batches per row of this block, S = 8 NB slots per row, C = 8 / NB rows per chunk of 64 slots.
-//  * The metadata of a chunk -- 64 codes, 64 values, C rows -- is three coalesced loads (one slot per lane), requested two chunks ahead;
-//    a row's codes and values are picked out of the lanes (v_readlane, constant lane): wave-uniform, in scalar registers, no dependent
-//    scalar-load round trips in the walk (a first version that fetched them per row through the scalar cache spent 0.9 us per row).
-//  * Every vector-memory instruction of the loop is unconditional -- a slot that is not a gather requests row 0 of u (one line, resident
-//    in the CU's L1 after the first touch) and its value is never used: the compiler can then count the requests in flight exactly and
-//    wait for row r's only (with requests behind wave-uniform branches it waits for ALL of them at every use: no prefetching at all).
-//  * Blocks are padded to whole chunks with copies of their last row (smg_bgs.hpp): no tail code.  Requests beyond the last chunk
-//    repeat rows of the last chunk and are never consumed.
-template <int D, int NB>
-__device__ __forceinline__ void bgs_walk(const int* prow, const int* ecol, const double* eval, const int m, const int chunk0, const double* b,
-                                         double* u, const int ld, const size_t coff, double* ringw, const int lane)
+// The phases of one block as one of its 4 waves sees them.  LP: row slots per phase and wave; NB: batches per row, S = 8 NB entry slots.
+//  * Unit (block, phase, wave): 64 NB codes + values and 16 row words, NB + NB + 1 coalesced loads requested two phases ahead.
+//  * The memory requests of a row slot -- its S gathers and its right-hand side -- go out one PHASE ahead: slot r of phase p + 1 is
+//    requested when slot r of phase p has been stored (what is gathered from memory belongs to other blocks, which this launch does not
+//    touch: the barrier between the phases does not concern it).  Every vector-memory instruction of the loop is unconditional -- a slot
+//    that is not a gather requests row 0 of u (one line, resident in the CU's L1 after the first touch) and its value is never used: the
+//    compiler then counts the requests in flight exactly and waits for this row's only (requests behind wave-uniform branches make it
+//    wait for ALL of them at every use); the scheduling barriers keep the rows in program order.
+//  * Neighbours inside the block: xs[local][lane], old or new as the order requires -- LDS is updated in place, the rows of one phase
+//    (one vertex colour) share no entry, phases are separated by workgroup barriers.
+template <int LP, int NB>
+__device__ __forceinline__ void bgs_block(const int* urow, const int* ecol, const double* eval, const int unit0, const int nph, const int ent0,
+                                          const double* b, double* u, const int ld, const size_t coff, double (*xs)[64], const int lane, const int wave)
 {
-    constexpr int S = NB * BGS_BATCH, C = 8 / NB;
-    static_assert(C % D == 0, "the slot of a row must be a constant of the unrolled chunk");
-    const int nch = (m + C - 1) / C;
-    struct Meta { int c; double v; int r; };
-    auto load_meta = [&](const int ch) {
+    constexpr int S = NB * BGS_BATCH;
+    struct Meta { int c[NB]; double v[NB]; int r; };
+    auto load_meta = [&](const int p) {
         Meta M;
-        const size_t e = ((size_t)chunk0 + ch) * 64 + lane;
-        M.c = ecol[e];
-        M.v = eval[e];
-        M.r = prow[(size_t)ch * C + (lane & (C - 1))];
+        const size_t uu = (size_t)p * BGS_WAVES + wave;
+        const size_t e = (size_t)ent0 + uu * 64 * NB + lane;
+#pragma unroll
+        for (int h = 0; h < NB; h++) { M.c[h] = ecol[e + 64 * h]; M.v[h] = eval[e + 64 * h]; }
+        M.r = urow[((size_t)unit0 + uu) * 16 + (lane & 15)];
         return M;
     };
-    auto code_of = [](const Meta& M, const int e) { return __builtin_amdgcn_readlane(M.c, e); };
+    auto code_of = [](const Meta& M, const int e) { return __builtin_amdgcn_readlane(M.c[e / 64], e % 64); };
     auto val_of = [](const Meta& M, const int e) {
-        const long long bits = __double_as_longlong(M.v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), e), hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), e);
+        const long long bits = __double_as_longlong(M.v[e / 64]);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), e % 64), hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), e % 64);
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     };
-    double xg[D][S], bb[D];
-    int rid[D];
-    // requests of row rr of a chunk into slot s: its S gathers and its right-hand side
-    auto fetch = [&](const int s, const Meta& M, const int rr) {
-        const int row = __builtin_amdgcn_readlane(M.r, rr);
-        rid[s] = row;
-        bb[s] = b[(size_t)row * ld + coff];
+    double xg[LP][S], bb[LP];
+    int rid[LP];
+    auto fetch = [&](const int r, const Meta& M) {
+        const int row = __builtin_amdgcn_readlane(M.r, r);
+        rid[r] = row;
+        bb[r] = b[(size_t)row * ld + coff];
 #pragma unroll
         for (int t = 0; t < S; t++) {
-            const int c = code_of(M, rr * S + t);
-            xg[s][t] = u[(size_t)(c > 0 ? c : 0) * ld + coff];
+            const int c = code_of(M, r * S + t);
+            xg[r][t] = u[(size_t)(c > 0 ? c : 0) * ld + coff];
         }
     };
-    Meta cur = load_meta(0), nxt = load_meta(nch > 1 ? 1 : 0);
+    Meta cur = load_meta(0), nxt = load_meta(nph > 1 ? 1 : 0);
 #pragma unroll
-    for (int s = 0; s < D; s++) fetch(s, cur, s);
-    for (int ch = 0; ch < nch; ch++) {
-        const Meta nn = load_meta(ch + 2 < nch ? ch + 2 : nch - 1);
+    for (int r = 0; r < LP; r++) fetch(r, cur);
+    for (int p = 0; p < nph; p++) {
+        const Meta nn = load_meta(p + 2 < nph ? p + 2 : nph - 1);
 #pragma unroll
-        for (int r = 0; r < C; r++) {
-            __builtin_amdgcn_sched_barrier(0);      // rows stay in program order: the requests of row r + D go out BEHIND row r's arithmetic
-            const int s = r % D;
+        for (int r = 0; r < LP; r++) {
+            __builtin_amdgcn_sched_barrier(0);
             int cc[S];
             double vv[S], rv[S];
 #pragma unroll
             for (int t = 0; t < S; t++) { cc[t] = code_of(cur, r * S + t); vv[t] = val_of(cur, r * S + t); }
-            // ring operands (all S slots: a slot that is not a ring entry reads ring slot 0 and drops it)
+            // operands from the block's iterate (all S slots: a slot that is not a local entry reads local row 0 and drops it)
 #pragma unroll
             for (int t = 0; t < S; t++) {
-                int rs = BGS_RING0 - cc[t];
-                rs = (rs < 0 || rs > BGS_RING - 1) ? 0 : rs;
-                rv[t] = ringw[rs * 64];
+                int l = BGS_LOCAL0 - cc[t];
+                l = (l < 0 || l > BGS_ROWS - 1) ? 0 : l;
+                rv[t] = xs[l][lane];
             }
             // the row: products in ascending slot = ascending column of the bgs order, separate multiply and add
             double acc = 0.0, diag = 1.0;
 #pragma unroll
             for (int t = 0; t < S; t++) {
-                const double x = cc[t] >= 0 ? xg[s][t] : rv[t];
+                const double x = cc[t] >= 0 ? xg[r][t] : rv[t];
                 const double nacc = acc + vv[t] * x;
-                acc = (cc[t] >= 0 || cc[t] <= BGS_RING0) ? nacc : acc;
+                acc = (cc[t] >= 0 || cc[t] <= BGS_LOCAL0) ? nacc : acc;
                 diag = cc[t] == BGS_DIAG ? vv[t] : diag;
             }
-            const double nv = (bb[s] - acc) / diag;
-            const int pos = ch * C + r;
-            ringw[((pos < m ? pos : m - 1) % BGS_RING) * 64] = nv;       // (copies of the last row rewrite its slot)
-            u[(size_t)rid[s] * ld + coff] = nv;
-            // requests of row r + D
+            const double nv = (bb[r] - acc) / diag;
+            xs[__builtin_amdgcn_readlane(cur.r, 8 + r)][lane] = nv;
+            u[(size_t)rid[r] * ld + coff] = nv;
             __builtin_amdgcn_sched_barrier(0);
-            if (r + D < C) fetch(s, cur, r + D);
-            else fetch(s, nxt, r + D - C);
+            fetch(r, nxt);       // the same slot of the next phase (after the last phase: that phase's rows once more, never consumed)
         }
+        __syncthreads();
         cur = nxt;
         nxt = nn;
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void k_bgs(const int* hdr, const int* prow, const int* ecol, const double* eval, int b_begin, int b_end, int n_wg,
+template <int LP>
+__global__ __launch_bounds__(256) void k_bgs(const int* hdr, const int* brow, const int* urow, const int* ecol, const double* eval, int b_begin, int n_wg,
                                              const double* b, double* u, int ld, const int* done)
 {
-    __shared__ double ring[4][BGS_RING][64];
+    __shared__ double xs[BGS_ROWS][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (load_flag(done)) return;       // after convergence the stream's launches write nothing (60 us launches: the wait costs nothing here)
-    const int bid = xcd_remap(blockIdx.x, n_wg);
-    const int blk = __builtin_amdgcn_readfirstlane(b_begin + bid * 4 + wave);
-    if (blk >= b_end) return;
+    if (load_flag(done)) return;       // after convergence the stream's launches write nothing (uniform over the launch)
+    const int blk = b_begin + xcd_remap(blockIdx.x, n_wg);
     const size_t coff = (size_t)blockIdx.y * 64 + lane;
-    const int roff = hdr[blk * 4 + 0], m = hdr[blk * 4 + 1], chunk0 = hdr[blk * 4 + 2], nb = hdr[blk * 4 + 3];
-    double* ringw = &ring[wave][0][lane];
-    if (nb == 1) bgs_walk<D, 1>(prow + roff, ecol, eval, m, chunk0, b, u, ld, coff, ringw, lane);
-    else bgs_walk<(D >= 2 ? D / 2 : 1), 2>(prow + roff, ecol, eval, m, chunk0, b, u, ld, coff, ringw, lane);
-}
-
-static int bgs_depth()
-{
-    static const int v = getenv("SMG_BGS_DEPTH") ? atoi(getenv("SMG_BGS_DEPTH")) : 4;
-    return v;
+    const int* H = hdr + (size_t)blk * BGS_HDR;
+    const int unit0 = H[0], nph = H[1], nb = H[3], ent0 = H[4];
+    // the block's own rows, once: local row l of wave l % 4
+    {
+        double own[BGS_ROWS / BGS_WAVES];
+#pragma unroll
+        for (int q = 0; q < BGS_ROWS / BGS_WAVES; q++) own[q] = u[(size_t)brow[(size_t)blk * BGS_ROWS + wave + BGS_WAVES * q] * ld + coff];
+#pragma unroll
+        for (int q = 0; q < BGS_ROWS / BGS_WAVES; q++) xs[wave + BGS_WAVES * q][lane] = own[q];
+    }
+    __syncthreads();
+    if (nb == 1) bgs_block<LP, 1>(urow, ecol, eval, unit0, nph, ent0, b, u, ld, coff, xs, lane, wave);
+    else bgs_block<LP, 2>(urow, ecol, eval, unit0, nph, ent0, b, u, ld, coff, xs, lane, wave);
 }
 
 hipError_t launch_bgs(const BgsDev& P, int b_begin, int b_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st)
@@ -133,14 +128,15 @@ hipError_t launch_bgs(const BgsDev& P, int b_begin, int b_end, const double* b, 
     if (b_end <= b_begin) return hipSuccess;
     if (k % 64 != 0) return hipErrorInvalidValue;
     const int* done = ctrl ? &ctrl->done : never_done();
-    const int n_wg = (b_end - b_begin + 3) / 4;
+    const int n_wg = b_end - b_begin;
     const dim3 grid((unsigned)n_wg, (unsigned)(k / 64));
-#define SMG_BGS_LAUNCH(DD) hipLaunchKernelGGL((k_bgs<DD>), grid, dim3(256), 0, st, P.hdr, P.prow, P.ecol, P.eval, b_begin, b_end, n_wg, b, u, k, done)
-    switch (bgs_depth()) {
-        case 1: SMG_BGS_LAUNCH(1); break;
-        case 2: SMG_BGS_LAUNCH(2); break;
-        case 8: SMG_BGS_LAUNCH(8); break;
-        default: SMG_BGS_LAUNCH(4); break;
+#define SMG_BGS_LAUNCH(LL) hipLaunchKernelGGL((k_bgs<LL>), grid, dim3(256), 0, st, P.hdr, P.brow, P.urow, P.ecol, P.eval, b_begin, n_wg, b, u, k, done)
+    switch (P.lp) {
+        case 4: SMG_BGS_LAUNCH(4); break;
+        case 5: SMG_BGS_LAUNCH(5); break;
+        case 6: SMG_BGS_LAUNCH(6); break;
+        case 7: case 8: SMG_BGS_LAUNCH(8); break;
+        default: return hipErrorInvalidValue;
     }
 #undef SMG_BGS_LAUNCH
     return hipGetLastError();

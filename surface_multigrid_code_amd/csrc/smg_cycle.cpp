@@ -138,23 +138,23 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
     { int rc = ensure_A_int(h, lv); if (rc) return rc; }
     if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
     const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
-    BgsPlan P = build_bgs(G, std::max(rows_env, 8));
+    BgsPlan P = build_bgs(G, Lv.ord.color_ptr, std::min(std::max(rows_env, 8), (int)BGS_ROWS));
     if (P.empty()) return SMG_OK;
     std::vector<int> map(P.eentry.size());
     for (size_t i = 0; i < map.size(); i++) {
         const int e = P.eentry[i];
         map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
     }
-    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.rows.upload(P.prow)); HIPCHK(B.ecol.upload(P.ecol));
+    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.brow.upload(P.brow)); HIPCHK(B.urow.upload(P.urow)); HIPCHK(B.ecol.upload(P.ecol));
     HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map));
-    B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors;
-    B.view.hdr = B.hdr.p; B.view.prow = B.rows.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
-    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_blk_ptr = P.blk_ptr; B.rim = P.rim; B.ring_hits = P.ring_hits;
+    B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors; B.view.lp = P.lp;
+    B.view.hdr = B.hdr.p; B.view.brow = B.brow.p; B.view.urow = B.urow.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
+    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_blk_ptr = P.blk_ptr; B.rim = P.rim; B.fill = P.fill;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
     if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
     if (env_int("SMG_DEBUG_BGS", 0))
-        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, rim %.3f rows gathered per row beyond the iterate, %.1f %% of the in-block earlier neighbours from the ring\n",
-                     lv, Lv.n, P.n_blocks, P.n_colors, P.rim, 100.0 * P.ring_hits);
+        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, %d row slots per phase and wave (%.0f %% of the slots hold a row of their own), rim %.3f rows gathered per row beyond the iterate\n",
+                     lv, Lv.n, P.n_blocks, P.n_colors, P.lp, 100.0 * P.fill, P.rim);
     return SMG_OK;
 }
 
@@ -1167,7 +1167,7 @@ extern "C" int smg_level_get_block_gs_order(smg_hierarchy* h, int lv, int k, int
     if (color_ptr) std::copy(Q->color_ptr.begin(), Q->color_ptr.end(), color_ptr);
     if (blk_ptr) std::copy(Q->host_blk_ptr.begin(), Q->host_blk_ptr.end(), blk_ptr);
     if (rows) std::copy(Q->host_rows.begin(), Q->host_rows.end(), rows);
-    if (stats) { stats[0] = Q->rim; stats[1] = Q->ring_hits; }
+    if (stats) { stats[0] = Q->rim; stats[1] = Q->fill; }
     return 1;
 }
 

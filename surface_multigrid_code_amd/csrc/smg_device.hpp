@@ -135,10 +135,11 @@ hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, c
 
 // ---- Gauss-Seidel sweep for blocks of 64 right-hand-side columns: block-sequential order (smg_bgs.hpp plan, smg_bgs_device.hip kernel) ----
 struct BgsDev {
-    int n_blocks = 0, n_colors = 0;
-    const int* hdr = nullptr;         // per block: offset into prow, rows, first chunk, batches per row
-    const int* prow = nullptr;        // rows of the blocks, padded per block to whole chunks
-    const int* ecol = nullptr;        // chunks x 64 entry codes
+    int n_blocks = 0, n_colors = 0, lp = 0;   // lp: row slots per (block, vertex colour, wave)
+    const int* hdr = nullptr;         // per block BGS_HDR ints: first unit, phases, rows, batches per row, first entry slot
+    const int* brow = nullptr;        // 64 per block: row of local index l
+    const int* urow = nullptr;        // 16 per unit (block, phase, wave): rows of the row slots, their local indices
+    const int* ecol = nullptr;        // 64 NB entry codes per unit
     const double* eval = nullptr;
 };
 // the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 64)

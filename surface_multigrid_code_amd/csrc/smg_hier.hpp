@@ -96,12 +96,12 @@ struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
 };
 
 struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a level (smg_bgs.hpp)
-    DevBuf<int> hdr, rows, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
+    DevBuf<int> hdr, brow, urow, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
     DevBuf<double> eval;
     BgsDev view;
     std::vector<int> color_ptr;      // blocks of colour c
     std::vector<int> host_rows, host_blk_ptr;      // the bgs order (position -> internal row), positions per block: introspection, tests
-    double rim = 0.0, ring_hits = 0.0;
+    double rim = 0.0, fill = 0.0;
     bool tried = false;
 };
 

@@ -47,7 +47,7 @@ def test_block_gauss_seidel_is_the_lexicographic_sweep_in_the_block_order(smg, o
     rng = np.random.default_rng(5)
     for lv in range(mg.n_levels - 1):
         info = check_plan(mg, lv, k)
-        assert 0.0 < info["rim"] < 2.0 and info["ring_hits"] > 0.9
+        assert 0.0 < info["rim"] < 2.0 and 0.4 < info["fill"] <= 1.0
         n = mg.rows(lv)
         perm = mg.perm(lv)                   # internal -> caller
         order = info["rows"]                 # position -> internal

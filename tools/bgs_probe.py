@@ -19,5 +19,5 @@ for lv in range(min(3, mg.n_levels - 1)):
     info = mg.block_gs_order(lv, k)
     nnz = mg.matrix(lv, "A").nnz
     alg = 12 * nnz + 4 * (n + 1) + 24 * n * k
-    print("level %d: %7d rows  colours %7.1f us  blocks %7.1f us  (%d blocks, %d block colours, rim %.3f, ring %.3f)  algorithmic %.0f MB -> %.2f / %.2f TB/s"
-          % (lv, n, t_col, t_blk, len(info["blk_ptr"]) - 1, len(info["color_ptr"]) - 1, info["rim"], info["ring_hits"], alg / 1e6, alg / t_col / 1e6, alg / t_blk / 1e6), flush=True)
+    print("level %d: %7d rows  colours %7.1f us  blocks %7.1f us  (%d blocks, %d block colours, rim %.3f, fill %.3f)  algorithmic %.0f MB -> %.2f / %.2f TB/s"
+          % (lv, n, t_col, t_blk, len(info["blk_ptr"]) - 1, len(info["color_ptr"]) - 1, info["rim"], info["fill"], alg / 1e6, alg / t_col / 1e6, alg / t_blk / 1e6), flush=True)

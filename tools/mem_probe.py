@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""what one handle holds in HBM, stage by stage (ogre.obj): python tools/mem_probe.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import surface_multigrid_code_amd as smg
+from surface_multigrid_code_amd import mesh
+L = smg._lib.load()
+dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
+V, F = mesh.read_triangle_mesh("ogre.smgm"); V = mesh.normalize_unit_area(V, F)
+mg0 = smg.mg_precompute(V, F, 0.25, 500, 1)
+Ps = [mg0.matrix(l, "P_full") for l in range(1, mg0.n_levels)]
+Mb = mesh.massmatrix(V, F, "barycentric"); A = (Mb - 0.01 * mesh.cotmatrix(V, F)).tocsr(); A.sort_indices()
+b0 = L.smg_device_bytes_live()
+h = smg.Hierarchy.from_prolongs(Ps)
+h.precompute(A)
+b1 = L.smg_device_bytes_live()
+n = A.shape[0]
+rhs = Mb @ np.random.default_rng(1).uniform(-1, 1, n)
+h.solve(rhs, np.zeros(n), None, smg.SolveOpts(tol=1e-10, max_iter=30))
+b2 = L.smg_device_bytes_live()
+h.precompute(A)     # value-only
+b3 = L.smg_device_bytes_live()
+print("rows", [h.rows(l) for l in range(h.n_levels)])
+print("after precompute %.1f MB, after a solve %.1f MB, after a value-only re-precompute %.1f MB" % ((b1 - b0) / 1e6, (b2 - b0) / 1e6, (b3 - b0) / 1e6))
+if os.environ.get("SMG_DEBUG_MEM"): pass
