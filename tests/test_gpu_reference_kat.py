@@ -57,4 +57,4 @@ def test_reference_pinned_hierarchy_reproduced_on_the_gpu_box_and_solved_on(smg,
     conv2, z2, rh2 = orc.solve(B, z0, bval, tol=1e-9, max_iter=2000)
     assert conv and conv2 and abs(len(rh) - len(rh2)) <= max(2, len(rh2) // 10)
     assert np.linalg.norm(z - z2) <= 1e-8 * np.linalg.norm(z2)
-    assert np.array_equal(z[b], bval)
+    assert np.array_equal(np.asarray(z)[b].ravel(), bval)

@@ -90,7 +90,8 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "C3"
     A, Ps, label = block_system(smg, mesh, wl)
     res = {"workload": label + " -> kron(S, C3), DOF = 3 v + d, P (x) I_3", "nnz": int(A.nnz)}
-    for mode, sm in (("block", "gs"), ("scalar", "gs"), ("block", "hybrid_chebyshev"), ("scalar", "hybrid_chebyshev")):
+    runs = (("block", "gs"),) if "--block-only" in sys.argv else (("block", "gs"), ("scalar", "gs"), ("block", "hybrid_chebyshev"), ("scalar", "hybrid_chebyshev"))
+    for mode, sm in runs:
         res["%s_%s" % (mode, sm)] = measure(smg, torch, A, Ps, mode, sm)
     if "--json" in sys.argv:
         print(json.dumps(res))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun).  Outputs under gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -29,11 +29,23 @@ for wl in C3 C5; do
 done
 rocprofv3 --kernel-trace --stats -d $OUT/c5t -o t -- python tools/prof_kernels.py --workload C5 --reps 50 --cycles 5 > $OUT/c5t.log 2>&1
 python tools/rocpd_stats.py $OUT/c5t/t_results.db $OUT/${TAG}_c5_kernel_stats.csv > /dev/null
+# 3b. the wide (k >= 8) kernels a column-sharded job runs on every GPU: C3 with 64 and with 8 columns (8 = the 8-way shard of 64), counters + kernel table
+tools/pmc_wide.sh $TAG 64 8 > $OUT/pmc_wide.log 2>&1
+cp gpurun_out/pmc_wide/${TAG}_* $OUT/ 2>/dev/null
+# 3c. the block (3-DOF) kernels: k_bsr3<...> on the C3 x 3 system
+mkdir -p $OUT/B3
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | tr " " "_")
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/B3/pmc_$n -o p -- python tools/block3_time.py C3 --block-only > $OUT/B3/pmc_$n.log 2>&1
+done
+python tools/pmc_summary.py $OUT/B3 > $OUT/${TAG}_pmc_summary_block3.json
 python tools/make_traffic.py $OUT/${TAG}_pmc_summary_C3.json $OUT/${TAG}_pmc_summary_C5.json $TAG > $OUT/traffic.json
 # 4. where the cycle's time goes, level by level (graph replay, hipEvents): the reference's Gauss-Seidel cycle with and without the one-launch
 #    relax() of the small levels, and the Chebyshev hybrid
 { echo "== Gauss-Seidel everywhere (reference cycle)"; python tools/level_times.py 2>/dev/null; echo "== the same with SMG_TILED=0 (one launch per colour on every level)"; SMG_TILED=0 python tools/level_times.py 2>/dev/null;
   echo "== hybrid Chebyshev (GS above 300 k rows)"; SMG_TOOL_SMOOTHER=hybrid_chebyshev:300000 python tools/level_times.py 2>/dev/null; } > $OUT/${TAG}_level_times.txt
 python tools/block3_time.py C3 > $OUT/${TAG}_block3_c3.txt 2>/dev/null
-rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5  # keep the summaries only (the dbs are large)
+python tools/multi_mesh.py > $OUT/${TAG}_multi_mesh.txt 2>/dev/null
+python tools/reprecompute_time.py > $OUT/${TAG}_reprecompute.txt 2>/dev/null
+rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5 $OUT/B3  # keep the summaries only (the dbs are large)
 ls -la $OUT
