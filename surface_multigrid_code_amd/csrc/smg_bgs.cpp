@@ -13,7 +13,45 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
     const int n = G.nr;
     if (n == 0 || block_rows < 2 || block_rows > BGS_ROWS || vcp.size() < 2 || vcp.back() != n) return R;
     int nb = 0;
-    const std::vector<int> part = partition_tiles(G, block_rows, &nb);
+    std::vector<int> part = partition_tiles(G, block_rows, &nb);
+    // A block whose rim (the distinct rows of other blocks it reads) exceeds BGS_RIM_GOAL is cut in two (first / second half of a
+    // breadth-first order of its rows): the LDS image of EVERY block of the level is sized by the largest rim, and the few elongated or
+    // irregular blocks with a rim of 100+ rows would cost all the others a third of their occupancy.
+    for (int pass = 0; pass < 4; pass++) {
+        std::vector<std::vector<int>> mem((size_t)nb);
+        for (int i = 0; i < n; i++) mem[(size_t)part[(size_t)i]].push_back(i);
+        std::vector<int> fat;
+        for (int b = 0; b < nb; b++) {
+            std::vector<int> rim;
+            for (int i : mem[(size_t)b])
+                for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) if (part[(size_t)G.col[(size_t)p]] != b) rim.push_back(G.col[(size_t)p]);
+            std::sort(rim.begin(), rim.end());
+            if ((int)(std::unique(rim.begin(), rim.end()) - rim.begin()) > BGS_RIM_GOAL && mem[(size_t)b].size() >= 8) fat.push_back(b);
+        }
+        if (fat.empty()) break;
+        for (int b : fat) {
+            const std::vector<int>& M = mem[(size_t)b];
+            // breadth-first order inside the block from its first row (other components appended)
+            std::vector<int> order;
+            std::vector<char> seen(M.size(), 0);
+            auto loc = [&](int row) { return (int)(std::lower_bound(M.begin(), M.end(), row) - M.begin()); };
+            for (size_t s0 = 0; s0 < M.size(); s0++) {
+                if (seen[s0]) continue;
+                seen[s0] = 1; order.push_back((int)s0);
+                for (size_t head = order.size() - 1; head < order.size(); head++) {
+                    const int v = M[(size_t)order[head]];
+                    for (int p = G.ptr[(size_t)v]; p < G.ptr[(size_t)v + 1]; p++) {
+                        const int w = G.col[(size_t)p];
+                        if (part[(size_t)w] != b) continue;
+                        const int lw = loc(w);
+                        if (!seen[(size_t)lw]) { seen[(size_t)lw] = 1; order.push_back(lw); }
+                    }
+                }
+            }
+            for (size_t t = order.size() / 2; t < order.size(); t++) part[(size_t)M[(size_t)order[t]]] = nb;
+            nb++;
+        }
+    }
     // members of every block (ascending row)
     std::vector<int> mptr((size_t)nb + 1, 0), members((size_t)n);
     for (int i = 0; i < n; i++) mptr[(size_t)part[(size_t)i] + 1]++;
@@ -72,100 +110,102 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
         for (int t = 0; t < cnt; t++) { R.rows[(size_t)base + t] = members[(size_t)m0 + t]; pos[(size_t)members[(size_t)m0 + t]] = base + t; }
     }
     auto vcolour = [&](int row) { return (int)(std::upper_bound(vcp.begin(), vcp.end(), row) - vcp.begin()) - 1; };
-    // per block: phases = the vertex colours present, rows of a phase dealt round-robin to the waves; batches per row
-    struct Blk { int nph = 0, nb = 1; std::vector<int> ph_ptr; };      // ph_ptr: positions (relative to the block) where the phases start
+    // per block: its rim (rows of other blocks it reads, ascending), units (chunks of <= 16 rows of one vertex colour), batches per row
+    struct Blk { int nb = 1; std::vector<int> rim; std::vector<int> unit_first, unit_cnt; };      // unit_first: position relative to the block
     std::vector<Blk> info((size_t)nb);
-    int lp = 1;
-    bool bad = false;
-    for (int q = 0; q < nb; q++) {
-        Blk& I = info[(size_t)q];
-        const int base = R.blk_ptr[(size_t)q], m = R.blk_ptr[(size_t)q + 1] - base;
-        if (m > BGS_ROWS) { bad = true; break; }
-        int wmax = 1, last = -1;
-        for (int t = 0; t < m; t++) {
-            const int i = R.rows[(size_t)base + t], c = vcolour(i);
-            if (c != last) { I.ph_ptr.push_back(t); last = c; }
-            wmax = std::max(wmax, G.ptr[(size_t)i + 1] - G.ptr[(size_t)i]);
+    std::vector<char> bad((size_t)nb, 0);
+    parallel_for(nb, 32, [&](long q0, long q1) {
+        for (long q = q0; q < q1; q++) {
+            Blk& I = info[(size_t)q];
+            const int base = R.blk_ptr[(size_t)q], end = R.blk_ptr[(size_t)q + 1], m = end - base;
+            if (m > BGS_ROWS) { bad[(size_t)q] = 1; continue; }
+            int wmax = 1, last = -1, run = 0;
+            for (int t = 0; t < m; t++) {
+                const int i = R.rows[(size_t)base + t], c = vcolour(i);
+                if (c != last || run == BGS_UROWS) { I.unit_first.push_back(t); I.unit_cnt.push_back(0); last = c; run = 0; }
+                I.unit_cnt.back()++; run++;
+                int w = 0;
+                bool diag = false;
+                for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                    const int j = G.col[(size_t)p];
+                    if (j == i) { diag = true; continue; }
+                    w++;
+                    const int pj = pos[(size_t)j];
+                    if (pj < base || pj >= end) I.rim.push_back(j);
+                }
+                if (!diag) bad[(size_t)q] = 1;
+                wmax = std::max(wmax, w);
+            }
+            std::sort(I.rim.begin(), I.rim.end());
+            I.rim.erase(std::unique(I.rim.begin(), I.rim.end()), I.rim.end());
+            I.nb = (wmax + BGS_BATCH - 1) / BGS_BATCH;
+            if (I.nb > BGS_MAX_BATCHES || (int)I.rim.size() > BGS_RIM_MAX) bad[(size_t)q] = 1;
         }
-        I.ph_ptr.push_back(m);
-        I.nph = (int)I.ph_ptr.size() - 1;
-        I.nb = (wmax + BGS_BATCH - 1) / BGS_BATCH;
-        if (I.nb > BGS_MAX_BATCHES) { bad = true; break; }
-        for (int p = 0; p < I.nph; p++) lp = std::max(lp, (I.ph_ptr[(size_t)p + 1] - I.ph_ptr[(size_t)p] + BGS_WAVES - 1) / BGS_WAVES);
-    }
-    if (bad || lp > BGS_LP_MAX) return BgsPlan();
-    lp = std::max(lp, 4);
-    if (lp == 7) lp = 8;      // (the kernel is instantiated for 4, 5, 6 and 8 row slots)
-    R.lp = lp;
+    });
+    for (char c : bad) if (c) return BgsPlan();
+    int max_rim = 0;
+    for (int q = 0; q < nb; q++) max_rim = std::max(max_rim, (int)info[(size_t)q].rim.size());
+    const int XR = (BGS_ROWS + max_rim + 127) / 128 * 128;
+    R.xrows = XR;
     R.hdr.assign((size_t)nb * BGS_HDR, 0);
-    R.brow.assign((size_t)nb * BGS_ROWS, 0);
+    R.xrow.assign((size_t)nb * XR, 0);
     std::vector<long> unit0((size_t)nb + 1, 0), ent0((size_t)nb + 1, 0);
     for (int q = 0; q < nb; q++) {
         const Blk& I = info[(size_t)q];
-        unit0[(size_t)q + 1] = unit0[(size_t)q] + (long)I.nph * BGS_WAVES;
-        ent0[(size_t)q + 1] = ent0[(size_t)q] + (long)I.nph * BGS_WAVES * 64 * I.nb;
-        R.hdr[(size_t)q * BGS_HDR + 0] = (int)unit0[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 1] = I.nph;
-        R.hdr[(size_t)q * BGS_HDR + 2] = R.blk_ptr[(size_t)q + 1] - R.blk_ptr[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 3] = I.nb;
-        R.hdr[(size_t)q * BGS_HDR + 4] = (int)ent0[(size_t)q];
+        const long nu = (long)I.unit_first.size();
+        unit0[(size_t)q + 1] = unit0[(size_t)q] + nu;
+        ent0[(size_t)q + 1] = ent0[(size_t)q] + nu * BGS_UROWS * BGS_BATCH * I.nb;
+        R.hdr[(size_t)q * BGS_HDR + 0] = (int)unit0[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 1] = (int)nu;
+        R.hdr[(size_t)q * BGS_HDR + 2] = I.nb; R.hdr[(size_t)q * BGS_HDR + 3] = (int)ent0[(size_t)q];
+        R.hdr[(size_t)q * BGS_HDR + 4] = BGS_ROWS + ((int)I.rim.size() + 63) / 64 * 64;
     }
     if (ent0[(size_t)nb] > 0x7fffffffl) return BgsPlan();
-    R.urow.assign((size_t)unit0[(size_t)nb] * 16, 0);
-    R.ecol.assign((size_t)ent0[(size_t)nb], BGS_PAD);
+    const size_t NU = (size_t)unit0[(size_t)nb];
+    R.ugrow.assign(NU * BGS_UROWS, 0); R.ulrow.assign(NU * BGS_UROWS, 0); R.udiag.assign(NU * BGS_UROWS, 1.0); R.dentry.assign(NU * BGS_UROWS, -1);
+    R.eidx.assign((size_t)ent0[(size_t)nb], 0);
     R.eval.assign((size_t)ent0[(size_t)nb], 0.0);
     R.eentry.assign((size_t)ent0[(size_t)nb], -1);
-    std::vector<long> rim_cnt((size_t)nb, 0);
-    std::vector<char> no_diag((size_t)nb, 0);
     parallel_for(nb, 32, [&](long q0, long q1) {
         std::vector<std::pair<int, int>> ent;     // (position of the column, entry of G)
-        std::vector<int> foreign;
         for (long q = q0; q < q1; q++) {
-            foreign.clear();
             const Blk& I = info[(size_t)q];
             const int base = R.blk_ptr[(size_t)q], end = R.blk_ptr[(size_t)q + 1], m = end - base;
-            for (int l = 0; l < BGS_ROWS; l++) R.brow[(size_t)q * BGS_ROWS + l] = R.rows[(size_t)base + (l < m ? l : 0)];
+            int* X = &R.xrow[(size_t)q * XR];
+            for (int l = 0; l < XR; l++) X[l] = R.rows[(size_t)base];
+            for (int l = 0; l < m; l++) X[l] = R.rows[(size_t)base + l];
+            for (size_t z = 0; z < I.rim.size(); z++) X[BGS_ROWS + z] = I.rim[z];
             const size_t S = (size_t)I.nb * BGS_BATCH;
-            for (int p = 0; p < I.nph; p++) {
-                const int t0 = I.ph_ptr[(size_t)p], cnt = I.ph_ptr[(size_t)p + 1] - t0;
-                for (int w = 0; w < BGS_WAVES; w++) {
-                    const size_t u = (size_t)unit0[(size_t)q] + (size_t)p * BGS_WAVES + w;
-                    const size_t e0 = (size_t)ent0[(size_t)q] + ((size_t)p * BGS_WAVES + w) * 64 * I.nb;
-                    for (int r = 0; r < lp; r++) {
-                        // the wave's r-th row of the phase: local w + 4 r; beyond the phase's rows: one of its rows again
-                        int t = w + BGS_WAVES * r;
-                        const bool repeat = t >= cnt;
-                        if (repeat) t = t % cnt;
-                        const int loc = t0 + t, i = R.rows[(size_t)base + loc];
-                        R.urow[u * 16 + r] = i;
-                        R.urow[u * 16 + 8 + r] = loc;
-                        ent.clear();
-                        for (int pp = G.ptr[(size_t)i]; pp < G.ptr[(size_t)i + 1]; pp++) ent.emplace_back(pos[(size_t)G.col[(size_t)pp]], pp);
-                        std::sort(ent.begin(), ent.end());
-                        size_t s = e0 + (size_t)r * S;
-                        bool diag = false;
-                        for (const auto& e : ent) {
-                            const int pj = e.first, j = G.col[(size_t)e.second];
-                            int code;
-                            if (j == i) { code = BGS_DIAG; diag = true; }
-                            else if (pj >= base && pj < end) code = BGS_LOCAL0 - (pj - base);
-                            else { code = j; if (!repeat) foreign.push_back(j); }
-                            R.ecol[s] = code; R.eval[s] = G.val[(size_t)e.second]; R.eentry[s] = e.second;
-                            s++;
-                        }
-                        if (!diag) no_diag[(size_t)q] = 1;
+            for (size_t un = 0; un < I.unit_first.size(); un++) {
+                const size_t u = (size_t)unit0[(size_t)q] + un;
+                for (int r = 0; r < BGS_UROWS; r++) {
+                    const int loc = I.unit_first[un] + (r < I.unit_cnt[un] ? r : 0);        // a slot without a row of its own: the unit's first row again
+                    const int i = R.rows[(size_t)base + loc];
+                    R.ugrow[u * BGS_UROWS + r] = i;
+                    R.ulrow[u * BGS_UROWS + r] = loc;
+                    ent.clear();
+                    for (int pp = G.ptr[(size_t)i]; pp < G.ptr[(size_t)i + 1]; pp++) {
+                        if (G.col[(size_t)pp] == i) { R.udiag[u * BGS_UROWS + r] = G.val[(size_t)pp]; R.dentry[u * BGS_UROWS + r] = pp; }
+                        else ent.emplace_back(pos[(size_t)G.col[(size_t)pp]], pp);
                     }
-                    for (int r = lp; r < 8; r++) { R.urow[u * 16 + r] = R.urow[u * 16]; R.urow[u * 16 + 8 + r] = R.urow[u * 16 + 8]; }
+                    std::sort(ent.begin(), ent.end());
+                    size_t sl = (size_t)ent0[(size_t)q] + (un * BGS_UROWS + r) * S;
+                    for (const auto& e : ent) {
+                        const int pj = e.first, j = G.col[(size_t)e.second];
+                        int l;
+                        if (pj >= base && pj < end) l = pj - base;
+                        else l = BGS_ROWS + (int)(std::lower_bound(I.rim.begin(), I.rim.end(), j) - I.rim.begin());
+                        R.eidx[sl] = l; R.eval[sl] = G.val[(size_t)e.second]; R.eentry[sl] = e.second;
+                        sl++;
+                    }
                 }
             }
-            std::sort(foreign.begin(), foreign.end());
-            rim_cnt[(size_t)q] = (long)(std::unique(foreign.begin(), foreign.end()) - foreign.begin());
         }
     });
-    for (char c : no_diag) if (c) return BgsPlan();
     long rim = 0;
-    for (int q = 0; q < nb; q++) rim += rim_cnt[(size_t)q];
+    for (int q = 0; q < nb; q++) rim += (long)info[(size_t)q].rim.size();
     R.n = n; R.n_blocks = nb; R.n_colors = ncol;
     R.rim = (double)rim / n;
-    R.fill = (double)n / ((double)unit0[(size_t)nb] * lp);
+    R.fill = (double)n / ((double)NU * BGS_UROWS);
     return R;
 }
 

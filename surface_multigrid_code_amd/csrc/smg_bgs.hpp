@@ -7,20 +7,22 @@
 // launch at 5.2 TB/s, i.e. AT the memory's rate).
 //
 // Here the level is cut into compact BLOCKS of <= 64 rows (recursive breadth-first bisection, smg_tiled.cpp), the blocks are coloured
-// (blocks of one colour share no matrix entry), and a sweep is one launch per BLOCK colour in which a workgroup of 4 waves owns a block:
-// its 64 x 64 iterate values (rows x columns) are read ONCE into LDS, the block's rows are updated vertex colour by vertex colour (the
-// colours of the level's numbering; a workgroup barrier between them, the rows of a colour dealt round-robin to the waves), every
-// neighbour inside the block comes out of LDS -- old or new, whatever the order requires, because LDS is updated in place -- and only
-// the block's rim (~0.65 n rows at 60-row blocks) is gathered from memory.  Per sweep the iterate is read ~1.65 times instead of 3.
+// (blocks of one colour share no matrix entry), and a sweep is one launch per BLOCK colour in which a wavefront owns (block, 16 columns):
+// the block's rows AND its rim (the rows of other blocks it reads: ~0.65 per row) are read once, 128 B per row, into 16 KB of LDS; then
+// the lanes are 16 ROWS x 4 columns -- a lane holds its row's entries (local indices into the LDS image, values) in registers, like the
+// one-lane-per-row kernels of the k < 8 path, and re-uses them for all 16 columns -- and the block's rows are updated vertex colour by
+// vertex colour (rows of one colour share no entry), in place in LDS, so every later row finds old or new neighbours as the order
+// requires; results go straight to memory.  No barrier, no wave-uniform bookkeeping per row: that is what sank the first two designs
+// (profiles/r04_bgs_experiments.txt).  Per sweep the iterate is read ~1.65 times instead of 3.
 //
 // This IS the reference's lexicographic sweep on the numbering "block colour, block, vertex colour, row" (bgs order): per row the products
 // are added in ascending column of THAT numbering, so the oracle on the permuted system reproduces it bit for bit (tests/test_gpu_bgs.py).
 // It is another valid Gauss-Seidel order than the multi-colour one of the k < 64 kernels: iterates differ between the two paths,
 // converged solutions do not.
 //
-// (Round 4 first built the walk as ONE wave per block, row after row, the fresh neighbours in a ring in LDS: bit-exact and slower than the
-// colour launches -- 64 dependent rows of ~250 instructions per wave, 80 us per launch whatever the prefetch depth.  The vertex colours
-// inside the block cut that chain to ~20 rows per wave.)
+// (Round 4 first built the walk with lanes across the 64 COLUMNS and a wave handling one row at a time -- one wave per block with a ring of
+// fresh values, then a workgroup per block with vertex-colour phases: bit-exact both, and 1.6 - 2 x SLOWER than the colour launches,
+// ~1 us of wave-uniform control per row.)
 #pragma once
 #include <vector>
 
@@ -28,31 +30,31 @@
 
 namespace smg {
 
-constexpr int BGS_ROWS = 64;          // rows of a block at most (their iterate: 32 KB of LDS per workgroup)
-constexpr int BGS_WAVES = 4;          // waves of the workgroup that owns a block
+constexpr int BGS_ROWS = 64;          // rows of a block at most
+constexpr int BGS_RIM_GOAL = 64;      // blocks with a larger rim are cut in two by the plan (the LDS image of every block is sized by the level's largest rim)
+constexpr int BGS_RIM_MAX = 192;      // rows of other blocks a block may read at most (its rim); a level with a larger rim keeps the colour launches
+constexpr int BGS_COLS = 16;          // columns per wavefront: a wave owns (block, 16 columns); 16 x xrows doubles of LDS (16 KB at a rim of 64)
+constexpr int BGS_UROWS = 16;         // rows per unit: lanes = 16 rows x 4 columns, four passes for the wave's 16 columns
 constexpr int BGS_BATCH = 8;          // entry slots per batch (a row holds NB batches, NB the same for all rows of a block)
-constexpr int BGS_MAX_BATCHES = 2;    // per row: levels with rows of more than 16 entries keep the multi-colour launches
-constexpr int BGS_LP_MAX = 8;         // rows per (block, vertex colour, wave) at most (8 rows x 8 slots = the 64 lanes of a metadata load)
-constexpr int BGS_HDR = 5;            // ints per block header
-constexpr int BGS_PAD = -1;           // entry codes below 0: padding,
-constexpr int BGS_DIAG = -2;          //   the row's diagonal,
-constexpr int BGS_LOCAL0 = -3;        //   row l of the block's LDS iterate as BGS_LOCAL0 - l
+constexpr int BGS_MAX_BATCHES = 2;    // per row: levels with rows of more than 16 off-diagonal entries keep the multi-colour launches
+constexpr int BGS_HDR = 5;            // ints per block header: first unit, units, batches per row NB, first entry slot, local rows in use (multiple of 64)
 
 struct BgsPlan {
     int n = 0, n_blocks = 0, n_colors = 0;
-    int lp = 0;                       // rows per (block, vertex colour, wave), padded: the same for the whole level (4 .. BGS_LP_MAX)
+    int xrows = 0;                    // rows of a block's extended iterate in LDS: BGS_ROWS + the largest rim of the level, rounded up to a multiple of 128;
+                                      // local index l < BGS_ROWS: own row, else rim row l - BGS_ROWS
     std::vector<int> color_ptr;       // blocks of colour c: [color_ptr[c], color_ptr[c + 1])
     std::vector<int> blk_ptr;         // rows of block b: positions [blk_ptr[b], blk_ptr[b + 1]) of `rows`
     std::vector<int> rows;            // position in the bgs order -> row (internal numbering)
-    // ---- what the kernel reads.  A unit = one (block, phase, wave): lp row slots, 64 NB entry slots (slot = row slot * 8 NB + entry; row
-    // slots beyond lp and entries beyond the row's are padding).  A row slot the wave has no row for repeats a row of the SAME phase of the
-    // block (updating a row twice within a phase reproduces its value: its neighbours belong to other phases) -- no tail code.
-    std::vector<int> hdr;             // per block BGS_HDR ints: first unit, phases (vertex colours present), rows of the block, batches per row NB, first entry slot
-    std::vector<int> brow;            // BGS_ROWS per block: row of local index l (beyond the block's rows: its first row again)
-    std::vector<int> urow;            // 16 per unit: rows of the lp row slots [0, 8), their local indices [8, 16)
-    std::vector<int> ecol;            // 64 NB per unit: >= 0 row to gather, else BGS_*
-    std::vector<double> eval;
-    std::vector<int> eentry;          // like eval: index of the entry of G the slot holds (-1: padding) -- value refresh
+    // ---- what the kernel reads.  A unit = up to 16 rows of one vertex colour of a block (a colour of more rows takes several units); row
+    // slots without a row of their own repeat the unit's first row (the same value is computed and stored twice: harmless).
+    std::vector<int> hdr;             // per block BGS_HDR ints
+    std::vector<int> xrow;            // xrows per block: the row behind local index l (unused slots: the block's first row)
+    std::vector<int> ugrow, ulrow;    // 16 per unit: row, local index of the row
+    std::vector<double> udiag;        // 16 per unit: a_ii
+    std::vector<int> eidx;            // 16 x 8 NB per unit: local index of the entry's column (padding: 0 with value +0.0)
+    std::vector<double> eval;         //   ... its value; off-diagonal entries in ascending column of the bgs order
+    std::vector<int> eentry, dentry;  // like eval / udiag: index of the entry of G the slot holds (-1: padding) -- value refresh
     double rim = 0.0;                 // (distinct (block, foreign row) pairs) / n: what a sweep gathers beyond the iterate itself
     double fill = 0.0;                // n / row slots: the share of the walk's row updates that are not repeats
     bool empty() const { return n_blocks == 0; }
@@ -60,8 +62,8 @@ struct BgsPlan {
 
 // G: the matrix the smoother streams (A, or A^T where A is not bit-symmetric), internal numbering, structurally symmetric, diagonal stored.
 // color_ptr: the vertex colours of the level's numbering (rows of colour c: [color_ptr[c], color_ptr[c + 1]); rows of a colour share no entry).
-// Returns an empty plan when a row has no stored diagonal or more than BGS_MAX_BATCHES * BGS_BATCH entries, or a block holds more than
-// BGS_WAVES * BGS_LP_MAX rows of one colour.
+// Returns an empty plan when a row has no stored diagonal or more than BGS_MAX_BATCHES * BGS_BATCH off-diagonal entries, or a block reads
+// more than BGS_RIM_MAX rows of other blocks.
 BgsPlan build_bgs(const Csr& G, const std::vector<int>& color_ptr, int block_rows = BGS_ROWS);
 
 // compact parts of <= tile_rows rows (smg_tiled.cpp)

@@ -44,7 +44,7 @@ static const TiledDev* tiled_plan(const smg_hierarchy* h, int lv, int k, int swe
     if (!tiled_wanted(h, lv, k, sweeps)) return nullptr;
     const TiledBuf& B = h->lv[lv].tiled[sweeps];
     // k columns go through the tiles in groups of up to 3, whose iterates share the workgroup's 64 KB of LDS
-    return B.view.n_tiles > 0 && (size_t)B.view.max_ext * std::min(k, 3) * sizeof(double) <= 64 * 1024 ? &B.view : nullptr;
+    return B.view.n_tiles > 0 && (size_t)B.view.max_ext * std::min(k, 3) * sizeof(double) + TILED_LDS_STATIC <= 64 * 1024 ? &B.view : nullptr;
 }
 static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
 {
@@ -57,7 +57,7 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
     // larger ones run too few workgroups.
     static const int rows_env = env_int("SMG_TILED_ROWS", 0), nt_env = env_int("SMG_TILED_NT", 0);
     const int tile_rows0 = rows_env > 0 ? rows_env : 256;
-    constexpr int max_ext = 8192;    // 64 KB of LDS
+    constexpr int max_ext = (64 * 1024 - TILED_LDS_STATIC) / 8;    // 64 KB of LDS, the kernel's static header included
     // the matrix the smoother streams, in the internal numbering; entry -> index into the level's values in the caller's CSR order
     std::vector<int> tsrc;
     Csr AT;
@@ -101,7 +101,10 @@ int smg::refresh_tiled_values(smg_hierarchy* h)
             if (B.view.n_tiles > 0) HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
         }
         BgsBuf& Q = h->lv[lv].bgs;
-        if (Q.view.n_blocks > 0) HIPCHK(launch_gather_vals(Q.eval.p, h->lv[lv].d_Aval.p, Q.map.p, Q.eval.n, h->stream));
+        if (Q.view.n_blocks > 0) {
+            HIPCHK(launch_gather_vals(Q.eval.p, h->lv[lv].d_Aval.p, Q.map.p, Q.eval.n, h->stream));
+            HIPCHK(launch_gather_vals(Q.udiag.p, h->lv[lv].d_Aval.p, Q.mapd.p, Q.udiag.n, h->stream));
+        }
     }
     return SMG_OK;
 }
@@ -116,7 +119,7 @@ void smg::drop_tiled(smg_hierarchy* h)
 static bool bgs_wanted(const smg_hierarchy* h, int lv, int k)
 {
     static const int on = env_int("SMG_BGS", 1);
-    if (!on || h->bs != 1 || h->precision != 0 || k < 64 || k % 64 != 0 || lv < 0 || lv >= h->n_levels - 1 || h->bgs_min_rows < 0) return false;
+    if (!on || h->bs != 1 || h->precision != 0 || k < BGS_COLS || k % BGS_COLS != 0 || lv < 0 || lv >= h->n_levels - 1 || h->bgs_min_rows < 0) return false;
     if (level_kind(h, lv) != LV_GS) return false;
     return h->lv[lv].n >= h->bgs_min_rows;
 }
@@ -140,21 +143,28 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
     const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
     BgsPlan P = build_bgs(G, Lv.ord.color_ptr, std::min(std::max(rows_env, 8), (int)BGS_ROWS));
     if (P.empty()) return SMG_OK;
-    std::vector<int> map(P.eentry.size());
-    for (size_t i = 0; i < map.size(); i++) {
-        const int e = P.eentry[i];
-        map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
-    }
-    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.brow.upload(P.brow)); HIPCHK(B.urow.upload(P.urow)); HIPCHK(B.ecol.upload(P.ecol));
-    HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map));
-    B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors; B.view.lp = P.lp;
-    B.view.hdr = B.hdr.p; B.view.brow = B.brow.p; B.view.urow = B.urow.p; B.view.ecol = B.ecol.p; B.view.eval = B.eval.p;
+    auto to_level_value = [&](const std::vector<int>& entries) {
+        std::vector<int> m(entries.size());
+        for (size_t i = 0; i < m.size(); i++) {
+            const int e = entries[i];
+            m[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
+        }
+        return m;
+    };
+    const std::vector<int> map = to_level_value(P.eentry), mapd = to_level_value(P.dentry);
+    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.xrow.upload(P.xrow)); HIPCHK(B.ugrow.upload(P.ugrow)); HIPCHK(B.ulrow.upload(P.ulrow)); HIPCHK(B.udiag.upload(P.udiag));
+    HIPCHK(B.eidx.upload(P.eidx)); HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map)); HIPCHK(B.mapd.upload(mapd));
+    B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors; B.view.xrows = P.xrows;
+    B.view.hdr = B.hdr.p; B.view.xrow = B.xrow.p; B.view.ugrow = B.ugrow.p; B.view.ulrow = B.ulrow.p; B.view.udiag = B.udiag.p; B.view.eidx = B.eidx.p; B.view.eval = B.eval.p;
     B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_blk_ptr = P.blk_ptr; B.rim = P.rim; B.fill = P.fill;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
-    if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
+    if (h->host_stale && Lv.d_Aval.p) {
+        HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
+        HIPCHK(launch_gather_vals(B.udiag.p, Lv.d_Aval.p, B.mapd.p, B.udiag.n, h->stream));
+    }
     if (env_int("SMG_DEBUG_BGS", 0))
-        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, %d row slots per phase and wave (%.0f %% of the slots hold a row of their own), rim %.3f rows gathered per row beyond the iterate\n",
-                     lv, Lv.n, P.n_blocks, P.n_colors, P.lp, 100.0 * P.fill, P.rim);
+        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, %.0f %% of the units' row slots hold a row of their own, rim %.3f rows read per row beyond the iterate, LDS image of %d rows\n",
+                     lv, Lv.n, P.n_blocks, P.n_colors, 100.0 * P.fill, P.rim, P.xrows);
     return SMG_OK;
 }
 

@@ -135,14 +135,16 @@ hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, c
 
 // ---- Gauss-Seidel sweep for blocks of 64 right-hand-side columns: block-sequential order (smg_bgs.hpp plan, smg_bgs_device.hip kernel) ----
 struct BgsDev {
-    int n_blocks = 0, n_colors = 0, lp = 0;   // lp: row slots per (block, vertex colour, wave)
-    const int* hdr = nullptr;         // per block BGS_HDR ints: first unit, phases, rows, batches per row, first entry slot
-    const int* brow = nullptr;        // 64 per block: row of local index l
-    const int* urow = nullptr;        // 16 per unit (block, phase, wave): rows of the row slots, their local indices
-    const int* ecol = nullptr;        // 64 NB entry codes per unit
-    const double* eval = nullptr;
+    int n_blocks = 0, n_colors = 0, xrows = 0;   // xrows: rows of a block's LDS image (own rows + the level's largest rim, a multiple of 128)
+    const int* hdr = nullptr;         // per block BGS_HDR ints: first unit, units, batches per row, first entry slot, local rows in use
+    const int* xrow = nullptr;        // xrows per block: the row behind local index l (own rows, then the rim)
+    const int* ugrow = nullptr;       // 16 per unit: row, ...
+    const int* ulrow = nullptr;       //   ... its local index, ...
+    const double* udiag = nullptr;    //   ... its diagonal entry
+    const int* eidx = nullptr;        // 16 x 8 NB per unit: local index of the entry's column
+    const double* eval = nullptr;     //   ... its value
 };
-// the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 64)
+// the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 16)
 hipError_t launch_bgs(const BgsDev& P, int b_begin, int b_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 
 // ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------

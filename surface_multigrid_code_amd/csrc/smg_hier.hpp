@@ -96,8 +96,8 @@ struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
 };
 
 struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a level (smg_bgs.hpp)
-    DevBuf<int> hdr, brow, urow, ecol, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
-    DevBuf<double> eval;
+    DevBuf<int> hdr, xrow, ugrow, ulrow, eidx, map, mapd;   // map / mapd: value slot / diagonal slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
+    DevBuf<double> eval, udiag;
     BgsDev view;
     std::vector<int> color_ptr;      // blocks of colour c
     std::vector<int> host_rows, host_blk_ptr;      // the bgs order (position -> internal row), positions per block: introspection, tests

@@ -27,6 +27,7 @@ constexpr int TILED_THREADS = 512; // threads of a tile's workgroup = most rows 
 //   [4 + d] rows of the colour within d rings of the tile, d = 0 .. TILED_PMAX
 constexpr int TILED_CSTRIDE = 4 + TILED_PMAX + 1;
 constexpr int TILED_HDR = 4 + TILED_NCMAX * TILED_CSTRIDE;
+constexpr int TILED_LDS_STATIC = 512;   // bytes of static LDS of k_tiled_gs (the tile header, TILED_HDR ints) on top of the dynamic iterate: counted in every LDS bound
 
 struct TiledGs {
     int n_tiles = 0, nc = 0, sweeps = 0, P = 0, max_ext = 0;

@@ -123,7 +123,8 @@ static void launch_tiled_one(const TiledDev& Tl, const double* x, const double* 
 // columns go through in groups of up to 3 (the mean-curvature-flow callers' k = 3 is one launch)
 hipError_t launch_tiled_gs(const TiledDev& Tl, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st)
 {
-    if (Tl.n_tiles <= 0 || k < 1 || (size_t)Tl.max_ext * (k < 3 ? k : 3) * sizeof(double) > 64 * 1024) return hipErrorInvalidValue;
+    // dynamic LDS (the extended tile's iterate) + the kernel's static header words must fit the 64 KB a workgroup gets without further ado
+    if (Tl.n_tiles <= 0 || k < 1 || (size_t)Tl.max_ext * (k < 3 ? k : 3) * sizeof(double) + TILED_LDS_STATIC > 64 * 1024) return hipErrorInvalidValue;
     const int* done = ctrl ? &ctrl->done : never_done();
     for (int c = 0; c < k; c += 3) {
         const int kb = k - c < 3 ? k - c : 3;
@@ -138,7 +139,7 @@ hipError_t launch_tiled_gs(const TiledDev& Tl, const double* x, const double* b,
 hipError_t tiled_gs_prepare(int max_ext)
 {
     // the plans are built with at most 8192 local rows: 64 KB of LDS, what a workgroup may ask for without further ado
-    return max_ext * (int)sizeof(double) <= 64 * 1024 ? hipSuccess : hipErrorInvalidValue;
+    return (size_t)max_ext * sizeof(double) + TILED_LDS_STATIC <= 64 * 1024 ? hipSuccess : hipErrorInvalidValue;
 }
 
 }  // namespace smg
