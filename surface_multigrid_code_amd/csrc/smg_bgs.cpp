@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <queue>
 
 namespace smg {
 
@@ -76,20 +77,60 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
             a.erase(std::unique(a.begin(), a.end()), a.end());
         }
     });
-    // greedy colouring, blocks of many neighbours first (ties: bisection order); blocks of one colour share no entry of G
-    std::vector<int> order((size_t)nb), colour((size_t)nb, -1);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return adj[(size_t)a].size() > adj[(size_t)b].size(); });
+    // Colouring of the block graph (blocks of one colour share no entry of G): DSATUR -- always the block that sees the most colours, ties
+    // by degree, then index -- followed by attempts to empty the smallest class (a block moves to another colour none of its neighbours
+    // has).  Every colour is a launch with its own ramp and tail, and first-fit left a fifth and a sixth class of a few blocks each.
+    std::vector<int> colour((size_t)nb, -1);
     int ncol = 0;
     {
-        std::vector<int> mark;
-        for (int b : order) {
-            mark.assign((size_t)ncol + 1, 0);
-            for (int o : adj[(size_t)b]) if (colour[(size_t)o] >= 0) mark[(size_t)colour[(size_t)o]] = 1;
+        std::vector<unsigned> seen((size_t)nb, 0u);       // bit c: a neighbour has colour c (c < 32)
+        std::vector<int> nsat((size_t)nb, 0);
+        std::vector<char> done((size_t)nb, 0);
+        // buckets by saturation would be O(n); with ~16 k blocks a scan per step of a priority queue with lazy deletion is plenty
+        struct E { int sat, deg, b; bool operator<(const E& o) const { return sat != o.sat ? sat < o.sat : (deg != o.deg ? deg < o.deg : b > o.b); } };
+        std::priority_queue<E> pq;
+        for (int b = 0; b < nb; b++) pq.push({0, (int)adj[(size_t)b].size(), b});
+        while (!pq.empty()) {
+            const E e = pq.top();
+            pq.pop();
+            if (done[(size_t)e.b] || e.sat != nsat[(size_t)e.b]) continue;
             int c = 0;
-            while (mark[(size_t)c]) c++;
-            colour[(size_t)b] = c;
+            while (c < 31 && (seen[(size_t)e.b] >> c & 1u)) c++;
+            colour[(size_t)e.b] = c;
+            done[(size_t)e.b] = 1;
             ncol = std::max(ncol, c + 1);
+            for (int o : adj[(size_t)e.b])
+                if (!done[(size_t)o] && !(seen[(size_t)o] >> c & 1u)) { seen[(size_t)o] |= 1u << c; nsat[(size_t)o]++; pq.push({nsat[(size_t)o], (int)adj[(size_t)o].size(), o}); }
+        }
+        if (ncol >= 31) return BgsPlan();
+        // empty the smallest class while that works
+        for (int guard = 0; guard < 8 && ncol > 3; guard++) {
+            std::vector<int> cnt((size_t)ncol, 0);
+            for (int b = 0; b < nb; b++) cnt[(size_t)colour[(size_t)b]]++;
+            const int small = (int)(std::min_element(cnt.begin(), cnt.end()) - cnt.begin());
+            bool all_moved = true;
+            for (int b = 0; b < nb; b++) {
+                if (colour[(size_t)b] != small) continue;
+                unsigned used = 0u;
+                for (int o : adj[(size_t)b]) used |= 1u << colour[(size_t)o];
+                int c = -1;
+                for (int t = 0; t < ncol; t++) if (t != small && !(used >> t & 1u)) { c = t; break; }
+                if (c < 0) {     // one exchange deep: a neighbour of the only blocking colour may itself move elsewhere
+                    for (int t = 0; t < ncol && c < 0; t++) {
+                        if (t == small) continue;
+                        int blocker = -1, nblock = 0;
+                        for (int o : adj[(size_t)b]) if (colour[(size_t)o] == t) { blocker = o; nblock++; }
+                        if (nblock != 1) continue;
+                        unsigned u2 = 1u << small;
+                        for (int o : adj[(size_t)blocker]) u2 |= 1u << colour[(size_t)o];
+                        for (int t2 = 0; t2 < ncol; t2++) if (t2 != t && !(u2 >> t2 & 1u)) { colour[(size_t)blocker] = t2; c = t; break; }
+                    }
+                }
+                if (c >= 0) colour[(size_t)b] = c; else all_moved = false;
+            }
+            if (!all_moved) break;
+            for (int b = 0; b < nb; b++) if (colour[(size_t)b] > small) colour[(size_t)b]--;
+            ncol--;
         }
     }
     // blocks in the order (colour, bisection id): neighbours in space stay neighbours in the launch (shared rims meet in one L2)

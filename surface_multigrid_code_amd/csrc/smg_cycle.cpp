@@ -113,9 +113,9 @@ void smg::drop_tiled(smg_hierarchy* h)
     for (auto& Lv : h->lv) { for (auto& B : Lv.tiled) B = TiledBuf(); Lv.bgs = BgsBuf(); }
 }
 
-// ---- block-sequential Gauss-Seidel for solves with a multiple of 64 columns (smg_bgs.hpp): one launch per BLOCK colour -----------------
-// Which levels: scalar fp64 hierarchies, Gauss-Seidel, k % 64 == 0, at least bgs_min_rows rows (smg_hierarchy_set_block_gs; default
-// 100 000, SMG_BGS_MIN_ROWS; SMG_BGS=0 switches it off).  Below, a sweep is a few launches of a few microseconds: nothing to win.
+// ---- block Gauss-Seidel for solves with a multiple of 16 columns (smg_bgs.hpp): one launch per BLOCK colour -----------------
+// Which levels: scalar fp64 hierarchies, Gauss-Seidel, k % 16 == 0, at least bgs_min_rows rows (smg_hierarchy_set_block_gs; default: never;
+// SMG_BGS_MIN_ROWS; SMG_BGS=0 switches it off).  Measured at C3 (tools/bgs_cycle.py): worth it from ~500 000 rows on.
 static bool bgs_wanted(const smg_hierarchy* h, int lv, int k)
 {
     static const int on = env_int("SMG_BGS", 1);
@@ -141,7 +141,9 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
     { int rc = ensure_A_int(h, lv); if (rc) return rc; }
     if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
     const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
+    const auto t_plan0 = std::chrono::steady_clock::now();
     BgsPlan P = build_bgs(G, Lv.ord.color_ptr, std::min(std::max(rows_env, 8), (int)BGS_ROWS));
+    const double plan_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan0).count();
     if (P.empty()) return SMG_OK;
     auto to_level_value = [&](const std::vector<int>& entries) {
         std::vector<int> m(entries.size());
@@ -163,8 +165,8 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
         HIPCHK(launch_gather_vals(B.udiag.p, Lv.d_Aval.p, B.mapd.p, B.udiag.n, h->stream));
     }
     if (env_int("SMG_DEBUG_BGS", 0))
-        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, %.0f %% of the units' row slots hold a row of their own, rim %.3f rows read per row beyond the iterate, LDS image of %d rows\n",
-                     lv, Lv.n, P.n_blocks, P.n_colors, 100.0 * P.fill, P.rim, P.xrows);
+        std::fprintf(stderr, "block Gauss-Seidel level %d: %d rows, %d blocks in %d colours, %.0f %% of the units' row slots hold a row of their own, rim %.3f rows read per row beyond the iterate, LDS image of %d rows; plan built in %.0f ms\n",
+                     lv, Lv.n, P.n_blocks, P.n_colors, 100.0 * P.fill, P.rim, P.xrows, plan_ms);
     return SMG_OK;
 }
 

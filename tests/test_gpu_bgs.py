@@ -1,4 +1,4 @@
-"""GPU (-m gpu): relax() for blocks of 64 right-hand-side columns -- block-sequential Gauss-Seidel (csrc/smg_bgs.hpp).
+"""GPU (-m gpu): relax() for many right-hand-side columns (k a multiple of 16) -- block Gauss-Seidel (csrc/smg_bgs.hpp).
 
 The reference's relax() with k > 1 columns (src/mg_VCycle.cpp:161-177) is k independent lexicographic sweeps.  With k % 64 == 0 libsmg
 sweeps big levels in the order (block colour, block, position in the block): the checker is the oracle -- the reference's lexicographic
@@ -38,7 +38,7 @@ def check_plan(mg, lv, k):
     return info
 
 
-@pytest.mark.parametrize("kind,k", [("mcf", 64), ("poisson", 128)])
+@pytest.mark.parametrize("kind,k", [("mcf", 64), ("poisson", 128), ("mcf", 16), ("poisson", 48)])
 def test_block_gauss_seidel_is_the_lexicographic_sweep_in_the_block_order(smg, oracle_mod, kind, k):
     p = subdiv_problem(kind=kind, k=k, n_sub=2, n_pins=40 if kind == "poisson" else 0)
     mg = smg.Hierarchy.from_prolongs(p["Ps"])
@@ -58,7 +58,7 @@ def test_block_gauss_seidel_is_the_lexicographic_sweep_in_the_block_order(smg, o
             got = mg.relax(lv, b, x, iters)[to_bgs]
             ref = oi.relax(0, b[to_bgs], x[to_bgs], iters)
             assert np.array_equal(got, ref), "block Gauss-Seidel not bit-exact on level %d (%d sweeps)" % (lv, iters)
-    # fewer columns, or not a multiple of 64: the multi-colour path, untouched
+    # fewer columns, or not a multiple of 16: the multi-colour path, untouched
     assert mg.block_gs_order(0, 8) is None and mg.block_gs_order(0, 40) is None
     mg.set_block_gs(-1)
     assert mg.block_gs_order(0, k) is None
