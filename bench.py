@@ -335,6 +335,7 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
     z0 = torch.zeros_like(rhs)
     red = reduce_closure(world, stream_ar)
     opts = smg.SolveOpts(tol=tol, max_iter=60, smoother="gs")
+    block_gs = None
     sharded_solve_native(mg, rhs if kl else None, z0 if kl else None, red, None, opts)      # warm: graph capture for this k
     torch.cuda.synchronize()
     if world > 1:
@@ -362,6 +363,25 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
         zt = torch.empty_like(z0)
         mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
         ms = float(np.median(times)) / steps
+        # the same job with the block Gauss-Seidel sweeps on the fine level (smg_hierarchy_set_block_gs, an option: another valid sweep order,
+        # the iterate read ~1.65 instead of 3 times per sweep); only where this rank's column count is a multiple of 16
+        if kl % 16 == 0 and kl >= 16 and world == 1:
+            try:
+                mg.set_block_gs(500000)
+                cb, rhb = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), zt.data_ptr(), n, kl, opts=opts)
+                mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs"))
+                block(warmup)
+                tb = timed_repeats(torch, dist, world, dev, stream, block, steps, repeats)
+                mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
+                info = mg.block_gs_order(0, kl)
+                block_gs = {"ms_per_step": float(np.median(tb)) / steps, "cycles_to_tol": len(rhb) - 1, "converged": bool(cb), "levels": [0],
+                            "blocks": len(info["blk_ptr"]) - 1, "block_colours": len(info["color_ptr"]) - 1, "rim_rows_per_row": info["rim"],
+                            "relax1_level0_us": {"block": mg.bench_relax(0, kl, 1, 10)}}
+                mg.set_block_gs(-1)
+                block_gs["relax1_level0_us"]["multi_colour"] = mg.bench_relax(0, kl, 1, 10)
+            except Exception as e:   # noqa: BLE001
+                block_gs = {"error": repr(e)}
+                mg.set_block_gs(-1)
     same = True
     if world > 1:
         hbuf = torch.zeros(64, dtype=torch.float64, device=dev)
@@ -384,6 +404,7 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
             "bytes_per_step": int(mg.vcycle_bytes(kl, 2, 2)) if kl else None,
             "gbs": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9) if (kl and ms) else None,
             "frac": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kl and ms) else None,
+            "block_gs_option": block_gs,
             "solve": {"tol": tol, "converged": bool(conv), "cycles": len(rh) - 1, "wall_ms": 1e3 * wall, "same_history_on_all_ranks": same,
                       "final_residual": float(rh[-1]) if len(rh) else None}}
 

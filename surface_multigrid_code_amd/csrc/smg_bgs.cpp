@@ -1,4 +1,4 @@
-// smg_bgs.cpp -- host side of the block-sequential Gauss-Seidel sweep for many right-hand sides (smg_bgs.hpp): blocks, block colours,
+// smg_bgs.cpp -- host side of the block Gauss-Seidel sweep for many right-hand sides (smg_bgs.hpp): blocks, block colours,
 // the order inside a block, the per-row entry batches in ascending column of the bgs order.
 #include "smg_bgs.hpp"
 

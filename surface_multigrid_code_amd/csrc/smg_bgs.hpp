@@ -1,4 +1,4 @@
-// smg_bgs.hpp -- relax() for MANY right-hand sides (k a multiple of 64): block Gauss-Seidel with the block's iterate in LDS.
+// smg_bgs.hpp -- relax() for MANY right-hand sides (k a multiple of 16): block Gauss-Seidel with the block's iterate in LDS.
 //
 // The reference's relax() with k > 1 (src/mg_VCycle.cpp:161-177) is k independent lexicographic sweeps.  With one lane per COLUMN a
 // wavefront works on one row at a time (k_sell_wide, KW = 64) and the multi-colour order of the narrow kernels costs this path 5.4 n k 8
@@ -17,7 +17,7 @@
 //
 // This IS the reference's lexicographic sweep on the numbering "block colour, block, vertex colour, row" (bgs order): per row the products
 // are added in ascending column of THAT numbering, so the oracle on the permuted system reproduces it bit for bit (tests/test_gpu_bgs.py).
-// It is another valid Gauss-Seidel order than the multi-colour one of the k < 64 kernels: iterates differ between the two paths,
+// It is another valid Gauss-Seidel order than the multi-colour one of the other kernels: iterates differ between the two paths,
 // converged solutions do not.
 //
 // (Round 4 first built the walk with lanes across the 64 COLUMNS and a wave handling one row at a time -- one wave per block with a ring of
