@@ -366,6 +366,10 @@ long smg_vcycle_bytes(const smg_hierarchy *h, int k, int pre, int post);
  * *n_tiles = 0: the level does not qualify for tiling (too many colours, rows wider than 12 entries). */
 int smg_debug_check_tiling_plan(smg_hierarchy *h, int lv, int sweeps, int tile_rows, int *n_tiles, int *max_ext_rows, double *redundancy,
                                 double *max_abs_diff);
+/* Test hook: builds the block Gauss-Seidel plan of level lv (smg_hierarchy_set_block_gs) on the host and executes it on the host the way the
+ * kernel does, against the plain lexicographic sweep in the block order; *max_abs_diff must be 0.  Checks the plan's invariants on the way.
+ * Needs no GPU (after the host half of smg_precompute).  *n_blocks = 0: the level does not qualify. */
+int smg_debug_check_block_gs_plan(smg_hierarchy *h, int lv, int block_rows, int *n_blocks, int *n_colors, double *rim, double *fill, double *max_abs_diff);
 /* Test hook: raises the stall flag of the sparse triangular solves on the device, as a wait that gave up would (csrc/smg_coarse_device.hip).
  * The next solve's waits then give up at once, its coarse corrections are NaN, and the next synchronising entry point returns SMG_ERR_HIP
  * and clears the flag.  Fails unless the handle holds a sparse coarse factorisation. */

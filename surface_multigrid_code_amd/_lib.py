@@ -99,6 +99,7 @@ def load():
         "smg_hierarchy_set_coarse_dense_max": (i, [vp, i]),
         "smg_hierarchy_set_block_gs": (i, [vp, i]),
         "smg_debug_raise_coarse_stall": (i, [vp]),
+        "smg_debug_check_block_gs_plan": (i, [vp, i, i, ip, ip, dp, dp, dp]),
         "smg_level_get_block_gs_order": (i, [vp, i, i, ip, ip, ip, ip, ip, dp]),
         "smg_hierarchy_coarse_solver": (i, [vp, lp]),
         "smg_hierarchy_set_block_mode": (i, [vp, i]),

@@ -583,6 +583,97 @@ extern "C" int smg_debug_check_tiling_plan(smg_hierarchy* h, int lv, int sweeps,
     });
 }
 
+// The block Gauss-Seidel plan of level lv (smg_bgs.hpp) built on the host and EXECUTED on the host the way k_bgs executes it -- per block an image
+// of its rows and its rim, units of <= 16 rows updated in place from local indices -- against the plain lexicographic sweep in the bgs order
+// (the reference's relax(), src/mg_VCycle.cpp:146-160, on that numbering): *max_abs_diff must be 0.  Also checks the plan's invariants (every row in
+// exactly one block, blocks of one colour share no entry, local indices inside the image).  Works without a GPU once the host half of
+// smg_precompute has run.  Returns SMG_OK with *n_blocks = 0 when the level does not qualify.
+extern "C" int smg_debug_check_block_gs_plan(smg_hierarchy* h, int lv, int block_rows, int* n_blocks, int* n_colors, double* rim, double* fill, double* max_abs_diff)
+{
+    return guarded("smg_debug_check_block_gs_plan", [&]() -> int {
+        if (!h || lv < 0 || lv >= h->n_levels - 1 || block_rows < 8) return fail(SMG_ERR_INVALID, "smg_debug_check_block_gs_plan: bad arguments");
+        int rc = ensure_A_int(h, lv);
+        if (rc) return rc;
+        Level& Lv = h->lv[lv];
+        if (Lv.A_int.nr != Lv.n || Lv.n == 0 || h->bs != 1) return fail(SMG_ERR_INVALID, "smg_debug_check_block_gs_plan: the host half of smg_precompute has not run (scalar hierarchies only)");
+        const Csr& G = Lv.A_int;
+        const int n = G.nr;
+        const BgsPlan P = build_bgs(G, Lv.ord.color_ptr, std::min(block_rows, (int)BGS_ROWS));
+        if (n_blocks) *n_blocks = P.n_blocks;
+        if (n_colors) *n_colors = P.n_colors;
+        if (rim) *rim = P.rim;
+        if (fill) *fill = P.fill;
+        if (max_abs_diff) *max_abs_diff = 0.0;
+        if (P.empty()) return SMG_OK;
+        // invariants
+        std::vector<int> blk_of((size_t)n, -1), col_of_blk((size_t)P.n_blocks, -1);
+        for (int c = 0; c < P.n_colors; c++) for (int q = P.color_ptr[(size_t)c]; q < P.color_ptr[(size_t)c + 1]; q++) col_of_blk[(size_t)q] = c;
+        for (int q = 0; q < P.n_blocks; q++)
+            for (int t = P.blk_ptr[(size_t)q]; t < P.blk_ptr[(size_t)q + 1]; t++) {
+                const int i = P.rows[(size_t)t];
+                if (i < 0 || i >= n || blk_of[(size_t)i] >= 0) return fail(SMG_ERR_INVALID, "block plan: row %d is not in exactly one block", i);
+                blk_of[(size_t)i] = q;
+            }
+        for (int i = 0; i < n; i++) {
+            if (blk_of[(size_t)i] < 0) return fail(SMG_ERR_INVALID, "block plan: row %d is in no block", i);
+            for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                const int j = G.col[(size_t)p];
+                if (blk_of[(size_t)j] != blk_of[(size_t)i] && col_of_blk[(size_t)blk_of[(size_t)j]] == col_of_blk[(size_t)blk_of[(size_t)i]])
+                    return fail(SMG_ERR_INVALID, "block plan: blocks %d and %d share an entry and a colour", blk_of[(size_t)i], blk_of[(size_t)j]);
+            }
+        }
+        std::vector<double> x((size_t)n), b((size_t)n), ref, y;
+        for (int i = 0; i < n; i++) { x[(size_t)i] = std::sin(0.37 * i) + 0.25 * std::cos(1.3 * i); b[(size_t)i] = std::cos(0.11 * i) - 0.5 * std::sin(2.1 * i); }
+        // reference: rows one after the other in the bgs order, products in ascending column OF THAT ORDER
+        std::vector<int> pos((size_t)n);
+        for (int t = 0; t < n; t++) pos[(size_t)P.rows[(size_t)t]] = t;
+        ref = x;
+        std::vector<std::pair<int, int>> ent;
+        for (int t = 0; t < n; t++) {
+            const int i = P.rows[(size_t)t];
+            ent.clear();
+            double diag = 1.0;
+            for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                if (G.col[(size_t)p] == i) diag = G.val[(size_t)p]; else ent.emplace_back(pos[(size_t)G.col[(size_t)p]], p);
+            }
+            std::sort(ent.begin(), ent.end());
+            double acc = 0.0;
+            for (const auto& e : ent) acc += G.val[(size_t)e.second] * ref[(size_t)G.col[(size_t)e.second]];
+            ref[(size_t)i] = (b[(size_t)i] - acc) / diag;
+        }
+        // the plan, executed like k_bgs (one column): block colour by block colour, an image per block, units in place
+        y = x;
+        std::vector<double> xs((size_t)P.xrows);
+        for (int q = 0; q < P.n_blocks; q++) {
+            const int* H = P.hdr.data() + (size_t)q * BGS_HDR;
+            const int unit0 = H[0], nu = H[1], S = H[2] * BGS_BATCH, ent0 = H[3];
+            for (int l = 0; l < P.xrows; l++) xs[(size_t)l] = y[(size_t)P.xrow[(size_t)q * P.xrows + l]];
+            for (int un = 0; un < nu; un++) {
+                double out[BGS_UROWS];
+                for (int r = 0; r < BGS_UROWS; r++) {
+                    const size_t w = ((size_t)unit0 + un) * BGS_UROWS + r, e = (size_t)ent0 + ((size_t)un * BGS_UROWS + r) * S;
+                    double acc = 0.0;
+                    for (int t = 0; t < S; t++) {
+                        const int l = P.eidx[e + t];
+                        if (l < 0 || l >= P.xrows) return fail(SMG_ERR_INVALID, "block plan: local index %d outside the image of %d rows", l, P.xrows);
+                        acc += P.eval[e + t] * xs[(size_t)l];
+                    }
+                    out[r] = (b[(size_t)P.ugrow[w]] - acc) / P.udiag[w];
+                }
+                for (int r = 0; r < BGS_UROWS; r++) {
+                    const size_t w = ((size_t)unit0 + un) * BGS_UROWS + r;
+                    xs[(size_t)P.ulrow[w]] = out[r];
+                    y[(size_t)P.ugrow[w]] = out[r];
+                }
+            }
+        }
+        double d = 0.0;
+        for (int i = 0; i < n; i++) d = std::max(d, std::fabs(y[(size_t)i] - ref[(size_t)i]));
+        if (max_abs_diff) *max_abs_diff = d;
+        return SMG_OK;
+    });
+}
+
 extern "C" int smg_debug_raise_coarse_stall(smg_hierarchy* h)
 {
     if (!h || !h->coarse_sparse || !h->c_err.p) return fail(SMG_ERR_INVALID, "smg_debug_raise_coarse_stall: no sparse coarse factorisation on this handle");

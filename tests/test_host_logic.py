@@ -562,6 +562,28 @@ def test_tiling_plan_reproduces_the_colour_sweeps_bit_for_bit(smg_mod):
             assert diff.value == 0.0, "level %d, %d sweeps, tiles of %d rows: the tiled sweeps differ by %g" % (lv, sweeps, tile_rows, diff.value)
 
 
+def test_block_gauss_seidel_plan_is_the_lexicographic_sweep_in_its_order(smg_mod):
+    """Block Gauss-Seidel for many right-hand sides (csrc/smg_bgs.hpp, round 4): the plan -- compact blocks, block colours, per block an image of
+    its rows and rim, units of <= 16 rows of one vertex colour with local indices -- executed on the host exactly as k_bgs executes it gives the
+    bits of the reference's lexicographic sweep (src/mg_VCycle.cpp:146-160) on the numbering (block colour, block, vertex colour, row); invariants:
+    every row in one block, blocks of one colour share no entry, few colours, a rim below one row per row.  Mesh levels with and without
+    constraints, Galerkin levels, several block sizes."""
+    import ctypes as C
+    smg = smg_mod
+    L = smg._lib.load()
+    for kind, pins in (("poisson", 40), ("mcf", 0)):
+        p = subdiv_problem(kind=kind, k=1, n_sub=2, n_pins=pins)
+        mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"])
+        for lv in range(mg.n_levels - 1):
+            for block_rows in (64, 32, 16):
+                nb, nc, rim, fill, diff = C.c_int(), C.c_int(), C.c_double(), C.c_double(), C.c_double(-1.0)
+                rc = L.smg_debug_check_block_gs_plan(mg.h, lv, block_rows, C.byref(nb), C.byref(nc), C.byref(rim), C.byref(fill), C.byref(diff))
+                assert rc == 0, L.smg_last_error()
+                assert nb.value >= mg.rows(lv) // block_rows and 3 <= nc.value <= 9
+                assert 0.0 < rim.value < 2.5 and (0.5 if block_rows == 64 else 0.1) < fill.value <= 1.0
+                assert diff.value == 0.0, "level %d, blocks of %d rows: the block sweep differs by %g" % (lv, block_rows, diff.value)
+
+
 def test_sparse_cholesky_of_the_coarse_solver(smg_mod):
     """csrc/smg_coarse.cpp (coarsest levels beyond the dense range; the reference: Eigen::SimplicialLDLT, src/min_quad_with_fixed_mg.cpp:47-48):
     nested dissection + up-looking Cholesky on mesh operators -- residual of a host solve with the factor at rounding level, fill O(n log n),
