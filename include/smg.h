@@ -192,11 +192,10 @@ int smg_level_get_block_image(const smg_hierarchy *h, int lv, int *n_slices, int
 /* relax() with MANY right-hand sides (reference k > 1 branch, src/mg_VCycle.cpp:161-177: k independent lexicographic sweeps).
  * With k a multiple of 16 (k >= 16) the levels of at least min_rows rows (default: never; SMG_BGS_MIN_ROWS; < 0: never; SMG_BGS=0: never)
  * can sweep BLOCK-wise: the level is cut into compact blocks of <= 64 rows, blocks are coloured, one launch per block colour; a wavefront
- * owns (block, 16 columns), reads the block's rows and its rim once into LDS and updates the block's rows vertex colour by vertex colour
- * there.  That is the reference's lexicographic sweep on the numbering (block colour, block, vertex colour, row) -- per kernel bit for bit
+ * owns (block, 16 columns), reads the block's rows and its rim once into LDS and updates the block's rows there, <= 16 independent rows at a time.  That is the reference's lexicographic sweep on the numbering (block colour, block, vertex colour, row) -- per kernel bit for bit
  * what the oracle computes on that numbering, smg_level_get_block_gs_order -- and reads the iterate ~1.65 times per sweep instead of 3
- * (the multi-colour order of the wide kernels re-reads it once per colour).  Measured at 1 M rows: the fine-level sweep 7 - 9 % faster at
- * 64 columns, 18 % at 32; the plan costs a graph partition of the level at the first such solve, so it is an option for
+ * (the multi-colour order of the wide kernels re-reads it once per colour).  Measured at 1 M rows: the fine-level sweep 8 - 10 % faster at
+ * 64 columns, 22 % at 32; the plan costs a graph partition of the level at the first such solve, so it is an option for
  * callers that solve often, not the default.  It is a different, equally valid Gauss-Seidel order than the multi-colour one: iterates of
  * the two paths differ, converged solutions agree to the tolerance (same cycle counts measured).  The outer residual is then a launch of
  * its own (the multi-colour path folds it into its first sweep).  Changing min_rows takes effect at the next solve. */

@@ -150,9 +150,13 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
         const int b = blocks[(size_t)q], m0 = mptr[(size_t)b], cnt = mptr[(size_t)b + 1] - m0, base = R.blk_ptr[(size_t)q];
         for (int t = 0; t < cnt; t++) { R.rows[(size_t)base + t] = members[(size_t)m0 + t]; pos[(size_t)members[(size_t)m0 + t]] = base + t; }
     }
-    auto vcolour = [&](int row) { return (int)(std::upper_bound(vcp.begin(), vcp.end(), row) - vcp.begin()) - 1; };
-    // per block: its rim (rows of other blocks it reads, ascending), units (chunks of <= 16 rows of one vertex colour), batches per row
-    struct Blk { int nb = 1; std::vector<int> rim; std::vector<int> unit_first, unit_cnt; };      // unit_first: position relative to the block
+    // per block: its rim (rows of other blocks it reads, ascending), units, batches per row.
+    // Units: <= 16 rows that are updated at once from the image as it stands and written back together.  What that needs: no two rows of a unit
+    // share an entry, and for every entry (i, j) inside the block with i before j in the bgs order, i sits in an EARLIER unit than j (j must see
+    // i's new value, i must see j's old one).  Rows are placed in bgs order into the first unit after all their earlier neighbours that still
+    // has room: the four vertex colours give a critical path of four units, and rows of a later colour whose earlier neighbours are all done
+    // fill the slots a colour class of 17 - 20 rows would otherwise waste in a second, nearly empty unit (64 -> ~5 units per block).
+    struct Blk { int nb = 1; std::vector<int> rim; std::vector<std::vector<int>> units; };      // units: positions relative to the block
     std::vector<Blk> info((size_t)nb);
     std::vector<char> bad((size_t)nb, 0);
     parallel_for(nb, 32, [&](long q0, long q1) {
@@ -160,12 +164,11 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
             Blk& I = info[(size_t)q];
             const int base = R.blk_ptr[(size_t)q], end = R.blk_ptr[(size_t)q + 1], m = end - base;
             if (m > BGS_ROWS) { bad[(size_t)q] = 1; continue; }
-            int wmax = 1, last = -1, run = 0;
+            int wmax = 1;
+            int unit_of[BGS_ROWS];
             for (int t = 0; t < m; t++) {
-                const int i = R.rows[(size_t)base + t], c = vcolour(i);
-                if (c != last || run == BGS_UROWS) { I.unit_first.push_back(t); I.unit_cnt.push_back(0); last = c; run = 0; }
-                I.unit_cnt.back()++; run++;
-                int w = 0;
+                const int i = R.rows[(size_t)base + t];
+                int w = 0, lb = 0;
                 bool diag = false;
                 for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
                     const int j = G.col[(size_t)p];
@@ -173,7 +176,13 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
                     w++;
                     const int pj = pos[(size_t)j];
                     if (pj < base || pj >= end) I.rim.push_back(j);
+                    else if (pj < base + t) lb = std::max(lb, unit_of[pj - base] + 1);
                 }
+                size_t un = (size_t)lb;
+                while (un < I.units.size() && (int)I.units[un].size() >= BGS_UROWS) un++;
+                if (un >= I.units.size()) I.units.resize(un + 1);
+                I.units[un].push_back(t);
+                unit_of[t] = (int)un;
                 if (!diag) bad[(size_t)q] = 1;
                 wmax = std::max(wmax, w);
             }
@@ -193,7 +202,7 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
     std::vector<long> unit0((size_t)nb + 1, 0), ent0((size_t)nb + 1, 0);
     for (int q = 0; q < nb; q++) {
         const Blk& I = info[(size_t)q];
-        const long nu = (long)I.unit_first.size();
+        const long nu = (long)I.units.size();
         unit0[(size_t)q + 1] = unit0[(size_t)q] + nu;
         ent0[(size_t)q + 1] = ent0[(size_t)q] + nu * BGS_UROWS * BGS_BATCH * I.nb;
         R.hdr[(size_t)q * BGS_HDR + 0] = (int)unit0[(size_t)q]; R.hdr[(size_t)q * BGS_HDR + 1] = (int)nu;
@@ -216,10 +225,10 @@ BgsPlan build_bgs(const Csr& G, const std::vector<int>& vcp, int block_rows)
             for (int l = 0; l < m; l++) X[l] = R.rows[(size_t)base + l];
             for (size_t z = 0; z < I.rim.size(); z++) X[BGS_ROWS + z] = I.rim[z];
             const size_t S = (size_t)I.nb * BGS_BATCH;
-            for (size_t un = 0; un < I.unit_first.size(); un++) {
+            for (size_t un = 0; un < I.units.size(); un++) {
                 const size_t u = (size_t)unit0[(size_t)q] + un;
                 for (int r = 0; r < BGS_UROWS; r++) {
-                    const int loc = I.unit_first[un] + (r < I.unit_cnt[un] ? r : 0);        // a slot without a row of its own: the unit's first row again
+                    const int loc = I.units[un][r < (int)I.units[un].size() ? (size_t)r : 0];        // a slot without a row of its own: the unit's first row again
                     const int i = R.rows[(size_t)base + loc];
                     R.ugrow[u * BGS_UROWS + r] = i;
                     R.ulrow[u * BGS_UROWS + r] = loc;
