@@ -972,6 +972,74 @@ __global__ __launch_bounds__(256) void k_dense_gemm_mfma(const double* __restric
     }
 }
 
+// The same product with CPW column tiles per workgroup: a wave's operand of the inverse feeds CPW matrix-core products instead of one, so
+// the inverse is streamed KC / (16 CPW) times instead of KC / 16 times (at 64 columns and CPW = 1 the launch re-reads 125 MB four times:
+// 92 us of a 4.3 ms iteration at C3 x 64; CPW = 2: 75 us).  Same inner ranges per wave, same order of the products, same final sum: the same bits.
+template <int KC, int CPW>
+__global__ __launch_bounds__(256) void k_dense_gemm_mfma_multi(const double* __restrict__ Ainv, int n, int lda, const double* __restrict__ b,
+                                                               double* u, int ld, const int* done, int kvalid)
+{
+    const int stop = load_flag(done);
+    constexpr int CB = KC / 16 / CPW, DEPTH = 6;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rb = blockIdx.x / CB, cb = blockIdx.x % CB;
+    const int row0 = rb * 16, col0 = cb * 16 * CPW;
+    const int lc = lane & 15, lr = lane >> 4;
+    const int per = lda / 16;                 // MFMA steps per wave (lda % 64 == 0)
+    const int s0 = per * w;
+    const double* pa = Ainv + (size_t)(4 * s0 + lr) * lda + row0 + lc;
+    const double* pb = b + (size_t)(4 * s0 + lr) * ld + col0 + lc;
+    const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ld;
+    v4f64_t acc[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) acc[c] = (v4f64_t){0.0, 0.0, 0.0, 0.0};
+    double av[DEPTH], bv[CPW][DEPTH];
+#pragma unroll
+    for (int t = 0; t < DEPTH; t++) {
+        av[t] = t < per ? pa[t * sa] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CPW; c++) bv[c][t] = (t < per && col0 + 16 * c + lc < kvalid) ? pb[t * sb + 16 * c] : 0.0;
+    }
+    for (int s = 0; s < per; s += DEPTH) {
+        double an[DEPTH], bn[CPW][DEPTH];
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++) {
+            const int q = s + DEPTH + t;
+            an[t] = q < per ? pa[q * sa] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CPW; c++) bn[c][t] = (q < per && col0 + 16 * c + lc < kvalid) ? pb[q * sb + 16 * c] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++)
+#pragma unroll
+            for (int c = 0; c < CPW; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[c][t], acc[c], 0, 0, 0);   // zero operands past the end
+#pragma unroll
+        for (int t = 0; t < DEPTH; t++) {
+            av[t] = an[t];
+#pragma unroll
+            for (int c = 0; c < CPW; c++) bv[c][t] = bn[c][t];
+        }
+    }
+    __shared__ double red[CPW][4][4][64];
+#pragma unroll
+    for (int c = 0; c < CPW; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[c][w][r][lane] = acc[c][r];
+    __syncthreads();
+    if (!stop) {
+        for (int c = w; c < CPW; c += 4) {       // wave c finishes column tile c
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = row0 + lr + 4 * r;
+                if (row < n && col0 + 16 * c + lc < kvalid) {
+                    const size_t o = (size_t)row * ld + col0 + 16 * c + lc;
+                    u[o] = u[o] + ((red[c][0][r][lane] + red[c][1][r][lane]) + (red[c][2][r][lane] + red[c][3][r][lane]));
+                }
+            }
+        }
+    }
+}
+
 // ---- k = 1, symmetric: the inverse of an SPD matrix is symmetric, so one column's product needs only the lower triangle of
 // tiles -- half the bytes of the (bandwidth-bound) coarse solve.  Tile (I, J), I >= J, yields A_IJ b_J (a share of y_I) and, off the
 // diagonal, A_IJ^T b_I (a share of y_J); the 64-row shares are summed per row in ascending block order by a second small launch:
@@ -1053,6 +1121,10 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
         static const int use_mfma = getenv("SMG_COARSE_MFMA") ? atoi(getenv("SMG_COARSE_MFMA")) : 1;   // A/B knob
         if constexpr (std::is_same<T, double>::value) {
             if (use_mfma && lda % 64 == 0) {
+                // 64 columns: two column tiles per workgroup (92 -> 75 us at 3 952 unknowns, same bits; four: too few workgroups, 91 us; two tiles at 32
+                // columns: 54 -> 63 us).  SMG_COARSE_CPW=1 is the A/B knob.
+                static const int cpw = getenv("SMG_COARSE_CPW") ? atoi(getenv("SMG_COARSE_CPW")) : 2;
+                if (kc == 64 && cpw == 2) { hipLaunchKernelGGL((k_dense_gemm_mfma_multi<64, 2>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); c0 += kv; continue; }
                 switch (kc) {
                     case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
                     case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
