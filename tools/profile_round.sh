@@ -33,11 +33,14 @@ python tools/rocpd_stats.py $OUT/c5t/t_results.db $OUT/${TAG}_c5_kernel_stats.cs
 # 3b. the wide (k >= 8) kernels a column-sharded job runs on every GPU: C3 with 64 and with 8 columns (8 = the 8-way shard of 64), counters + kernel table
 tools/pmc_wide.sh $TAG 64 8 > $OUT/pmc_wide.log 2>&1
 cp gpurun_out/pmc_wide/${TAG}_* $OUT/ 2>/dev/null
-# 3c. the block (3-DOF) kernels: k_bsr3<...> on the C3 x 3 system
+# 3c. the block (3-DOF) kernels: k_bsr3<...> on the C3 x 3 system (tools/prof_block3.py; rocprofv3 --pmc sometimes dies at start-up on this pool: up to three tries)
 mkdir -p $OUT/B3
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr " " "_")
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/B3/pmc_$n -o p -- python tools/block3_time.py C3 --block-only > $OUT/B3/pmc_$n.log 2>&1
+  for try in 1 2 3; do
+    rm -rf $OUT/B3/pmc_$n
+    rocprofv3 --pmc $c --kernel-trace -d $OUT/B3/pmc_$n -o p -- python tools/prof_block3.py C3 > $OUT/B3/pmc_$n.log 2>&1 && break
+  done
 done
 python tools/pmc_summary.py $OUT/B3 > $OUT/${TAG}_pmc_summary_block3.json
 python tools/make_traffic.py $OUT/${TAG}_pmc_summary_C3.json $OUT/${TAG}_pmc_summary_C5.json $TAG > $OUT/traffic.json
