@@ -2,10 +2,10 @@
 // One wavefront per row, rows in dependency order (forward: ascending, backward: descending); a row's lanes wait for the rows they read
 // by polling the values themselves in HBM (agent-scope atomics; a word of all ones means "not there yet"), form their products, and the
 // wave reduces them in a fixed order: the result does not depend on timing.
-// FORWARD PROGRESS rests on an assumption about the hardware, not on a guarantee of HIP: a wave only waits for rows whose workgroup has a
-// lower index in the same launch, and the dispatcher starts workgroups in index order (a workgroup of index w is resident or finished
-// before any of index > w starts).  That holds on gfx950 with the whole device to the process; CU masking, preemption by another queue or
-// a partitioned mode could in principle park a low-index workgroup behind spinning high-index ones.  Hence the bounded spins: a wait that
+// FORWARD PROGRESS: a wave draws a ticket when it starts (one atomic per wave) and takes the row of that number in the dependency order, so
+// a wave only ever waits for rows whose waves have STARTED before it -- whatever order the dispatcher starts workgroups in (rounds 3's
+// version took the launch index and with it the assumption that workgroups start in index order).  What is still assumed: a resident wave
+// keeps being scheduled (no preemption that parks it for good behind spinning ones).  Hence the bounded spins all the same: a wait that
 // gives up raises *err, poisons its result with NaN, every later wait gives up at once, and the host sees SMG_ERR_HIP at the next
 // synchronising call (smg_cycle.cpp: coarse_stall_check) -- a lost solve, never a hung device and never a silently wrong correction.
 #include <hip/hip_runtime.h>
@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256) void k_sptrsv(SparseCholDev F, const double* _
 {
     if (load_flag(done)) return;      // the loop has ended: uniform over the launch
     const int lane = threadIdx.x & 63;
-    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    // The wave's place in the dependency order is a TICKET drawn when it starts, not its launch index: whatever order the dispatcher starts
+    // workgroups in, every row this wave can wait for belongs to a wave that drew its ticket earlier, i.e. is running or done.
+    // (one ticket of four rows per workgroup: 4 k atomics on one word instead of 16 k -- as one per wave they cost 0.5 of 2.9 ms)
+    __shared__ int ticket;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(F.err + 1 + (BACK ? 1 : 0), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int r = __builtin_amdgcn_readfirstlane(ticket + (int)(threadIdx.x >> 6));
     if (r >= F.n) return;
     const int i = BACK ? F.n - 1 - r : r;
     const int* ptr = BACK ? F.cptr : F.rptr;
@@ -152,6 +158,8 @@ template <int KC>
 static hipError_t sptrsv_pass(const SparseCholDev& F, const double* b, double* u, int ld, const int* done, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(F.work, 0xFF, (size_t)2 * F.n * KC * sizeof(double), st);      // every value "not there yet"
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(F.err + 1, 0, 2 * sizeof(int), st);                                       // the two launches' ticket counters
     if (e != hipSuccess) return e;
     const int nb = (F.n + 3) / 4;
     hipLaunchKernelGGL((k_sptrsv<false, KC>), dim3(nb), dim3(256), 0, st, F, b, u, ld, done);

@@ -168,7 +168,7 @@ struct SparseCholDev {
     const int *cptr = nullptr, *crow = nullptr;      // ... and by columns
     const double *rval = nullptr, *cval = nullptr, *diag = nullptr;
     double* work = nullptr;                          // 2 n KC (KC = columns per pass, sparse_coarse_work_cols): the forward solve's z, the backward solve's x
-    int* err = nullptr;                              // raised when a wait gave up
+    int* err = nullptr;                              // [0] raised when a wait gave up; [1], [2]: ticket counters of the forward / backward launch
 };
 // u[:, c] += (L L^T)^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)
 hipError_t launch_sparse_coarse_solve(const SparseCholDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);

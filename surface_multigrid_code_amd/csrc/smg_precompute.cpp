@@ -569,8 +569,8 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
     HIPCHK(h->c_cptr.upload_in_place(F.cptr, &moved)); HIPCHK(h->c_crow.upload_in_place(F.crow, &moved)); HIPCHK(h->c_rval.upload_in_place(F.rval, &moved));
     HIPCHK(h->c_cval.upload_in_place(F.cval, &moved)); HIPCHK(h->c_diag.upload_in_place(F.diag, &moved));
     HIPCHK(h->c_work.ensure((size_t)2 * F.n));
-    HIPCHK(h->c_err.ensure(1));
-    HIPCHK(hipMemset(h->c_err.p, 0, sizeof(int)));
+    HIPCHK(h->c_err.ensure(4));          // [0] the stall flag, [1] / [2] the ticket counters of the forward / backward launch
+    HIPCHK(hipMemset(h->c_err.p, 0, 4 * sizeof(int)));
     if (moved || h->c_work.p != work0 || h->c_err.p != err0) drop_graphs(h);
     SparseCholDev& V = h->c_view;
     V.n = F.n; V.perm = h->c_perm.p; V.rptr = h->c_rptr.p; V.rcol = h->c_rcol.p; V.cptr = h->c_cptr.p; V.crow = h->c_crow.p;
