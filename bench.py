@@ -754,17 +754,25 @@ def main():
     # scaling point.)  SMG_BENCH_BACKEND=gloo / SMG_BENCH_ALLOW_SHARED=1: the CPU-side exercise of the N > 1 code path on fewer GPUs.
     preflight = None
     if world > 1:
+        # identity of the device this rank computes on: node + device index (ranks that share a GPU share both); uuid / PCI ids ride along as
+        # information only (not every runtime reports them, and a run must not be refused because they are missing or all alike)
         pr = torch.cuda.get_device_properties(dev)
-        ident = "%s|%s|%s|%s" % (os.uname().nodename, getattr(pr, "uuid", ""), getattr(pr, "pci_bus_id", ""), getattr(pr, "pci_device_id", ""))
-        if ident.count("|") == 3 and ident.split("|")[1:] == ["", "", ""]:
-            ident = "%s|index %d" % (os.uname().nodename, local_rank % ndev)
+        extra = "|".join(str(getattr(pr, a)) for a in ("uuid", "pci_bus_id", "pci_device_id") if getattr(pr, a, None) not in (None, ""))
+        ident = "%s|device %d|%s" % (os.uname().nodename, local_rank % ndev, extra)
         idents = [None] * world
         dist.all_gather_object(idents, ident)
         comm_ranks = stream_ar.n_ranks() if stream_ar is not None else dist.get_world_size()
-        preflight = {"rccl_comm_ranks": int(comm_ranks), "distinct_devices": len(set(idents)), "devices": idents, "backend": dist.get_backend(),
+        infos = [None] * world
+        dist.all_gather_object(infos, extra)
+        preflight = {"rccl_comm_ranks": int(comm_ranks), "distinct_devices": len(set(idents)), "devices": idents, "device_info": infos, "visible_devices_per_rank": ndev, "backend": dist.get_backend(),
                      "allreduce": "RCCL communicator of libsmg's own (ncclCommCount)" if stream_ar is not None else "torch.distributed process group"}
         shared_ok = os.environ.get("SMG_BENCH_BACKEND", "nccl") != "nccl" or os.environ.get("SMG_BENCH_ALLOW_SHARED") == "1"
-        if (preflight["rccl_comm_ranks"] != world or preflight["distinct_devices"] != world) and not shared_ok:
+        # two ranks with the same key share a device for sure when they see several devices (same index) or report the same non-empty uuid / PCI
+        # ids; a rank that sees ONE device and cannot name it (launcher-side masking, no uuid) proves nothing either way: RCCL itself refuses a
+        # communicator with a duplicate GPU, so the communicator's rank count stays the hard criterion there
+        evidence = ndev > 1 or any(infos)
+        preflight["sharing_detectable"] = bool(evidence)
+        if (preflight["rccl_comm_ranks"] != world or (evidence and preflight["distinct_devices"] != world)) and not shared_ok:
             if rank == 0:
                 print("bench: multi-GPU pre-flight FAILED: --gpus %d needs %d RCCL ranks on %d distinct devices, found %s"
                       % (world, world, world, json.dumps(preflight)), file=sys.stderr)
