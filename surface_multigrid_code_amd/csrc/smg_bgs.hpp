@@ -10,12 +10,13 @@
 // (blocks of one colour share no matrix entry), and a sweep is one launch per BLOCK colour in which a wavefront owns (block, 16 columns):
 // the block's rows AND its rim (the rows of other blocks it reads: ~0.65 per row) are read once, 128 B per row, into 16 KB of LDS; then
 // the lanes are 16 ROWS x 4 columns -- a lane holds its row's entries (local indices into the LDS image, values) in registers, like the
-// one-lane-per-row kernels of the k < 8 path, and re-uses them for all 16 columns -- and the block's rows are updated vertex colour by
-// vertex colour (rows of one colour share no entry), in place in LDS, so every later row finds old or new neighbours as the order
-// requires; results go straight to memory.  No barrier, no wave-uniform bookkeeping per row: that is what sank the first two designs
+// one-lane-per-row kernels of the k < 8 path, and re-uses them for all 16 columns -- and the block's rows are updated UNIT by unit, in place
+// in LDS: a unit is <= 16 rows none of which reads another (level scheduling of the block's rows in the bgs order: a row joins the first
+// unit after those of the earlier rows it reads), so every later row finds old or new neighbours as the order requires; results go
+// straight to memory.  No barrier, no wave-uniform bookkeeping per row: that is what sank the first two designs
 // (profiles/r04_bgs_experiments.txt).  Per sweep the iterate is read ~1.65 times instead of 3.
 //
-// This IS the reference's lexicographic sweep on the numbering "block colour, block, vertex colour, row" (bgs order): per row the products
+// This IS the reference's lexicographic sweep on the numbering "block colour, block, vertex colour, row" (bgs order; the units only group rows of that order that do not read each other): per row the products
 // are added in ascending column of THAT numbering, so the oracle on the permuted system reproduces it bit for bit (tests/test_gpu_bgs.py).
 // It is another valid Gauss-Seidel order than the multi-colour one of the other kernels: iterates differ between the two paths,
 // converged solutions do not.
@@ -46,8 +47,8 @@ struct BgsPlan {
     std::vector<int> color_ptr;       // blocks of colour c: [color_ptr[c], color_ptr[c + 1])
     std::vector<int> blk_ptr;         // rows of block b: positions [blk_ptr[b], blk_ptr[b + 1]) of `rows`
     std::vector<int> rows;            // position in the bgs order -> row (internal numbering)
-    // ---- what the kernel reads.  A unit = up to 16 rows of one vertex colour of a block (a colour of more rows takes several units); row
-    // slots without a row of their own repeat the unit's first row (the same value is computed and stored twice: harmless).
+    // ---- what the kernel reads.  A unit = up to 16 rows of a block that read none of each other (level scheduling over the block's rows in
+    // the bgs order); row slots without a row of their own repeat the unit's first row (the same value is computed and stored twice: harmless).
     std::vector<int> hdr;             // per block BGS_HDR ints
     std::vector<int> xrow;            // xrows per block: the row behind local index l (unused slots: the block's first row)
     std::vector<int> ugrow, ulrow;    // 16 per unit: row, local index of the row

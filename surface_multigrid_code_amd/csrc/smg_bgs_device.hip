@@ -3,7 +3,7 @@
 // One wavefront = (one block of <= 64 rows of the level, 16 columns).  The block's rows and its rim -- <= 128 rows x 16 columns -- are read
 // once into LDS (128 B per row: a cache line); then the lanes are 16 rows x 4 columns: a lane keeps its row's entries (local indices into
 // the LDS image + values, the diagonal, four right-hand sides) in registers and runs four passes, one per column it owns; the block's rows
-// are updated unit by unit (<= 16 rows of one vertex colour: they share no entry), in place in LDS, results stored straight to memory.
+// are updated unit by unit (<= 16 rows that read none of each other), in place in LDS, results stored straight to memory.
 // No barrier (one wave, in-order LDS), no wave-uniform bookkeeping.  Bound: HBM -- per row and 16 columns 128 B of the iterate once, 128 B
 // of b, 128 B stored, ~0.65 x 128 B of rim, and the matrix entries once per 16 columns.
 #include <hip/hip_runtime.h>
