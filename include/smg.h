@@ -217,6 +217,20 @@ int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks,
  * *factor_entries: n^2 resp. the entries of L. */
 int smg_hierarchy_set_coarse_dense_max(smg_hierarchy *h, int n_max);
 int smg_hierarchy_coarse_solver(const smg_hierarchy *h, long *factor_entries);
+/* Inside the dense range, coarsest levels of at least n_min unknowns (default 2048, or SMG_COARSE_SCHUR_MIN; n_min < 0: unchanged) can be factored by
+ * ONE LEVEL OF EXACT BLOCK ELIMINATION instead of a dense inverse of the whole matrix (csrc/smg_schur.hpp): the rows are cut into compact blocks
+ * of <= 64, a vertex cover of the entries between blocks becomes the separator, every block is inverted in LDS, and only the separator's Schur
+ * complement (~0.43 n rows on the Galerkin operator of a surface mesh) is inverted densely: 0.9 ms instead of 2.4 at 3 952 unknowns -- which is what
+ * the time-stepping callers (05_example_mean_curvature_flow/main.cpp:74, 06: implicit_euler_mg_balloon.h:75) pay at every value-only smg_precompute.
+ * coarseSolve becomes g = b_S - sum W_i^T b_i, x_S = S^-1 g, x_i = D_i^-1 b_i - W_i x_S: three launches instead of two, a quarter of the bytes;
+ * per cycle within a few us of the dense product (one column: +4 us at 3 952 unknowns, 64 columns: -7).  Same answer to rounding (<= 1e-11 from LDL^T),
+ * bit-identical from run to run; available in fp32 for the mixed-precision cycle.
+ * when: 0 never; 1 from the first smg_precompute on; 2 (default, or SMG_COARSE_SCHUR) from the first VALUE-ONLY re-precompute on -- the choice by cost:
+ * a handle that is factored once and solved many times keeps the dense inverse and its slightly cheaper cycles, a handle whose values change pays the
+ * factorisation at every step and gets the cheap one (the switch itself costs one plan on the host, ~ms, once).
+ * smg_hierarchy_coarse_solver returns 2 for it, *factor_entries = the doubles it keeps.  A matrix whose blocks touch more than 128 separator rows each,
+ * or whose separator exceeds 0.7 n, keeps the dense inverse. */
+int smg_hierarchy_set_coarse_schur(smg_hierarchy *h, int when, int n_min);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],
  * and for lv >= 1: i32 n_rows i32 n_cols i32 nnz i32 ptr[n_rows+1] i32 col[nnz] f64 val[nnz]. */
@@ -373,6 +387,9 @@ int smg_debug_check_block_gs_plan(smg_hierarchy *h, int lv, int block_rows, int 
  * The next solve's waits then give up at once, its coarse corrections are NaN, and the next synchronising entry point returns SMG_ERR_HIP
  * and clears the flag.  Fails unless the handle holds a sparse coarse factorisation. */
 int smg_debug_raise_coarse_stall(smg_hierarchy *h);
+/* Test hook: the plan of the Schur-complement coarse solver built for the SPD matrix (ptr, col, val; lower triangle counts) and executed ON THE HOST
+ * the way the kernels read it: x = A^-1 b.  *n_blocks = 0: no plan for this matrix (x untouched).  Needs no GPU. */
+int smg_debug_schur_solve_host(int n, const int *ptr, const int *col, const double *val, const double *b, double *x, int *n_blocks, int *n_sep);
 /* Sparse Cholesky of the coarse solver (csrc/smg_coarse.hpp) on an SPD matrix given in CSR (both triangles): nested-dissection order,
  * factorisation, and the relative residual |b - A x| / |b| of a host solve with the factor for a deterministic right-hand side.
  * Returns SMG_ERR_INVALID when a pivot is not positive. */

@@ -97,6 +97,8 @@ def load():
         "smg_debug_check_tiling_plan": (i, [vp, i, i, i, ip, ip, dp, dp]),
         "smg_debug_check_sparse_cholesky": (i, [i, ip, ip, dp, lp, ip, dp]),
         "smg_hierarchy_set_coarse_dense_max": (i, [vp, i]),
+        "smg_hierarchy_set_coarse_schur": (i, [vp, i, i]),
+        "smg_debug_schur_solve_host": (i, [i, ip, ip, dp, dp, dp, ip, ip]),
         "smg_hierarchy_set_block_gs": (i, [vp, i]),
         "smg_debug_raise_coarse_stall": (i, [vp]),
         "smg_debug_check_block_gs_plan": (i, [vp, i, i, ip, ip, dp, dp, dp]),

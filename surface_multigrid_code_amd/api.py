@@ -309,10 +309,16 @@ class Hierarchy:
         """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""
         _chk(self.L.smg_hierarchy_set_coarse_dense_max(self.h, int(n_max)), "smg_hierarchy_set_coarse_dense_max")
 
+    def set_coarse_schur(self, when="refactor", n_min=-1):
+        """Coarsest levels of at least n_min unknowns (default 2048; -1: unchanged) inside the dense range are factored by block elimination +
+        a dense Schur complement of the separator instead of a dense inverse of the whole matrix: 'never', 'always' (from the first precompute
+        on) or 'refactor' (default: from the first value-only re-precompute on -- what a time-stepping caller does)."""
+        _chk(self.L.smg_hierarchy_set_coarse_schur(self.h, {"never": 0, "always": 1, "refactor": 2}[when], int(n_min)), "smg_hierarchy_set_coarse_schur")
+
     def coarse_solver(self):
         ne = C.c_long()
         kind = self.L.smg_hierarchy_coarse_solver(self.h, C.byref(ne))
-        return {"kind": "sparse_cholesky" if kind == 1 else "dense_inverse", "factor_entries": ne.value}
+        return {"kind": {1: "sparse_cholesky", 2: "schur_complement"}.get(kind, "dense_inverse"), "factor_entries": ne.value}
 
     # ---- block (3-DOF) variant
     def set_block_mode(self, mode="auto"):

@@ -225,6 +225,8 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     h->lv.resize(n_levels);
     h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 16384);
     h->bgs_min_rows = env_int("SMG_BGS_MIN_ROWS", -1);
+    h->coarse_schur_when = std::min(2, std::max(0, env_int("SMG_COARSE_SCHUR", 2)));
+    h->coarse_schur_min = env_int("SMG_COARSE_SCHUR_MIN", 2048);
     return h;
 }
 
@@ -317,8 +319,16 @@ extern "C" int smg_hierarchy_set_coarse_dense_max(smg_hierarchy* h, int n_max)
 extern "C" int smg_hierarchy_coarse_solver(const smg_hierarchy* h, long* factor_entries)
 {
     if (!h) return SMG_ERR_INVALID;
-    if (factor_entries) *factor_entries = h->coarse_sparse ? h->chol.nnzL() : (long)h->nc_pad * h->nc_pad;
-    return h->coarse_sparse ? 1 : 0;
+    if (factor_entries) *factor_entries = h->coarse_sparse ? h->chol.nnzL() : h->coarse_schur ? (long)h->schur.off_C : (long)h->nc_pad * h->nc_pad;
+    return h->coarse_sparse ? 1 : h->coarse_schur ? 2 : 0;
+}
+extern "C" int smg_hierarchy_set_coarse_schur(smg_hierarchy* h, int when, int n_min)
+{
+    if (!h || when < 0 || when > 2) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_schur: bad arguments (when: 0 never, 1 always, 2 from the first value-only re-precompute on)");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_schur called during a split-phase solve");
+    if (n_min < 0) n_min = h->coarse_schur_min;
+    if (when != h->coarse_schur_when || n_min != h->coarse_schur_min) { h->coarse_schur_when = when; h->coarse_schur_min = n_min; h->precomputed = false; }   // the next smg_precompute is a full one
+    return SMG_OK;
 }
 
 extern "C" int smg_hierarchy_set_chebyshev(smg_hierarchy* h, double cheby_fraction)
@@ -844,4 +854,94 @@ extern "C" int smg_mesh_torus(int nu, int nv, double R, double r, double* V, int
     std::copy(m.V.begin(), m.V.end(), V);
     std::copy(m.F.begin(), m.F.end(), F);
     return SMG_OK;
+}
+
+// Test hook (tests/test_host_logic.py): the plan of the Schur-complement coarse solver (smg_schur.hpp) built for the matrix (ptr, col, val) and EXECUTED ON THE
+// HOST exactly as the kernels of smg_schur_device.hip use it -- scatter lists, unit padding, per-block inverse and panels, the sum lists of the Schur
+// complement, the three solve steps -- so every index the device reads is checked without a GPU.  x = A^-1 b (k = 1); *n_blocks = 0: no plan for this matrix.
+extern "C" int smg_debug_schur_solve_host(int n, const int* ptr, const int* col, const double* val, const double* b, double* x, int* n_blocks, int* n_sep)
+{
+    return guarded("smg_debug_schur_solve_host", [&]() -> int {
+        if (n <= 0 || !ptr || !col || !val || !b || !x) return fail(SMG_ERR_INVALID, "smg_debug_schur_solve_host: bad arguments");
+        const Csr A = csr_from_arrays(n, n, ptr, col, val);
+        const SchurPlan P = build_schur(A);
+        if (n_blocks) *n_blocks = P.nb;
+        if (n_sep) *n_sep = P.ns;
+        if (P.empty()) return SMG_OK;
+        // in-place inverse of an SPD matrix by Gauss-Jordan without pivoting (what the device does, unblocked)
+        auto invert = [](double* M, int m, int ld) {
+            for (int p = 0; p < m; p++) {
+                const double d = 1.0 / M[(size_t)p * ld + p];
+                for (int j = 0; j < m; j++) M[(size_t)p * ld + j] *= d;
+                M[(size_t)p * ld + p] = d;
+                for (int i = 0; i < m; i++) {
+                    if (i == p) continue;
+                    const double f = M[(size_t)i * ld + p];
+                    if (f == 0.0) continue;
+                    for (int j = 0; j < m; j++) if (j != p) M[(size_t)i * ld + j] -= f * M[(size_t)p * ld + j];
+                    M[(size_t)i * ld + p] = -f * d;
+                }
+            }
+        };
+        std::vector<double> arena((size_t)P.total, 0.0);
+        for (size_t e = 0; e < P.pos.size(); e++) {
+            if (P.pos[e] >= 0) arena[(size_t)P.pos[e]] = A.val[e];
+            if (P.pos2[e] >= 0) arena[(size_t)P.pos2[e]] = A.val[e];
+        }
+        for (long long o : P.ones) arena[(size_t)o] = 1.0;
+        double* D = arena.data() + P.off_D; double* PT = arena.data() + P.off_P; double* WT = arena.data() + P.off_W; double* S = arena.data() + P.off_S; double* C = arena.data() + P.off_C;
+        for (int i = 0; i < P.nb; i++) {
+            double* Di = D + (size_t)i * 4096;
+            invert(Di, 64, 64);
+            for (int r = 0; r < 64; r++) for (int c = r + 1; c < 64; c++) Di[r * 64 + c] = Di[c * 64 + r];
+            const int s0 = P.sptr[(size_t)i], m = P.sptr[(size_t)i + 1] - s0;
+            for (int c = 0; c < m; c++)
+                for (int r = 0; r < 64; r++) {
+                    double acc = 0.0;
+                    for (int rp = 0; rp < 64; rp++) acc += Di[r * 64 + rp] * PT[(size_t)64 * (s0 + c) + rp];
+                    WT[(size_t)64 * (s0 + c) + r] = acc;
+                }
+            for (int c1 = 0; c1 < m; c1++)
+                for (int c2 = 0; c2 <= c1; c2++) {
+                    double acc = 0.0;
+                    for (int r = 0; r < 64; r++) acc += PT[(size_t)64 * (s0 + c1) + r] * WT[(size_t)64 * (s0 + c2) + r];
+                    C[(size_t)P.coff[(size_t)i] + (size_t)c1 * m + c2] = acc;
+                }
+        }
+        for (size_t d = 0; d < P.rdst.size(); d++) {
+            double s = arena[(size_t)P.rdst[d]];
+            for (int q = P.rptr[d]; q < P.rptr[d + 1]; q++) s -= C[(size_t)P.rsrc[(size_t)q]];
+            arena[(size_t)P.rdst[d]] = s;
+            if (P.rdst2[d] >= 0) arena[(size_t)P.rdst2[d]] = s;
+        }
+        invert(S, P.ns_pad, P.ns_pad);
+        std::vector<double> g((size_t)P.ns_pad, 0.0), xs((size_t)P.ns_pad, 0.0);
+        for (int j = 0; j < P.ns; j++) {
+            double acc = 0.0;
+            for (int q = P.aptr[(size_t)j]; q < P.aptr[(size_t)j + 1]; q++) {
+                const int i = P.ablk[(size_t)q];
+                for (int r = 0; r < 64; r++) {
+                    const int row = P.irow[(size_t)i * 64 + r];
+                    if (row >= 0) acc += WT[(size_t)64 * P.apan[(size_t)q] + r] * b[row];
+                }
+            }
+            g[(size_t)j] = b[P.srow[(size_t)j]] - acc;
+        }
+        for (int i = 0; i < P.ns_pad; i++) { double acc = 0.0; for (int j = 0; j < P.ns_pad; j++) acc += S[(size_t)i * P.ns_pad + j] * g[(size_t)j]; xs[(size_t)i] = acc; }
+        for (int j = 0; j < P.ns; j++) x[P.srow[(size_t)j]] = xs[(size_t)j];
+        for (int i = 0; i < P.nb; i++) {
+            const int s0 = P.sptr[(size_t)i], m = P.sptr[(size_t)i + 1] - s0;
+            if (P.bsize[(size_t)i] < 1 || P.bsize[(size_t)i] > 64) return fail(SMG_ERR_INVALID, "schur plan: block %d has %d rows", i, P.bsize[(size_t)i]);
+            for (int r = 0; r < 64; r++) {
+                const int row = P.irow[(size_t)i * 64 + r];
+                if ((row >= 0) != (r < P.bsize[(size_t)i])) return fail(SMG_ERR_INVALID, "schur plan: block %d: slots and size disagree", i);
+                if (row < 0) continue;
+                double acc = 0.0;
+                for (int rp = 0; rp < 64; rp++) { const int rw = P.irow[(size_t)i * 64 + rp]; if (rw >= 0) acc += D[(size_t)i * 4096 + rp * 64 + r] * b[rw]; }
+                for (int s = 0; s < m; s++) acc -= WT[(size_t)64 * (s0 + s) + r] * xs[(size_t)P.sidx[(size_t)s0 + s]];
+                x[row] = acc;
+            }
+        }
+        return SMG_OK;
+    });
 }

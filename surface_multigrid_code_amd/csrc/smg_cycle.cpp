@@ -226,6 +226,17 @@ static int ensure_work(smg_hierarchy* h, int k)
             HIPCHK(hipMemsetAsync(Lv.d.p, 0, (size_t)Lv.n * h->kcap * sizeof(double), h->stream));
         }
     }
+    if (h->coarse_schur) {       // the separator's right-hand side and solution (the solver may have arrived with a value-only re-precompute, after the vectors)
+        const size_t need = (size_t)h->sch.view.ns_pad * std::max(h->kcap, 1);
+        if (h->sch.g.n < need || h->sch.xs.n < need) {
+            drop_graphs(h);
+            HIPCHK(h->sch.g.alloc(need));
+            HIPCHK(h->sch.xs.alloc(need));
+            HIPCHK(hipMemsetAsync(h->sch.g.p, 0, need * sizeof(double), h->stream));
+            HIPCHK(hipMemsetAsync(h->sch.xs.p, 0, need * sizeof(double), h->stream));
+        }
+        h->sch.view.g = h->sch.g.p; h->sch.view.xs = h->sch.xs.p;
+    }
     if (h->coarse_sparse) {      // the triangular solves take up to 64 columns per pass: 2 n doubles of scratch per column of a pass
         const size_t need = (size_t)2 * h->chol.n * sparse_coarse_work_cols(std::max(h->kcap, 1));
         if (h->c_work.n < need) {
@@ -272,8 +283,14 @@ static int ensure_fp32(smg_hierarchy* h, int k)
                 if ((rc = mk(Lv.dPT, Lv.pt32, Lv.dPT32))) return rc;
             }
         }
-        HIPCHK(h->d_Ainv32.ensure((size_t)h->nc_pad * h->nc_pad));
-        HIPCHK(launch_cvt_f64_f32(h->d_Ainv32.p, h->d_Ainv.p, (size_t)h->nc_pad * h->nc_pad, h->stream));
+        if (h->coarse_schur) {
+            HIPCHK(h->sch.arena32.ensure((size_t)h->schur.off_C));          // blocks, panels and the separator's inverse (the products behind them are scratch)
+            HIPCHK(launch_cvt_f64_f32(h->sch.arena32.p, h->sch.arena.p, (size_t)h->schur.off_C, h->stream));
+            h->sch.view.arena32 = h->sch.arena32.p;
+        } else {
+            HIPCHK(h->d_Ainv32.ensure((size_t)h->nc_pad * h->nc_pad));
+            HIPCHK(launch_cvt_f64_f32(h->d_Ainv32.p, h->d_Ainv.p, (size_t)h->nc_pad * h->nc_pad, h->stream));
+        }
         h->f32_valid = true;
     }
     if (k > h->kcap32) {
@@ -302,6 +319,17 @@ static int ensure_fp32(smg_hierarchy* h, int k)
             HIPCHK(Lv.d32.alloc((size_t)Lv.n * h->kcap32));
             HIPCHK(hipMemsetAsync(Lv.d32.p, 0, (size_t)Lv.n * h->kcap32 * sizeof(float), h->stream));
         }
+    }
+    if (h->coarse_schur) {
+        const size_t need = (size_t)h->sch.view.ns_pad * std::max(h->kcap32, 1);
+        if (h->sch.g32.n < need || h->sch.xs32.n < need) {
+            drop_graphs(h);
+            HIPCHK(h->sch.g32.alloc(need));
+            HIPCHK(h->sch.xs32.alloc(need));
+            HIPCHK(hipMemsetAsync(h->sch.g32.p, 0, need * sizeof(float), h->stream));
+            HIPCHK(hipMemsetAsync(h->sch.xs32.p, 0, need * sizeof(float), h->stream));
+        }
+        h->sch.view.g32 = h->sch.g32.p; h->sch.view.xs32 = h->sch.xs32.p;
     }
     return SMG_OK;
 }
@@ -362,6 +390,7 @@ template <> struct Prec<double> {
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
     {
         if (h->coarse_sparse) return launch_sparse_coarse_solve(h->c_view, L.b.p, L.u.p, k, ctrl, h->stream);
+        if (h->coarse_schur) return launch_schur_solve(h->sch.view, L.b.p, L.u.p, k, ctrl, h->stream);
         return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p);
     }
     // an operation with the level's matrix in whatever format it lives in: SELL panels, or 3 x 3 blocks on block hierarchies.
@@ -393,7 +422,10 @@ template <> struct Prec<float> {
                            hipStream_t st, float* zero_rows = nullptr, const FirstColour* first = nullptr, double omega = 1.0)
     { return launch_sell_f32(m, V, s0, s1, x, bb, y, k, ctrl, st, zero_rows, first, omega); }
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
-    { return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p); }
+    {
+        if (h->coarse_schur) return launch_schur_solve_f32(h->sch.view, L.b32.p, L.u32.p, k, ctrl, h->stream);
+        return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p);
+    }
     static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const float* x, const float* bb, float* y, int k,
                           const Ctrl* ctrl, const FirstColour* fc = nullptr, double omega = 1.0)
     {   // (block hierarchies have no fp32 images: ensure_fp32 refuses them)
@@ -1428,6 +1460,7 @@ extern "C" long smg_vcycle_bytes(const smg_hierarchy* h, int k, int pre, int pos
     }
     const long nc = h->lv[L - 1].n;
     if (h->coarse_sparse) tot += (2 * 12 * h->chol.nnzL() + 3 * 8 * nc + 24 * nc) * k;    // both triangles of L, once per column
+    else if (h->coarse_schur) tot += 8 * (h->schur.off_P + 2 * (h->schur.off_S - h->schur.off_W) + (long)h->schur.ns_pad * h->schur.ns_pad) + 24 * nc * k;   // blocks, the panels twice, S^-1
     else tot += 8 * nc * nc + 24 * nc * k;
     if (h->bs == 3) tot += 76 * h->lv[0].bA.blocks + 4L * (h->lv[0].n / 3 + 1) + 16L * h->lv[0].n * k;
     else tot += 12 * h->lv[0].A.nnz() + 4L * (h->lv[0].n + 1) + 16L * h->lv[0].n * k;

@@ -17,6 +17,7 @@
 
 #include "smg_device.hpp"
 #include "smg_device_inl.hpp"
+#include "smg_gj_inl.hpp"
 
 namespace smg {
 
@@ -1152,6 +1153,20 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
     }
     return hipGetLastError();
 }
+hipError_t launch_sym_gemv_tiles(const double* Ainv, int lda, const double* b, double* part, hipStream_t st)
+{
+    if (lda <= 0 || lda % 64) return hipErrorInvalidValue;
+    const int nt = lda / 64;
+    hipLaunchKernelGGL((k_sym_gemv_tiles<double>), dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Ainv, lda, b, part, nt);
+    return hipGetLastError();
+}
+hipError_t launch_sym_gemv_tiles_f32(const float* Ainv, int lda, const float* b, float* part, hipStream_t st)
+{
+    if (lda <= 0 || lda % 64) return hipErrorInvalidValue;
+    const int nt = lda / 64;
+    hipLaunchKernelGGL((k_sym_gemv_tiles<float>), dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Ainv, lda, b, part, nt);
+    return hipGetLastError();
+}
 hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
                                  const Ctrl* ctrl, hipStream_t st, double* sym_work)
 {
@@ -1205,86 +1220,7 @@ hipError_t launch_add_correction(double* z, const float* e, size_t n, const Ctrl
 // Blocked Gauss-Jordan inversion (no pivoting; the matrix is SPD), block size 64, 64x64 update tiles.  Every step streams
 // the whole matrix once (read + write), so the block size is the number of passes: 64 halves the traffic of 32; the update
 // walks the 64 pivot columns in two halves of 32 to stay inside 64 KB of LDS.
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int GJ_NB = 64;
 constexpr int GJ_H = 32;   // sub-panel width staged through LDS
-
-// In-place inverse of a 64 x 64 (SPD) block held in LDS, by a workgroup of 256 threads: Gauss-Jordan in four steps of 16 -- the
-// 16 x 16 pivot is inverted by one wave on its own (16 eliminations, no workgroup barrier), the row panel and the rank-16 update
-// run on the matrix cores -- 12 workgroup barriers instead of the 128 of the element-wise elimination, and far fewer LDS reads
-// (35 us -> 17 us for the stand-alone kernel; what remains is the chain of 64 dependent eliminations).
-// Must be entered by all threads, with `a` complete (barrier before the call is the caller's).
-__device__ __forceinline__ void gj_invert64(double (*a)[GJ_NB + 1], double (*Rb)[GJ_NB + 1], double (*Cb)[17])
-{
-    const int t = threadIdx.x;
-    for (int kk = 0; kk < 4; kk++) {
-        const int P = 16 * kk;
-        if (t < 64) {
-            const int jj = t & 15, ig = t >> 4;           // rows ig + 4 q of the pivot, column jj
-            for (int p = 0; p < 16; p++) {
-                // reciprocal of the pivot: hardware estimate + two Newton steps (the IEEE division sequence is several times longer
-                // and sits on the one serial chain of the whole inversion)
-                const double piv = a[P + p][P + p], r = a[P + p][P + jj];
-                double d = __builtin_amdgcn_rcp(piv);
-                d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
-                d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
-                double f[4], cur[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { f[q] = a[P + ig + 4 * q][P + p]; cur[q] = a[P + ig + 4 * q][P + jj]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = ig + 4 * q;
-                    double val;
-                    if (i == p) val = (jj == p) ? d : r * d;
-                    else val = (jj == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
-                    a[P + i][P + jj] = val;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-        // row panel D^-1 a[P.., :] (one 16 x 16 tile per wave; the inverse itself in the pivot columns) and a copy of the column panel
-        const int w = t >> 6, lane = t & 63, lr = lane >> 4, lc = lane & 15;
-        {
-            if (w == kk) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) Rb[lr + 4 * r][16 * w + lc] = a[P + lr + 4 * r][16 * w + lc];
-            } else {
-                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[P + lc][P + 4 * q + lr], a[P + 4 * q + lr][16 * w + lc], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) Rb[lr + 4 * r][16 * w + lc] = acc[r];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const int e = t + 256 * q; Cb[e >> 4][e & 15] = a[e >> 4][P + (e & 15)]; }
-        __syncthreads();
-        // rank-16 update, four 16 x 16 tiles (tix >> 2, tix & 3) per wave; the pivot rows take the row panel
-#pragma unroll
-        for (int tix = w; tix < 16; tix += 4) {
-            const int ti = tix >> 2, tj = tix & 3;
-            if (ti == kk) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) a[P + lr + 4 * r][16 * tj + lc] = Rb[lr + 4 * r][16 * tj + lc];
-            } else {
-                v4f64 acc;
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[r] = tj == kk ? 0.0 : a[16 * ti + lr + 4 * r][16 * tj + lc];
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Cb[16 * ti + lc][4 * q + lr], Rb[4 * q + lr][16 * tj + lc], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) a[16 * ti + lr + 4 * r][16 * tj + lc] = acc[r];
-            }
-        }
-        __syncthreads();
-    }
-}
 
 // inverse of the first 64 x 64 pivot block (the later ones are inverted by the look-ahead of k_gj_update)
 __global__ __launch_bounds__(256) void k_gj_diag(const double* M, int n, int kb, double* dinv)

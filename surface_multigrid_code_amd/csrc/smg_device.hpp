@@ -174,6 +174,28 @@ struct SparseCholDev {
 hipError_t launch_sparse_coarse_solve(const SparseCholDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 int sparse_coarse_work_cols(int k);   // F.work must hold 2 n sparse_coarse_work_cols(k) doubles for a solve with k columns
 
+// ---- Schur-complement coarse solver (smg_schur.hpp): interior blocks of <= 64 rows eliminated exactly, the separator inverted densely ----
+constexpr int SCHUR_M_MAX_DEV = 128;                 // = SCHUR_M_MAX (smg_schur.hpp): separator rows a block touches at most
+struct SchurDev {
+    int n = 0, nb = 0, ns = 0, ns_pad = 0;
+    const int *irow = nullptr, *bsize = nullptr, *srow = nullptr, *sptr = nullptr, *sidx = nullptr, *aptr = nullptr, *ablk = nullptr, *apan = nullptr;
+    double* arena = nullptr;                         // [D^-1 blocks][P^T panels][W^T panels][S^-1][products]: smg_schur.hpp
+    float* arena32 = nullptr;                        // fp32 image of the arena (mixed-precision cycle), or null
+    long long off_D = 0, off_P = 0, off_W = 0, off_S = 0, off_C = 0;
+    const long long *coff = nullptr, *pos = nullptr, *pos2 = nullptr, *ones = nullptr, *rdst = nullptr, *rdst2 = nullptr, *rsrc = nullptr;
+    const int* rptr = nullptr;
+    int nnz = 0, n_ones = 0, n_red = 0;
+    double *g = nullptr, *xs = nullptr;              // ns_pad x k each: the separator's right-hand side and solution
+    float *g32 = nullptr, *xs32 = nullptr;
+    double* sym_work = nullptr;                      // (ns_pad / 64)^2 x 64: the k = 1 product with S^-1 through its lower triangle
+    double* gj_work = nullptr;                       // launch_spd_inverse's scratch for ns_pad
+};
+// arena <- the factorisation of the matrix whose values (CSR order of the plan's matrix) are vals
+hipError_t launch_schur_factor(const SchurDev& F, const double* vals, hipStream_t st);
+// u[:, c] += A^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)
+hipError_t launch_schur_solve(const SchurDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+hipError_t launch_schur_solve_f32(const SchurDev& F, const float* b, float* u, int k, const Ctrl* ctrl, hipStream_t st);
+
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 
@@ -195,6 +217,9 @@ hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const doubl
                                  const Ctrl* ctrl, hipStream_t st, double* sym_work = nullptr);
 hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
                                      const Ctrl* ctrl, hipStream_t st, float* sym_work = nullptr);
+// first half of the symmetric k = 1 product alone: part[(I * (lda / 64) + J) * 64 + r] = the share of tile (I, J) in row 64 I + r of Ainv b; lda % 64 == 0
+hipError_t launch_sym_gemv_tiles(const double* Ainv, int lda, const double* b, double* part, hipStream_t st);
+hipError_t launch_sym_gemv_tiles_f32(const float* Ainv, int lda, const float* b, float* part, hipStream_t st);
 // mixed precision glue
 hipError_t launch_cvt_f64_f32(float* dst, const double* src, size_t n, hipStream_t st);
 hipError_t launch_residual_to_f32(float* b32, float* u32, const double* r64, size_t n, const Ctrl* ctrl, hipStream_t st);

@@ -17,6 +17,7 @@
 #include "smg_sparse.hpp"
 #include "smg_tiled.hpp"
 #include "smg_bgs.hpp"
+#include "smg_schur.hpp"
 
 namespace smg {
 
@@ -216,6 +217,22 @@ struct smg_hierarchy {
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;
     smg::SparseCholDev c_view;
+    // ... or, in the upper part of the dense range (smg_schur.hpp): interior blocks of <= 64 rows eliminated exactly, the separator's Schur
+    // complement inverted densely -- the factorisation the time-stepping callers repeat costs (separator / n)^3 of the dense inverse's
+    bool coarse_schur = false;
+    int coarse_schur_when = 2;      // smg_hierarchy_set_coarse_schur: 0 never, 1 from the first smg_precompute on, 2 from the first VALUE-ONLY re-precompute on (a caller
+                                    // that sends new values for an old pattern pays the factorisation at every step; one that does not, only the solves)
+    int coarse_schur_min = 2048;    // ... for coarsest levels of at least this many unknowns (and within the dense range)
+    bool schur_declined = false;    // the current coarsest matrix has no plan (smg_schur.hpp): not tried again until the next full precompute
+    smg::SchurPlan schur;
+    struct SchurBuf {
+        smg::DevBuf<int> irow, bsize, srow, sptr, sidx, aptr, ablk, acol, rptr;
+        smg::DevBuf<long long> coff, pos, pos2, ones, rdst, rdst2, rsrc;
+        smg::DevBuf<double> arena, g, xs, sym, gj;
+        smg::DevBuf<float> arena32, g32, xs32;
+        smg::SchurDev view;
+        void release() { *this = SchurBuf(); }
+    } sch;
     bool f32_valid = false;
     int kcap32 = 0;
     // ---- block (3-DOF) variant: 1 = scalar kernels, 3 = the level matrices live in 3 x 3 blocks ----

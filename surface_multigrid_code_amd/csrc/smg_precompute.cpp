@@ -576,8 +576,49 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
     V.n = F.n; V.perm = h->c_perm.p; V.rptr = h->c_rptr.p; V.rcol = h->c_rcol.p; V.cptr = h->c_cptr.p; V.crow = h->c_crow.p;
     V.rval = h->c_rval.p; V.cval = h->c_cval.p; V.diag = h->c_diag.p; V.work = h->c_work.p; V.err = h->c_err.p;
     h->coarse_sparse = true;
+    h->coarse_schur = false; h->sch.release(); h->schur = SchurPlan();
     h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release();
     tm.lap("device: sparse coarse factor uploaded");
+    return SMG_OK;
+}
+
+// ---- Schur-complement coarse solver (smg_schur.hpp): the plan of a coarsest matrix in the upper part of the dense range, on the device --
+static bool schur_wanted(const smg_hierarchy* h, int n, int when)
+{
+    return h->coarse_schur_when == when && h->coarse_schur_min >= 0 && n >= h->coarse_schur_min && !h->schur_declined;
+}
+// *planned: h->sch holds the plan of Ac (the arena still to be factored); not: no plan for this matrix (the dense inverse serves)
+static int coarse_plan_schur(smg_hierarchy* h, const Csr& Ac, bool* planned)
+{
+    *planned = false;
+    static_assert(SCHUR_M_MAX == SCHUR_M_MAX_DEV && SCHUR_B == 64, "smg_schur.hpp and smg_device.hpp disagree");
+    StageTimer tm;
+    h->schur = build_schur(Ac);
+    const SchurPlan& P = h->schur;
+    if (P.empty()) return SMG_OK;
+    smg_hierarchy::SchurBuf& B = h->sch;
+    HIPCHK(B.irow.upload(P.irow)); HIPCHK(B.bsize.upload(P.bsize)); HIPCHK(B.srow.upload(P.srow)); HIPCHK(B.sptr.upload(P.sptr)); HIPCHK(B.sidx.upload(P.sidx));
+    HIPCHK(B.aptr.upload(P.aptr)); HIPCHK(B.ablk.upload(P.ablk)); HIPCHK(B.acol.upload(P.apan)); HIPCHK(B.rptr.upload(P.rptr));
+    HIPCHK(B.coff.upload(P.coff)); HIPCHK(B.pos.upload(P.pos)); HIPCHK(B.pos2.upload(P.pos2)); HIPCHK(B.ones.upload(P.ones));
+    HIPCHK(B.rdst.upload(P.rdst)); HIPCHK(B.rdst2.upload(P.rdst2)); HIPCHK(B.rsrc.upload(P.rsrc));
+    HIPCHK(B.arena.alloc((size_t)P.total));
+    HIPCHK(B.gj.alloc((size_t)2 * P.ns_pad * 64 + 2 * 64 * 64));
+    if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(B.sym.alloc((size_t)(P.ns_pad / 64) * (P.ns_pad / 64) * 64)); else B.sym.release();
+    B.arena32.release(); B.g.release(); B.xs.release(); B.g32.release(); B.xs32.release();
+    SchurDev& V = B.view;
+    V = SchurDev();
+    V.n = P.n; V.nb = P.nb; V.ns = P.ns; V.ns_pad = P.ns_pad;
+    V.irow = B.irow.p; V.bsize = B.bsize.p; V.srow = B.srow.p; V.sptr = B.sptr.p; V.sidx = B.sidx.p; V.aptr = B.aptr.p; V.ablk = B.ablk.p; V.apan = B.acol.p;
+    V.arena = B.arena.p;
+    V.off_D = P.off_D; V.off_P = P.off_P; V.off_W = P.off_W; V.off_S = P.off_S; V.off_C = P.off_C;
+    V.coff = B.coff.p; V.pos = B.pos.p; V.pos2 = B.pos2.p; V.ones = B.ones.p; V.rdst = B.rdst.p; V.rdst2 = B.rdst2.p; V.rsrc = B.rsrc.p; V.rptr = B.rptr.p;
+    V.nnz = (int)P.pos.size(); V.n_ones = (int)P.ones.size(); V.n_red = (int)P.rdst.size();
+    V.sym_work = B.sym.p; V.gj_work = B.gj.p;
+    if (env_int("SMG_DEBUG_SCHUR", 0))
+        std::fprintf(stderr, "[smg schur] %d unknowns: %d interior blocks, %d separator rows (padded %d), %.1f separator rows per block, arena %.1f MB\n", P.n, P.nb, P.ns, P.ns_pad,
+                     (double)P.sidx.size() / P.nb, 8e-6 * (double)P.total);
+    tm.lap("host: plan of the Schur-complement coarse solver, uploaded");
+    *planned = true;
     return SMG_OK;
 }
 
@@ -641,6 +682,23 @@ static int coarse_images(smg_hierarchy* h)
     const int nc = Lc.n;
     const int np = ((nc + 63) / 64) * 64;
     h->nc = nc; h->nc_pad = np;
+    h->coarse_schur = false;
+    h->schur_declined = false;
+    if (schur_wanted(h, nc, 1)) {
+        bool planned = false;
+        const int rc = coarse_plan_schur(h, Lc.A, &planned);
+        if (rc) return rc;
+        if (planned) {
+            DevBuf<double> d_val;
+            HIPCHK(d_val.upload(Lc.A.val));
+            HIPCHK(launch_schur_factor(h->sch.view, d_val.p, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->coarse_schur = true;
+            h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release();
+            return SMG_OK;
+        }
+    }
+    h->sch.release(); h->schur = SchurPlan();
     // dense image on the device: the few entries travel, not n^2 zeros
     std::vector<long long> pos((size_t)Lc.A.nnz());
     for (int i = 0; i < nc; i++)
@@ -1005,7 +1063,7 @@ static int build_recipes(smg_hierarchy* h)
                 pos[p] = (long long)i * h->nc_pad + Lc.A.col[p];
                 if (Lc.A.col[p] == i) dg.push_back(p);
             }
-        if (!h->coarse_sparse) HIPCHK(h->d_dense_pos.upload(pos));
+        if (!h->coarse_sparse && !h->coarse_schur) HIPCHK(h->d_dense_pos.upload(pos));
         HIPCHK(h->d_diag_idx.upload(dg));
     }
     if (!h->has_known && h->lhs_src.size() != (size_t)h->lv[0].A.nnz()) {
@@ -1046,13 +1104,34 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
             }
         }
     }
-    // coarsest: dense image + inverse (solver.compute(Ac), :47-48 / :253-254), or the sparse factorisation on the host from the new values
+    // coarsest: solver.compute(Ac) (:47-48 / :253-254) -- the sparse factorisation on the host from the new values, or on the device the
+    // Schur-complement factorisation resp. the dense inverse
+    if (!h->coarse_sparse && !h->coarse_schur && schur_wanted(h, h->nc, 2)) {
+        // New values for an old pattern: this caller is a time stepper (05: a new matrix every flow step, 06: ten per step), and from here on the
+        // coarse factorisation is what each of its steps pays -- the Schur-complement solver factors in a third of the dense inverse's time and
+        // solves within a few us of it (csrc/smg_schur.hpp).  The plan is built once, now.
+        bool planned = false;
+        const int rc = coarse_plan_schur(h, h->lv[L - 1].A, &planned);
+        if (rc) return rc;
+        if (planned) {
+            HIPCHK(hipStreamSynchronize(st));
+            drop_graphs(h);                      // the captured coarse solves point at the dense inverse
+            h->coarse_schur = true;
+            h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release(); h->d_dense_pos.release();
+        } else {
+            h->schur_declined = true;
+            h->sch.release(); h->schur = SchurPlan();
+        }
+    }
     if (h->coarse_sparse) {
         Level& Lc = h->lv[L - 1];
         HIPCHK(hipMemcpyAsync(Lc.A.val.data(), Lc.d_Aval.p, Lc.A.val.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         int rc = coarse_factor_sparse(h, Lc.A, true);
         if (rc) return rc;
+    } else if (h->coarse_schur) {
+        HIPCHK(launch_schur_factor(h->sch.view, h->lv[L - 1].d_Aval.p, st));
+        HIPCHK(hipStreamSynchronize(st));
     } else {
         const Level& Lc = h->lv[L - 1];
         HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));

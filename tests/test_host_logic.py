@@ -608,3 +608,47 @@ def test_sparse_cholesky_of_the_coarse_solver(smg_mod):
     rc = L.smg_debug_check_sparse_cholesky(n, ptr.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)),
                                            bad.ctypes.data_as(C.POINTER(C.c_double)), None, None, None)
     assert rc == -1
+
+
+def test_schur_coarse_solver_plan_executed_on_the_host(smg_mod):
+    """csrc/smg_schur.cpp (the coarse solver of the upper part of the dense range; the reference: solver.compute / solver.solve,
+    src/min_quad_with_fixed_mg.cpp:47-48, src/mg_VCycle.cpp:181-201): the plan -- blocks of <= 64 rows, separator, scatter lists, sum lists of the
+    Schur complement, the lists of the three solve steps -- executed on the host the way the kernels read it, against scipy's sparse LU: to
+    rounding.  A Galerkin-like operator (two-ring stencil) and a one-ring one; a block-diagonal matrix (no separator) has no plan."""
+    import ctypes as C
+    import scipy.sparse.linalg as spla
+    smg = smg_mod
+    L = smg._lib.load()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.smg_debug_schur_solve_host.argtypes = [C.c_int, ip, ip, dp, dp, dp, ip, ip]
+    rng = np.random.default_rng(3)
+
+    def run(A):
+        A = A.tocsr(); A.sort_indices()
+        n = A.shape[0]
+        ptr, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        b, x = rng.uniform(-1, 1, n), np.zeros(n)
+        nb, ns = C.c_int(), C.c_int()
+        rc = L.smg_debug_schur_solve_host(n, ptr.ctypes.data_as(ip), col.ctypes.data_as(ip), val.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                                          C.byref(nb), C.byref(ns))
+        assert rc == 0
+        return nb.value, ns.value, b, x
+
+    V, F = M.read_smgm("ogre_sim.smgm")
+    V = M.normalize_unit_area(V, F)
+    A1 = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+    A2 = (A1 @ A1 + 1e-3 * sp.identity(A1.shape[0])).tocsr()            # SPD, two-ring pattern: what a Galerkin product looks like
+    for A, sep_max in ((A1, 0.35), (A2, 0.6)):
+        n = A.shape[0]
+        nb, ns, b, x = run(A)
+        assert nb >= n // 64 and 0 < ns <= sep_max * n, (n, nb, ns)
+        ref = spla.spsolve(A.tocsc(), b)
+        assert np.linalg.norm(x - ref) <= 1e-11 * np.linalg.norm(ref)
+    # only the lower triangle (caller numbering) counts, as for SimplicialLDLT: garbage above the diagonal changes nothing
+    Au = A1.tolil(copy=True)
+    r, c = sp.triu(A1, 1).nonzero()
+    Au[r[:50], c[:50]] = 7.0
+    _, _, b, x = run(Au.tocsr())
+    assert np.linalg.norm(x - spla.spsolve(A1.tocsc(), b)) <= 1e-11 * np.linalg.norm(x)
+    nb, ns, _, _ = run(sp.identity(300, format="csr") * 2.0)
+    assert nb == 0
