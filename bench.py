@@ -102,11 +102,39 @@ def precompute_known_s(smg, mesh, mg, Vf, Ff, n_pins=346):
         return {"error": repr(e)}
 
 
+def reprecompute_leg(smg, mg, A, torch):
+    """What the time-stepping callers pay at every step (05_example_mean_curvature_flow/main.cpp:74, 06: implicit_euler_mg_balloon.h:75): a value-only
+    smg_precompute, new values already in HBM -- Galerkin recipes, panel refresh, coarse factorisation.  With the dense inverse of the coarsest matrix and
+    with the Schur-complement solver the default policy moves to at the first such call (csrc/smg_schur.hpp); the V-cycle with each beside it.
+    Runs last on the handle (the headline above was measured on the dense inverse a handle factored once keeps)."""
+    d = torch.from_numpy(np.ascontiguousarray(A.data)).cuda()
+
+    def med(reps=7):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); mg.precompute_values_device(d.data_ptr()); torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return float(np.median(ts))
+
+    out = {"what": "median wall ms of smg_precompute_values_device (same pattern, values in HBM), 7 calls; V-cycle us = one graph-replayed V(2,2), 1 column"}
+    for when, key in (("never", "dense_inverse"), ("refactor", "schur_complement")):
+        mg.set_coarse_schur(when)
+        mg.precompute(A)                       # full: the policy changed
+        mg.precompute(A)                       # value-only: recipes built; under 'refactor' the coarse solver moves here
+        mg.precompute_values_device(d.data_ptr())
+        cs = mg.coarse_solver()
+        out[key] = {"coarse_solver": cs["kind"], "factor_entries": cs["factor_entries"], "reprecompute_ms": med(), "vcycle_us": mg.bench_vcycle(0, 1, 2, 2, 50),
+                    "coarse_solve_us": mg.bench_vcycle(mg.n_levels - 1, 1, 2, 2, 200)}
+    out["coarse_unknowns"] = int(mg.rows(mg.n_levels - 1))
+    out["default_policy"] = "dense inverse until the first value-only re-precompute, Schur complement from then on (smg_hierarchy_set_coarse_schur)"
+    return out
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources: profiles/traffic.json carries the hash of the sources its PMC passes ran on
     (tools/make_traffic.py); a committed traffic figure is only reported while it still describes the kernels that are timed."""
     hsh = hashlib.sha256()
-    for f in ("smg_device.hip", "smg_device.hpp", "smg_device_inl.hpp"):
+    for f in ("smg_device.hip", "smg_device.hpp", "smg_device_inl.hpp", "smg_gj_inl.hpp"):
         with open(os.path.join(ROOT, "surface_multigrid_code_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
@@ -675,6 +703,7 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the out-of-cache roofline leg (C5, 4.19 M vertices)")
     ap.add_argument("--no-multi-mesh", action="store_true", help="skip the leg with M independent ogre.obj-size solves on one GPU")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 (ogre.obj, k = 64, column-sharded) leg")
+    ap.add_argument("--no-reprecompute", action="store_true", help="skip the value-only re-precompute leg (dense inverse vs Schur-complement coarse solver)")
     ap.add_argument("--no-block3", action="store_true", help="skip the block (3-DOF) leg (C3 mesh, kron(S, C3) system)")
     ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
     ap.add_argument("--no-c3k64", action="store_true", help="skip the C3 x 64 columns column-sharded (strong scaling) leg")
@@ -997,6 +1026,12 @@ def main():
                 raise
         if rank == 0:
             out["c3_k64_sharded"] = c3k
+    # ---- row f-2: the value-only re-precompute of the time-stepping callers, rank 0 at N = 1 only (last use of the C3 handle)
+    if rank == 0 and world == 1 and not args.no_reprecompute and args.workload == "C3":
+        try:
+            out["reprecompute"] = reprecompute_leg(smg, mg, A, torch)
+        except Exception as e:
+            out["reprecompute"] = {"error": repr(e)}
     # ---- block (3-DOF) kernels, rank 0 at N = 1 only
     if rank == 0 and world == 1 and not args.no_block3 and args.workload == "C3":
         try:

@@ -9,9 +9,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int GJ_NB = 64;
 
 // In-place inverse of a 64 x 64 (SPD) block held in LDS, by a workgroup of 256 threads: Gauss-Jordan in four steps of 16 -- the
-// 16 x 16 pivot is inverted by one wave on its own (16 eliminations, no workgroup barrier), the row panel and the rank-16 update
-// run on the matrix cores -- 12 workgroup barriers instead of the 128 of the element-wise elimination, and far fewer LDS reads
-// (35 us -> 17 us for the stand-alone kernel; what remains is the chain of 64 dependent eliminations).
+// 16 x 16 pivot is inverted by one wave on its own, in registers (16 eliminations, no workgroup barrier, no LDS), the row panel and the
+// rank-16 update run on the matrix cores -- 12 workgroup barriers instead of the 128 of the element-wise elimination
+// (35 us -> 17 us for the stand-alone kernel with the pivot in LDS; what remains is the chain of 64 dependent eliminations).
 // Must be entered by all threads, with `a` complete (barrier before the call is the caller's).
 __device__ __forceinline__ void gj_invert64(double (*a)[GJ_NB + 1], double (*Rb)[GJ_NB + 1], double (*Cb)[17])
 {
@@ -19,30 +19,37 @@ __device__ __forceinline__ void gj_invert64(double (*a)[GJ_NB + 1], double (*Rb)
     for (int kk = 0; kk < 4; kk++) {
         const int P = 16 * kk;
         if (t < 64) {
+            // the 16 x 16 pivot in the registers of one wave: lane (jj, ig) holds rows ig + 4 q of column jj; what an elimination needs of other
+            // lanes -- row p and column p -- comes through the cross-lane network (ds_bpermute / v_readlane), not through LDS stores, fences and
+            // wave barriers: 16 eliminations 3.2 -> ~1.2 us, and they are the serial chain of every Gauss-Jordan step on a small matrix
             const int jj = t & 15, ig = t >> 4;           // rows ig + 4 q of the pivot, column jj
+            double cur[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) cur[q] = a[P + ig + 4 * q][P + jj];
+#pragma unroll
             for (int p = 0; p < 16; p++) {
                 // reciprocal of the pivot: hardware estimate + two Newton steps (the IEEE division sequence is several times longer
                 // and sits on the one serial chain of the whole inversion)
-                const double piv = a[P + p][P + p], r = a[P + p][P + jj];
+                const int src = p + 16 * (p & 3);                                  // the lane that holds a[p][p], in cur[p >> 2]
+                const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cur[p >> 2]), src), __builtin_amdgcn_readlane(__double2loint(cur[p >> 2]), src));
+                const double r = __shfl(cur[p >> 2], jj + 16 * (p & 3));           // a[p][jj]
+                double f[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) f[q] = __shfl(cur[q], p + 16 * ig);    // a[ig + 4 q][p]
                 double d = __builtin_amdgcn_rcp(piv);
                 d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
                 d = __builtin_fma(d, __builtin_fma(-piv, d, 1.0), d);
-                double f[4], cur[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { f[q] = a[P + ig + 4 * q][P + p]; cur[q] = a[P + ig + 4 * q][P + jj]; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = ig + 4 * q;
                     double val;
                     if (i == p) val = (jj == p) ? d : r * d;
                     else val = (jj == p) ? -(f[q] * d) : cur[q] - f[q] * (r * d);
-                    a[P + i][P + jj] = val;
+                    cur[q] = val;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[P + ig + 4 * q][P + jj] = cur[q];
         }
         __syncthreads();
         // row panel D^-1 a[P.., :] (one 16 x 16 tile per wave; the inverse itself in the pivot columns) and a copy of the column panel

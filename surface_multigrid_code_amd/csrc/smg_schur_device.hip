@@ -23,6 +23,12 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
+// the value lane `src` (a compile-time constant) holds, in every lane
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
 __global__ void k_schur_scatter(double* __restrict__ arena, const long long* __restrict__ pos, const long long* __restrict__ pos2, const double* __restrict__ val, int nnz,
                                 const long long* __restrict__ ones, int n_ones)
 {
@@ -51,38 +57,60 @@ __global__ __launch_bounds__(256) void k_schur_blocks(double* arena, long long o
     const int i = blockIdx.x, t = threadIdx.x;
     double* D = arena + off_D + (size_t)i * (GJ_NB * GJ_NB);
     for (int e = t; e < GJ_NB * GJ_NB; e += 256) a[e >> 6][e & 63] = D[e];
+    const int s0 = sptr[i], m = sptr[i + 1] - s0;
+    const double* P = arena + off_P + (size_t)64 * s0;
+    double* W = arena + off_W + (size_t)64 * s0;
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    // a column of P_i^T is ONE vector load whose 64 values are handed round by v_readlane; the wave's columns w, w + 4, .. arrive four at a time, the
+    // next four travelling while these are multiplied -- and the first four behind the inversion.  Measured with wall_clock64 (block 0 of C3's plan,
+    // 59 us): load 4.3, inversion 15.6, mirror + store 1.9, W 13.2, image 5.8, products 18.0 -- the two product phases are bound by instruction issue
+    // (two v_readlane per multiply-add; four columns per LDS read: no faster); the matrix cores would take them to ~1 us each: not done, 3 % of a
+    // re-precompute.
+    double nx[4], cu[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nx[q] = w + 4 * q < m ? P[64 * (w + 4 * q) + lane] : 0.0;
     __syncthreads();
     gj_invert64(a, Rb, Cb);
     for (int e = t; e < GJ_NB * GJ_NB; e += 256) { const int r = e >> 6, c = e & 63; if (c > r) a[r][c] = a[c][r]; }
     __syncthreads();
     for (int e = t; e < GJ_NB * GJ_NB; e += 256) D[e] = a[e >> 6][e & 63];
-    const int s0 = sptr[i], m = sptr[i + 1] - s0;
-    const double* P = arena + off_P + (size_t)64 * s0;
-    double* W = arena + off_W + (size_t)64 * s0;
-    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    for (int c = w; c < m; c += 4) {
-        const double* pc = P + 64 * c;                  // wave-uniform: scalar loads
-        double acc = 0.0;
-#pragma unroll 16
-        for (int rp = 0; rp < 64; rp++) acc += a[lane][rp] * pc[rp];
-        W[64 * c + lane] = acc;
+    for (int c0 = w; c0 < m; c0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { cu[q] = nx[q]; const int cn = c0 + 16 + 4 * q; nx[q] = cn < m ? P[64 * cn + lane] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = c0 + 4 * q;
+            if (c >= m) break;
+            double acc = 0.0;
+#pragma unroll
+            for (int rp = 0; rp < 64; rp++) acc += a[lane][rp] * lane_value(cu[q], rp);
+            W[64 * c + lane] = acc;
+        }
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();     // (orders the workgroup's own stores to W before its loads below; an agent-scope fence here wrote back the L2 the preceding memsets had dirtied: 40 us)
     double* C = arena + off_C + coff[i];
     for (int b0 = 0; b0 < m; b0 += SCHUR_WL) {           // (one pass unless the block touches more than 96 separator rows)
         const int nb = min(SCHUR_WL, m - b0);
         if (b0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) nx[q] = b0 + w + 4 * q < m ? P[64 * (b0 + w + 4 * q) + lane] : 0.0;
         for (int e = t; e < nb * 64; e += 256) lds[(e >> 6) * 65 + (e & 63)] = W[64 * b0 + e];
         __syncthreads();
-        for (int c1 = b0 + w; c1 < m; c1 += 4) {          // C[c1][c2], c2 <= c1: lanes = c2 inside the image
-            const double* p1 = P + 64 * c1;               // wave-uniform
-            for (int cc = lane; cc < nb && b0 + cc <= c1; cc += 64) {
-                const double* wl = lds + cc * 65;
-                double acc = 0.0;
-#pragma unroll 16
-                for (int r = 0; r < 64; r++) acc += p1[r] * wl[r];
-                C[(size_t)c1 * m + b0 + cc] = acc;
+        for (int c0 = b0 + w; c0 < m; c0 += 16) {         // C[c1][c2], c2 <= c1: lanes = c2 inside the image
+#pragma unroll
+            for (int q = 0; q < 4; q++) { cu[q] = nx[q]; const int cn = c0 + 16 + 4 * q; nx[q] = cn < m ? P[64 * cn + lane] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c1 = c0 + 4 * q;
+                if (c1 >= m) break;
+                for (int c8 = 0; c8 < nb && b0 + c8 <= c1; c8 += 64) {       // (wave-uniform trip count)
+                    const int cc = c8 + lane;
+                    const double* wl = lds + min(cc, nb - 1) * 65;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 64; r++) acc += lane_value(cu[q], r) * wl[r];
+                    if (cc < nb && b0 + cc <= c1) C[(size_t)c1 * m + b0 + cc] = acc;
+                }
             }
         }
     }
