@@ -227,6 +227,8 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     h->bgs_min_rows = env_int("SMG_BGS_MIN_ROWS", -1);
     h->coarse_schur_when = std::min(2, std::max(0, env_int("SMG_COARSE_SCHUR", 2)));
     h->coarse_schur_min = env_int("SMG_COARSE_SCHUR_MIN", 2048);
+    h->coarse_schur_big = env_int("SMG_COARSE_SCHUR_BIG", 6144);
+    h->coarse_schur_max = env_int("SMG_COARSE_SCHUR_MAX", 65536);
     return h;
 }
 

@@ -223,6 +223,9 @@ struct smg_hierarchy {
     int coarse_schur_when = 2;      // smg_hierarchy_set_coarse_schur: 0 never, 1 from the first smg_precompute on, 2 from the first VALUE-ONLY re-precompute on (a caller
                                     // that sends new values for an old pattern pays the factorisation at every step; one that does not, only the solves)
     int coarse_schur_min = 2048;    // ... for coarsest levels of at least this many unknowns (and within the dense range)
+    int coarse_schur_big = 6144;    // under `when` = 2: coarsest levels of at least this many unknowns take it from the FIRST precompute on -- there it is also the cheaper one
+                                    // to apply (15 804 unknowns: 38 us and 182 MB against 204 us and 2 GB) and to build
+    int coarse_schur_max = 65536;   // ... and up to this size it stands in for the sparse factorisation above coarse_dense_max (only S, ~0.27 n rows there, is dense)
     bool schur_declined = false;    // the current coarsest matrix has no plan (smg_schur.hpp): not tried again until the next full precompute
     smg::SchurPlan schur;
     struct SchurBuf {

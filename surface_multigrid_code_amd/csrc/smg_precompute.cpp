@@ -583,9 +583,13 @@ static int coarse_factor_sparse(smg_hierarchy* h, const Csr& Ac, bool reuse)
 }
 
 // ---- Schur-complement coarse solver (smg_schur.hpp): the plan of a coarsest matrix in the upper part of the dense range, on the device --
-static bool schur_wanted(const smg_hierarchy* h, int n, int when)
+// phase 1: at a full precompute; phase 2: at a value-only re-precompute of a handle that still holds the dense inverse
+static bool schur_wanted(const smg_hierarchy* h, int n, int phase)
 {
-    return h->coarse_schur_when == when && h->coarse_schur_min >= 0 && n >= h->coarse_schur_min && !h->schur_declined;
+    if (h->coarse_schur_when == 0 || h->coarse_schur_min < 0 || n < h->coarse_schur_min || n > h->coarse_schur_max || h->schur_declined) return false;
+    if (phase == 2) return h->coarse_schur_when == 2;
+    // from the start: on request, where it is the cheaper solver to apply as well, and where a dense inverse of the whole matrix is not allowed
+    return h->coarse_schur_when == 1 || n >= h->coarse_schur_big || n > h->coarse_dense_max;
 }
 // *planned: h->sch holds the plan of Ac (the arena still to be factored); not: no plan for this matrix (the dense inverse serves)
 static int coarse_plan_schur(smg_hierarchy* h, const Csr& Ac, bool* planned)
@@ -674,14 +678,8 @@ static int coarse_images(smg_hierarchy* h)
         Sell S = build_sell(Lc.A_int, nullptr, SELL_C, false);
         HIPCHK(Lc.dA.upload(S));
     }
-    if (Lc.n > h->coarse_dense_max) {
-        h->nc = Lc.n; h->nc_pad = Lc.n;
-        return coarse_factor_sparse(h, Lc.A, false);
-    }
-    h->coarse_sparse = false;
     const int nc = Lc.n;
     const int np = ((nc + 63) / 64) * 64;
-    h->nc = nc; h->nc_pad = np;
     h->coarse_schur = false;
     h->schur_declined = false;
     if (schur_wanted(h, nc, 1)) {
@@ -693,12 +691,23 @@ static int coarse_images(smg_hierarchy* h)
             HIPCHK(d_val.upload(Lc.A.val));
             HIPCHK(launch_schur_factor(h->sch.view, d_val.p, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
+            h->nc = nc; h->nc_pad = np;
             h->coarse_schur = true;
+            if (h->coarse_sparse) {   // the handle held a sparse factorisation (another matrix, another policy)
+                h->coarse_sparse = false;
+                h->c_perm.release(); h->c_rptr.release(); h->c_rcol.release(); h->c_cptr.release(); h->c_crow.release(); h->c_rval.release(); h->c_cval.release(); h->c_diag.release(); h->c_work.release();
+            }
             h->d_Ainv.release(); h->d_Ainv32.release(); h->d_sympart.release();
             return SMG_OK;
         }
     }
     h->sch.release(); h->schur = SchurPlan();
+    if (Lc.n > h->coarse_dense_max) {
+        h->nc = Lc.n; h->nc_pad = Lc.n;
+        return coarse_factor_sparse(h, Lc.A, false);
+    }
+    h->coarse_sparse = false;
+    h->nc = nc; h->nc_pad = np;
     // dense image on the device: the few entries travel, not n^2 zeros
     std::vector<long long> pos((size_t)Lc.A.nnz());
     for (int i = 0; i < nc; i++)

@@ -21,6 +21,7 @@ def test_sparse_coarse_solver_on_small_hierarchies_matches_the_dense_one(smg, or
     p = subdiv_problem(kind="mcf", k=k, n_sub=2)
     mg = smg.Hierarchy.from_prolongs(p["Ps"])
     mg.set_coarse_dense_max(0)
+    mg.set_coarse_schur("never")            # (by default the Schur-complement solver would stand in up to 65 536 unknowns)
     mg.precompute(p["A"])
     cs = mg.coarse_solver()
     nc = mg.rows(mg.n_levels - 1)
@@ -65,6 +66,7 @@ def test_one_and_two_level_calls_on_a_15k_mesh(smg, oracle_mod):
     xref = sla.spsolve(A.tocsc(), rhs)
     # 1 level: the whole mesh is the coarsest level
     mg1 = smg.Hierarchy(1)
+    mg1.set_coarse_schur("never")
     mg1.set_coarse_dense_max(8192)            # (the default, 16384, would still invert these 15 804 unknowns densely: 2 GB, 0.3 ms per solve)
     mg1.precompute(A)
     cs = mg1.coarse_solver()
@@ -83,6 +85,7 @@ def test_one_and_two_level_calls_on_a_15k_mesh(smg, oracle_mod):
     mg2.precompute(A)
     assert mg2.coarse_solver()["kind"] == "dense_inverse"
     r_dense = mg2.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=60))
+    mg2.set_coarse_schur("never")
     mg2.set_coarse_dense_max(1000)
     mg2.precompute(A)
     assert mg2.coarse_solver()["kind"] == "sparse_cholesky"
@@ -103,6 +106,7 @@ def test_dense_inverse_of_a_coarsest_level_beyond_8192_unknowns(smg, oracle_mod)
     A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
     rng = np.random.default_rng(17)
     mg = smg.Hierarchy(1)
+    mg.set_coarse_schur("never")                       # (by default a coarsest level of this size takes the Schur-complement solver from the start)
     mg.precompute(A)
     cs = mg.coarse_solver()
     assert cs["kind"] == "dense_inverse" and n >= 8192
@@ -128,6 +132,7 @@ def test_a_stalled_triangular_solve_surfaces_as_an_error_code_not_as_a_result(sm
     p = subdiv_problem(kind="mcf", k=8, n_sub=2)
     mg = smg.Hierarchy.from_prolongs(p["Ps"])
     mg.set_coarse_dense_max(0)
+    mg.set_coarse_schur("never")            # (by default the Schur-complement solver would stand in up to 65 536 unknowns)
     mg.precompute(p["A"])
     nc = mg.rows(mg.n_levels - 1)
     rng = np.random.default_rng(4)
@@ -159,6 +164,7 @@ def test_many_columns_cost_the_sparse_triangular_solves_little_more_than_one(smg
     n = V.shape[0]
     A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
     mg = smg.Hierarchy(1)
+    mg.set_coarse_schur("never")
     mg.set_coarse_dense_max(8192)
     mg.precompute(A)
     assert mg.coarse_solver()["kind"] == "sparse_cholesky"
@@ -247,3 +253,33 @@ def test_schur_complement_coarse_solver_on_a_galerkin_operator_of_4k_unknowns_an
     assert len(a[2]) == len(b[2]) and np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
     print("value-only re-precompute, 3 952 coarse unknowns: schur %.2f ms, dense %.2f ms" % (1e3 * out["schur_complement"][1], 1e3 * out["dense_inverse"][1]))
     assert out["schur_complement"][1] * 1.5 <= out["dense_inverse"][1]
+
+
+def test_large_coarsest_levels_take_the_schur_complement_from_the_start_also_beyond_the_dense_range(smg, oracle_mod):
+    """Default policy, large coarsest levels (1-level calls: the whole mesh is the coarsest level, src/mg_VCycle.cpp:28-33).  From 6 144 unknowns on the
+    Schur-complement solver is cheaper to build AND to apply than the dense inverse (15 804 unknowns: 182 MB and 38 us per solve against 2 GB and 204 us),
+    so it is taken at the first precompute; and up to 65 536 unknowns it stands in for the sparse Cholesky factorisation above the dense range (63 210
+    unknowns: only the separator, 0.27 n rows, is inverted densely).  One cycle = the direct solve: against the oracle's LDL^T resp. scipy."""
+    import scipy.sparse.linalg as sla
+    V, F = M.read_smgm("bunny_15K_init.smgm")
+    V = M.normalize_unit_area(V, F)
+    rng = np.random.default_rng(5)
+    for n_sub in (0, 1):
+        if n_sub:
+            V, F, _ = M.subdivision_hierarchy(V, F, 1)
+        n = V.shape[0]
+        A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+        mg = smg.Hierarchy(1)
+        mg.precompute(A)
+        cs = mg.coarse_solver()
+        assert cs["kind"] == "schur_complement" and cs["factor_entries"] < 0.2 * n * n, (n, cs)
+        rhs, z0 = rng.uniform(-1, 1, (n, 3)), np.zeros((n, 3))
+        a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-9, max_iter=5))
+        assert a[0] and len(a[2]) == 2
+        if n_sub == 0:
+            o1 = oracle_mod.OracleMG([]); o1.precompute(A)
+            b = o1.solve(rhs, z0, tol=1e-9, max_iter=5)
+            assert np.linalg.norm(a[1] - b[1]) <= 1e-10 * np.linalg.norm(b[1])
+        # (the coarsest matrix carries the reference's +1e-12 on its diagonal: 2e-8 relative to the lumped masses -- hence 1e-6 against the plain solve)
+        assert np.linalg.norm(a[1] - sla.spsolve(A.tocsc(), rhs).reshape(n, 3)) <= 1e-6 * np.linalg.norm(a[1])
+        assert np.linalg.norm(A @ a[1] - rhs) <= 1e-7 * np.linalg.norm(rhs)
