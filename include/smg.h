@@ -206,30 +206,37 @@ int smg_hierarchy_set_block_gs(smg_hierarchy *h, int min_rows);
  * slots that hold a row of their own (the rest repeat one)}.  Any pointer may be NULL.  Returns 1 when level lv sweeps block-sequentially for this k, 0 when
  * it does not (nothing is written then), < 0 on error. */
 int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks, int *n_colors, int *color_ptr, int *blk_ptr, int *rows, double *stats);
-/* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).
- * Up to n_max unknowns (default 16384, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device and applied as a dense,
- * bandwidth-bound product (8 n^2 bytes of HBM -- 2 GB at 16 k --, half of them streamed per cycle and column; <= 1e-11 from LDL^T):
- * 0.02 ms per cycle at 4 k unknowns, 0.15 ms at 12 k, against 2.6 ms for the sparse solves at 16 k -- lower n_max to trade time for memory.  Above: a sparse Cholesky factorisation P A P^T = L L^T -- what the
- * reference's Eigen::SimplicialLDLT does -- computed on the host during smg_precompute (nested-dissection order), with the two
- * triangular solves on the device (one launch each, rows wait for the rows they read; deterministic).  So mg_precompute's nVCoarsest
- * may be anything the reference accepts, down to a 1-level call on the whole mesh, in O(n log n) memory.  Not available with the sparse
- * factorisation: the mixed-precision cycle.  smg_hierarchy_coarse_solver: 0 dense inverse / 1 sparse Cholesky after a precompute;
- * *factor_entries: n^2 resp. the entries of L. */
+/* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).  Three of them,
+ * chosen by size and by what the caller does (all: <= 1e-11 from LDL^T, deterministic):
+ *  - DENSE INVERSE, up to n_max unknowns (smg_hierarchy_set_coarse_dense_max, default 16384, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device
+ *    (blocked symmetric Gauss-Jordan on the matrix cores) and applied as a bandwidth-bound product (8 n^2 bytes of HBM, half of them streamed per cycle and
+ *    column): 0.02 ms per cycle at 4 k unknowns, 0.2 ms at 16 k; the cheapest to apply below ~6 k unknowns, n^3 flops to build (2.4 ms at 4 k, 0.1 s at 16 k).
+ *  - SCHUR COMPLEMENT (smg_hierarchy_set_coarse_schur below): one level of exact block elimination, only the separator (0.27 - 0.43 n rows) inverted densely.
+ *  - SPARSE CHOLESKY P A P^T = L L^T -- what the reference's Eigen::SimplicialLDLT does -- computed on the host during smg_precompute (nested-dissection
+ *    order), the two triangular solves on the device (one launch each, rows wait for the rows they read): O(n log n) memory, 2.6 ms per solve at 16 k
+ *    unknowns, 16 ms at 63 k; for coarsest levels beyond the other two, or on request.  Not available with it: the mixed-precision cycle.
+ * So mg_precompute's nVCoarsest may be anything the reference accepts, down to a 1-level call on the whole mesh.
+ * smg_hierarchy_coarse_solver: 0 dense inverse / 1 sparse Cholesky / 2 Schur complement after a precompute; *factor_entries: n^2, the entries of L, resp. the
+ * doubles the Schur solver keeps. */
 int smg_hierarchy_set_coarse_dense_max(smg_hierarchy *h, int n_max);
 int smg_hierarchy_coarse_solver(const smg_hierarchy *h, long *factor_entries);
-/* Inside the dense range, coarsest levels of at least n_min unknowns (default 2048, or SMG_COARSE_SCHUR_MIN; n_min < 0: unchanged) can be factored by
- * ONE LEVEL OF EXACT BLOCK ELIMINATION instead of a dense inverse of the whole matrix (csrc/smg_schur.hpp): the rows are cut into compact blocks
- * of <= 64, a vertex cover of the entries between blocks becomes the separator, every block is inverted in LDS, and only the separator's Schur
- * complement (~0.43 n rows on the Galerkin operator of a surface mesh) is inverted densely: 0.9 ms instead of 2.4 at 3 952 unknowns -- which is what
- * the time-stepping callers (05_example_mean_curvature_flow/main.cpp:74, 06: implicit_euler_mg_balloon.h:75) pay at every value-only smg_precompute.
- * coarseSolve becomes g = b_S - sum W_i^T b_i, x_S = S^-1 g, x_i = D_i^-1 b_i - W_i x_S: three launches instead of two, a quarter of the bytes;
- * per cycle within a few us of the dense product (one column: +4 us at 3 952 unknowns, 64 columns: -7).  Same answer to rounding (<= 1e-11 from LDL^T),
- * bit-identical from run to run; available in fp32 for the mixed-precision cycle.
- * when: 0 never; 1 from the first smg_precompute on; 2 (default, or SMG_COARSE_SCHUR) from the first VALUE-ONLY re-precompute on -- the choice by cost:
- * a handle that is factored once and solved many times keeps the dense inverse and its slightly cheaper cycles, a handle whose values change pays the
- * factorisation at every step and gets the cheap one (the switch itself costs one plan on the host, ~ms, once).
- * smg_hierarchy_coarse_solver returns 2 for it, *factor_entries = the doubles it keeps.  A matrix whose blocks touch more than 128 separator rows each,
- * or whose separator exceeds 0.7 n, keeps the dense inverse. */
+/* The Schur-complement coarse solver (csrc/smg_schur.hpp): the rows are cut into compact blocks of <= 64, a vertex cover of the entries between blocks becomes
+ * the separator, every block is inverted in LDS, and only the separator's Schur complement is inverted densely.  coarseSolve becomes g = b_S - sum W_i^T b_i,
+ * x_S = S^-1 g, x_i = D_i^-1 b_i - W_i x_S: three launches instead of two, a quarter of the bytes (or less).  Same answer to rounding, bit-identical from
+ * run to run; available in fp32 for the mixed-precision cycle.  For coarsest levels of n_min (default 2048, or SMG_COARSE_SCHUR_MIN; n_min < 0: unchanged)
+ * to 65 536 (SMG_COARSE_SCHUR_MAX) unknowns:
+ *   when = 0  never;
+ *   when = 1  from the first smg_precompute on;
+ *   when = 2  (default, or SMG_COARSE_SCHUR) THE CHOICE BY COST:
+ *             - below 6 144 unknowns (SMG_COARSE_SCHUR_BIG) a handle that is factored once keeps the dense inverse (its cycle is ~4 us cheaper at 4 k unknowns);
+ *               the first VALUE-ONLY re-precompute moves it to the Schur complement -- a caller that sends new values for an old pattern (05_example_mean_
+ *               curvature_flow/main.cpp:74, 06: implicit_euler_mg_balloon.h:75) pays the factorisation at every step: 0.9 ms instead of 2.4 at 3 952 unknowns,
+ *               value-only smg_precompute 3.1 -> 1.4 ms (the switch itself costs one plan on the host, ~ms, once);
+ *             - from 6 144 unknowns on it is cheaper to build AND to apply: taken at the first precompute (15 804 unknowns: 38 us per solve and 182 MB
+ *               against 204 us and 2 GB);
+ *             - above n_max (smg_hierarchy_set_coarse_dense_max) it stands in for the sparse factorisation (63 210 unknowns: 0.30 ms per solve against
+ *               15.8 ms, 2.6 GB against 0.1 GB).
+ * A matrix whose blocks touch more than 128 separator rows each, or whose separator exceeds 0.7 n, keeps the dense inverse resp. the sparse factorisation. */
 int smg_hierarchy_set_coarse_schur(smg_hierarchy *h, int when, int n_min);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],

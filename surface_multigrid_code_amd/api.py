@@ -310,9 +310,9 @@ class Hierarchy:
         _chk(self.L.smg_hierarchy_set_coarse_dense_max(self.h, int(n_max)), "smg_hierarchy_set_coarse_dense_max")
 
     def set_coarse_schur(self, when="refactor", n_min=-1):
-        """Coarsest levels of at least n_min unknowns (default 2048; -1: unchanged) inside the dense range are factored by block elimination +
-        a dense Schur complement of the separator instead of a dense inverse of the whole matrix: 'never', 'always' (from the first precompute
-        on) or 'refactor' (default: from the first value-only re-precompute on -- what a time-stepping caller does)."""
+        """The Schur-complement coarse solver (block elimination + dense inverse of the separator only) for coarsest levels of n_min (default 2048;
+        -1: unchanged) to 65 536 unknowns: 'never', 'always' (from the first precompute on) or 'refactor' (default, the choice by cost: below 6 144
+        unknowns from the first value-only re-precompute on -- what a time-stepping caller does --, from 6 144 on and above the dense range at once)."""
         _chk(self.L.smg_hierarchy_set_coarse_schur(self.h, {"never": 0, "always": 1, "refactor": 2}[when], int(n_min)), "smg_hierarchy_set_coarse_schur")
 
     def coarse_solver(self):
