@@ -283,3 +283,45 @@ def test_large_coarsest_levels_take_the_schur_complement_from_the_start_also_bey
         # (the coarsest matrix carries the reference's +1e-12 on its diagonal: 2e-8 relative to the lumped masses -- hence 1e-6 against the plain solve)
         assert np.linalg.norm(a[1] - sla.spsolve(A.tocsc(), rhs).reshape(n, 3)) <= 1e-6 * np.linalg.norm(a[1])
         assert np.linalg.norm(A @ a[1] - rhs) <= 1e-7 * np.linalg.norm(rhs)
+
+
+def test_schur_complement_on_a_block_system_and_the_fallback_when_no_plan_exists(smg, oracle_mod):
+    """(i) A 3-DOF system (kron(S, C3) on ogre_sim, 3 x 3 block kernels; coarsest level: three coupled unknowns per vertex, ~54 entries per row): blocks of
+    64 rows are 21 vertices, the separator is two thirds of the matrix and blocks touch up to ~100 separator rows -- the second pass of the block kernel's
+    LDS image (more than 96) -- coarse_solve against the oracle's LDL^T, solves as with the dense inverse.  (ii) A matrix without a useful separator (a
+    four-ring pattern: the vertex cover exceeds 0.7 n) keeps the dense inverse although the Schur complement was asked for, and solves."""
+    from test_gpu_block import build_block
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod, kron=True, nVCoarsest=600)
+    assert mg.coarse_solver()["kind"] == "dense_inverse"
+    sch = smg.Hierarchy.from_prolongs(Ps)
+    sch.set_coarse_schur("always", 1)
+    sch.precompute(A)
+    nc = sch.rows(sch.n_levels - 1)
+    cs = sch.coarse_solver()
+    assert sch.block_size() == 3 and cs["kind"] == "schur_complement", cs
+    rng = np.random.default_rng(8)
+    for k in (1, 3, 16):
+        B, u = rng.uniform(-1, 1, (nc, k)), rng.uniform(-1, 1, (nc, k))
+        got, ref = sch.coarse_solve(B, u), orc.coarse_solve(B, u)
+        assert abs(got - ref).max() <= 1e-11 * abs(ref).max()
+    n3 = A.shape[0]
+    rhs, z0 = rng.uniform(-1, 1, (n3, 2)), np.zeros((n3, 2))
+    o = smg.SolveOpts(tol=1e-10, max_iter=80)
+    a, b = sch.solve(rhs, z0, None, o), mg.solve(rhs, z0, None, o)
+    assert a[0] and b[0] and len(a[2]) == len(b[2]) and np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(b[1])
+    # (ii)
+    Vs, Fs = M.read_smgm("ogre_sim.smgm")
+    Vs = M.normalize_unit_area(Vs, Fs)
+    A1 = (M.massmatrix(Vs, Fs, "barycentric") - 0.01 * M.cotmatrix(Vs, Fs)).tocsr()
+    P4 = (abs(A1) > 0).astype(np.float64)
+    P4 = (P4 @ P4 @ P4 @ P4).tocsr()                                        # the four-ring pattern, ~60 entries per row
+    P4.data[:] = -0.5 / np.diff(P4.indptr).max()
+    A4 = (P4 - sp.diags(P4.diagonal()) + sp.identity(P4.shape[0])).tocsr(); A4.sort_indices()     # symmetric, strictly diagonally dominant
+    one = smg.Hierarchy(1)
+    one.set_coarse_schur("always", 1)
+    one.precompute(A4)
+    assert one.coarse_solver()["kind"] == "dense_inverse"
+    n = A4.shape[0]
+    rhs = rng.uniform(-1, 1, (n, 1))
+    r = one.solve(rhs, np.zeros((n, 1)), None, smg.SolveOpts(tol=1e-9, max_iter=5))
+    assert r[0] and np.linalg.norm(A4 @ r[1] - rhs) <= 1e-7 * np.linalg.norm(rhs)
