@@ -605,8 +605,11 @@ static int coarse_plan_schur(smg_hierarchy* h, const Csr& Ac, bool* planned)
     HIPCHK(B.aptr.upload(P.aptr)); HIPCHK(B.ablk.upload(P.ablk)); HIPCHK(B.acol.upload(P.apan)); HIPCHK(B.rptr.upload(P.rptr));
     HIPCHK(B.coff.upload(P.coff)); HIPCHK(B.pos.upload(P.pos)); HIPCHK(B.pos2.upload(P.pos2)); HIPCHK(B.ones.upload(P.ones));
     HIPCHK(B.rdst.upload(P.rdst)); HIPCHK(B.rdst2.upload(P.rdst2)); HIPCHK(B.rsrc.upload(P.rsrc));
-    HIPCHK(B.arena.alloc((size_t)P.total));
-    HIPCHK(B.gj.alloc((size_t)2 * P.ns_pad * 64 + 2 * 64 * 64));
+    if (B.arena.alloc((size_t)P.total) != hipSuccess || B.gj.alloc((size_t)2 * P.ns_pad * 64 + 2 * 64 * 64) != hipSuccess) {
+        (void)hipGetLastError();              // no room for the separator's dense inverse: the other solvers serve
+        B.release(); h->schur = SchurPlan();
+        return SMG_OK;
+    }
     if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(B.sym.alloc((size_t)(P.ns_pad / 64) * (P.ns_pad / 64) * 64)); else B.sym.release();
     B.arena32.release(); B.g.release(); B.xs.release(); B.g32.release(); B.xs32.release();
     SchurDev& V = B.view;

@@ -61,7 +61,7 @@ SchurPlan build_schur(const Csr& A, int block_rows)
     Pn.n = n;
     Pn.ns = (int)Pn.srow.size();
     Pn.ns_pad = (Pn.ns + 63) / 64 * 64;
-    if (Pn.nb == 0 || Pn.ns == 0 || (double)Pn.ns > 0.7 * n) return SchurPlan();
+    if (Pn.nb == 0 || Pn.ns == 0 || (double)Pn.ns > 0.7 * n || Pn.ns > SCHUR_NS_MAX) return SchurPlan();
     // ---- the separator rows every block touches (its local columns), and the inverse lists
     Pn.sptr.assign((size_t)Pn.nb + 1, 0);
     {

@@ -24,6 +24,7 @@ namespace smg {
 
 constexpr int SCHUR_B = 64;        // rows of an interior block at most
 constexpr int SCHUR_M_MAX = 128;   // separator rows a block may touch at most (more: no plan, the dense inverse is used)
+constexpr int SCHUR_NS_MAX = 24576; // separator rows at most (its inverse is dense: 4.8 GB there); more: no plan
 
 struct SchurPlan {
     int n = 0, nb = 0;                     // unknowns; interior blocks
@@ -45,8 +46,8 @@ struct SchurPlan {
     bool empty() const { return nb == 0; }
 };
 
-// A: square, structurally symmetric, rows sorted, diagonal stored.  Empty plan when a block touches more than SCHUR_M_MAX separator rows
-// or the separator is more than 0.7 n (nothing gained).
+// A: square, structurally symmetric, rows sorted, diagonal stored.  Empty plan when a block touches more than SCHUR_M_MAX separator rows,
+// the separator is more than 0.7 n (nothing gained) or more than SCHUR_NS_MAX rows (its dense inverse would not be small).
 SchurPlan build_schur(const Csr& A, int block_rows = SCHUR_B);
 
 }  // namespace smg
