@@ -353,7 +353,8 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     }
     tm.lap("host: transposes of P");
     std::thread cl_thread;
-    struct ClJoin { std::thread& t; ~ClJoin() { if (t.joinable()) t.join(); } } cl_join{cl_thread};     // (it reads this frame)
+    std::atomic<int> coarsest_A{0};      // 1: the coarsest level's matrix exists (the colouring thread may look at it), 2: it never will (error path)
+    struct ClJoin { std::thread& t; std::atomic<int>& st; ~ClJoin() { int z = 0; st.compare_exchange_strong(z, 2); if (t.joinable()) t.join(); } } cl_join{cl_thread, coarsest_A};     // (it reads this frame)
     bool cl_started = false, cl_fresh = false;
     uint64_t cl_key = 0;
     double cl_ms = 0.0;
@@ -365,6 +366,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
             return fail(SMG_ERR_INVALID, "P_%d has %d rows but level %d has %d unknowns", lv, Lv.P.nr, lv - 1, h->lv[lv - 1].A.nr);
         Csr tmp = spgemm(Lv.PT, h->lv[lv - 1].A);
         Lv.A = spgemm(tmp, Lv.P);
+        if (lv == L - 1) coarsest_A.store(1, std::memory_order_release);
         // The coarsest smoothed level is coloured from scratch, every finer one waits for its colours (they are inherited, coarse to
         // fine), and the search takes longer than all that is left to do here: it starts the moment that level's matrix exists.
         if (lv == L - 2 && L >= 3 && !blk && use_rcm && host_threads() > 1) {
@@ -375,7 +377,25 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 cl_key = pattern_key(lv);
                 if (!(cl_key == Lw.ord_key && (int)Lw.ord.perm.size() == Lw.A.nr)) {
                     const std::vector<int> r = rcm_order(Lw.A);
-                    Lw.ord = make_ordering(Lw.A, 512, nullptr, &r);
+                    // When this level is a mid-point subdivision of the coarsest one (every row of P has one or two entries), a 4-colouring of the
+                    // coarsest level's small graph -- found by the all-out search -- is handed down exactly like between the finer levels; the search on
+                    // this level itself may end with five colours, which every finer level then pays for (no inheritance: a from-scratch colouring of a
+                    // million rows took 1.3 s and the cycle 5 launches per sweep instead of 4 on the C3 mesh stopped at 15 804 coarse unknowns).
+                    std::vector<int> inherited;
+                    const std::vector<int>* preset = nullptr;
+                    {
+                        const Level& Lc = h->lv[lv + 1];
+                        bool subdiv = Lc.P.nr == Lw.A.nr && Lc.P.nc <= 65536;
+                        for (int i = 0; i < Lc.P.nr && subdiv; i++) if (Lc.P.ptr[i + 1] - Lc.P.ptr[i] > 2) subdiv = false;
+                        if (subdiv) {
+                            while (coarsest_A.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                            if (coarsest_A.load(std::memory_order_acquire) == 1) {
+                                const Ordering oc = make_ordering(Lc.A, 512, nullptr, nullptr);
+                                if (oc.n_colors() <= 4 && (int)oc.color_of.size() == Lc.A.nr && subdivision_colors(Lc.P, oc.color_of, Lw.A, inherited)) preset = &inherited;
+                            }
+                        }
+                    }
+                    Lw.ord = make_ordering(Lw.A, 512, preset, &r);
                     Lw.ord_key = cl_key;
                     cl_fresh = true;
                 }
