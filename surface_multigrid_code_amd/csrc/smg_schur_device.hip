@@ -23,12 +23,6 @@ __device__ __forceinline__ T wave_sum(T v)
     return v;
 }
 
-// the value lane `src` (a compile-time constant) holds, in every lane
-__device__ __forceinline__ double lane_value(double v, int src)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-
 __global__ void k_schur_scatter(double* __restrict__ arena, const long long* __restrict__ pos, const long long* __restrict__ pos2, const double* __restrict__ val, int nnz,
                                 const long long* __restrict__ ones, int n_ones)
 {
@@ -43,8 +37,13 @@ __global__ void k_schur_scatter(double* __restrict__ arena, const long long* __r
 }
 
 // one workgroup per interior block: D_i -> D_i^-1 (exactly symmetric: the lower triangle mirrored), W_i^T = (D_i^-1 P_i)^T, C_i = P_i^T W_i (lower triangle).
-// LDS: the block and the inversion's two panels first; once W_i is out, the same 50 KB hold W_i^T (96 columns at a time, pitch 65: lanes = columns c2 of
-// C read conflict-free) for the products -- from memory, four loads per wave in flight, they took 0.15 of the kernel's 0.18 ms.
+// The two products run on the fp64 matrix cores (v_mfma_f64_16x16x4: A operand lane -> A[lane & 15][lane >> 4], B operand lane -> B[lane >> 4][lane & 15],
+// register r of the result -> row (lane >> 4) + 4 r, column lane & 15), 16 x 16 tiles, the 64-deep sum in 16 steps:
+//   W (64 x m)  = D^-1 (LDS) x P_i      (P_i[r][c] = P^T[c][r]: a lane's 16 B operands of a tile column are loaded once and meet the four row tiles)
+//   C (m x m)   = P_i^T x W             (A operand from P^T in memory, once per tile row; B operand from the image of W^T in LDS, pitch 65)
+// With lanes as rows / columns and the other operand handed round by v_readlane the two phases took 13 + 18 of the kernel's 75 us (instruction issue:
+// two v_readlane per multiply-add); phases of block 0 of C3's plan before that, by wall_clock64: load 4.3, inversion 15.6, mirror + store 1.9, image 5.8.
+// LDS: the block and the inversion's two panels first; once W_i is out, the same 50 KB hold W_i^T (96 columns at a time).
 constexpr int SCHUR_WL = 96;                                     // columns of W_i^T the LDS image holds (96 x 65 <= 64 x 65 + 16 x 65 + 64 x 17)
 __global__ __launch_bounds__(256) void k_schur_blocks(double* arena, long long off_D, long long off_P, long long off_W, long long off_C, const int* __restrict__ sptr,
                                                       const long long* __restrict__ coff)
@@ -53,63 +52,86 @@ __global__ __launch_bounds__(256) void k_schur_blocks(double* arena, long long o
     double (*a)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(lds);
     double (*Rb)[GJ_NB + 1] = reinterpret_cast<double (*)[GJ_NB + 1]>(lds + GJ_NB * (GJ_NB + 1));
     double (*Cb)[17] = reinterpret_cast<double (*)[17]>(lds + GJ_NB * (GJ_NB + 1) + 16 * (GJ_NB + 1));
-    static_assert(SCHUR_WL * 65 <= GJ_NB * (GJ_NB + 1) + 16 * (GJ_NB + 1) + GJ_NB * 17, "the image of W does not fit the inversion's LDS");
+    static_assert(SCHUR_WL * 65 <= GJ_NB * (GJ_NB + 1) + 16 * (GJ_NB + 1) + GJ_NB * 17 && SCHUR_WL % 16 == 0, "the image of W does not fit the inversion's LDS");
     const int i = blockIdx.x, t = threadIdx.x;
     double* D = arena + off_D + (size_t)i * (GJ_NB * GJ_NB);
-    for (int e = t; e < GJ_NB * GJ_NB; e += 256) a[e >> 6][e & 63] = D[e];
+    {
+        double v[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = D[t + 256 * e];
+#pragma unroll
+        for (int e = 0; e < 16; e++) a[(t + 256 * e) >> 6][t & 63] = v[e];
+    }
     const int s0 = sptr[i], m = sptr[i + 1] - s0;
     const double* P = arena + off_P + (size_t)64 * s0;
     double* W = arena + off_W + (size_t)64 * s0;
     const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    // a column of P_i^T is ONE vector load whose 64 values are handed round by v_readlane; the wave's columns w, w + 4, .. arrive four at a time, the
-    // next four travelling while these are multiplied -- and the first four behind the inversion.  Measured with wall_clock64 (block 0 of C3's plan,
-    // 59 us): load 4.3, inversion 15.6, mirror + store 1.9, W 13.2, image 5.8, products 18.0 -- the two product phases are bound by instruction issue
-    // (two v_readlane per multiply-add; four columns per LDS read: no faster); the matrix cores would take them to ~1 us each: not done, 3 % of a
-    // re-precompute.
-    double nx[4], cu[4];
+    const int lr = lane >> 4, lc = lane & 15;
+    const int T = (m + 15) / 16;                                  // 16-column tiles of the panel
+    // the B operands of this wave's first tile column of W: requested now, they arrive behind the inversion
+    double bv[16];
+    {
+        const int c = 16 * w + lc;
 #pragma unroll
-    for (int q = 0; q < 4; q++) nx[q] = w + 4 * q < m ? P[64 * (w + 4 * q) + lane] : 0.0;
+        for (int q = 0; q < 16; q++) bv[q] = (w < T && c < m) ? P[64 * c + 4 * q + lr] : 0.0;
+    }
     __syncthreads();
     gj_invert64(a, Rb, Cb);
     for (int e = t; e < GJ_NB * GJ_NB; e += 256) { const int r = e >> 6, c = e & 63; if (c > r) a[r][c] = a[c][r]; }
     __syncthreads();
-    for (int e = t; e < GJ_NB * GJ_NB; e += 256) D[e] = a[e >> 6][e & 63];
-    for (int c0 = w; c0 < m; c0 += 16) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) { cu[q] = nx[q]; const int cn = c0 + 16 + 4 * q; nx[q] = cn < m ? P[64 * cn + lane] : 0.0; }
+    for (int e = 0; e < 16; e++) D[t + 256 * e] = a[(t + 256 * e) >> 6][t & 63];
+    for (int tj = w; tj < T; tj += 4) {
+        const int c = 16 * tj + lc;
+        double bn[16];                                            // the next tile column's operands travel while this one is multiplied
+        {
+            const int cn = c + 64;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c0 + 4 * q;
-            if (c >= m) break;
-            double acc = 0.0;
-#pragma unroll
-            for (int rp = 0; rp < 64; rp++) acc += a[lane][rp] * lane_value(cu[q], rp);
-            W[64 * c + lane] = acc;
+            for (int q = 0; q < 16; q++) bn[q] = (tj + 4 < T && cn < m) ? P[64 * cn + 4 * q + lr] : 0.0;
         }
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++) {
+            v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[16 * ti + lc][4 * q + lr], bv[q], acc, 0, 0, 0);
+            if (c < m) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) W[64 * c + 16 * ti + lr + 4 * r] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) bv[q] = bn[q];
     }
     __syncthreads();     // (orders the workgroup's own stores to W before its loads below; an agent-scope fence here wrote back the L2 the preceding memsets had dirtied: 40 us)
     double* C = arena + off_C + coff[i];
     for (int b0 = 0; b0 < m; b0 += SCHUR_WL) {           // (one pass unless the block touches more than 96 separator rows)
         const int nb = min(SCHUR_WL, m - b0);
         if (b0) __syncthreads();
+        for (int e0 = t; e0 < nb * 64; e0 += 256 * 8) {
+            double v[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) nx[q] = b0 + w + 4 * q < m ? P[64 * (b0 + w + 4 * q) + lane] : 0.0;
-        for (int e = t; e < nb * 64; e += 256) lds[(e >> 6) * 65 + (e & 63)] = W[64 * b0 + e];
+            for (int q = 0; q < 8; q++) { const int e = e0 + 256 * q; v[q] = e < nb * 64 ? W[64 * b0 + e] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int e = e0 + 256 * q; if (e < nb * 64) lds[(e >> 6) * 65 + (e & 63)] = v[q]; }
+        }
+        for (int e = nb * 64 + t; e < ((nb + 15) / 16) * 16 * 64; e += 256) lds[(e >> 6) * 65 + (e & 63)] = 0.0;      // the image's last tile, beyond the panel
         __syncthreads();
-        for (int c0 = b0 + w; c0 < m; c0 += 16) {         // C[c1][c2], c2 <= c1: lanes = c2 inside the image
+        const int t2a = b0 / 16, t2b = (b0 + nb + 15) / 16;       // tile columns of C this image serves
+        for (int t1 = t2a + w; t1 < T; t1 += 4) {                  // C[c1][c2], c2 <= c1: tile rows over the waves
+            const int c1l = 16 * t1 + lc;
+            double av[16];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { cu[q] = nx[q]; const int cn = c0 + 16 + 4 * q; nx[q] = cn < m ? P[64 * cn + lane] : 0.0; }
+            for (int q = 0; q < 16; q++) av[q] = c1l < m ? P[64 * c1l + 4 * q + lr] : 0.0;
+            for (int t2 = t2a; t2 < t2b && t2 <= t1; t2++) {
+                const double* wl = lds + (16 * (t2 - t2a) + lc) * 65 + lr;
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int c1 = c0 + 4 * q;
-                if (c1 >= m) break;
-                for (int c8 = 0; c8 < nb && b0 + c8 <= c1; c8 += 64) {       // (wave-uniform trip count)
-                    const int cc = c8 + lane;
-                    const double* wl = lds + min(cc, nb - 1) * 65;
-                    double acc = 0.0;
+                for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], wl[4 * q], acc, 0, 0, 0);
+                const int c2 = 16 * t2 + lc;
 #pragma unroll
-                    for (int r = 0; r < 64; r++) acc += lane_value(cu[q], r) * wl[r];
-                    if (cc < nb && b0 + cc <= c1) C[(size_t)c1 * m + b0 + cc] = acc;
+                for (int r = 0; r < 4; r++) {
+                    const int c1 = 16 * t1 + lr + 4 * r;
+                    if (c1 < m && c2 <= c1) C[(size_t)c1 * m + c2] = acc[r];
                 }
             }
         }
