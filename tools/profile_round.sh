@@ -53,9 +53,6 @@ python tools/multi_mesh.py > $OUT/${TAG}_multi_mesh.txt 2>/dev/null
 python tools/reprecompute_time.py > $OUT/${TAG}_reprecompute.txt 2>/dev/null
 # 5. the coarse solver chosen by cost: dense inverse against the Schur-complement solver -- re-precompute, V-cycle and coarse solve per column count,
 #    the flow step, the block system; the kernels of three re-precomputes and of the coarse solves under rocprofv3
-{ SMG_DEBUG_SCHUR=1 python tools/schur_time.py C3 2>&1 | grep -v amdgpu.ids; echo; echo "== mean-curvature-flow step (tools/mcf_step_time.py)"; python tools/mcf_step_time.py 2>/dev/null | tail -4;
-  echo; echo "== block (3-DOF) benchmark system (tools/block_reprecompute.py)"; (cd tools && SMG_DEBUG_SCHUR=1 python block_reprecompute.py 2>&1 | grep -v amdgpu.ids | tail -4); } > $OUT/${TAG}_schur.txt
-rocprofv3 --kernel-trace --stats -d $OUT/sch -o t -- python tools/schur_prof.py > $OUT/sch.log 2>&1
-python tools/rocpd_stats.py $OUT/sch/t_results.db $OUT/${TAG}_schur_kernel_stats.csv > /dev/null
+bash tools/schur_legs.sh > /dev/null 2>&1
 rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5 $OUT/B3 $OUT/sch  # keep the summaries only (the dbs are large)
 ls -la $OUT
