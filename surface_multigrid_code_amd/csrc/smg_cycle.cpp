@@ -208,7 +208,7 @@ static int ensure_work(smg_hierarchy* h, int k)
         }
         // colour by colour (the level-0 head of an outer iteration, enqueue_residual_ss) every launch rounds its block count up on its own
         maxblocks += (h->lv[0].dA.color_slice_ptr.size() + 1) * (size_t)((k + 3) / 4 + 8);
-        HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1)));
+        HIPCHK(h->d_partials.alloc(std::max<size_t>(maxblocks, 1) + (size_t)ss_partials_room()));
         h->kcap = k;
     }
     // Jacobi-smoothed levels ping-pong between u and a second iterate

@@ -767,8 +767,41 @@ __global__ void k_decide(Ctrl* ctrl, const double* sumsq)
     decide_body(ctrl, *sumsq);
 }
 
+// Many partial sums (64 columns of a million rows leave 250 000 of them: one workgroup spent 40 us reading 2 MB): SS_STAGE_WGS workgroups first, each
+// over a fixed contiguous share, into the SS_STAGE_WGS doubles behind the partials (the buffer has that room: ensure_work); the final kernel then sums
+// those.  Fixed shares, fixed order inside a share: the same bits on every run and on every rank.
+constexpr int SS_STAGE_MIN = 16384, SS_STAGE_WGS = 128;
+__global__ __launch_bounds__(256) void k_ss_stage(const double* __restrict__ partials, int n, double* __restrict__ out, const int* done)
+{
+    if (load_flag(done)) return;
+    __shared__ double red[256];
+    const int per = (n + SS_STAGE_WGS - 1) / SS_STAGE_WGS;
+    const int i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    double s = 0.0;
+#pragma unroll 8
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+// returns where the (possibly staged) partial sums are and how many
+static const double* ss_stage(const double* partials, int& n, const Ctrl* ctrl, hipStream_t st)
+{
+    if (n < SS_STAGE_MIN) return partials;
+    double* out = const_cast<double*>(partials) + n;
+    hipLaunchKernelGGL(k_ss_stage, dim3(SS_STAGE_WGS), dim3(256), 0, st, partials, n, out, &ctrl->done);
+    n = SS_STAGE_WGS;
+    return out;
+}
+int ss_partials_room() { return SS_STAGE_WGS; }
+
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st, double* out)
 {
+    partials = ss_stage(partials, n, ctrl, st);
     hipLaunchKernelGGL(k_ss_finalize, dim3(1), dim3(256), 0, st, partials, n, ctrl, out ? out : &ctrl->sumsq);
     return hipGetLastError();
 }
@@ -813,6 +846,7 @@ hipError_t launch_restore_if_just_done(double* dst, const double* src, size_t n,
 }
 hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, hipStream_t st)
 {
+    partials = ss_stage(partials, n, ctrl, st);
     hipLaunchKernelGGL(k_ss_finalize_decide, dim3(1), dim3(256), 0, st, partials, n, ctrl);
     return hipGetLastError();
 }

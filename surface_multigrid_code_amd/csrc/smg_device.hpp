@@ -199,6 +199,9 @@ hipError_t launch_schur_solve_f32(const SchurDev& F, const float* b, float* u, i
 int sell_blocks(int n_slices);  // 4 slices (waves) per 256-thread block
 int sell_wide_blocks(int n_slices, int k);  // partial-sum slots the wide (k >= 8) path needs
 
+// ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).  The buffer must have ss_partials_room() doubles of room behind the n partials
+// (large n: a first launch leaves per-share sums there).
+int ss_partials_room();
 // ctrl->sumsq = sum(partials[0..n)) in a fixed order (deterministic).
 hipError_t launch_ss_finalize(const double* partials, int n, Ctrl* ctrl, hipStream_t st, double* out = nullptr);   // out: where the sum goes (default ctrl->sumsq)
 // r = sqrt(*sumsq); append to r_his; done = (r < ctrl->tol) or non-finite.  No-op when already done.
