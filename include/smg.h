@@ -177,7 +177,7 @@ int smg_mg_precompute_block(const double *V, int nV, const int *F, int nF, float
  * Constraints: pinned VERTICES (all three DOFs 3v, 3v+1, 3v+2 in `known`) keep the structure -- the reference's slices and column drops
  * (src/min_quad_with_fixed_mg.cpp:137-257) are formed on the scalar matrices and factor as Pv' (x) I_3 again -- and stay on the block
  * kernels; constraints on single degrees of freedom select the scalar path (mode 3: smg_precompute fails and says so).
- * Not available on block hierarchies: the mixed-precision cycle. */
+ * The mixed-precision cycle (smg_solve_opts.precision) is available: the V-cycle runs on an fp32 image of the 3 x 3-block panels. */
 int smg_hierarchy_set_block_mode(smg_hierarchy *h, int mode);
 int smg_hierarchy_block_size(const smg_hierarchy *h);   /* 1 or 3: what the last smg_precompute decided */
 /* block image of A_lv (lv < n_levels - 1, block hierarchies only): stored 3 x 3 blocks, allocated block slots (SELL padding

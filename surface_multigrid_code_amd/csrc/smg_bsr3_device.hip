@@ -14,31 +14,33 @@
 
 namespace smg {
 
-template <bool LD1>
-__device__ __forceinline__ void gather3(const double* x, int c, int ld, bool use, double (&out)[3])
+template <bool LD1, typename T>
+__device__ __forceinline__ void gather3(const T* x, int c, int ld, bool use, T (&out)[3])
 {
     if constexpr (LD1) {
-        gather_kb<3, double>(x + (size_t)3 * (size_t)(c < 0 ? 0 : c), use, out);
+        gather_kb<3, T>(x + (size_t)3 * (size_t)(c < 0 ? 0 : c), use, out);
     } else {
         const size_t o = (size_t)3 * (size_t)(c < 0 ? 0 : c) * (size_t)ld;
-        out[0] = use ? x[o] : 0.0;
-        out[1] = use ? x[o + (size_t)ld] : 0.0;
-        out[2] = use ? x[o + 2 * (size_t)ld] : 0.0;
+        out[0] = use ? x[o] : (T)0;
+        out[1] = use ? x[o + (size_t)ld] : (T)0;
+        out[2] = use ? x[o + 2 * (size_t)ld] : (T)0;
     }
 }
 
-// MODE: SELL_AX, SELL_RESID, SELL_RESID_SS, SELL_GS, SELL_JACOBI, SELL_CHEBY (smg_device.hpp; same meaning per scalar row).
+// MODE: SELL_AX, SELL_RESID, SELL_RESID_SS, SELL_RESID_BOTH, SELL_GS, SELL_JACOBI, SELL_CHEBY (smg_device.hpp; same meaning per scalar row).
 // x / b / y / dvec: row-major (3 n_v) x ld blocks, already offset to the column this launch handles.
-template <int MODE, bool LD1>
-__global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_val, const int* a_slice_off, const int* a_slice_row, const int* a_slice_w,
-                                              const int* a_order, int s_begin, int s_end, int n_blocks, int use_order, const double* x, const double* b,
-                                              double* y, int ld, const int* done, double* partials, double omega, double c1, double* dvec)
+// T = double: the reference's arithmetic; T = float: the fp32 image of the mixed-precision cycle (same order of operations in fp32).
+template <int MODE, bool LD1, typename T>
+__global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const T* a_val, const int* a_slice_off, const int* a_slice_row, const int* a_slice_w,
+                                              const int* a_order, int s_begin, int s_end, int n_blocks, int use_order, const T* x, const T* b,
+                                              T* y, int ld, const int* done, double* partials, double omega_d, double c1_d, T* dvec)
 {
-    constexpr bool GS = MODE == SELL_GS, JAC = MODE == SELL_JACOBI, CHEB = MODE == SELL_CHEBY, SS = MODE == SELL_RESID_SS;
+    constexpr bool GS = MODE == SELL_GS, JAC = MODE == SELL_JACOBI, CHEB = MODE == SELL_CHEBY, SS = MODE == SELL_RESID_SS, BOTH = MODE == SELL_RESID_BOTH;
+    const T omega = (T)omega_d, c1 = (T)c1_d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bid = xcd_remap(blockIdx.x, n_blocks);
     const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
-    double ss = 0.0;
+    double ss = 0.0;   // (always fp64)
     int stop = 0;
     if (ls < s_end) {
         const int s = (!GS && use_order) ? a_order[ls] : ls;
@@ -48,25 +50,25 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
         const int vtx = row0 + lane;
         const bool live = lane < nrow;
         const int* cp = a_col + (size_t)off * 64 + lane;
-        const double* vp = a_val + (size_t)off * 9 * 64 + lane;
+        const T* vp = a_val + (size_t)off * 9 * 64 + lane;
         const size_t o0 = (size_t)3 * (size_t)vtx * (size_t)ld;
-        double bv[3] = {0.0, 0.0, 0.0}, dold[3] = {0.0, 0.0, 0.0};
+        T bv[3] = {(T)0, (T)0, (T)0}, dold[3] = {(T)0, (T)0, (T)0};
         if (MODE != SELL_AX && live) {
 #pragma unroll
             for (int d = 0; d < 3; d++) bv[d] = b[o0 + (size_t)d * ld];
         }
-        if (CHEB && live && c1 != 0.0) {
+        if (CHEB && live && c1 != (T)0) {
 #pragma unroll
             for (int d = 0; d < 3; d++) dold[d] = dvec[o0 + (size_t)d * ld];
         }
-        double out[3] = {0.0, 0.0, 0.0};
+        T out[3] = {(T)0, (T)0, (T)0};
         if constexpr (!GS) {
             // the three rows of a vertex are independent: one pass over the block row
             constexpr int U = 4;
-            double acc[3] = {0.0, 0.0, 0.0}, diag[3] = {1.0, 1.0, 1.0}, xi[3] = {0.0, 0.0, 0.0};
+            T acc[3] = {(T)0, (T)0, (T)0}, diag[3] = {(T)1, (T)1, (T)1}, xi[3] = {(T)0, (T)0, (T)0};
             for (int j0 = 0; j0 < w; j0 += U) {
                 int c[U];
-                double v[U][9], xg[U][3];
+                T v[U][9], xg[U][3];
 #pragma unroll
                 for (int t = 0; t < U; t++) {
                     if (j0 + t < w) {   // wave-uniform
@@ -76,11 +78,11 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
                     } else {
                         c[t] = -1;
 #pragma unroll
-                        for (int e = 0; e < 9; e++) v[t][e] = 0.0;
+                        for (int e = 0; e < 9; e++) v[t][e] = (T)0;
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < U; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
+                for (int t = 0; t < U; t++) gather3<LD1, T>(x, c[t], ld, c[t] >= 0, xg[t]);
 #pragma unroll
                 for (int t = 0; t < U; t++) {
                     if (c[t] >= 0) {
@@ -99,15 +101,16 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
             for (int d = 0; d < 3; d++) {
                 if (MODE == SELL_AX) out[d] = acc[d];
                 else if (MODE == SELL_RESID) out[d] = bv[d] - acc[d];
-                else if (JAC) { const double t = (bv[d] - acc[d]) / diag[d]; out[d] = xi[d] + omega * (t - xi[d]); }
+                else if (BOTH) { out[d] = bv[d] - acc[d]; if (live) { const double t = (double)out[d]; ss += t * t; } }
+                else if (JAC) { const T t = (bv[d] - acc[d]) / diag[d]; out[d] = xi[d] + omega * (t - xi[d]); }
                 else if (CHEB) {
-                    const double t = (bv[d] - acc[d]) / diag[d];
-                    const double r = t - xi[d];
-                    const double dn = c1 != 0.0 ? c1 * dold[d] + omega * r : omega * r;
+                    const T t = (bv[d] - acc[d]) / diag[d];
+                    const T r = t - xi[d];
+                    const T dn = c1 != (T)0 ? c1 * dold[d] + omega * r : omega * r;
                     out[d] = xi[d] + dn;
                     dold[d] = dn;
                 }
-                else if (live) { const double t = bv[d] - acc[d]; ss += t * t; }
+                else if (live) { const double t = (double)(bv[d] - acc[d]); ss += t * t; }
             }
         } else {
             // Gauss-Seidel: row 3v, then 3v+1 with the new value of 3v, then 3v+2 with both.  The block columns and the gathered values of
@@ -116,25 +119,25 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
             // Panel columns beyond WR (wide Galerkin rows) repeat their gathers per row.
             constexpr int WR = 8;
             int c[WR];
-            double xg[WR][3];
+            T xg[WR][3];
 #pragma unroll
             for (int t = 0; t < WR; t++) c[t] = t < w ? cp[(size_t)t * 64] : -1;
-            double v[WR][3], vn[WR][3];
+            T v[WR][3], vn[WR][3];
 #pragma unroll
             for (int t = 0; t < WR; t++)
 #pragma unroll
-                for (int e = 0; e < 3; e++) v[t][e] = t < w ? vp[((size_t)t * 9 + e) * 64] : 0.0;
+                for (int e = 0; e < 3; e++) v[t][e] = t < w ? vp[((size_t)t * 9 + e) * 64] : (T)0;
 #pragma unroll
-            for (int t = 0; t < WR; t++) gather3<LD1>(x, c[t], ld, c[t] >= 0, xg[t]);
+            for (int t = 0; t < WR; t++) gather3<LD1, T>(x, c[t], ld, c[t] >= 0, xg[t]);
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 if (d < 2) {
 #pragma unroll
                     for (int t = 0; t < WR; t++)
 #pragma unroll
-                        for (int e = 0; e < 3; e++) vn[t][e] = t < w ? vp[((size_t)t * 9 + 3 * (d + 1) + e) * 64] : 0.0;
+                        for (int e = 0; e < 3; e++) vn[t][e] = t < w ? vp[((size_t)t * 9 + 3 * (d + 1) + e) * 64] : (T)0;
                 }
-                double acc = 0.0, diag = 1.0;
+                T acc = (T)0, diag = (T)1;
 #pragma unroll
                 for (int t = 0; t < WR; t++) {
                     if (c[t] >= 0) {
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
                 }
                 for (int j0 = WR; j0 < w; j0 += 4) {      // the tail of a wide block row
                     int c2[4];
-                    double v2[4][3], x2[4][3];
+                    T v2[4][3], x2[4][3];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         if (j0 + t < w) {
@@ -158,11 +161,11 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
                         } else {
                             c2[t] = -1;
 #pragma unroll
-                            for (int e = 0; e < 3; e++) v2[t][e] = 0.0;
+                            for (int e = 0; e < 3; e++) v2[t][e] = (T)0;
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; t++) gather3<LD1>(x, c2[t], ld, c2[t] >= 0, x2[t]);
+                    for (int t = 0; t < 4; t++) gather3<LD1, T>(x, c2[t], ld, c2[t] >= 0, x2[t]);
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         if (c2[t] >= 0) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void k_bsr3(const int* a_col, const double* a_
         }
         if (SS && stop) ss = 0.0;
     }
-    if constexpr (SS) {
+    if constexpr (SS || BOTH) {
         __shared__ double red[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
@@ -253,9 +256,9 @@ hipError_t launch_bsr3_fill(const int* ptr, const int* col, const double* val, c
     return hipGetLastError();
 }
 
-template <int MODE>
-static hipError_t launch_bsr3_mode(const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
-                                   double* partials, int* n_blocks, hipStream_t st, double omega, double c1, double* dvec)
+template <int MODE, typename T>
+static hipError_t launch_bsr3_mode(const Bsr3Dev& A, const T* vals, int s_begin, int s_end, const T* x, const T* b, T* y, int k, const Ctrl* ctrl,
+                                   double* partials, int* n_blocks, hipStream_t st, double omega, double c1, T* dvec)
 {
     const int ns = s_end - s_begin;
     if (n_blocks) *n_blocks = 0;
@@ -264,16 +267,16 @@ static hipError_t launch_bsr3_mode(const Bsr3Dev& A, int s_begin, int s_end, con
     const int* done = ctrl ? &ctrl->done : never_done();
     const int use_order = (A.order && s_begin == 0 && s_end == A.n_slices) ? 1 : 0;
     for (int c = 0; c < k; c++) {
-        const double* xx = x ? x + c : nullptr;
-        const double* bb = b ? b + c : nullptr;
-        double* yy = y ? y + c : nullptr;
-        double* dd = dvec ? dvec + c : nullptr;
+        const T* xx = x ? x + c : nullptr;
+        const T* bb = b ? b + c : nullptr;
+        T* yy = y ? y + c : nullptr;
+        T* dd = dvec ? dvec + c : nullptr;
         double* pp = partials ? partials + (size_t)c * nb : nullptr;
         if (k == 1)
-            hipLaunchKernelGGL((k_bsr3<MODE, true>), dim3(nb), dim3(256), 0, st, A.col, A.val, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
+            hipLaunchKernelGGL((k_bsr3<MODE, true, T>), dim3(nb), dim3(256), 0, st, A.col, vals, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
                                use_order, xx, bb, yy, k, done, pp, omega, c1, dd);
         else
-            hipLaunchKernelGGL((k_bsr3<MODE, false>), dim3(nb), dim3(256), 0, st, A.col, A.val, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
+            hipLaunchKernelGGL((k_bsr3<MODE, false, T>), dim3(nb), dim3(256), 0, st, A.col, vals, A.slice_off, A.slice_row, A.slice_w, A.order, s_begin, s_end, nb,
                                use_order, xx, bb, yy, k, done, pp, omega, c1, dd);
     }
     if (n_blocks) *n_blocks = nb * k;
@@ -284,12 +287,27 @@ hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, 
                        double* partials, int* n_blocks, hipStream_t st, double omega, double c1, double* dvec)
 {
     switch (mode) {
-        case SELL_AX: return launch_bsr3_mode<SELL_AX>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
-        case SELL_RESID: return launch_bsr3_mode<SELL_RESID>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
-        case SELL_RESID_SS: return launch_bsr3_mode<SELL_RESID_SS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
-        case SELL_GS: return launch_bsr3_mode<SELL_GS>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
-        case SELL_JACOBI: return launch_bsr3_mode<SELL_JACOBI>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
-        case SELL_CHEBY: return launch_bsr3_mode<SELL_CHEBY>(A, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_AX: return launch_bsr3_mode<SELL_AX, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_RESID: return launch_bsr3_mode<SELL_RESID, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_RESID_SS: return launch_bsr3_mode<SELL_RESID_SS, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_RESID_BOTH: return launch_bsr3_mode<SELL_RESID_BOTH, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_GS: return launch_bsr3_mode<SELL_GS, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_JACOBI: return launch_bsr3_mode<SELL_JACOBI, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        case SELL_CHEBY: return launch_bsr3_mode<SELL_CHEBY, double>(A, A.val, s_begin, s_end, x, b, y, k, ctrl, partials, n_blocks, st, omega, c1, dvec);
+        default: return hipErrorInvalidValue;
+    }
+}
+// the fp32 image (Bsr3Dev::valf): what the V-cycle of the mixed-precision mode needs
+hipError_t launch_bsr3_f32(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, const float* x, const float* b, float* y, int k, const Ctrl* ctrl, hipStream_t st,
+                           double omega, double c1, float* dvec)
+{
+    if (!A.valf) return hipErrorInvalidValue;
+    switch (mode) {
+        case SELL_AX: return launch_bsr3_mode<SELL_AX, float>(A, A.valf, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, omega, c1, dvec);
+        case SELL_RESID: return launch_bsr3_mode<SELL_RESID, float>(A, A.valf, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, omega, c1, dvec);
+        case SELL_GS: return launch_bsr3_mode<SELL_GS, float>(A, A.valf, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, omega, c1, dvec);
+        case SELL_JACOBI: return launch_bsr3_mode<SELL_JACOBI, float>(A, A.valf, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, omega, c1, dvec);
+        case SELL_CHEBY: return launch_bsr3_mode<SELL_CHEBY, float>(A, A.valf, s_begin, s_end, x, b, y, k, ctrl, nullptr, nullptr, st, omega, c1, dvec);
         default: return hipErrorInvalidValue;
     }
 }

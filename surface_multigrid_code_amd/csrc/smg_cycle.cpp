@@ -254,7 +254,6 @@ static int ensure_work(smg_hierarchy* h, int k)
 static int ensure_fp32(smg_hierarchy* h, int k)
 {
     const int L = h->n_levels;
-    if (h->bs == 3) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available for block (3-DOF) hierarchies");
     if (h->coarse_sparse) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available with a sparse coarse factorisation (coarsest level of %d unknowns)", h->nc);
     if (!h->f32_valid) {
         drop_graphs(h);
@@ -274,7 +273,16 @@ static int ensure_fp32(smg_hierarchy* h, int k)
         for (int lv = 0; lv < L; lv++) {
             Level& Lv = h->lv[lv];
             int rc;
-            if (lv < L - 1) {
+            if (lv < L - 1 && h->bs == 3) {     // block hierarchies: the nine value planes of every panel column
+                auto mkb = [&](Bsr3Buf& B) -> int {
+                    HIPCHK(B.valf.ensure(B.val.n));
+                    HIPCHK(launch_cvt_f64_f32(B.valf.p, B.val.p, B.val.n, h->stream));
+                    B.view.valf = B.valf.p;
+                    return SMG_OK;
+                };
+                if ((rc = mkb(Lv.bA))) return rc;
+                if (Lv.gs_on_transpose) { if ((rc = mkb(Lv.bAT))) return rc; }
+            } else if (lv < L - 1) {
                 if ((rc = mk(Lv.dA, Lv.a32, Lv.dA32))) return rc;
                 if (Lv.gs_on_transpose) { if ((rc = mk(Lv.dAT, Lv.at32, Lv.dAT32))) return rc; }
             }
@@ -428,7 +436,11 @@ template <> struct Prec<float> {
     }
     static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const float* x, const float* bb, float* y, int k,
                           const Ctrl* ctrl, const FirstColour* fc = nullptr, double omega = 1.0)
-    {   // (block hierarchies have no fp32 images: ensure_fp32 refuses them)
+    {
+        if (h->bs == 3) {
+            const Bsr3Dev& V = (smoother_image && L.gs_on_transpose) ? L.bAT.view : L.bA.view;
+            return launch_bsr3_f32(m, V, s0, s1 < 0 ? V.n_slices : s1, x, bb, y, k, ctrl, h->stream, omega, fc ? fc->c1 : 0.0, fc ? fc->df : nullptr);
+        }
         const SellDev& V = smoother_image ? G(L) : A(L);
         return sell(m, V, s0, s1 < 0 ? V.n_slices : s1, x, bb, y, k, ctrl, h->stream, nullptr, fc, omega);
     }
@@ -694,7 +706,9 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
         return SMG_OK;
     }
     ProfGuard pg(h, "MG: outer residual");
-    if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
+    if (h->precision == 1 && h->bs == 3)
+        HIPCHK(launch_bsr3(SELL_RESID_BOTH, L0.bA.view, 0, L0.bA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
+    else if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
         HIPCHK(launch_sell(SELL_RESID_BOTH, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     else if (h->bs == 3)
         HIPCHK(launch_bsr3(SELL_RESID_SS, L0.bA.view, 0, L0.bA.view.n_slices, L0.u.p, L0.b.p, nullptr, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));

@@ -119,12 +119,16 @@ struct Bsr3Dev {
     const int* order = nullptr;      // optional region-major launch order, whole-matrix launches only
     const int* col = nullptr;        // block columns (vertices), -1 = padding
     const double* val = nullptr;     // nine planes per panel column
+    const float* valf = nullptr;     // ... their fp32 image (mixed-precision cycle), or null
 };
 // modes SELL_AX, _RESID, _RESID_SS, _GS (one vertex colour = slices [s_begin, s_end), in place: y == x), _JACOBI, _CHEBY with the meaning
 // they have per scalar row of the 3n x 3n matrix.  x / b / y / dvec: row-major (3 n_vert) x k.  omega, c1, dvec: as in launch_sell
 // (Jacobi damping; Chebyshev: omega = c2, c1, the update vector).  partials / n_blocks: SELL_RESID_SS, one double per launched block.
 hipError_t launch_bsr3(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, const double* x, const double* b, double* y, int k, const Ctrl* ctrl,
                        double* partials, int* n_blocks, hipStream_t st, double omega = 1.0, double c1 = 0.0, double* dvec = nullptr);
+// the same on the fp32 image (SELL_AX, _RESID, _GS, _JACOBI, _CHEBY); SELL_RESID_BOTH (fp64 only, above): y = b - A x and the partial sums of its squares
+hipError_t launch_bsr3_f32(SellMode mode, const Bsr3Dev& A, int s_begin, int s_end, const float* x, const float* b, float* y, int k, const Ctrl* ctrl, hipStream_t st,
+                           double omega = 1.0, double c1 = 0.0, float* dvec = nullptr);
 hipError_t launch_bsr3_gershgorin(const Bsr3Dev& A, double* out, hipStream_t st);
 int bsr3_blocks(int n_slices);
 // the image B (laid out on the host, Bsr3Buf::upload of a layout; panel_cols = its panel columns) filled on the device from the scalar CSR arrays of A

@@ -82,6 +82,7 @@ struct SellBuf {  // device image of one SELL matrix
 struct Bsr3Buf {  // device image of one block (3 x 3) SELL matrix, smg_bsr3.hpp
     DevBuf<int> slice_row, slice_off, slice_w, col, order;
     DevBuf<double> val;
+    DevBuf<float> valf;                         // fp32 image of val (mixed-precision cycle), made on demand
     Bsr3Dev view;
     std::vector<int> color_slice_ptr;
     long stored = 0, blocks = 0, padded = 0;   // scalar CSR entries / 3 x 3 blocks / allocated value slots (9 per panel slot)

@@ -199,9 +199,29 @@ def test_block_mode_refusals(smg):
     mg.precompute(A)
     n3 = A.shape[0]
     rhs, z0 = np.ones((n3, 1)), np.zeros((n3, 1))
-    with pytest.raises(smg.SmgError):
-        mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=10, precision="mixed"))
-    assert mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=60))[0]      # the handle is still usable
+    assert mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-8, max_iter=60))[0]
+
+
+@pytest.mark.parametrize("k,smoother", [(1, "gs"), (3, "gs"), (2, "hybrid_chebyshev")])
+def test_block_mixed_precision_reaches_fp64_accuracy(smg, oracle_mod, k, smoother):
+    """BASELINE config 5 (fp32 vs fp64) on a 3-DOF hierarchy ("no mixed precision on the block path"): the V-cycle runs on the
+    fp32 image of the 3 x 3-block panels (k_bsr3<.., float>: the same order of operations in fp32), the outer residual -- one fp64 launch that also
+    leaves the correction cycle's right-hand side (SELL_RESID_BOTH) -- and the update in fp64: the same tolerance is reached, the solution agrees with
+    the all-fp64 run at solver precision; also after a value-only re-precompute (the fp32 images are re-made)."""
+    V, F, A, Ps, mg, orc = build_block(smg, oracle_mod, kron=(k == 3))
+    n3 = A.shape[0]
+    rng = np.random.default_rng(12)
+    rhs, z0 = rng.uniform(-1, 1, (n3, k)), np.zeros((n3, k))
+    kw = dict(smoother=smoother, jacobi_max_rows=mg.rows(1)) if smoother != "gs" else {}
+    a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=120, **kw))
+    m = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=120, precision="mixed", **kw))
+    assert a[0] and m[0] and len(m[2]) <= len(a[2]) + 3
+    assert np.linalg.norm(m[1] - a[1]) <= 1e-8 * np.linalg.norm(a[1])
+    assert np.linalg.norm(rhs - A @ m[1]) < 1.5e-10 * np.sqrt(k)
+    A2 = (A + 0.25 * sp.diags(A.diagonal())).tocsr(); A2.sort_indices()
+    mg.precompute(A2)
+    m2 = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=120, precision="mixed", **kw))
+    assert m2[0] and np.linalg.norm(rhs - A2 @ m2[1]) < 1.5e-10 * np.sqrt(k)
 
 
 def test_block_images_filled_on_the_device_pass_the_same_tests():
