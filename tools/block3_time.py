@@ -79,6 +79,22 @@ def measure(smg, torch, A, Ps, mode, smoother="gs", reps=200):
                         "frac": sb / (spmv_us * 1e-6) / 1e9 / 8000.0}}
     if mg.block_size() == 3:
         out["block_stats"] = mg.block_stats(0)
+    # the mixed-precision mode on the same handle (fp32 V-cycle on the fp32 images, fp64 outer residual and update): ms per outer iteration, cycles to 1e-10
+    try:
+        om = smg.SolveOpts(tol=1e-10, max_iter=100, precision="mixed", **kw)
+        mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=om)
+        convm, rhm = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=om)
+        oom = smg.SolveOpts(tol=0.0, max_iter=1024, precision="mixed", **kw)
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=oom)
+        mg.outer_iterations(20)
+        ea.record(stream)
+        mg.outer_iterations(reps)
+        eb.record(stream)
+        torch.cuda.synchronize()
+        mg.solve_end(z.data_ptr(), n, max_iter=1024)
+        out["mixed_precision"] = {"ms_per_iteration": ea.elapsed_time(eb) / reps, "cycles_to_1e-10": len(rhm) - 1, "converged": bool(convm), "final_residual": float(rhm[-1])}
+    except Exception as e:
+        out["mixed_precision"] = {"error": repr(e)}
     del mg
     return out
 
