@@ -236,7 +236,7 @@ int smg_hierarchy_coarse_solver(const smg_hierarchy *h, long *factor_entries);
  *               against 204 us and 2 GB);
  *             - above n_max (smg_hierarchy_set_coarse_dense_max) it stands in for the sparse factorisation (63 210 unknowns: 0.30 ms per solve against
  *               15.8 ms, 2.6 GB against 0.1 GB).
- * A matrix whose blocks touch more than 128 separator rows each, or whose separator exceeds 0.7 n, keeps the dense inverse resp. the sparse factorisation. */
+ * A matrix whose blocks touch more than 128 separator rows each, or whose separator exceeds 0.7 n or 24 576 rows (its inverse is dense), keeps the dense inverse resp. the sparse factorisation. */
 int smg_hierarchy_set_coarse_schur(smg_hierarchy *h, int when, int n_min);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],
