@@ -203,38 +203,52 @@ class Hierarchy:
     def rows(self, lv):
         return self.L.smg_level_rows(self.h, lv)
 
-    def _piece(self, fn, name, lv, x, nout):
+    def _rows_checked(self, lv, name, *blocks):
+        """the C ABI takes bare pointers: a block of the wrong height would be read / written out of bounds"""
+        n = self.rows(lv)
+        for b in blocks:
+            if b.shape[0] != n:
+                raise ValueError("%s: level %d has %d rows, the block has %d (rows() is 0 before smg_precompute)" % (name, lv, n, b.shape[0]))
+        return n
+
+    def _piece(self, fn, name, lv, x, nout, nin=None):
         x = _colmajor(x)
+        if nin is not None and x.shape[0] != nin:
+            raise ValueError("%s: expected a block of %d rows, got %d" % (name, nin, x.shape[0]))
         y = np.zeros((nout, x.shape[1]), order="F")
         _chk(fn(self.h, lv, _dp(x), x.shape[1], _dp(y)), name)
         return y
 
     def A(self, lv, u):
-        return self._piece(self.L.smg_apply_A, "smg_apply_A", lv, u, self.rows(lv))
+        return self._piece(self.L.smg_apply_A, "smg_apply_A", lv, u, self.rows(lv), self.rows(lv))
 
     def restrict(self, lv, x):
-        return self._piece(self.L.smg_restrict, "smg_restrict", lv, x, self.rows(lv + 1))
+        return self._piece(self.L.smg_restrict, "smg_restrict", lv, x, self.rows(lv + 1), self.rows(lv))
 
     def prolong(self, lv, x):
-        return self._piece(self.L.smg_prolong, "smg_prolong", lv, x, self.rows(lv))
+        return self._piece(self.L.smg_prolong, "smg_prolong", lv, x, self.rows(lv), self.rows(lv + 1))
 
     def relax(self, lv, B, u, iters):
         B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        self._rows_checked(lv, "smg_relax", B, u)
         _chk(self.L.smg_relax(self.h, lv, _dp(B), B.shape[1], iters, _dp(u)), "smg_relax")
         return u
 
     def coarse_solve(self, B, u):
         B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        self._rows_checked(self.n_levels - 1, "smg_coarse_solve", B, u)
         _chk(self.L.smg_coarse_solve(self.h, _dp(B), B.shape[1], _dp(u)), "smg_coarse_solve")
         return u
 
     def vcycle(self, B, u, lv=0, pre=2, post=2):
         B, u = _colmajor(B), _colmajor(u).copy(order="F")
+        self._rows_checked(lv, "smg_vcycle", B, u)
         _chk(self.L.smg_vcycle(self.h, _dp(B), pre, post, lv, _dp(u), B.shape[1]), "smg_vcycle")
         return u
 
     def residual_norm(self, lv, B, u):
         B, u = _colmajor(B), _colmajor(u)
+        self._rows_checked(lv, "smg_residual_norm", B, u)
         out = C.c_double(0)
         _chk(self.L.smg_residual_norm(self.h, lv, _dp(B), _dp(u), B.shape[1], C.byref(out)), "smg_residual_norm")
         return out.value
