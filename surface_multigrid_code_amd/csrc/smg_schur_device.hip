@@ -4,7 +4,7 @@
 //                                products (fixed lists) -> S^-1 by the blocked Gauss-Jordan of the dense path (launch_spd_inverse)
 // solve  (every V-cycle):        g = b_S - sum W_i^T b_i  ->  x_S = S^-1 g (the dense path's products)  ->  u += [D_i^-1 b_i - W_i x_S ; x_S]
 // Two shapes of the solve kernels: k < 64 columns (lanes = the 64 rows of a block, eight columns in registers per pass) and k >= 64 (lanes = columns).
-// Bound: latency at these sizes (3 952 unknowns: 73 blocks, 1 680 separator rows) -- the factorisation is ~40 launches of a few us each.
+// Bound: latency at these sizes (3 952 unknowns: 64 blocks, 1 688 separator rows) -- the factorisation is ~60 launches of a few us each, chained through the 64 x 64 pivot inversions.
 #include <hip/hip_runtime.h>
 
 #include "smg_device.hpp"
