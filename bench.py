@@ -364,6 +364,7 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
     red = reduce_closure(world, stream_ar)
     opts = smg.SolveOpts(tol=tol, max_iter=60, smoother="gs")
     block_gs = None
+    mixed = None
     sharded_solve_native(mg, rhs if kl else None, z0 if kl else None, red, None, opts)      # warm: graph capture for this k
     torch.cuda.synchronize()
     if world > 1:
@@ -410,6 +411,19 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
             except Exception as e:   # noqa: BLE001
                 block_gs = {"error": repr(e)}
                 mg.set_block_gs(-1)
+        # the same job in the mixed-precision mode (fp32 V-cycle on fp32 images, fp64 outer residual and update: BASELINE config 5's comparison on the
+        # column-sharded job; an option -- the headline and this leg's ms_per_step are fp64 throughout)
+        if world == 1:
+            try:
+                om = smg.SolveOpts(tol=tol, max_iter=60, smoother="gs", precision="mixed")
+                cm, rhm = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), zt.data_ptr(), n, kl, opts=om)
+                mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, kl, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs", precision="mixed"))
+                block(warmup)
+                tm = timed_repeats(torch, dist, world, dev, stream, block, steps, repeats)
+                mg.solve_end(zt.data_ptr(), n, max_iter=HIS)
+                mixed = {"ms_per_step": float(np.median(tm)) / steps, "cycles_to_tol": len(rhm) - 1, "converged": bool(cm), "final_residual": float(rhm[-1])}
+            except Exception as e:   # noqa: BLE001
+                mixed = {"error": repr(e)}
     same = True
     if world > 1:
         hbuf = torch.zeros(64, dtype=torch.float64, device=dev)
@@ -433,6 +447,7 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
             "gbs": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9) if (kl and ms) else None,
             "frac": (mg.vcycle_bytes(kl, 2, 2) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (kl and ms) else None,
             "block_gs_option": block_gs,
+            "mixed_precision_option": mixed,
             "solve": {"tol": tol, "converged": bool(conv), "cycles": len(rh) - 1, "wall_ms": 1e3 * wall, "same_history_on_all_ranks": same,
                       "final_residual": float(rh[-1]) if len(rh) else None}}
 
