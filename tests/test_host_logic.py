@@ -652,3 +652,24 @@ def test_schur_coarse_solver_plan_executed_on_the_host(smg_mod):
     assert np.linalg.norm(x - spla.spsolve(A1.tocsc(), b)) <= 1e-11 * np.linalg.norm(x)
     nb, ns, _, _ = run(sp.identity(300, format="csr") * 2.0)
     assert nb == 0
+
+
+def test_coarsest_smoothed_level_inherits_its_colouring_from_the_coarsest_level(smg_mod):
+    """bunny_15K subdivided twice, three levels: the coarsest SMOOTHED level (63 210 rows) is a mid-point subdivision of the coarsest level (15 804).
+    Coloured from scratch that level ends with five colours and no finer level can inherit (five launches per sweep, a from-scratch colouring of every
+    finer level); the 4-colouring of the coarsest level's small graph is handed down instead (csrc/smg_precompute.cpp, colouring thread): four
+    colours on every smoothed level, each a valid colouring."""
+    smg = smg_mod
+    V, F = M.read_smgm("bunny_15K_init.smgm")
+    V = M.normalize_unit_area(V, F)
+    Vf, Ff, Ps = M.subdivision_hierarchy(V, F, 2)
+    A = (M.massmatrix(Vf, Ff, "barycentric") - 0.01 * M.cotmatrix(Vf, Ff)).tocsr(); A.sort_indices()
+    mg = _host_precompute(smg, smg.Hierarchy.from_prolongs(Ps), A)
+    assert mg.n_levels == 3 and mg.rows(1) == 63210 and mg.rows(2) == 15804
+    for lv in (0, 1):
+        cp = mg.colors(lv)
+        assert len(cp) - 1 == 4, "level %d: %d colours" % (lv, len(cp) - 1)
+        Ai = mg.matrix(lv, "A", internal=True).tocoo()
+        col_of = np.searchsorted(cp, np.arange(mg.rows(lv)), side="right") - 1
+        off = Ai.row != Ai.col
+        assert (col_of[Ai.row[off]] != col_of[Ai.col[off]]).all()
