@@ -69,6 +69,24 @@ def build_workload(name, smg, mesh):
         mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 6, n_extra_levels=0)
         Vf = mesh.normalize_unit_area(_onto_torus(Vf), Ff)
         label = "C6: torus (R=1, r=0.4) 64x64 x6 midpoint subdivision re-projected onto the torus, 16777216 verts, 7 levels, M_bary+0.01(-L), fp64"
+    elif name in ("C3dec", "C3pdec"):
+        # the C3 mesh (or its 252 834-vertex parent) under the REFERENCE's own hierarchy: mg_precompute(V, F, 0.25, 1000, 1)
+        # (src/mg_precompute.cpp:15-87, the call of 03_mg_solver/main.cpp:35-39) -- mid-point decimation + self-parameterisation,
+        # 3 entries per row of P, Galerkin operators of 18 - 30 entries per row; the subdivision operators are NOT used
+        V, F = mesh.read_triangle_mesh("bunny_15K_init.smgm")
+        V = mesh.normalize_unit_area(V, F)
+        nsub = 3 if name == "C3dec" else 2
+        mgs, Vf, Ff = smg.mg_precompute_subdiv(V, F, nsub, ratio=0.25, nVCoarsest=1000, n_extra_levels=0)
+        del mgs
+        t1 = time.time()
+        mg = smg.mg_precompute(Vf, Ff, 0.25, 1000, 1)
+        build_workload.mg_precompute_s = time.time() - t1
+        label = "%s: bunny_15K_init x%d midpoint subdivision, %d verts, hierarchy by mg_precompute(V, F, 0.25, 1000, midpoint) (SSP decimation, %d levels), M_bary+0.01(-L), fp64" % (name, nsub, Vf.shape[0], mg.n_levels)
+    elif name == "ogre":
+        V, F = mesh.read_triangle_mesh("ogre.smgm")
+        Vf, Ff = mesh.normalize_unit_area(V, F), F
+        mg = smg.mg_precompute(Vf, Ff, 0.25, 500, 1)
+        label = "ogre.obj (19985 verts), hierarchy by mg_precompute defaults (%d levels), M_bary+0.01(-L), fp64" % mg.n_levels
     elif name == "small":
         V, F = mesh.read_triangle_mesh("ogre_sim.smgm")
         V = mesh.normalize_unit_area(V, F)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMG_VERSION 400
+#define SMG_VERSION 500
 
 enum {
     SMG_OK = 0,
@@ -206,6 +206,21 @@ int smg_hierarchy_set_block_gs(smg_hierarchy *h, int min_rows);
  * slots that hold a row of their own (the rest repeat one)}.  Any pointer may be NULL.  Returns 1 when level lv sweeps block-sequentially for this k, 0 when
  * it does not (nothing is written then), < 0 on error. */
 int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks, int *n_colors, int *color_ptr, int *blk_ptr, int *rows, double *stats);
+/* relax() on the Galerkin levels of the REFERENCE's own hierarchies (smg_mg_precompute = src/mg_precompute.cpp:15-87: A_l = PT A P with 18 - 30 entries
+ * per row, 11 - 15 colours).  Such a level sweeps PIECE-wise: compact pieces of <= 64 rows, the piece graph coloured (4 - 6 colours whatever the rows'
+ * degree), one launch per piece colour, one wavefront per piece (lane = row, the row in registers, the piece's rows and rim in LDS, rows updated phase by
+ * phase there).  That is the reference's lexicographic sweep (src/mg_VCycle.cpp:146-160) on the numbering (piece colour, piece, local colour, row) -- per
+ * kernel bit for bit what the oracle computes on that numbering, smg_level_get_wave_gs_order.  A different, equally valid Gauss-Seidel order than the
+ * multi-colour one: iterates differ, converged solutions agree to the tolerance, cycle counts are the same (measured).
+ * mode: -1 (default) automatic = Gauss-Seidel levels of 512 - 600 000 rows with more than 5 colours or rows of more than 12 entries that have no
+ * one-launch relax() (overlapped tiling), 1 - 7 columns, fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range.
+ * SMG_WGS=0 / 1 / 2 overrides (off / automatic / every level).  Takes effect at the next solve. */
+int smg_hierarchy_set_wave_gs(smg_hierarchy *h, int mode);
+/* The piece-sequential order of level lv as a solve with k columns would use it (after smg_precompute; builds the plan): *n_pieces, *n_colors,
+ * color_ptr[n_colors + 1] (pieces per piece colour), piece_ptr[n_pieces + 1] (positions per piece), rows[n] (position -> row in the INTERNAL numbering,
+ * smg_level_get_perm), stats[3] = {rows gathered per row beyond the iterate itself, mean phases per piece, most phases of a piece}.  Any pointer may be
+ * NULL.  Returns 1 when level lv sweeps piece-wise for this k, 0 when it does not (nothing is written then), < 0 on error. */
+int smg_level_get_wave_gs_order(smg_hierarchy *h, int lv, int k, int *n_pieces, int *n_colors, int *color_ptr, int *piece_ptr, int *rows, double *stats);
 /* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).  Three of them,
  * chosen by size and by what the caller does (all: <= 1e-11 from LDL^T, deterministic):
  *  - DENSE INVERSE, up to n_max unknowns (smg_hierarchy_set_coarse_dense_max, default 16384, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device
@@ -390,6 +405,11 @@ int smg_debug_check_tiling_plan(smg_hierarchy *h, int lv, int sweeps, int tile_r
  * kernel does, against the plain lexicographic sweep in the block order; *max_abs_diff must be 0.  Checks the plan's invariants on the way.
  * Needs no GPU (after the host half of smg_precompute).  *n_blocks = 0: the level does not qualify. */
 int smg_debug_check_block_gs_plan(smg_hierarchy *h, int lv, int block_rows, int *n_blocks, int *n_colors, double *rim, double *fill, double *max_abs_diff);
+/* Test hook: builds the wave Gauss-Seidel plan of level lv (smg_hierarchy_set_wave_gs; pieces_mode 0 compact pieces, 1 pieces along breadth-first level
+ * sets) on the host and executes it on the host the way the kernel does, against the plain lexicographic sweep in the piece order; *max_abs_diff must be 0.
+ * stats[3] as smg_level_get_wave_gs_order.  Checks the plan's invariants on the way.  Needs no GPU (after the host half of smg_precompute).
+ * *n_pieces = 0: the level does not qualify (a row of more than 64 off-diagonal entries). */
+int smg_debug_check_wave_gs_plan(smg_hierarchy *h, int lv, int piece_rows, int pieces_mode, int *n_pieces, int *n_colors, double *stats, double *max_abs_diff);
 /* Test hook: raises the stall flag of the sparse triangular solves on the device, as a wait that gave up would (csrc/smg_coarse_device.hip).
  * The next solve's waits then give up at once, its coarse corrections are NaN, and the next synchronising entry point returns SMG_ERR_HIP
  * and clears the flag.  Fails unless the handle holds a sparse coarse factorisation. */

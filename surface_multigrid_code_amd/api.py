@@ -318,6 +318,35 @@ class Hierarchy:
         _chk(min(self.L.smg_level_get_block_gs_order(self.h, lv, int(k), None, None, _ip(cp), _ip(bp), _ip(rows), _dp(st)), 0), "smg_level_get_block_gs_order")
         return {"rows": rows, "blk_ptr": bp, "color_ptr": cp, "rim": st[0], "fill": st[1]}
 
+    # ---- piece-wise Gauss-Seidel on the Galerkin levels of decimated hierarchies (csrc/smg_wgs.hpp)
+    def set_wave_gs(self, mode="auto"):
+        """auto: levels the colour launches serve badly (> 5 colours or rows of > 12 entries); never; all: every Gauss-Seidel level in range"""
+        _chk(self.L.smg_hierarchy_set_wave_gs(self.h, {"auto": -1, "never": 0, "all": 1}[mode]), "smg_hierarchy_set_wave_gs")
+
+    def wave_gs_order(self, lv, k=1):
+        """None when level lv does not sweep piece-wise for k columns, else a dict: rows (position -> internal row), piece_ptr, color_ptr, rim,
+        phases_mean, phases_max"""
+        nb, nc = C.c_int(), C.c_int()
+        rc = self.L.smg_level_get_wave_gs_order(self.h, lv, int(k), C.byref(nb), C.byref(nc), None, None, None, None)
+        if rc < 0:
+            _chk(rc, "smg_level_get_wave_gs_order")
+        if rc == 0:
+            return None
+        cp, bp, rows, st = np.zeros(nc.value + 1, np.int32), np.zeros(nb.value + 1, np.int32), np.zeros(self.rows(lv), np.int32), np.zeros(3)
+        _chk(min(self.L.smg_level_get_wave_gs_order(self.h, lv, int(k), None, None, _ip(cp), _ip(bp), _ip(rows), _dp(st)), 0), "smg_level_get_wave_gs_order")
+        return {"rows": rows, "piece_ptr": bp, "color_ptr": cp, "rim": st[0], "phases_mean": st[1], "phases_max": int(st[2])}
+
+    def gs_order(self, lv, k=1):
+        """position -> internal row of the Gauss-Seidel order relax() uses on level lv with k columns: the piece order where the level sweeps
+        piece-wise, the block order where it sweeps block-wise, else the internal numbering itself (one launch per colour / overlapped tiling)"""
+        w = self.wave_gs_order(lv, k)
+        if w is not None:
+            return w["rows"]
+        b = self.block_gs_order(lv, k)
+        if b is not None:
+            return b["rows"]
+        return np.arange(self.rows(lv), dtype=np.int32)
+
     # ---- coarsest-level solver
     def set_coarse_dense_max(self, n_max):
         """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""

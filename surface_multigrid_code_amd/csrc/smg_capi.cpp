@@ -595,6 +595,73 @@ extern "C" int smg_debug_check_tiling_plan(smg_hierarchy* h, int lv, int sweeps,
     });
 }
 
+// The wave Gauss-Seidel plan of level lv (smg_wgs.hpp) built on the host and EXECUTED on the host the way k_wgs executes it (wgs_sweep_host: per piece an
+// image of its rows and its rim, phases in place, packed byte offsets) against the plain lexicographic sweep in the wgs order (the reference's relax(),
+// src/mg_VCycle.cpp:146-160, on that numbering): *max_abs_diff must be 0.  Checks the plan's invariants on the way.  Needs no GPU once the host half of
+// smg_precompute has run.  *n_pieces = 0: the level does not qualify.
+extern "C" int smg_debug_check_wave_gs_plan(smg_hierarchy* h, int lv, int piece_rows, int pieces_mode, int* n_pieces, int* n_colors, double* stats, double* max_abs_diff)
+{
+    return guarded("smg_debug_check_wave_gs_plan", [&]() -> int {
+        if (!h || lv < 0 || lv >= h->n_levels - 1 || piece_rows < 8) return fail(SMG_ERR_INVALID, "smg_debug_check_wave_gs_plan: bad arguments");
+        int rc = ensure_A_int(h, lv);
+        if (rc) return rc;
+        Level& Lv = h->lv[lv];
+        if (Lv.A_int.nr != Lv.n || Lv.n == 0 || h->bs != 1) return fail(SMG_ERR_INVALID, "smg_debug_check_wave_gs_plan: the host half of smg_precompute has not run (scalar hierarchies only)");
+        const Csr& G = Lv.A_int;
+        const int n = G.nr;
+        const WgsPlan P = build_wgs(G, std::min(piece_rows, (int)WGS_ROWS), pieces_mode);
+        if (n_pieces) *n_pieces = P.n_pieces;
+        if (n_colors) *n_colors = P.n_colors;
+        if (stats) { stats[0] = P.rim_ratio; stats[1] = P.phases_mean; stats[2] = (double)P.phases_max; }
+        if (max_abs_diff) *max_abs_diff = 0.0;
+        if (P.empty()) return SMG_OK;
+        // invariants: every row in exactly one piece of <= 64 rows; pieces of one colour share no entry
+        std::vector<int> pc_of((size_t)n, -1), col_of_pc((size_t)P.n_pieces, -1);
+        for (int c = 0; c < P.n_colors; c++) for (int q = P.color_ptr[(size_t)c]; q < P.color_ptr[(size_t)c + 1]; q++) col_of_pc[(size_t)q] = c;
+        for (int q = 0; q < P.n_pieces; q++) {
+            if (P.piece_ptr[(size_t)q + 1] - P.piece_ptr[(size_t)q] > WGS_ROWS) return fail(SMG_ERR_INVALID, "wave plan: piece %d has more than 64 rows", q);
+            for (int t = P.piece_ptr[(size_t)q]; t < P.piece_ptr[(size_t)q + 1]; t++) {
+                const int i = P.rows[(size_t)t];
+                if (i < 0 || i >= n || pc_of[(size_t)i] >= 0) return fail(SMG_ERR_INVALID, "wave plan: row %d is not in exactly one piece", i);
+                pc_of[(size_t)i] = q;
+            }
+        }
+        for (int i = 0; i < n; i++) {
+            if (pc_of[(size_t)i] < 0) return fail(SMG_ERR_INVALID, "wave plan: row %d is in no piece", i);
+            for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                const int j = G.col[(size_t)p];
+                if (pc_of[(size_t)j] != pc_of[(size_t)i] && col_of_pc[(size_t)pc_of[(size_t)j]] == col_of_pc[(size_t)pc_of[(size_t)i]])
+                    return fail(SMG_ERR_INVALID, "wave plan: pieces %d and %d share an entry and a colour", pc_of[(size_t)i], pc_of[(size_t)j]);
+            }
+        }
+        std::vector<double> x((size_t)n), b((size_t)n), ref, y;
+        for (int i = 0; i < n; i++) { x[(size_t)i] = std::sin(0.37 * i) + 0.25 * std::cos(1.3 * i); b[(size_t)i] = std::cos(0.11 * i) - 0.5 * std::sin(2.1 * i); }
+        // reference: rows one after the other in the wgs order, products in ascending column OF THAT ORDER
+        std::vector<int> pos((size_t)n);
+        for (int t = 0; t < n; t++) pos[(size_t)P.rows[(size_t)t]] = t;
+        ref = x;
+        std::vector<std::pair<int, int>> ent;
+        for (int t = 0; t < n; t++) {
+            const int i = P.rows[(size_t)t];
+            ent.clear();
+            double diag = 1.0;
+            for (int p = G.ptr[(size_t)i]; p < G.ptr[(size_t)i + 1]; p++) {
+                if (G.col[(size_t)p] == i) diag = G.val[(size_t)p]; else ent.emplace_back(pos[(size_t)G.col[(size_t)p]], p);
+            }
+            std::sort(ent.begin(), ent.end());
+            double acc = 0.0;
+            for (const auto& e : ent) acc += G.val[(size_t)e.second] * ref[(size_t)G.col[(size_t)e.second]];
+            ref[(size_t)i] = (b[(size_t)i] - acc) / diag;
+        }
+        y = x;
+        wgs_sweep_host(P, b.data(), y.data());
+        double d = 0.0;
+        for (int i = 0; i < n; i++) d = std::max(d, std::fabs(y[(size_t)i] - ref[(size_t)i]));
+        if (max_abs_diff) *max_abs_diff = d;
+        return SMG_OK;
+    });
+}
+
 // The block Gauss-Seidel plan of level lv (smg_bgs.hpp) built on the host and EXECUTED on the host the way k_bgs executes it -- per block an image
 // of its rows and its rim, units of <= 16 rows updated in place from local indices -- against the plain lexicographic sweep in the bgs order
 // (the reference's relax(), src/mg_VCycle.cpp:146-160, on that numbering): *max_abs_diff must be 0.  Also checks the plan's invariants (every row in

@@ -100,6 +100,11 @@ int smg::refresh_tiled_values(smg_hierarchy* h)
             TiledBuf& B = h->lv[lv].tiled[s];
             if (B.view.n_tiles > 0) HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
         }
+        WgsBuf& W = h->lv[lv].wgs;
+        if (W.view.n_pieces > 0) {
+            HIPCHK(launch_gather_vals(W.eval.p, h->lv[lv].d_Aval.p, W.map.p, W.eval.n, h->stream));
+            HIPCHK(launch_gather_vals(W.diag.p, h->lv[lv].d_Aval.p, W.mapd.p, W.diag.n, h->stream));
+        }
         BgsBuf& Q = h->lv[lv].bgs;
         if (Q.view.n_blocks > 0) {
             HIPCHK(launch_gather_vals(Q.eval.p, h->lv[lv].d_Aval.p, Q.map.p, Q.eval.n, h->stream));
@@ -110,7 +115,7 @@ int smg::refresh_tiled_values(smg_hierarchy* h)
 }
 void smg::drop_tiled(smg_hierarchy* h)
 {
-    for (auto& Lv : h->lv) { for (auto& B : Lv.tiled) B = TiledBuf(); Lv.bgs = BgsBuf(); }
+    for (auto& Lv : h->lv) { for (auto& B : Lv.tiled) B = TiledBuf(); Lv.bgs = BgsBuf(); Lv.wgs = WgsBuf(); }
 }
 
 // ---- block Gauss-Seidel for solves with a multiple of 16 columns (smg_bgs.hpp): one launch per BLOCK colour -----------------
@@ -170,6 +175,70 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
     return SMG_OK;
 }
 
+// ---- wave Gauss-Seidel on the Galerkin levels of decimated hierarchies (smg_wgs.hpp): one launch per PIECE colour ------------------
+// Which levels: scalar fp64 hierarchies, Gauss-Seidel, 1 - 7 columns, SMG_WGS_MIN_ROWS <= rows <= SMG_WGS_MAX_ROWS, no one-launch relax()
+// (overlapped tiling) available; automatic mode: only levels the colour launches serve badly -- more than TILED_NCMAX colours or rows of more
+// than TILED_WMAX entries, i.e. the Galerkin levels of the reference's own hierarchies (mg_precompute).  smg_hierarchy_set_wave_gs / SMG_WGS=0|1|2.
+static bool wgs_wanted(const smg_hierarchy* h, int lv, int k)
+{
+    static const int env = env_int("SMG_WGS", -1);
+    static const int max_rows = env_int("SMG_WGS_MAX_ROWS", 600000), min_rows = env_int("SMG_WGS_MIN_ROWS", 512);
+    const int mode = env >= 0 ? (env == 0 ? 0 : env == 1 ? -1 : 1) : h->wgs_mode;      // SMG_WGS: 0 off, 1 automatic, 2 every level in range
+    if (mode == 0 || h->bs != 1 || h->precision != 0 || k < 1 || k > 7 || lv < 0 || lv >= h->n_levels - 1) return false;
+    if (level_kind(h, lv) != LV_GS) return false;
+    const Level& Lv = h->lv[lv];
+    if (Lv.n < min_rows || Lv.n > max_rows) return false;
+    if (mode == 1) return true;
+    const SellBuf& Gs = Lv.gs_on_transpose ? Lv.dAT : Lv.dA;
+    return Lv.ord.n_colors() > TILED_NCMAX || Gs.view.w_max > TILED_WMAX;
+}
+static const WgsBuf* wgs_plan(const smg_hierarchy* h, int lv, int k)
+{
+    if (!wgs_wanted(h, lv, k)) return nullptr;
+    const WgsBuf& B = h->lv[lv].wgs;
+    return B.view.n_pieces > 0 ? &B : nullptr;
+}
+static int ensure_wgs(smg_hierarchy* h, int lv)
+{
+    Level& Lv = h->lv[lv];
+    WgsBuf& B = Lv.wgs;
+    if (B.tried) return SMG_OK;
+    B.tried = true;
+    static const int rows_env = env_int("SMG_WGS_ROWS", WGS_ROWS), mode_env = env_int("SMG_WGS_PIECES", 0);
+    std::vector<int> tsrc;
+    Csr AT;
+    { int rc = ensure_A_int(h, lv); if (rc) return rc; }
+    if (Lv.gs_on_transpose) AT = transpose(Lv.A_int, &tsrc);
+    const Csr& G = Lv.gs_on_transpose ? AT : Lv.A_int;
+    const auto t_plan0 = std::chrono::steady_clock::now();
+    WgsPlan P = build_wgs(G, std::min(std::max(rows_env, 8), (int)WGS_ROWS), mode_env);
+    const double plan_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan0).count();
+    if (P.empty()) return SMG_OK;
+    auto to_level_value = [&](const std::vector<int>& entries) {
+        std::vector<int> m(entries.size());
+        for (size_t i = 0; i < m.size(); i++) {
+            const int e = entries[i];
+            m[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
+        }
+        return m;
+    };
+    const std::vector<int> map = to_level_value(P.eentry), mapd = to_level_value(P.dentry);
+    HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.grow.upload(P.grow)); HIPCHK(B.meta.upload(P.meta)); HIPCHK(B.diag.upload(P.diag)); HIPCHK(B.rim.upload(P.rim));
+    HIPCHK(B.eoff.upload(P.eoff)); HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map)); HIPCHK(B.mapd.upload(mapd));
+    B.view.n_pieces = P.n_pieces; B.view.n_colors = P.n_colors; B.view.rim_pitch = P.rim_pitch; B.view.nb_max = P.nb_max;
+    B.view.hdr = B.hdr.p; B.view.grow = B.grow.p; B.view.meta = B.meta.p; B.view.diag = B.diag.p; B.view.rim = B.rim.p; B.view.eoff = B.eoff.p; B.view.eval = B.eval.p;
+    B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_piece_ptr = P.piece_ptr; B.rim_ratio = P.rim_ratio; B.phases_mean = P.phases_mean; B.phases_max = P.phases_max;
+    // after a value-only re-precompute the host copy of the values is stale: take them from the device copy (padding slots keep their +0.0, lanes without a row their 1.0)
+    if (h->host_stale && Lv.d_Aval.p) {
+        HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
+        HIPCHK(launch_gather_vals(B.diag.p, Lv.d_Aval.p, B.mapd.p, B.diag.n, h->stream));
+    }
+    if (env_int("SMG_DEBUG_WGS", 0))
+        std::fprintf(stderr, "wave Gauss-Seidel level %d: %d rows, %d pieces in %d colours, phases per piece %.1f (max %d), rim %.2f rows read per row beyond the iterate, rim pitch %d; plan built in %.0f ms\n",
+                     lv, Lv.n, P.n_pieces, P.n_colors, P.phases_mean, P.phases_max, P.rim_ratio, P.rim_pitch, plan_ms);
+    return SMG_OK;
+}
+
 // plans + second iterate for relax(sa) / relax(sb) wherever they are wanted (host work and uploads: never inside a graph capture)
 static int prepare_tiled(smg_hierarchy* h, int k, int sa, int sb)
 {
@@ -177,6 +246,7 @@ static int prepare_tiled(smg_hierarchy* h, int k, int sa, int sb)
         Level& Lv = h->lv[lv];
         for (int sw : {sa, sb}) if (tiled_wanted(h, lv, k, sw)) { int rc = ensure_tiled(h, lv, sw); if (rc) return rc; }
         if (bgs_wanted(h, lv, k) && !Lv.bgs.tried) { drop_graphs(h); int rc = ensure_bgs(h, lv); if (rc) return rc; }
+        if (wgs_wanted(h, lv, k) && !Lv.wgs.tried && !tiled_plan(h, lv, k, sa) && !tiled_plan(h, lv, k, sb)) { drop_graphs(h); int rc = ensure_wgs(h, lv); if (rc) return rc; }
         if ((tiled_plan(h, lv, k, sa) || tiled_plan(h, lv, k, sb)) && Lv.t.n < (size_t)Lv.n * std::max(h->kcap, 1)) {
             drop_graphs(h);
             HIPCHK(Lv.t.alloc((size_t)Lv.n * std::max(h->kcap, 1)));
@@ -469,6 +539,12 @@ static int enqueue_gs(smg_hierarchy* h, int lv, const T* b, T* u, int k, int ite
     Level& Lv = h->lv[lv];
     ProfGuard pg(h, "MG: relaxation");  // PROFC_NODE at src/mg_VCycle.cpp:121
     if (std::is_same<T, double>::value && first == FIRST_NONE) {
+        if (const WgsBuf* W = wgs_plan(h, lv, k)) {      // Galerkin levels of decimated hierarchies: one launch per piece colour (smg_wgs.hpp)
+            for (int it = 0; it < iters; it++)
+                for (size_t c = 0; c + 1 < W->color_ptr.size(); c++)
+                    HIPCHK(launch_wgs(W->view, W->color_ptr[c], W->color_ptr[c + 1], (const double*)b, (double*)u, k, ctrl, h->stream));
+            return SMG_OK;
+        }
         if (const BgsBuf* Q = bgs_plan(h, lv, k)) {      // many columns: one launch per block colour (smg_bgs.hpp)
             for (int it = 0; it < iters; it++)
                 for (size_t c = 0; c + 1 < Q->color_ptr.size(); c++)
@@ -585,7 +661,7 @@ static int enqueue_vcycle_t(smg_hierarchy* h, int lv, int k, int pre, int post, 
     const bool jac_c = kind_c != LV_GS;
     // (block hierarchies: the first launch of a coarse sweep is not a plain division -- row 3v+1 of the first colour already reads 3v)
     const bool tiled_c = level_kind(h, lv + 1) == LV_GS && pre > 0 && tiled_for<T>(h, Lc, lv + 1, k, pre) != nullptr;   // the coarse level runs all its phases itself
-    const bool fuse = h->bs == 1 && !tiled_c && !(std::is_same<T, double>::value && bgs_plan(h, lv + 1, k)) && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
+    const bool fuse = h->bs == 1 && !tiled_c && !(std::is_same<T, double>::value && (bgs_plan(h, lv + 1, k) || wgs_plan(h, lv + 1, k))) && fuse_first_colour() && lv + 1 < L - 1 && pre > 0 && Prec<T>::has_vals(Prec<T>::G(Lc)) && (jac_c ? Gc.n_all > 0 : Gc.n_first > 0);
     const int kt = k * h->bs;   // block hierarchies: dP / dPT hold the vertex-level factor of P (x) I_3, applied to 3 k columns
     {   // rc = PT r  (:43-44, :80) and uc = 0 (:46-47) in one launch: both are indexed by the coarse row
         ProfGuard pg(h, "MG: restrict");
@@ -670,7 +746,9 @@ static bool head_fusable(smg_hierarchy* h, int k)
     if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on || h->bs != 1) return false;
     Level& L0 = h->lv[0];
     if (L0.gs_on_transpose) return false;
-    if (bgs_plan(h, 0, k)) return false;   // block-sequential sweeps run in place; their head is the residual launch
+    if (bgs_plan(h, 0, k) || wgs_plan(h, 0, k)) return false;   // block- / piece-sequential sweeps run in place; their head is the residual launch
+    // a level 0 whose relax(pre) is ONE launch (overlapped tiling): residual launch + one launch beat a head of (colours x 2) launches
+    if (level_kind(h, 0) == LV_GS && tiled_plan(h, 0, k, h->pre) && L0.t.p) return false;
     const int kind = level_kind(h, 0);
     return kind == LV_GS ? h->pre >= 2 : h->pre >= 1;
 }
@@ -1226,6 +1304,33 @@ extern "C" int smg_level_get_block_gs_order(smg_hierarchy* h, int lv, int k, int
     if (blk_ptr) std::copy(Q->host_blk_ptr.begin(), Q->host_blk_ptr.end(), blk_ptr);
     if (rows) std::copy(Q->host_rows.begin(), Q->host_rows.end(), rows);
     if (stats) { stats[0] = Q->rim; stats[1] = Q->fill; }
+    return 1;
+}
+
+extern "C" int smg_hierarchy_set_wave_gs(smg_hierarchy* h, int mode)
+{
+    if (!h) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_wave_gs: null handle");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_wave_gs called during a split-phase solve");
+    if (mode < -1 || mode > 1) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_wave_gs: mode must be -1 (automatic), 0 (never) or 1 (every Gauss-Seidel level in range)");
+    if (mode != h->wgs_mode) { h->wgs_mode = mode; if (h->stream) drop_graphs(h); }
+    return SMG_OK;
+}
+extern "C" int smg_level_get_wave_gs_order(smg_hierarchy* h, int lv, int k, int* n_pieces, int* n_colors, int* color_ptr, int* piece_ptr, int* rows, double* stats)
+{
+    int rc = check_ready(h, "smg_level_get_wave_gs_order");
+    if (rc) return rc;
+    if (lv < 0 || lv >= h->n_levels || k < 1) return fail(SMG_ERR_INVALID, "smg_level_get_wave_gs_order: bad level / k");
+    if (!wgs_wanted(h, lv, k)) return 0;
+    DeviceScope dsc(h->device);
+    if ((rc = prepare_tiled(h, k, h->pre, h->post))) return rc;      // the one-launch relax() has precedence where it exists: decided there
+    const WgsBuf* Q = wgs_plan(h, lv, k);
+    if (!Q || tiled_plan(h, lv, k, h->pre) || tiled_plan(h, lv, k, h->post)) return 0;
+    if (n_pieces) *n_pieces = Q->view.n_pieces;
+    if (n_colors) *n_colors = Q->view.n_colors;
+    if (color_ptr) std::copy(Q->color_ptr.begin(), Q->color_ptr.end(), color_ptr);
+    if (piece_ptr) std::copy(Q->host_piece_ptr.begin(), Q->host_piece_ptr.end(), piece_ptr);
+    if (rows) std::copy(Q->host_rows.begin(), Q->host_rows.end(), rows);
+    if (stats) { stats[0] = Q->rim_ratio; stats[1] = Q->phases_mean; stats[2] = (double)Q->phases_max; }
     return 1;
 }
 

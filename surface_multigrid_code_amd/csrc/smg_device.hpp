@@ -151,6 +151,20 @@ struct BgsDev {
 // the blocks [b_begin, b_end) -- one block colour -- of one sweep, in place on u (row-major n x k, k a multiple of 16)
 hipError_t launch_bgs(const BgsDev& P, int b_begin, int b_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 
+// ---- Gauss-Seidel sweep of a Galerkin level of a decimated hierarchy: one wavefront per piece, one launch per piece colour (smg_wgs.hpp plan, smg_wgs_device.hip kernel) ----
+struct WgsDev {
+    int n_pieces = 0, n_colors = 0, rim_pitch = 0, nb_max = 0;   // nb_max: batches of 8 entry slots of the level's widest row
+    const int* hdr = nullptr;         // per piece WGS_HDR ints: first entry slot, batches per row, rim rows, phases, ...
+    const int* grow = nullptr;        // 64 per piece: the lane's row (-1: none), ...
+    const int* meta = nullptr;        //   ... the phase it is updated in | batches its row needs << 16, ...
+    const double* diag = nullptr;     //   ... its diagonal entry
+    const int* rim = nullptr;         // rim_pitch per piece: the rows behind local indices 64, 65, ...
+    const unsigned* eoff = nullptr;   // per piece 64 x 4 NB: byte offsets of two entry slots' columns in the one-column image, 16 + 16 bits
+    const double* eval = nullptr;     // per piece 64 x 8 NB: the values
+};
+// the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k, 1 <= k <= 8)
+hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+
 // ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------
 struct TiledDev {
     int n_tiles = 0, nc = 0, P = 0, sweeps = 0, max_ext = 0, w_max = 0, threads = 512;

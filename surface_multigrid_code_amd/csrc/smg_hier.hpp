@@ -17,6 +17,7 @@
 #include "smg_sparse.hpp"
 #include "smg_tiled.hpp"
 #include "smg_bgs.hpp"
+#include "smg_wgs.hpp"
 #include "smg_schur.hpp"
 
 namespace smg {
@@ -107,6 +108,18 @@ struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a 
     bool tried = false;
 };
 
+struct WgsBuf {  // device image of the wave Gauss-Seidel plan of a level (smg_wgs.hpp)
+    DevBuf<int> hdr, grow, meta, rim, map, mapd;   // map / mapd: value slot / diagonal slot -> index into Level::d_Aval (value-only re-precompute), -1 padding
+    DevBuf<unsigned> eoff;
+    DevBuf<double> eval, diag;
+    WgsDev view;
+    std::vector<int> color_ptr;      // pieces of colour c
+    std::vector<int> host_rows, host_piece_ptr;    // the wgs order (position -> internal row), positions per piece: introspection, tests
+    double rim_ratio = 0.0, phases_mean = 0.0;
+    int phases_max = 0;
+    bool tried = false;
+};
+
 // one element of std::vector<mg_data> (reference src/mg_data.h:11-27)
 struct Level {
     // ---- host, caller numbering: the mg_data fields ----
@@ -136,6 +149,7 @@ struct Level {
     Csr vpat;               // block hierarchies: the n_v x n_v pattern of the 3 x 3 blocks of A (caller's vertex numbering; values unused)
     bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
+    WgsBuf wgs;             // wave Gauss-Seidel plan of a Galerkin level of a decimated hierarchy, 1 - 8 columns (built on demand in ensure_work)
     BgsBuf bgs;             // block-sequential Gauss-Seidel plan for solves with a multiple of 64 columns (built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
     std::vector<int> A_int_src;   // A_int entry -> index into A.val
@@ -213,6 +227,7 @@ struct smg_hierarchy {
     // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
+    int wgs_mode = -1;              // smg_hierarchy_set_wave_gs: -1 automatic (levels the colour launches serve badly: > 5 colours or rows of > 12 entries), 0 never, 1 every Gauss-Seidel level in range
     int bgs_min_rows = -1;          // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 64 == 0 (< 0: never, the default)
     smg::SparseChol chol;
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;

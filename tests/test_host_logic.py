@@ -584,6 +584,35 @@ def test_block_gauss_seidel_plan_is_the_lexicographic_sweep_in_its_order(smg_mod
                 assert diff.value == 0.0, "level %d, blocks of %d rows: the block sweep differs by %g" % (lv, block_rows, diff.value)
 
 
+def test_wave_gauss_seidel_plan_is_the_lexicographic_sweep_in_its_order(smg_mod):
+    """Wave Gauss-Seidel on the Galerkin levels of the reference's own hierarchies (csrc/smg_wgs.hpp, round 5): the plan -- pieces of <= 64 rows (compact,
+    or cut along breadth-first level sets), piece colours, per piece an image of its rows and rim, phases, packed byte offsets -- executed on the host
+    exactly as k_wgs executes it gives the bits of the reference's lexicographic sweep (src/mg_VCycle.cpp:146-160) on the numbering (piece colour, piece,
+    local colour, row); invariants: every row in one piece, pieces of one colour share no entry, few colours, few phases.  Hierarchies by mg_precompute
+    (ogre.obj: 18 - 25 entries per row, restriction rows of up to 177 entries) and by subdivision."""
+    import ctypes as C
+    smg = smg_mod
+    L = smg._lib.load()
+    V, F = M.read_smgm("ogre.smgm")
+    V = M.normalize_unit_area(V, F)
+    mgd = smg.mg_precompute(V, F, 0.25, 200, 1)
+    A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    _host_precompute(smg, mgd, A)
+    p = subdiv_problem(kind="poisson", k=1, n_sub=2, n_pins=40)
+    mgs = _host_precompute(smg, smg.Hierarchy.from_prolongs(p["Ps"]), p["A"], p["known"])
+    for mg in (mgd, mgs):
+        for lv in range(mg.n_levels - 1):
+            for piece_rows, mode in ((64, 0), (32, 0), (64, 1), (16, 1)):
+                nb, nc, diff = C.c_int(), C.c_int(), C.c_double(-1.0)
+                st = np.zeros(3)
+                rc = L.smg_debug_check_wave_gs_plan(mg.h, lv, piece_rows, mode, C.byref(nb), C.byref(nc), st.ctypes.data_as(C.POINTER(C.c_double)), C.byref(diff))
+                assert rc == 0, L.smg_last_error()
+                assert nb.value >= mg.rows(lv) // piece_rows and 3 <= nc.value <= 10
+                assert 0.0 < st[0] < 6.0 and 1.0 <= st[1] <= st[2] <= 20
+                assert diff.value == 0.0, "level %d, pieces of %d rows (mode %d): the piece sweep differs by %g" % (lv, piece_rows, mode, diff.value)
+
+
 def test_sparse_cholesky_of_the_coarse_solver(smg_mod):
     """csrc/smg_coarse.cpp (coarsest levels beyond the dense range; the reference: Eigen::SimplicialLDLT, src/min_quad_with_fixed_mg.cpp:47-48):
     nested dissection + up-looking Cholesky on mesh operators -- residual of a host solve with the factor at rounding level, fill O(n log n),
