@@ -470,6 +470,113 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
                       "final_residual": float(rh[-1]) if len(rh) else None}}
 
 
+def host_info():
+    """CPU model + logical cores of this box, printed once per line (the CPU comparators beside the legs ran here)"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def oracle_cycle_ms(mg, A, rhs, budget_s=6.0, known=None, known_val=None):
+    """ms per outer iteration (residual + V(2,2) cycle) of the CPU oracle -- the reference's algorithm, 1 thread -- on the hierarchy of `mg`, bounded sample"""
+    from oracle.oracle import OracleMG
+    orc = OracleMG([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
+    t0 = time.time()
+    orc.precompute(A, known)
+    t_pre = time.time() - t0
+    z0 = np.zeros_like(rhs)
+    t0 = time.time()
+    orc.solve(rhs, z0, known_val, tol=0.0, max_iter=1)
+    t1 = time.time() - t0
+    m = int(max(2, min(400, budget_s / max(t1, 1e-6))))
+    t0 = time.time()
+    orc.solve(rhs, z0, known_val, tol=0.0, max_iter=m)
+    dt = time.time() - t0
+    return {"ms_per_cycle": 1e3 * dt / m, "v_cycles_per_s": m / dt, "cores": 1, "kind": "port", "precompute_s": t_pre,
+            "sample": "%d outer iterations, oracle/smg_oracle.c, gcc -O3, 1 thread" % m}
+
+
+def steady_ms(torch, stream, mg, rhs, z0, z, n, k, opts_kw, warm=30, iters=200, repeats=3, his=1024):
+    """ms per outer iteration, graph-replayed, HIP events on the solve stream (tol = 0: every iteration is a full one); median of `repeats`"""
+    import surface_multigrid_code_amd as smg
+    ts = []
+    mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, k, opts=smg.SolveOpts(tol=0.0, max_iter=his, **opts_kw))
+    mg.outer_iterations(warm)
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        ea.record(stream)
+        mg.outer_iterations(iters)
+        eb.record(stream)
+        torch.cuda.synchronize()
+        ts.append(ea.elapsed_time(eb) / iters)
+    mg.solve_end(z.data_ptr(), n, max_iter=his)
+    return float(np.median(ts))
+
+
+def c3_decimated_leg(smg, mesh, torch, dev, stream, ms_subdiv, bytes_subdiv):
+    """The C3 mesh under the REFERENCE's own kind of hierarchy: mg_precompute(V, F, 0.25, 1000, midpoint) on the 1 011 330-vertex mesh
+    (src/mg_precompute.cpp:15-87, get_prolong.cpp:45-56, the call of 03_mg_solver/main.cpp:35-39) -- SSP decimation, 3 entries per row of P,
+    Galerkin operators of 18 - 30 entries per row -- instead of the subdivision operators the headline's hierarchy is made of.  Same mesh,
+    same system, same right-hand side, the reference's Gauss-Seidel V(2,2): hierarchy-build seconds, the level table, ms per outer iteration,
+    its own algorithmic bytes and fraction of the HBM peak, cycles to 1e-10, the oracle beside it; `cost_per_byte_vs_subdivision` = (ms per
+    byte of this cycle) / (ms per byte of the headline's cycle)."""
+    mg, A, Mb, Vf, Ff, label, t_host = build_workload("C3dec", smg, mesh)
+    n = A.shape[0]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    mg.precompute(A)
+    t_pre = time.time() - t0
+    mg.set_stream(stream.cuda_stream)
+    rhs_h = Mb @ np.random.default_rng(100).uniform(-1.0, 1.0, n)
+    rhs = torch.from_numpy(rhs_h).to(dev)
+    z0 = torch.zeros(n, dtype=torch.float64, device=dev)
+    z = torch.empty_like(z0)
+    levels = []
+    for lv in range(mg.n_levels):
+        M = mg.matrix(lv, "A")
+        nn = np.diff(M.indptr)
+        row = {"rows": int(M.shape[0]), "entries_per_row": float(nn.mean()), "entries_per_row_max": int(nn.max())}
+        if lv < mg.n_levels - 1:
+            row["colors"] = len(mg.colors(lv)) - 1
+            w = mg.wave_gs_order(lv, 1)
+            row["relax"] = ("wave Gauss-Seidel: %d piece colours (launches per sweep), phases per piece %.1f (max %d)" % (len(w["color_ptr"]) - 1, w["phases_mean"], w["phases_max"])) if w is not None else "one launch per colour"
+        if lv > 0:
+            pn = np.diff(mg.matrix(lv, "PT").indptr)
+            row["P_entries_per_fine_row"] = float(mg.matrix(lv, "P").nnz) / mg.rows(lv - 1)
+            row["PT_entries_per_coarse_row_max"] = int(pn.max())
+        levels.append(row)
+    o = smg.SolveOpts(tol=1e-10, max_iter=100)
+    mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    cv, rh = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    ms = steady_ms(torch, stream, mg, rhs, z0, z, n, 1, dict(smoother="gs"))
+    byt = int(mg.vcycle_bytes(1, 2, 2))
+    mg.set_wave_gs("never")
+    ms_colour = steady_ms(torch, stream, mg, rhs, z0, z, n, 1, dict(smoother="gs"), iters=60)
+    cvc, rhc = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    mg.set_wave_gs("auto")
+    out = {"workload": label, "what": "outer iteration = residual + norm + break test + V(2,2), Gauss-Seidel on every level (the reference's cycle), 1 RHS column, graph-replayed; HIP events on the solve stream",
+           "setup_s": {"mesh_and_hierarchy_host": t_host, "mg_precompute_decimated": getattr(build_workload, "mg_precompute_s", None), "smg_precompute": t_pre},
+           "levels": levels, "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms, "bytes_per_step": byt, "gbs": byt / (ms * 1e-3) / 1e9,
+           "frac_of_hbm_peak": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cycles_to_1e-10": len(rh) - 1, "converged": bool(cv), "time_to_tol_ms": ms * (len(rh) - 1),
+           "one_launch_per_colour": {"ms_per_step": ms_colour, "cycles_to_1e-10": len(rhc) - 1, "converged": bool(cvc), "note": "the same handle with smg_hierarchy_set_wave_gs(h, 0): multi-colour order on every level"},
+           "cost_per_byte_vs_subdivision": (ms / byt) / (ms_subdiv / bytes_subdiv) if ms_subdiv and bytes_subdiv else None,
+           "subdivision_cycle": {"ms_per_step": ms_subdiv, "bytes_per_step": int(bytes_subdiv) if bytes_subdiv else None},
+           "device_bytes_live": int(smg._lib.load().smg_device_bytes_live())}
+    try:
+        out["cpu_baseline"] = oracle_cycle_ms(mg, A, rhs_h, budget_s=8.0)
+        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["ms_per_cycle"] / ms
+    except Exception as e:     # noqa: BLE001
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def block3_leg(smg, mesh, torch, with_scalar=True):
     """the block (3-DOF) kernels against the scalar kernels on the same 3n x 3n system -- C3 mesh, kron(S, C3) with a full
     SPD 3 x 3 coupling, hierarchy P (x) I_3 -- Gauss-Seidel V(2,2): ms per iteration, launches per sweep (colours), algorithmic bytes
@@ -739,6 +846,7 @@ def main():
     ap.add_argument("--no-reprecompute", action="store_true", help="skip the value-only re-precompute leg (dense inverse vs Schur-complement coarse solver)")
     ap.add_argument("--no-block3", action="store_true", help="skip the block (3-DOF) leg (C3 mesh, kron(S, C3) system)")
     ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
+    ap.add_argument("--no-c3dec", action="store_true", help="skip the leg with the reference's own (mg_precompute, SSP-decimated) hierarchy on the C3 mesh")
     ap.add_argument("--no-c3k64", action="store_true", help="skip the C3 x 64 columns column-sharded (strong scaling) leg")
     ap.add_argument("--repeats", type=int, default=9, help="the --steps iterations are timed this many times; the line reports the median repeat")
     ap.add_argument("--spmv-reps", type=int, default=500)
@@ -979,7 +1087,7 @@ def main():
                                 "bytes_per_step": ref["bytes_per_step"], "frac_of_hbm_peak": ref["frac_of_hbm_peak"]} if ref else None,
             "higher_is_better": True, "scaling": "weak",
             "scaling_note": "top-level value: one right-hand-side column per GPU, hierarchy replicated (fixed work per GPU as N grows); the c3_k64_sharded / c4_k64_sharded legs split a FIXED 64-column job over the ranks and say 'strong' themselves",
-            "vs_baseline": None,
+            "vs_baseline": None, "host": host_info(),
             "dtype": "f64" if args.precision == "f64" else "f64 outer loop + f32 V-cycle (mixed)", "data": "synthetic",
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],
@@ -1065,6 +1173,13 @@ def main():
             out["reprecompute"] = reprecompute_leg(smg, mg, A, torch)
         except Exception as e:
             out["reprecompute"] = {"error": repr(e)}
+    # ---- the same mesh under the reference's own kind of hierarchy (mg_precompute: SSP decimation), rank 0 at N = 1 only
+    if rank == 0 and world == 1 and not args.no_c3dec and args.workload == "C3":
+        try:
+            out["c3_decimated"] = c3_decimated_leg(smg, mesh, torch, dev, stream, out["reference_cycle"]["ms_per_step"] if out.get("reference_cycle") else out["ms_per_step"],
+                                                   out["reference_cycle"]["bytes_per_step"] if out.get("reference_cycle") else None)
+        except Exception as e:
+            out["c3_decimated"] = {"error": repr(e)}
     # ---- block (3-DOF) kernels, rank 0 at N = 1 only
     if rank == 0 and world == 1 and not args.no_block3 and args.workload == "C3":
         try:

@@ -204,7 +204,7 @@ static int ensure_wgs(smg_hierarchy* h, int lv)
     WgsBuf& B = Lv.wgs;
     if (B.tried) return SMG_OK;
     B.tried = true;
-    static const int rows_env = env_int("SMG_WGS_ROWS", WGS_ROWS), mode_env = env_int("SMG_WGS_PIECES", 0);
+    static const int rows_env = env_int("SMG_WGS_ROWS", WGS_ROWS), mode_env = env_int("SMG_WGS_PIECES", 1);
     std::vector<int> tsrc;
     Csr AT;
     { int rc = ensure_A_int(h, lv); if (rc) return rc; }

@@ -220,6 +220,96 @@ __global__ __launch_bounds__(64 * WPB) void k_sell(const int* a_col, const T* a_
     }
 }
 
+// ---- deep variant for WIDE rows (the operators of the reference's decimated hierarchies: Galerkin matrices of 18 - 30 entries per row, restriction
+// rows of 12 on average and 40 at most).  k_sell walks a slice in batches of 8 panel columns, each batch two dependent round trips (columns / values, then
+// the gathers): a 40-entry row is ten round trips, and on a level of 16 k rows that chain IS the launch (residual of the 15 804-row Galerkin level: 10.6 us).
+// Here the wave requests the WHOLE slice at once -- every panel column it has (guards are per-lane predicates on a per-lane copy of the slice's width:
+// a wave-uniform branch between two requests makes the compiler wait for the first), then every gather -- three round trips whatever the width; the sums
+// run over the registers in ascending column, separate multiply and add: the bits of k_sell.  fp64, SELL_AX (restriction incl. uc = 0 / fused first colour)
+// and SELL_RESID, KB <= 3 columns per lane.
+template <int MODE, int KB, int NBMAX>
+__global__ __launch_bounds__(256) void k_sell_deep(const int* a_col, const double* a_val, const int* a_order, const int* a_slice_off, int a_stride, int s_begin, int s_end,
+                                                   int n_blocks, int use_order, const double* x, const int* a_slice_row, const int* a_slice_w, const double* b, double* y, int ld,
+                                                   const int* done, CoarseInit<double> z)
+{
+    constexpr int C = 64, S = NBMAX * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bid = xcd_remap(blockIdx.x, n_blocks);
+    const int ls = __builtin_amdgcn_readfirstlane(s_begin + bid * 4 + wave);
+    if (ls >= s_end) return;
+    const int s = use_order ? a_order[ls] : ls;
+    const int stop = load_flag(done);
+    const int oz = __builtin_amdgcn_mbcnt_lo(~0u, 0u) >> 6;      // 0, opaque: the slice's table entries as per-lane values
+    const int row0 = a_slice_row[s + oz], nrow = a_slice_row[s + 1 + oz] - row0, w = a_slice_w[s + oz];
+    const int off0 = a_stride ? s * a_stride : a_slice_off[s + oz];
+    const int rowb = row0 + lane;
+    const bool live = lane < nrow;
+    const int* cp = a_col + (size_t)off0 * C + lane;
+    const double* vp = a_val + (size_t)off0 * C + lane;
+    int c[S];
+    double v[S];
+#pragma unroll
+    for (int bt = 0; bt < NBMAX; bt++) {
+        if (bt * 8 < w) {
+#pragma unroll
+            for (int t = bt * 8; t < bt * 8 + 8; t++) {
+                const int tt = t < w ? t : w - 1;        // a column beyond the slice's width: its last one again (same line), dropped below
+                c[t] = cp[(size_t)tt * C];
+                v[t] = vp[(size_t)tt * C];
+            }
+        } else {
+#pragma unroll
+            for (int t = bt * 8; t < bt * 8 + 8; t++) { c[t] = -1; v[t] = 0.0; }
+        }
+    }
+    double zd = 1.0, bv[KB];
+    if (MODE == SELL_AX && live && rowb < z.n_first) zd = z.gs_val[z.diag_slot[rowb]];
+#pragma unroll
+    for (int q = 0; q < KB; q++) bv[q] = (MODE == SELL_RESID && live) ? b[(size_t)rowb * ld + q] : 0.0;
+    double xv[S][KB];
+#pragma unroll
+    for (int t = 0; t < S; t++) {
+        const bool use = c[t] >= 0 && t < w;
+        if (!use) v[t] = 0.0;                              // padding: +0.0 times 0.0 leaves a sum that started at +0 as it is
+        gather_kb<KB, double>(x + (size_t)(use ? c[t] : 0) * ld, use, xv[t]);
+    }
+    double acc[KB];
+#pragma unroll
+    for (int q = 0; q < KB; q++) acc[q] = 0.0;
+#pragma unroll
+    for (int bt = 0; bt < NBMAX; bt++) {
+        if (bt * 8 < w) {
+#pragma unroll
+            for (int t = bt * 8; t < bt * 8 + 8; t++)
+#pragma unroll
+                for (int q = 0; q < KB; q++) acc[q] += v[t] * xv[t][q];
+        }
+    }
+    if (live && !stop) {
+        const size_t o = (size_t)rowb * ld;
+#pragma unroll
+        for (int q = 0; q < KB; q++) {
+            if (MODE == SELL_AX) {
+                y[o + q] = acc[q];
+                if (z.u) {
+                    const double t = acc[q] / zd;
+                    if (z.jacobi == 2) { const double dn = z.omega * (t - 0.0); z.u[o + q] = 0.0 + dn; z.d[o + q] = dn; }
+                    else z.u[o + q] = rowb < z.n_first ? (z.jacobi ? 0.0 + z.omega * (t - 0.0) : t) : 0.0;
+                }
+            } else y[o + q] = bv[q] - acc[q];
+        }
+    }
+}
+// which launches take the deep variant: SMG_DEEP=0 switches it off (A/B knob; same bits either way)
+static bool deep_wanted(int mode, int w_max, int kb)
+{
+    static const int on = getenv("SMG_DEEP") ? atoi(getenv("SMG_DEEP")) : 1;
+    static const int wmin = getenv("SMG_DEEP_MIN_W") ? atoi(getenv("SMG_DEEP_MIN_W")) : 13;
+    if (!on || (mode != SELL_AX && mode != SELL_RESID) || w_max < wmin || w_max > 64) return false;
+    const int nbm = w_max <= 24 ? 3 : w_max <= 40 ? 5 : 8;
+    return nbm == 3 ? kb <= 3 : nbm == 5 ? kb <= 2 : kb == 1;
+}
+
 // ---- wide multi-RHS variant --------------------------------------------------------------------------------------
 // For k >= 8 right-hand sides the lanes run ACROSS COLUMNS: lane = (g, c) with c = lane % KW the column inside a block of
 // KW in {8,16,32,64} columns and g = lane / KW one of G = 64/KW rows handled concurrently.  A neighbour gather is then
@@ -571,6 +661,27 @@ static hipError_t launch_sell_mode(const SellDev& A, int s_begin, int s_end_in, 
         double* pp = partials ? partials + poff : nullptr;
         const CoarseInit<T> zz = coarse_init<T>(zero_rows, c0, first, omega);
         poff += (size_t)nb;
+        if constexpr (std::is_same<T, double>::value && (MODE == SELL_AX || MODE == SELL_RESID)) {
+            // (k = 4 on a matrix the deep variant serves with 3 columns per lane: 3 + 1)
+            int kd = kb;
+            if (kd == 4 && !deep_wanted(MODE, A.w_max, 4) && deep_wanted(MODE, A.w_max, 2)) kd = 2;
+            if (deep_wanted(MODE, A.w_max, kd) || (kd > 1 && deep_wanted(MODE, A.w_max, 1))) {
+                for (int cc = 0; cc < kb;) {
+                    int kk = kb - cc;
+                    while (kk > 1 && !deep_wanted(MODE, A.w_max, kk)) kk--;
+                    const int nbm = A.w_max <= 24 ? 3 : A.w_max <= 40 ? 5 : 8;
+                    const CoarseInit<T> zc = coarse_init<T>(zero_rows, c0 + cc, first, omega);
+#define SMG_DEEP_LAUNCH(KB, NB) hipLaunchKernelGGL((k_sell_deep<MODE, KB, NB>), dim3(nb), dim3(256), 0, st, A.col, A.val, A.order, A.slice_off, A.stride, s_begin, s_end, nb, use_order, \
+                                                   xx ? xx + cc : nullptr, A.slice_row, A.slice_w, bb ? bb + cc : nullptr, yy + cc, k, done, zc)
+                    if (nbm == 3) { if (kk == 1) SMG_DEEP_LAUNCH(1, 3); else if (kk == 2) SMG_DEEP_LAUNCH(2, 3); else SMG_DEEP_LAUNCH(3, 3); }
+                    else if (nbm == 5) { if (kk == 1) SMG_DEEP_LAUNCH(1, 5); else SMG_DEEP_LAUNCH(2, 5); }
+                    else SMG_DEEP_LAUNCH(1, 8);
+#undef SMG_DEEP_LAUNCH
+                    cc += kk;
+                }
+                continue;
+            }
+        }
         switch (kb) {
             case 1: {
                 // the usual widths get kernels with the look-ahead count fixed at compile time (no branch per panel column)

@@ -777,7 +777,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
             if (Lp.P_device_filled) Lp.P_int = Csr(); else Lp.P_int = permute(Lp.P, Lw.ord.perm, Lp.ord.perm);
         });
         tasks.push_back([h, &Lw, &Lp] {
-            static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+            static const int long_min = env_int("SMG_LONG_ROW_MIN", 65);
             bool ok = device_fill_rows(h, Lp.PT.nr);
             if (ok && long_min > 0) for (int r = 0; r < Lp.PT.nr && ok; r++) if (Lp.PT.ptr[(size_t)r + 1] - Lp.PT.ptr[(size_t)r] >= long_min) ok = false;   // long rows leave the panels: host path
             Lp.PT_device_filled = ok;
@@ -906,7 +906,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         // rows with many entries (a coarse vertex of a decimated level that absorbed dozens of fine ones) leave the panels:
         // a panel row is one chain of dependent batches and the longest one sets the duration of the restriction launch
         // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
-        static const int long_min = env_int("SMG_LONG_ROW_MIN", 17);
+        static const int long_min = env_int("SMG_LONG_ROW_MIN", 65);
         if (!blk && Lp.PT_device_filled) {
             eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut, h->aux[2]);
             if (eQ == hipSuccess) eQ = Lp.dPT.upload_long({}, {0}, {}, {});

@@ -73,7 +73,7 @@ int colour_graph(const std::vector<std::vector<int>>& adj, std::vector<int>& col
 
 // Pieces along the breadth-first level sets of G: a level set is a closed band of the surface one graph hop wide, its rows read only their own
 // and the two neighbouring level sets.  Every connected part of a level set is walked from one of its ends and cut into runs of <= piece_rows rows.
-std::vector<int> partition_bands(const Csr& G, int piece_rows, int* n_pieces)
+std::vector<int> partition_bands(const Csr& G, int piece_rows, int* n_pieces, std::vector<int>* hint)
 {
     const int n = G.nr;
     std::vector<int> dist((size_t)n, -1), order;
@@ -134,9 +134,15 @@ std::vector<int> partition_bands(const Csr& G, int piece_rows, int* n_pieces)
         const int end1 = comp.back();
         walk_from(end1, d, walk, 2);                 // from a far end: the walk runs along the band
         const int m = (int)walk.size();
-        const int runs = (m + piece_rows - 1) / piece_rows, len = (m + runs - 1) / runs;
+        // an EVEN number of runs where there is more than one: the runs of a closed band then alternate all the way round, and with the parity of the
+        // level set that is a 4-colouring of the pieces by construction (hint; build_wgs verifies it and repairs what a branching level set breaks)
+        int runs = (m + piece_rows - 1) / piece_rows;
+        if (runs > 1 && (runs & 1)) runs++;
+        const int len = (m + runs - 1) / runs;
         for (int t = 0; t < m; t++) part[(size_t)walk[(size_t)t]] = np + t / len;
-        np += runs;
+        const int made = (m + len - 1) / len;
+        if (hint) for (int r = 0; r < made; r++) hint->push_back(2 * (d & 1) + (r & 1));
+        np += made;
         for (int v : walk) seen[(size_t)v] = 0;
     }
     *n_pieces = np;
@@ -159,7 +165,8 @@ WgsPlan build_wgs(const Csr& G, int piece_rows, int mode)
         if (!ok) return R;
     }
     int np = 0;
-    std::vector<int> part = mode == 1 ? partition_bands(G, piece_rows, &np) : partition_tiles(G, piece_rows, &np);
+    std::vector<int> hint;
+    std::vector<int> part = mode == 1 ? partition_bands(G, piece_rows, &np, &hint) : partition_tiles(G, piece_rows, &np);
     // a piece whose rim exceeds the image is cut in two (first / second half of a breadth-first order of its rows)
     for (int pass = 0; pass < 6; pass++) {
         std::vector<std::vector<int>> mem((size_t)np);
@@ -194,6 +201,7 @@ WgsPlan build_wgs(const Csr& G, int piece_rows, int mode)
             }
             for (size_t t = order.size() / 2; t < order.size(); t++) part[(size_t)M[(size_t)order[t]]] = np;
             np++;
+            if (!hint.empty()) hint.push_back(-1);
         }
     }
     // members of every piece (ascending row)
@@ -222,8 +230,35 @@ WgsPlan build_wgs(const Csr& G, int piece_rows, int mode)
         }
     });
     std::vector<int> colour;
-    const int ncol = colour_graph(adj, colour);
+    int ncol = colour_graph(adj, colour);
     if (ncol < 1) return R;
+    if ((int)hint.size() == np) {
+        // the constructed colouring of band pieces (level-set parity, run parity): kept where it is valid; a piece in conflict (branching level sets,
+        // pieces cut again for their rim) takes the first colour none of its neighbours has.  Used when it needs fewer colours than DSATUR found --
+        // or as many, but without a nearly empty class (every class is a launch per sweep)
+        std::vector<int> hc = hint;
+        std::vector<int> redo;
+        for (int b = 0; b < np; b++) {
+            bool clash = hc[(size_t)b] < 0;
+            for (int o : adj[(size_t)b]) if (o < b && hc[(size_t)o] == hc[(size_t)b]) clash = true;
+            if (clash) { hc[(size_t)b] = -1; redo.push_back(b); }
+        }
+        int hcol = 4;
+        bool ok = true;
+        for (int b : redo) {
+            unsigned used = 0u;
+            for (int o : adj[(size_t)b]) if (hc[(size_t)o] >= 0) used |= 1u << hc[(size_t)o];
+            int c = 0;
+            while (c < 31 && (used >> c & 1u)) c++;
+            if (c >= 31) { ok = false; break; }
+            hc[(size_t)b] = c;
+            hcol = std::max(hcol, c + 1);
+        }
+        if (ok) {
+            auto smallest = [&](const std::vector<int>& col, int nc) { std::vector<int> cnt((size_t)nc, 0); for (int c : col) cnt[(size_t)c]++; return *std::min_element(cnt.begin(), cnt.end()); };
+            if (hcol < ncol || (hcol == ncol && smallest(hc, hcol) > smallest(colour, ncol))) { colour.swap(hc); ncol = hcol; }
+        }
+    }
     // pieces in the order (colour, partition id): neighbours in space stay neighbours in the launch
     std::vector<int> pieces((size_t)np);
     std::iota(pieces.begin(), pieces.end(), 0);
@@ -292,7 +327,7 @@ WgsPlan build_wgs(const Csr& G, int piece_rows, int mode)
     for (char c : bad) if (c) return WgsPlan();
     int max_rim = 1;
     for (int q = 0; q < np; q++) max_rim = std::max(max_rim, (int)info[(size_t)q].rim.size());
-    const int RP = (max_rim + 63) / 64 * 64;
+    const int RP = wgs_rim_pitch(max_rim);
     R.rim_pitch = RP;
     R.hdr.assign((size_t)np * WGS_HDR, 0);
     std::vector<long> ent0((size_t)np + 1, 0);

@@ -32,9 +32,11 @@ constexpr int WGS_BATCH = 8;          // entry slots per batch; a piece's rows a
 constexpr int WGS_MAX_BATCHES = 8;    // rows of more than 64 off-diagonal entries: the level keeps the colour launches
 constexpr int WGS_HDR = 8;            // ints per piece: [0] first entry slot  [1] NB  [2] rim rows  [3] phases  [4] first rim slot  [5] rows  [6] reserved  [7] reserved
 
+inline int wgs_rim_pitch(int max_rim) { return max_rim <= 2 * WGS_ROWS ? 2 * WGS_ROWS : max_rim <= 4 * WGS_ROWS ? 4 * WGS_ROWS : 7 * WGS_ROWS; }
+
 struct WgsPlan {
     int n = 0, n_pieces = 0, n_colors = 0;
-    int rim_pitch = 0;                // rim slots per piece (the level's largest rim rounded up to a multiple of 64; unused slots repeat the piece's first row)
+    int rim_pitch = 0;                // rim slots per piece: wgs_rim_pitch(the level's largest rim) = 128, 256 or 448 (the kernel's variants); unused slots repeat the piece's first row
     std::vector<int> color_ptr;       // pieces of colour c: [color_ptr[c], color_ptr[c + 1])
     std::vector<int> piece_ptr;       // rows of piece q: positions [piece_ptr[q], piece_ptr[q + 1]) of `rows`
     std::vector<int> rows;            // position in the wgs order -> row (internal numbering)
@@ -63,7 +65,8 @@ struct WgsPlan {
 WgsPlan build_wgs(const Csr& G, int piece_rows = WGS_ROWS, int mode = 0);
 
 // pieces of <= piece_rows rows cut along the breadth-first level sets of G (smg_wgs.cpp)
-std::vector<int> partition_bands(const Csr& G, int piece_rows, int* n_pieces);
+// hint (optional): a colour 0 .. 3 per piece -- 2 x (parity of the level set) + (parity of the run inside it)
+std::vector<int> partition_bands(const Csr& G, int piece_rows, int* n_pieces, std::vector<int>* hint = nullptr);
 
 // The plan executed on the host the way k_wgs executes it (one column, in place on u) -- the checker of the plan's bookkeeping (tests, CPU lane).
 void wgs_sweep_host(const WgsPlan& P, const double* b, double* u);

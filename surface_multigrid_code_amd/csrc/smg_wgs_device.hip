@@ -20,17 +20,19 @@ namespace smg {
 // One lane's row: `nbl` batches of 8 entry slots (values + packed byte offsets into the one-column image).  Only the batches the row needs are
 // requested (per-lane guard: on a big level the padding of a piece's shorter rows would otherwise be a third of the matrix stream); the offsets of
 // the others stay 0 -- a valid address, their LDS reads are issued but never consumed.
-template <int NBMAX, int KB>
+// Everything in front of the phases is straight-line code: a branch between two requests makes the compiler wait for the first one (the rim's gathers
+// behind `if (slot < rim_pitch)` were one round trip EACH: 8.7 -> 5.x us per launch).  RIMI = rim slots per lane: the plan pads every piece's rim list to
+// 64 RIMI row numbers (unused ones repeat the piece's first row: harmless gathers of a line that is needed anyway).
+template <int NBMAX, int KB, int RIMI>
 __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const int* __restrict__ grow, const int* __restrict__ meta, const double* __restrict__ diag,
                                             const int* __restrict__ rim, const unsigned* __restrict__ eoff, const double* __restrict__ eval, int q_begin, int n_wg, int rim_pitch,
-                                            const double* __restrict__ b, double* u, int ld, const int* done)
+                                            const double* __restrict__ b, double* u, int ld, const int* done, int dbg_phases)
 {
-    extern __shared__ double xsd[];       // (64 + rim_pitch) x KB doubles: the piece's rows, then its rim
+    __shared__ double xsd[(WGS_ROWS + RIMI * WGS_ROWS) * KB];       // the piece's rows, then its rim
     const char* xs = reinterpret_cast<const char*>(xsd);
     constexpr int S = NBMAX * WGS_BATCH;
-    constexpr int RIMI = WGS_RIM_MAX / WGS_ROWS;      // rim slots per lane at most
     const int lane = threadIdx.x;
-    if (load_flag(done)) return;          // after convergence the stream's launches write nothing (uniform over the launch)
+    const int stop = load_flag(done);     // after convergence the stream's launches write nothing; waited for at the first store only
     const int q = q_begin + xcd_remap(blockIdx.x, n_wg);      // neighbouring pieces on one XCD: shared rims meet in one L2
     const int* H = hdr + (size_t)q * WGS_HDR;
     const size_t w = (size_t)q * WGS_ROWS + lane;
@@ -41,9 +43,9 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
     {
         const int* rq = rim + (size_t)q * rim_pitch + lane;
 #pragma unroll
-        for (int i = 0; i < RIMI; i++) rg[i] = i * WGS_ROWS < rim_pitch ? rq[i * WGS_ROWS] : 0;
+        for (int i = 0; i < RIMI; i++) rg[i] = rq[i * WGS_ROWS];
     }
-    const int e0 = H[0], nph = H[3];
+    const int e0 = H[0], nph = H[3] < dbg_phases ? H[3] : dbg_phases;
     const int ph = mt & 0xffff, nbl = mt >> 16;
     // ---- round trip 2: the row (guarded per lane), the iterate of the piece and its rim, the right-hand side
     unsigned wo[S / 2];
@@ -69,16 +71,14 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
     double own[KB], bv[KB], rv[RIMI][KB];
     gather_kb<KB, double>(u + (size_t)(gr >= 0 ? gr : 0) * ld, gr >= 0, own);
 #pragma unroll
-    for (int i = 0; i < RIMI; i++) gather_kb<KB, double>(u + (size_t)rg[i] * ld, i * WGS_ROWS < rim_pitch, rv[i]);
+    for (int i = 0; i < RIMI; i++) gather_kb<KB, double>(u + (size_t)rg[i] * ld, true, rv[i]);
     gather_kb<KB, double>(b + (size_t)(gr >= 0 ? gr : 0) * ld, gr >= 0, bv);
 #pragma unroll
     for (int c = 0; c < KB; c++) xsd[lane * KB + c] = own[c];
 #pragma unroll
     for (int i = 0; i < RIMI; i++)
-        if (i * WGS_ROWS < rim_pitch) {
 #pragma unroll
-            for (int c = 0; c < KB; c++) xsd[(WGS_ROWS + i * WGS_ROWS + lane) * KB + c] = rv[i][c];
-        }
+        for (int c = 0; c < KB; c++) xsd[(WGS_ROWS + i * WGS_ROWS + lane) * KB + c] = rv[i][c];
     __builtin_amdgcn_wave_barrier();      // one wave: LDS runs its instructions in order -- the image is complete for every later read
     // ---- the phases: rows that read none of each other, all earlier neighbours in earlier phases.  Batch bt + 2's operands are requested while batch
     // bt is added up (ascending column of the wgs order, separate multiply and add; padding: +0.0 times the row's own, finite, value).
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
             for (int c = 0; c < KB; c++) {
                 const double out = (bv[c] - acc[c]) / dg;
                 xsd[lane * KB + c] = out;
-                up[c] = out;
+                if (!stop) up[c] = out;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -126,20 +126,23 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
 hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st)
 {
     if (q_end <= q_begin) return hipSuccess;
-    if (k < 1 || k > 8 || P.rim_pitch > WGS_RIM_MAX || P.nb_max < 1 || P.nb_max > WGS_MAX_BATCHES) return hipErrorInvalidValue;
+    if (k < 1 || k > 8 || P.nb_max < 1 || P.nb_max > WGS_MAX_BATCHES) return hipErrorInvalidValue;
+    if (P.rim_pitch != 2 * WGS_ROWS && P.rim_pitch != 4 * WGS_ROWS && P.rim_pitch != 7 * WGS_ROWS) return hipErrorInvalidValue;     // wgs_rim_pitch()
     const int* done = ctrl ? &ctrl->done : never_done();
     const int n_wg = q_end - q_begin;
+    static const int dbg = getenv("SMG_DEBUG_WGS_PHASES") ? atoi(getenv("SMG_DEBUG_WGS_PHASES")) : 1 << 20;   // timing probe (wrong results)
     for (int c0 = 0; c0 < k;) {
         int kb = k - c0;
         if (kb > 4) kb = (kb + 1) / 2;         // 5 -> 3 + 2, 6 -> 3 + 3, 7 -> 4 + 3, 8 -> 4 + 4
-        const size_t lds = (size_t)(WGS_ROWS + P.rim_pitch) * kb * sizeof(double);
-#define SMG_WGS_LAUNCH(NB, KB) hipLaunchKernelGGL((k_wgs<NB, KB>), dim3((unsigned)n_wg), dim3(64), lds, st, P.hdr, P.grow, P.meta, P.diag, P.rim, P.eoff, P.eval, q_begin, n_wg, P.rim_pitch, b + c0, u + c0, k, done)
-#define SMG_WGS_NB(KB) do { if (P.nb_max <= 3) SMG_WGS_LAUNCH(3, KB); else if (P.nb_max <= 5) SMG_WGS_LAUNCH(5, KB); else SMG_WGS_LAUNCH(8, KB); } while (0)
+#define SMG_WGS_LAUNCH(NB, KB, RI) hipLaunchKernelGGL((k_wgs<NB, KB, RI>), dim3((unsigned)n_wg), dim3(64), 0, st, P.hdr, P.grow, P.meta, P.diag, P.rim, P.eoff, P.eval, q_begin, n_wg, P.rim_pitch, b + c0, u + c0, k, done, dbg)
+#define SMG_WGS_RI(NB, KB) do { if (P.rim_pitch == 2 * WGS_ROWS) SMG_WGS_LAUNCH(NB, KB, 2); else if (P.rim_pitch == 4 * WGS_ROWS) SMG_WGS_LAUNCH(NB, KB, 4); else SMG_WGS_LAUNCH(NB, KB, 7); } while (0)
+#define SMG_WGS_NB(KB) do { if (P.nb_max <= 3) SMG_WGS_RI(3, KB); else if (P.nb_max <= 5) SMG_WGS_RI(5, KB); else SMG_WGS_RI(8, KB); } while (0)
         if (kb == 1) SMG_WGS_NB(1);
         else if (kb == 2) SMG_WGS_NB(2);
         else if (kb == 3) SMG_WGS_NB(3);
         else SMG_WGS_NB(4);
 #undef SMG_WGS_NB
+#undef SMG_WGS_RI
 #undef SMG_WGS_LAUNCH
         c0 += kb;
     }

@@ -150,6 +150,57 @@ def test_c3_poisson_with_346_pins_full_size_against_oracle(c3, oracle_mod):
     assert np.linalg.norm(z[unk, 0][perm0] - z2[:, 0]) <= 1e-9 * np.linalg.norm(z2)
 
 
+def test_c3_parent_under_the_references_own_hierarchy_against_oracle(smg_mod, oracle_mod):
+    """The reference's own kind of hierarchy at size: mg_precompute(V, F, 0.25, 1000, midpoint) -- src/mg_precompute.cpp:15-87,
+    get_prolong.cpp:45-56, the call of 03_mg_solver/main.cpp:35-39 -- on the 252 834-vertex parent of the C3 mesh: 4 levels, 3 entries per row of P,
+    Galerkin operators of 18 - 27 entries per row.  Every kernel on every level bit for bit against the oracle in the order the device sweeps
+    (the Galerkin levels sweep piece-wise, csrc/smg_wgs.hpp), then the solve against the oracle on the system renumbered level by level into
+    those orders: the reference's lexicographic cycle on it IS the device's cycle, iteration for iteration."""
+    import scipy.sparse as sp
+    smg, mesh = smg_mod, smg_mod.mesh
+    import bench as B
+    from test_gpu_parity import gs_bit_exact, oracle_on_device_numbering
+    mg, A, Mb, Vf, Ff, label, _ = B.build_workload("C3pdec", smg, mesh)
+    n = A.shape[0]
+    assert n == 252834 and mg.n_levels == 4
+    mg.precompute(A)
+    L = mg.n_levels
+    rng = np.random.default_rng(7)
+    for lv in range(L - 1):
+        nn = np.diff(mg.matrix(lv, "A").indptr)
+        P = mg.matrix(lv + 1, "P")
+        assert P.nnz == 3 * mg.rows(lv)                                    # get_prolong.cpp:48-54: three stored entries per fine row
+        if lv >= 1:
+            assert nn.mean() > 15 and mg.wave_gs_order(lv, 1) is not None  # a Galerkin level of the reference's construction, swept piece-wise
+        m, mc = mg.rows(lv), mg.rows(lv + 1)
+        perm, permc = mg.perm(lv), mg.perm(lv + 1)
+        oi = oracle_on_device_numbering(oracle_mod, mg, lv)
+        x, b, xc = rng.uniform(-1, 1, (m, 1)), rng.uniform(-1, 1, (m, 1)), rng.uniform(-1, 1, (mc, 1))
+        assert np.array_equal(mg.A(lv, x)[perm], oi.A(0, x[perm])), "SpMV, level %d" % lv
+        assert np.array_equal(mg.restrict(lv, x)[permc], oi.restrict(0, x[perm])), "restriction, level %d" % lv
+        assert np.array_equal(mg.prolong(lv, xc)[perm], oi.prolong(0, xc[permc])), "prolongation, level %d" % lv
+        assert gs_bit_exact(oracle_mod, mg, lv, b, x, 2), "Gauss-Seidel, level %d" % lv
+    rhs = Mb @ np.random.default_rng(100).uniform(-1, 1, n)
+    z0 = np.zeros(n)
+    tol = 1e-9 * np.linalg.norm(rhs)
+    conv, z, rh = mg.solve(rhs, z0, None, smg.SolveOpts(tol=tol, max_iter=40))
+    assert conv
+    # the oracle on the system in the device's sweep orders (position -> caller, level by level; the coarsest level in its internal numbering)
+    to = [mg.perm(l)[mg.gs_order(l, 1)] for l in range(L - 1)] + [mg.perm(L - 1)]
+    Ps = [sp.csr_matrix(mg.matrix(l, "P"))[to[l - 1]][:, to[l]].tocsc() for l in range(1, L)]
+    orc = oracle_mod.OracleMG(Ps)
+    orc.precompute(sp.csr_matrix(A)[to[0]][:, to[0]].tocsr())
+    conv2, z2, rh2 = orc.solve(rhs[to[0]], z0[to[0]], tol=tol, max_iter=40)
+    assert conv2 and len(rh2) == len(rh)
+    np.testing.assert_allclose(rh, rh2, rtol=1e-6)
+    assert np.linalg.norm(z[to[0], 0] - z2[:, 0]) <= 1e-9 * np.linalg.norm(z2)
+    # ... and against the reference's lexicographic cycle in the CALLER's numbering: another sweep order, same solution, same cycle count (+-2)
+    orc_c = oracle_mod.OracleMG([mg.matrix(l, "P_full") for l in range(1, L)])
+    orc_c.precompute(A)
+    conv3, z3, rh3 = orc_c.solve(rhs, z0, tol=tol, max_iter=40)
+    assert conv3 and abs(len(rh3) - len(rh)) <= 2 and np.linalg.norm(z[:, 0] - z3[:, 0]) <= 1e-7 * np.linalg.norm(z3)
+
+
 def test_c5_solve_against_oracle_all_core(smg_mod, oracle_mod):
     """BASELINE config C5 (4 194 304 vertices, 6 levels): the fp64 solve against the oracle in the device numbering (all-core mode:
     seconds instead of minutes), iteration for iteration; the mixed-precision solve lands on the same solution."""
