@@ -276,7 +276,7 @@ def roofline_c5(smg, mesh, torch, dev, stream, reps=200):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     spmv_us, spmv_all = median_us(torch, stream, lambda: mg.raw_spmv(0, 0, x.data_ptr(), None, y.data_ptr()), reps // 2, 5)
-    gs_us, gs_all = median_us(torch, stream, lambda: mg.raw_relax(0, b.data_ptr(), u.data_ptr(), 1, 1), reps // 4, 5)
+    gs_us = float(np.median([mg.bench_relax(0, 1, 10, max(reps // 20, 8)) / 10.0 for _ in range(5)]))      # graph replay (smg_bench_relax): no host launch cost in the figure
     cyc_us = mg.bench_vcycle(0, 1, 2, 2, 30)
     spmv_bytes = mg.spmv_bytes(0, 1)
     gs_bytes = 12 * A.nnz + 4 * (n + 1) + 24 * n
@@ -577,6 +577,67 @@ def c3_decimated_leg(smg, mesh, torch, dev, stream, ms_subdiv, bytes_subdiv):
     return out
 
 
+def c1_leg(smg, mesh, torch, dev, stream):
+    """BASELINE config C1 (the reference's own CPU-runnable case): 03_mg_solver/main.cpp:29-75 -- A = -cotmatrix, the longest boundary loop pinned to 0,
+    B = M_voronoi 1, z0 = 0, hierarchy by mg_precompute defaults, tol 1e-3 / maxIter 20 -- on bunny.obj (BASELINE names it) and ogre.obj (what main.cpp:29
+    loads): cycles and wall time of the drop-in solve on the GPU and of the oracle (the reference's algorithm, 1 thread) on this host; steady-state ms per
+    outer iteration of both."""
+    out = {}
+    for name in ("bunny", "ogre"):
+        V, F = mesh.read_triangle_mesh(name + ".smgm")
+        V = mesh.normalize_unit_area(V, F)
+        n = V.shape[0]
+        t0 = time.time()
+        mg = smg.mg_precompute(V, F, 0.25, 500, 1)
+        t_h = time.time() - t0
+        A = (-mesh.cotmatrix(V, F)).tocsr()
+        A.sort_indices()
+        b = mesh.boundary_loop(F)
+        Bv = mesh.massmatrix(V, F, "voronoi") @ np.ones(n)
+        Bv[b] = 0.0
+        t0 = time.time()
+        mg.precompute(A, b)
+        t_p = time.time() - t0
+        mg.set_stream(stream.cuda_stream)
+        kv = np.zeros(len(b))
+        rec = {"verts": int(n), "pinned": int(len(b)), "levels": [mg.rows(l) for l in range(mg.n_levels)], "setup_s": {"mg_precompute": t_h, "smg_precompute": t_p}}
+        for tol, mx in ((1e-3, 20), (1e-10, 100)):
+            o = smg.SolveOpts(tol=tol, max_iter=mx)
+            mg.solve(Bv, np.zeros(n), kv, o)                      # warm (graph capture)
+            t0 = time.perf_counter()
+            cv, z, rh = mg.solve(Bv, np.zeros(n), kv, o)          # host vectors in, host vectors out: what the drop-in caller sees
+            rec["tol_%g" % tol] = {"converged": bool(cv), "cycles": len(rh) - 1, "solve_wall_ms_host_vectors": 1e3 * (time.perf_counter() - t0), "final_residual": float(rh[-1])}
+        nu = mg.rows(0)
+        rhs = torch.zeros(n, dtype=torch.float64, device=dev); rhs.copy_(torch.from_numpy(Bv))
+        z0 = torch.zeros(n, dtype=torch.float64, device=dev); zz = torch.empty_like(z0)
+        kvd = torch.zeros(len(b), dtype=torch.float64, device=dev)
+        mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, known_val_ptr=kvd.data_ptr(), ld_kv=len(b), opts=smg.SolveOpts(tol=0.0, max_iter=1024))
+        mg.outer_iterations(30)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); ea.record(stream); mg.outer_iterations(300); eb.record(stream); torch.cuda.synchronize()
+        mg.solve_end(zz.data_ptr(), n, max_iter=1024)
+        rec["ms_per_step"] = ea.elapsed_time(eb) / 300
+        rec["unknowns"] = int(nu)
+        try:
+            from oracle.oracle import OracleMG
+            orc = OracleMG([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
+            orc.precompute(A, b)
+            cpu = {}
+            for tol, mx in ((1e-3, 20), (1e-10, 100)):
+                t0 = time.perf_counter()
+                cv2, z2, rh2 = orc.solve(Bv, np.zeros(n), kv, tol=tol, max_iter=mx)
+                cpu["tol_%g" % tol] = {"converged": bool(cv2), "cycles": len(rh2) - 1, "solve_wall_ms": 1e3 * (time.perf_counter() - t0)}
+            cpu.update(oracle_cycle_ms(mg, A, Bv, budget_s=2.0, known=b, known_val=kv))
+            rec["cpu_baseline"] = cpu
+            rec["speedup_vs_cpu_baseline_per_cycle"] = cpu["ms_per_cycle"] / rec["ms_per_step"]
+        except Exception as e:     # noqa: BLE001
+            rec["cpu_baseline"] = {"error": repr(e)}
+        out[name + ".obj"] = rec
+        del mg
+    out["what"] = "03_mg_solver on the reference's own meshes: GPU = libsmg (Gauss-Seidel V(2,2), graph-replayed); cpu_baseline = oracle/smg_oracle.c, 1 thread, this host"
+    return out
+
+
 def block3_leg(smg, mesh, torch, with_scalar=True):
     """the block (3-DOF) kernels against the scalar kernels on the same 3n x 3n system -- C3 mesh, kron(S, C3) with a full
     SPD 3 x 3 coupling, hierarchy P (x) I_3 -- Gauss-Seidel V(2,2): ms per iteration, launches per sweep (colours), algorithmic bytes
@@ -656,6 +717,15 @@ def multi_mesh_leg(smg, mesh, torch, dev, counts=(1, 2, 4, 8), steps=300, repeat
         res[str(m)] = {"handles": m, "v_cycles_per_s_aggregate": m * steps / dt, "ms_per_cycle_per_handle": 1e3 * dt / steps, "wall_ms": [1e3 * t for t in times]}
     live1 = int(L.smg_device_bytes_live())
     base = res[str(counts[0])]["v_cycles_per_s_aggregate"]
+    # kernel nodes of one outer iteration of this hierarchy: per smoothed level 4 sweeps x (piece colours or colours, or 1 for a one-launch relax) + residual + transfers
+    graph_nodes = 4
+    for l in range(handles[0].n_levels - 1):
+        w = handles[0].wave_gs_order(l, 1)
+        graph_nodes += 4 * ((len(w["color_ptr"]) - 1) if w is not None else (len(handles[0].colors(l)) - 1)) + 4
+    try:
+        cpu = oracle_cycle_ms(handles[0], A, Mb @ np.random.default_rng(300).uniform(-1.0, 1.0, n), budget_s=3.0)
+    except Exception as e:     # noqa: BLE001
+        cpu = {"error": repr(e)}
     del handles, vecs
     # ---- the same M meshes as ONE block-diagonal system in ONE handle (disjoint union: P_l = diag(P_l^i), A = diag(A^i)): every launch
     # serves all M meshes, so the launch latency is shared instead of multiplied.  Hierarchy with nVCoarsest = 100 (the coarsest level of the
@@ -701,11 +771,10 @@ def multi_mesh_leg(smg, mesh, torch, dev, counts=(1, 2, 4, 8), steps=300, repeat
     out = {"workload": "ogre.obj (19 985 verts, %d levels from smg_mg_precompute), M_bary + 0.01(-L), one RHS column per mesh, Gauss-Seidel V(2,2)" % mg0.n_levels,
            "what": "M independent handles (own streams) driven by M host threads at once; wall clock until all streams drained; median of %d" % repeats,
            "by_handles": res, "speedup_at_%d" % max(counts): res[str(max(counts))]["v_cycles_per_s_aggregate"] / base,
-           "by_handles_note": "two handles overlap (1.9 x); beyond, the aggregate FALLS: an outer iteration is one hipGraphLaunch of ~80 kernel nodes and the runtime "
-                              "enqueues them at 2.3 - 3.3 us per node under a process-wide lock, so M threads submit no faster than one (M = 8: 2.5 ms per cycle and handle "
-                              "= 8 x 80 x 3.3 us of host enqueue + the cross-queue signals); GPU_MAX_HW_QUEUES = 8 / 16 make it worse (profiles/r04_multi_mesh.txt). "
-                              "Independent meshes on one GPU belong in ONE handle: union_in_one_handle",
-           "union_in_one_handle": union,
+           "by_handles_note": ("aggregate V-cycles/s with M handles relative to one: %s -- an outer iteration is one hipGraphLaunch of ~%d kernel nodes which the runtime enqueues under a "
+                               "process-wide lock, so M host threads submit no faster than one (profiles/r04_multi_mesh.txt); independent meshes on one GPU belong in ONE handle: union_in_one_handle"
+                               % (", ".join("M = %s: %.2f x" % (m, res[str(m)]["v_cycles_per_s_aggregate"] / base) for m in counts), graph_nodes)),
+           "union_in_one_handle": union, "cpu_baseline": cpu,
            "device_bytes_per_handle": (live1 - live0) // M,
            "hierarchy_algorithmic_bytes": int(sum(12 * mg0.matrix(l, "P_full").nnz for l in range(1, mg0.n_levels)) * 2 + 12 * A.nnz)}
     return out
@@ -822,7 +891,15 @@ def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, 
     if rank != 0:
         return None
     ms = 1e3 * dt / steps
-    return {"workload": "C4: ogre.obj (19985 verts), M_bary+0.01(-L), k = 64 RHS columns (U + 61 synthetic M g_j), mg_precompute hierarchy",
+    cpu = None
+    if world == 1:
+        try:    # the reference's algorithm on this host, 1 thread: the 64-column outer iteration (k independent lexicographic sweeps per relax())
+            cpu = oracle_cycle_ms(mg, A, np.asfortranarray(RHS), budget_s=4.0)
+            cpu["column_cycles_per_s"] = K64 * cpu["v_cycles_per_s"]
+        except Exception as e:     # noqa: BLE001
+            cpu = {"error": repr(e)}
+    return {"cpu_baseline": cpu, "speedup_vs_cpu_baseline": (cpu["ms_per_cycle"] / ms) if cpu and "ms_per_cycle" in cpu else None,
+            "workload": "C4: ogre.obj (19985 verts), M_bary+0.01(-L), k = 64 RHS columns (U + 61 synthetic M g_j), mg_precompute hierarchy",
             "levels": [mg.rows(l) for l in range(mg.n_levels)], "colors": [len(mg.colors(l)) - 1 for l in range(mg.n_levels - 1)],
             "k": K64, "columns_per_gpu": kl, "n_gpus": world, "scaling": "strong", "smoother": smoother_kw["smoother"],
             "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms, "column_cycles_per_s": K64 * 1e3 / ms,
@@ -847,6 +924,7 @@ def main():
     ap.add_argument("--no-block3", action="store_true", help="skip the block (3-DOF) leg (C3 mesh, kron(S, C3) system)")
     ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
     ap.add_argument("--no-c3dec", action="store_true", help="skip the leg with the reference's own (mg_precompute, SSP-decimated) hierarchy on the C3 mesh")
+    ap.add_argument("--no-c1", action="store_true", help="skip the C1 leg (03_mg_solver on bunny.obj / ogre.obj, GPU and oracle)")
     ap.add_argument("--no-c3k64", action="store_true", help="skip the C3 x 64 columns column-sharded (strong scaling) leg")
     ap.add_argument("--repeats", type=int, default=9, help="the --steps iterations are timed this many times; the line reports the median repeat")
     ap.add_argument("--spmv-reps", type=int, default=500)
@@ -1061,7 +1139,8 @@ def main():
         # ---- one full Gauss-Seidel sweep on level 0 (all colours), same byte model + b read
         bvec = torch.from_numpy(rhs_h).to(dev)
         u = torch.zeros_like(bvec)
-        gs_us, gs_all = median_us(torch, stream, lambda: mg.raw_relax(0, bvec.data_ptr(), u.data_ptr(), 1, 1), 40, 5, warm=5)
+        gs_all = [mg.bench_relax(0, 1, 10, 8) / 10.0 for _ in range(5)]      # graph replay (smg_bench_relax): no host launch cost in the figure
+        gs_us = float(np.median(gs_all))
         nnz0 = A.nnz
         gs_bytes = 12 * nnz0 + 4 * (n + 1) + 24 * n
         # ---- per-scope timing of the V-cycle (profc mirror; eager launches with hipEvents)
@@ -1118,7 +1197,8 @@ def main():
                          "frac_of_sustainable": spmv_gbs / HBM_SUSTAINABLE_GBS},
             "roofline_gs_sweep": {"kernel": "k_sell<SELL_GS,1> x colours (one fine-level sweep)", "bound": "hbm",
                                   "achieved": gs_bytes / (gs_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": gs_bytes / (gs_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "us_per_sweep": gs_us,
+                                  "frac": gs_bytes / (gs_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "us_per_sweep": gs_us, "us_per_sweep_repeats": gs_all,
+                                  "timing": "median of 5 graph-replayed loops of 8 x relax(10) = 80 sweeps (smg_bench_relax, HIP events on the launch stream)",
                                   "bytes_per_sweep": int(gs_bytes)},
             "roofline_vcycle": {"bound": "hbm", "cycle": args.smoother, "bytes_per_step": int(vcyc_bytes),
                                 "achieved": vcyc_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1180,6 +1260,12 @@ def main():
                                                    out["reference_cycle"]["bytes_per_step"] if out.get("reference_cycle") else None)
         except Exception as e:
             out["c3_decimated"] = {"error": repr(e)}
+    # ---- BASELINE config C1: the reference's 03_mg_solver on its own meshes, GPU and oracle side by side, rank 0 at N = 1 only
+    if rank == 0 and world == 1 and not args.no_c1:
+        try:
+            out["c1_03_mg_solver"] = c1_leg(smg, mesh, torch, dev, stream)
+        except Exception as e:
+            out["c1_03_mg_solver"] = {"error": repr(e)}
     # ---- block (3-DOF) kernels, rank 0 at N = 1 only
     if rank == 0 and world == 1 and not args.no_block3 and args.workload == "C3":
         try:

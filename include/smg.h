@@ -126,7 +126,10 @@ int smg_level_get_mesh(const smg_hierarchy *h, int lv, int *nV, int *nF, double 
  * cases (interior, one boundary end point, boundary edge with its snap candidates), the reference's validity and quality thresholds;
  * same P structure (3 stored entries per row, rows sum to 1).  Written from the formulation on own data structures; reproduces the
  * reference's checked-in 08_subdiv_remesh outputs point for point (tests/golden/bunny_remesh_500.npz).  Ties between exactly
- * equal-cost edges may be broken differently than libigl's edge numbering does (csrc/smg_decimate.cpp). */
+ * equal-cost edges may be broken differently than libigl's edge numbering does (csrc/smg_decimate.cpp).
+ * ONLY dec_type 1 (mid-point, the default of every reference caller: src/mg_precompute.cpp:94, 03_mg_solver/main.cpp:37) restates the reference and is
+ * pinned against its outputs.  dec_type 0 and 2 run the same collapse machinery with LIBSMG'S OWN cost and placement (quadric error / end-point placement as
+ * described above): they are NOT restatements of src/SSP_qslim.cpp / src/SSP_vertexRemoval.cpp and no parity with them is claimed. */
 int smg_mg_precompute(const double *V, int nV, const int *F, int nF, float ratio, int nVCoarsest, int dec_type,
                       smg_hierarchy **out);
 /* The same with an opt-in departure from the reference's plain greedy collapse order: a surviving vertex may stand for at most
@@ -213,7 +216,8 @@ int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks,
  * kernel bit for bit what the oracle computes on that numbering, smg_level_get_wave_gs_order.  A different, equally valid Gauss-Seidel order than the
  * multi-colour one: iterates differ, converged solutions agree to the tolerance, cycle counts are the same (measured).
  * mode: -1 (default) automatic = Gauss-Seidel levels of 512 - 600 000 rows with more than 5 colours or rows of more than 12 entries that have no
- * one-launch relax() (overlapped tiling), 1 - 7 columns, fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range.
+ * one-launch relax() (overlapped tiling), any number of columns (the order of a level's sweep never depends on k: a column-sharded solve iterates bit for bit
+ * like the fused one), fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range.
  * SMG_WGS=0 / 1 / 2 overrides (off / automatic / every level).  Takes effect at the next solve. */
 int smg_hierarchy_set_wave_gs(smg_hierarchy *h, int mode);
 /* The piece-sequential order of level lv as a solve with k columns would use it (after smg_precompute; builds the plan): *n_pieces, *n_colors,
@@ -249,9 +253,13 @@ int smg_hierarchy_coarse_solver(const smg_hierarchy *h, long *factor_entries);
  *               value-only smg_precompute 3.1 -> 1.4 ms (the switch itself costs one plan on the host, ~ms, once);
  *             - from 6 144 unknowns on it is cheaper to build AND to apply: taken at the first precompute (15 804 unknowns: 38 us per solve and 182 MB
  *               against 204 us and 2 GB);
- *             - above n_max (smg_hierarchy_set_coarse_dense_max) it stands in for the sparse factorisation (63 210 unknowns: 0.30 ms per solve against
- *               15.8 ms, 2.6 GB against 0.1 GB).
- * A matrix whose blocks touch more than 128 separator rows each, or whose separator exceeds 0.7 n or 24 576 rows (its inverse is dense), keeps the dense inverse resp. the sparse factorisation. */
+ *             - above the DEFAULT n_max (16 384) it stands in for the sparse factorisation (63 210 unknowns: 0.30 ms per solve against 15.8 ms, 2.6 GB
+ *               against 0.1 GB).  A caller who SET n_max (smg_hierarchy_set_coarse_dense_max, SMG_COARSE_DENSE_MAX) gets the sparse factorisation above it --
+ *               that call bounds memory, and the separator's inverse is dense -- unless when = 1 asks for the Schur solver explicitly.
+ * A matrix whose blocks touch more than 128 separator rows each, or whose separator exceeds 0.7 n or 24 576 rows (its inverse is dense), or whose arena
+ * would exceed SMG_SCHUR_ARENA_MAX_MB (default 6 144) or does not fit the device, keeps the dense inverse resp. the sparse factorisation (nothing half-built
+ * stays behind).  After every factorisation the diagonals of the inverted blocks and of S^-1 are checked: a coarsest matrix that is not positive definite
+ * fails smg_precompute with SMG_ERR_INVALID, as the sparse factorisation does. */
 int smg_hierarchy_set_coarse_schur(smg_hierarchy *h, int when, int n_min);
 /* On-disk hierarchy ({P_full_l}, optional V/F per level): build the expensive hierarchy once, ship it as a fixture.
  * Format (little endian): "SMGH" u32 version=1 i32 n_levels, then per level: i32 nV i32 nF f64 V[3nV] i32 F[3nF],

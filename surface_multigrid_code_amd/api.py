@@ -300,9 +300,9 @@ class Hierarchy:
         """rows of level lv's first colour the restriction launch of level lv - 1 can update itself (0: not available)"""
         return self.L.smg_level_first_colour_rows(self.h, lv)
 
-    # ---- block-sequential Gauss-Seidel for solves with a multiple of 64 columns
+    # ---- block-sequential Gauss-Seidel for solves with a multiple of 16 columns (k % 16 == 0, k >= 16)
     def set_block_gs(self, min_rows):
-        """levels of at least min_rows rows sweep block-sequentially when k % 64 == 0 (< 0: never)"""
+        """levels of at least min_rows rows sweep block-sequentially when k % 16 == 0, k >= 16 (< 0: never)"""
         _chk(self.L.smg_hierarchy_set_block_gs(self.h, int(min_rows)), "smg_hierarchy_set_block_gs")
 
     def block_gs_order(self, lv, k):

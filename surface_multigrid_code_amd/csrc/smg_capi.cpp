@@ -224,6 +224,7 @@ extern "C" smg_hierarchy* smg_hierarchy_create(int n_levels)
     h->n_levels = n_levels;
     h->lv.resize(n_levels);
     h->coarse_dense_max = env_int("SMG_COARSE_DENSE_MAX", 16384);
+    h->coarse_dense_max_user = std::getenv("SMG_COARSE_DENSE_MAX") != nullptr;
     h->bgs_min_rows = env_int("SMG_BGS_MIN_ROWS", -1);
     h->coarse_schur_when = std::min(2, std::max(0, env_int("SMG_COARSE_SCHUR", 2)));
     h->coarse_schur_min = env_int("SMG_COARSE_SCHUR_MIN", 2048);
@@ -315,7 +316,7 @@ extern "C" int smg_hierarchy_set_coarse_dense_max(smg_hierarchy* h, int n_max)
 {
     if (!h || n_max < 0) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_dense_max: bad arguments");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_coarse_dense_max called during a split-phase solve");
-    if (n_max != h->coarse_dense_max) { h->coarse_dense_max = n_max; h->precomputed = false; }   // the next smg_precompute is a full one
+    if (n_max != h->coarse_dense_max || !h->coarse_dense_max_user) { h->coarse_dense_max = n_max; h->coarse_dense_max_user = true; h->precomputed = false; }   // the next smg_precompute is a full one
     return SMG_OK;
 }
 extern "C" int smg_hierarchy_coarse_solver(const smg_hierarchy* h, long* factor_entries)

@@ -176,7 +176,7 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
 }
 
 // ---- wave Gauss-Seidel on the Galerkin levels of decimated hierarchies (smg_wgs.hpp): one launch per PIECE colour ------------------
-// Which levels: scalar fp64 hierarchies, Gauss-Seidel, 1 - 7 columns, SMG_WGS_MIN_ROWS <= rows <= SMG_WGS_MAX_ROWS, no one-launch relax()
+// Which levels: scalar fp64 hierarchies, Gauss-Seidel, any number of columns, SMG_WGS_MIN_ROWS <= rows <= SMG_WGS_MAX_ROWS, no one-launch relax()
 // (overlapped tiling) available; automatic mode: only levels the colour launches serve badly -- more than TILED_NCMAX colours or rows of more
 // than TILED_WMAX entries, i.e. the Galerkin levels of the reference's own hierarchies (mg_precompute).  smg_hierarchy_set_wave_gs / SMG_WGS=0|1|2.
 static bool wgs_wanted(const smg_hierarchy* h, int lv, int k)
@@ -184,7 +184,7 @@ static bool wgs_wanted(const smg_hierarchy* h, int lv, int k)
     static const int env = env_int("SMG_WGS", -1);
     static const int max_rows = env_int("SMG_WGS_MAX_ROWS", 600000), min_rows = env_int("SMG_WGS_MIN_ROWS", 512);
     const int mode = env >= 0 ? (env == 0 ? 0 : env == 1 ? -1 : 1) : h->wgs_mode;      // SMG_WGS: 0 off, 1 automatic, 2 every level in range
-    if (mode == 0 || h->bs != 1 || h->precision != 0 || k < 1 || k > 7 || lv < 0 || lv >= h->n_levels - 1) return false;
+    if (mode == 0 || h->bs != 1 || h->precision != 0 || k < 1 || lv < 0 || lv >= h->n_levels - 1) return false;      // (every k: the order of a level's sweep must not depend on how the columns are sharded)
     if (level_kind(h, lv) != LV_GS) return false;
     const Level& Lv = h->lv[lv];
     if (Lv.n < min_rows || Lv.n > max_rows) return false;

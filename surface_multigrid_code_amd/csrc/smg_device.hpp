@@ -210,6 +210,8 @@ struct SchurDev {
 };
 // arena <- the factorisation of the matrix whose values (CSR order of the plan's matrix) are vals
 hipError_t launch_schur_factor(const SchurDev& F, const double* vals, hipStream_t st);
+// *d_flag = 1 when the factorisation in the arena cannot be that of an SPD matrix (a non-positive or non-finite diagonal entry of an inverse), else 0
+hipError_t launch_schur_check(const SchurDev& F, int* d_flag, hipStream_t st);
 // u[:, c] += A^-1 b[:, c] for the k columns of the row-major n x k blocks (caller numbering of the coarsest level)
 hipError_t launch_schur_solve(const SchurDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 hipError_t launch_schur_solve_f32(const SchurDev& F, const float* b, float* u, int k, const Ctrl* ctrl, hipStream_t st);

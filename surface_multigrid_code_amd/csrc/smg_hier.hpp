@@ -150,7 +150,7 @@ struct Level {
     bool A_bit_symmetric = false;  // A == A^T bit for bit (checked on the host half when the device fill is a candidate)
     TiledBuf tiled[4];      // overlapped-tiling plans of relax(sweeps), sweeps = 1 .. 3 (index = sweeps; built on demand in ensure_work)
     WgsBuf wgs;             // wave Gauss-Seidel plan of a Galerkin level of a decimated hierarchy, 1 - 8 columns (built on demand in ensure_work)
-    BgsBuf bgs;             // block-sequential Gauss-Seidel plan for solves with a multiple of 64 columns (built on demand in ensure_work)
+    BgsBuf bgs;             // block-sequential Gauss-Seidel plan for solves with a multiple of 16 columns (BGS_COLS) (built on demand in ensure_work)
     // ---- value-only re-precompute (fixed sparsity, csrc/smg_capi.cpp: fast path of smg_precompute) ----
     std::vector<int> A_int_src;   // A_int entry -> index into A.val
     DevBuf<double> d_Aval;        // values of A in the caller's CSR order: the canonical device copy
@@ -227,8 +227,9 @@ struct smg_hierarchy {
     // ... or, for coarsest levels beyond the dense range (smg_coarse.hpp): sparse Cholesky, factored on the host, solved on the device
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
+    bool coarse_dense_max_user = false;   // ... was called: above it the caller gets the sparse factorisation, not the Schur stand-in (schur_wanted)
     int wgs_mode = -1;              // smg_hierarchy_set_wave_gs: -1 automatic (levels the colour launches serve badly: > 5 colours or rows of > 12 entries), 0 never, 1 every Gauss-Seidel level in range
-    int bgs_min_rows = -1;          // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 64 == 0 (< 0: never, the default)
+    int bgs_min_rows = -1;          // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 16 == 0, k >= 16 (< 0: never, the default)
     smg::SparseChol chol;
     smg::DevBuf<int> c_perm, c_rptr, c_rcol, c_cptr, c_crow, c_err;
     smg::DevBuf<double> c_rval, c_cval, c_diag, c_work;

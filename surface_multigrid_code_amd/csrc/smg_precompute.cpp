@@ -358,6 +358,26 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     bool cl_started = false, cl_fresh = false;
     uint64_t cl_key = 0;
     double cl_ms = 0.0;
+    // The coarsest smoothed level inherits a 4-colouring from the coarsest level when it is a mid-point subdivision of it (every row of P has one or two
+    // entries): the coarsest level's small graph gets the all-out search, its colours are handed down exactly like between the finer levels.  The search
+    // on the level itself may end with five colours, which every finer level then pays for (no inheritance: a from-scratch colouring of a million rows
+    // took 1.3 s and the cycle 5 launches per sweep instead of 4 on the C3 mesh stopped at 15 804 coarse unknowns).  Used by BOTH ways the level gets its
+    // numbering -- the side thread below and the task of the from-scratch path -- so that the numbering depends on the matrix alone, not on how many host
+    // threads there are.
+    auto looks_subdivided = [&](int lv) {
+        if (blk || lv != L - 2 || L < 2) return false;
+        const Level& Lw = h->lv[lv];
+        const Level& Lc = h->lv[lv + 1];
+        bool subdiv = Lc.P.nr == Lw.A.nr && Lc.P.nc <= 65536;
+        for (int i = 0; i < Lc.P.nr && subdiv; i++) if (Lc.P.ptr[i + 1] - Lc.P.ptr[i] > 2) subdiv = false;
+        return subdiv;
+    };
+    auto preset_from_coarsest = [&](int lv, std::vector<int>& inherited) {      // needs the coarsest level's matrix
+        const Level& Lw = h->lv[lv];
+        const Level& Lc = h->lv[lv + 1];
+        const Ordering oc = make_ordering(Lc.A, 512, nullptr, nullptr);
+        return oc.n_colors() <= 4 && (int)oc.color_of.size() == Lc.A.nr && subdivision_colors(Lc.P, oc.color_of, Lw.A, inherited);
+    };
     // Galerkin  A_l = (PT_l * A_{l-1}) * P_l  (:25, :227)
     for (int lv = 1; lv < L; lv++) {
         Level& Lv = h->lv[lv];
@@ -377,23 +397,11 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 cl_key = pattern_key(lv);
                 if (!(cl_key == Lw.ord_key && (int)Lw.ord.perm.size() == Lw.A.nr)) {
                     const std::vector<int> r = rcm_order(Lw.A);
-                    // When this level is a mid-point subdivision of the coarsest one (every row of P has one or two entries), a 4-colouring of the
-                    // coarsest level's small graph -- found by the all-out search -- is handed down exactly like between the finer levels; the search on
-                    // this level itself may end with five colours, which every finer level then pays for (no inheritance: a from-scratch colouring of a
-                    // million rows took 1.3 s and the cycle 5 launches per sweep instead of 4 on the C3 mesh stopped at 15 804 coarse unknowns).
                     std::vector<int> inherited;
                     const std::vector<int>* preset = nullptr;
-                    {
-                        const Level& Lc = h->lv[lv + 1];
-                        bool subdiv = Lc.P.nr == Lw.A.nr && Lc.P.nc <= 65536;
-                        for (int i = 0; i < Lc.P.nr && subdiv; i++) if (Lc.P.ptr[i + 1] - Lc.P.ptr[i] > 2) subdiv = false;
-                        if (subdiv) {
-                            while (coarsest_A.load(std::memory_order_acquire) == 0) std::this_thread::yield();
-                            if (coarsest_A.load(std::memory_order_acquire) == 1) {
-                                const Ordering oc = make_ordering(Lc.A, 512, nullptr, nullptr);
-                                if (oc.n_colors() <= 4 && (int)oc.color_of.size() == Lc.A.nr && subdivision_colors(Lc.P, oc.color_of, Lw.A, inherited)) preset = &inherited;
-                            }
-                        }
+                    if (looks_subdivided(lv)) {
+                        while (coarsest_A.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                        if (coarsest_A.load(std::memory_order_acquire) == 1 && preset_from_coarsest(lv, inherited)) preset = &inherited;
                     }
                     Lw.ord = make_ordering(Lw.A, 512, preset, &r);
                     Lw.ord_key = cl_key;
@@ -469,7 +477,9 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 Level& Lv = h->lv[L - 2];
                 const auto t0 = std::chrono::steady_clock::now();
                 rcm[L - 2] = rcm_order(graph(L - 2));
-                order_of(L - 2) = make_ordering(graph(L - 2), 512, nullptr, &rcm[L - 2]);
+                std::vector<int> inherited;
+                const bool have = looks_subdivided(L - 2) && preset_from_coarsest(L - 2, inherited);      // (all Galerkin products exist here)
+                order_of(L - 2) = make_ordering(graph(L - 2), 512, have ? &inherited : nullptr, &rcm[L - 2]);
                 (void)Lv;
                 if (tm.on) std::fprintf(stderr, "[smg timing] host:   (coarsest smoothed level: order + colouring from scratch %.1f ms)\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 Lv.ord_key = keys[L - 2];
@@ -510,8 +520,9 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 std::vector<int> inherited;
                 const Level& Lc = h->lv[lv + 1];
                 const Ordering& Oc = order_of(lv + 1);
-                const bool ok = (lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
-                                subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited);
+                const bool ok = ((lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
+                                 subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited)) ||
+                                (looks_subdivided(lv) && preset_from_coarsest(lv, inherited));      // (SMG_ORDER=induced: the coarsest smoothed level is numbered here)
                 if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
                 order_of(lv) = make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
                 if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
@@ -609,7 +620,21 @@ static bool schur_wanted(const smg_hierarchy* h, int n, int phase)
     if (h->coarse_schur_when == 0 || h->coarse_schur_min < 0 || n < h->coarse_schur_min || n > h->coarse_schur_max || h->schur_declined) return false;
     if (phase == 2) return h->coarse_schur_when == 2;
     // from the start: on request, where it is the cheaper solver to apply as well, and where a dense inverse of the whole matrix is not allowed
-    return h->coarse_schur_when == 1 || n >= h->coarse_schur_big || n > h->coarse_dense_max;
+    // (a caller who SET coarse_dense_max asked for the sparse factorisation above it -- to bound memory, say: the Schur solver stands in for the sparse one
+    //  beyond the dense range only while that range is the default)
+    if (n > h->coarse_dense_max) return h->coarse_schur_when == 1 || !h->coarse_dense_max_user;
+    return h->coarse_schur_when == 1 || n >= h->coarse_schur_big;
+}
+// after launch_schur_factor on h->stream: synchronises, and fails like the sparse path when the matrix cannot have been positive definite
+static int schur_check_spd(smg_hierarchy* h, int n)
+{
+    HIPCHK(h->c_err.ensure(4));
+    HIPCHK(launch_schur_check(h->sch.view, h->c_err.p + 3, h->stream));
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->c_err.p + 3, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (flag) return fail(SMG_ERR_INVALID, "coarsest matrix (%d unknowns) is not positive definite: the block elimination met a non-positive or non-finite pivot", n);
+    return SMG_OK;
 }
 // *planned: h->sch holds the plan of Ac (the arena still to be factored); not: no plan for this matrix (the dense inverse serves)
 static int coarse_plan_schur(smg_hierarchy* h, const Csr& Ac, bool* planned)
@@ -621,16 +646,24 @@ static int coarse_plan_schur(smg_hierarchy* h, const Csr& Ac, bool* planned)
     const SchurPlan& P = h->schur;
     if (P.empty()) return SMG_OK;
     smg_hierarchy::SchurBuf& B = h->sch;
-    HIPCHK(B.irow.upload(P.irow)); HIPCHK(B.bsize.upload(P.bsize)); HIPCHK(B.srow.upload(P.srow)); HIPCHK(B.sptr.upload(P.sptr)); HIPCHK(B.sidx.upload(P.sidx));
-    HIPCHK(B.aptr.upload(P.aptr)); HIPCHK(B.ablk.upload(P.ablk)); HIPCHK(B.acol.upload(P.apan)); HIPCHK(B.rptr.upload(P.rptr));
-    HIPCHK(B.coff.upload(P.coff)); HIPCHK(B.pos.upload(P.pos)); HIPCHK(B.pos2.upload(P.pos2)); HIPCHK(B.ones.upload(P.ones));
-    HIPCHK(B.rdst.upload(P.rdst)); HIPCHK(B.rdst2.upload(P.rdst2)); HIPCHK(B.rsrc.upload(P.rsrc));
-    if (B.arena.alloc((size_t)P.total) != hipSuccess || B.gj.alloc((size_t)2 * P.ns_pad * 64 + 2 * 64 * 64) != hipSuccess) {
-        (void)hipGetLastError();              // no room for the separator's dense inverse: the other solvers serve
+    // Any allocation or upload that fails -- the arena of the separator's dense inverse above all, on the value-only path with the dense inverse of the
+    // whole matrix still resident -- declines the plan (nothing half-built stays behind) and the other solvers serve: a device that is nearly full keeps
+    // working.  A byte budget bounds the arena besides the row cap (SMG_SCHUR_ARENA_MAX_MB, default 6144: 4.8 GB at the 24 576-row cap of the separator).
+    static const long long arena_max = (long long)env_int("SMG_SCHUR_ARENA_MAX_MB", 6144) * (1ll << 20);
+    hipError_t e = (long long)P.total * (long long)sizeof(double) > arena_max ? hipErrorOutOfMemory : hipSuccess;
+    auto up = [&](auto& buf, const auto& v) { if (e == hipSuccess) e = buf.upload(v); };
+    up(B.irow, P.irow); up(B.bsize, P.bsize); up(B.srow, P.srow); up(B.sptr, P.sptr); up(B.sidx, P.sidx);
+    up(B.aptr, P.aptr); up(B.ablk, P.ablk); up(B.acol, P.apan); up(B.rptr, P.rptr);
+    up(B.coff, P.coff); up(B.pos, P.pos); up(B.pos2, P.pos2); up(B.ones, P.ones);
+    up(B.rdst, P.rdst); up(B.rdst2, P.rdst2); up(B.rsrc, P.rsrc);
+    if (e == hipSuccess) e = B.arena.alloc((size_t)P.total);
+    if (e == hipSuccess) e = B.gj.alloc((size_t)2 * P.ns_pad * 64 + 2 * 64 * 64);
+    if (e == hipSuccess) { if (env_int("SMG_SYM_COARSE", 1)) e = B.sym.alloc((size_t)(P.ns_pad / 64) * (P.ns_pad / 64) * 64); else B.sym.release(); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         B.release(); h->schur = SchurPlan();
         return SMG_OK;
     }
-    if (env_int("SMG_SYM_COARSE", 1)) HIPCHK(B.sym.alloc((size_t)(P.ns_pad / 64) * (P.ns_pad / 64) * 64)); else B.sym.release();
     B.arena32.release(); B.g.release(); B.xs.release(); B.g32.release(); B.xs32.release();
     SchurDev& V = B.view;
     V = SchurDev();
@@ -713,7 +746,7 @@ static int coarse_images(smg_hierarchy* h)
             DevBuf<double> d_val;
             HIPCHK(d_val.upload(Lc.A.val));
             HIPCHK(launch_schur_factor(h->sch.view, d_val.p, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            { int rc2 = schur_check_spd(h, nc); if (rc2) return rc2; }
             h->nc = nc; h->nc_pad = np;
             h->coarse_schur = true;
             if (h->coarse_sparse) {   // the handle held a sparse factorisation (another matrix, another policy)
@@ -1163,7 +1196,7 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
         if (rc) return rc;
     } else if (h->coarse_schur) {
         HIPCHK(launch_schur_factor(h->sch.view, h->lv[L - 1].d_Aval.p, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { int rc2 = schur_check_spd(h, h->nc); if (rc2) return rc2; }
     } else {
         const Level& Lc = h->lv[L - 1];
         HIPCHK(launch_dense_from_csr(h->d_Ainv.p, h->nc_pad, h->nc, Lc.d_Aval.p, h->d_dense_pos.p, (int)Lc.A.nnz(), st));

@@ -458,6 +458,29 @@ hipError_t launch_schur_factor(const SchurDev& F, const double* vals, hipStream_
     return launch_spd_inverse(F.arena + F.off_S, F.ns_pad, F.gj_work, st);
 }
 
+// The inverse of a symmetric positive definite matrix has a positive diagonal: after launch_schur_factor every diagonal entry of the inverted interior blocks
+// and of S^-1 must be finite and > 0.  The elimination runs without pivoting and without a failure signal of its own (like the dense path); a coarsest
+// matrix that is not SPD shows here -- *flag is raised -- instead of as Inf / NaN corrections in some later solve.
+__global__ __launch_bounds__(256) void k_schur_check(const double* __restrict__ arena, long long off_D, int nb, long long off_S, int ns_pad, int* flag)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nd = (long long)nb * 64;
+    double x;
+    if (t < nd) x = arena[off_D + (t / 64) * 4096 + (t % 64) * 65];
+    else if (t < nd + ns_pad) { const long long j = t - nd; x = arena[off_S + j * ns_pad + j]; }
+    else return;
+    if (!(x > 0.0) || !(x < 1.0e300)) *flag = 1;
+}
+hipError_t launch_schur_check(const SchurDev& F, int* d_flag, hipStream_t st)
+{
+    if (F.nb <= 0 || !d_flag) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const long long tot = (long long)F.nb * 64 + F.ns_pad;
+    hipLaunchKernelGGL(k_schur_check, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, F.arena, F.off_D, F.nb, F.off_S, F.ns_pad, d_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_schur_solve(const SchurDev& F, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st) { return schur_solve<double>(F, b, u, k, ctrl, st); }
 hipError_t launch_schur_solve_f32(const SchurDev& F, const float* b, float* u, int k, const Ctrl* ctrl, hipStream_t st) { return schur_solve<float>(F, b, u, k, ctrl, st); }
 

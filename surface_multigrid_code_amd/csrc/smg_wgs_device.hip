@@ -26,7 +26,7 @@ namespace smg {
 template <int NBMAX, int KB, int RIMI>
 __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const int* __restrict__ grow, const int* __restrict__ meta, const double* __restrict__ diag,
                                             const int* __restrict__ rim, const unsigned* __restrict__ eoff, const double* __restrict__ eval, int q_begin, int n_wg, int rim_pitch,
-                                            const double* __restrict__ b, double* u, int ld, const int* done, int dbg_phases)
+                                            const double* __restrict__ b_in, double* u_in, int ld, const int* done, int dbg_phases)
 {
     __shared__ double xsd[(WGS_ROWS + RIMI * WGS_ROWS) * KB];       // the piece's rows, then its rim
     const char* xs = reinterpret_cast<const char*>(xsd);
@@ -34,6 +34,8 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
     const int lane = threadIdx.x;
     const int stop = load_flag(done);     // after convergence the stream's launches write nothing; waited for at the first store only
     const int q = q_begin + xcd_remap(blockIdx.x, n_wg);      // neighbouring pieces on one XCD: shared rims meet in one L2
+    const double* __restrict__ b = b_in + (size_t)blockIdx.y * KB;          // many columns: groups of KB ride in the grid's second dimension (the piece's row re-read from L2 per group, the vectors once)
+    double* u = u_in + (size_t)blockIdx.y * KB;
     const int* H = hdr + (size_t)q * WGS_HDR;
     const size_t w = (size_t)q * WGS_ROWS + lane;
     // ---- round trip 1: the lane's row number, phase and length; the rim's row numbers; the piece header (scalar)
@@ -122,19 +124,27 @@ __global__ __launch_bounds__(64) void k_wgs(const int* __restrict__ hdr, const i
     }
 }
 
-// the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k, 1 <= k <= 8: column groups of <= 4)
+// the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k).  Up to 7 columns: one or two launches (groups of <= 4
+// columns per lane); 8 and more: groups of 4 in the grid's second dimension, one launch (+ one for k % 4 columns).  The order of the sweep does not depend
+// on k: a column-sharded solve (smg_solve_sharded) iterates bit for bit like the fused one.
 hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st)
 {
     if (q_end <= q_begin) return hipSuccess;
-    if (k < 1 || k > 8 || P.nb_max < 1 || P.nb_max > WGS_MAX_BATCHES) return hipErrorInvalidValue;
+    if (k < 1 || k > 4 * 65535 || P.nb_max < 1 || P.nb_max > WGS_MAX_BATCHES) return hipErrorInvalidValue;
     if (P.rim_pitch != 2 * WGS_ROWS && P.rim_pitch != 4 * WGS_ROWS && P.rim_pitch != 7 * WGS_ROWS) return hipErrorInvalidValue;     // wgs_rim_pitch()
     const int* done = ctrl ? &ctrl->done : never_done();
     const int n_wg = q_end - q_begin;
     static const int dbg = getenv("SMG_DEBUG_WGS_PHASES") ? atoi(getenv("SMG_DEBUG_WGS_PHASES")) : 1 << 20;   // timing probe (wrong results)
+    // Columns per lane: on a latency-bound level (few pieces per launch) a phase costs its instruction count, and four columns per lane are four times the
+    // multiply-adds of one -- groups of 2 side by side in the grid's second dimension (ogre.obj, 5 038 rows: k = 4 in 367 us per cycle as one group of 4,
+    // as two groups of 2 like k = 2); a big level re-reads its rows per group, so it takes groups of 4.
+    static const int small_pieces = getenv("SMG_WGS_KB2_MAX_PIECES") ? atoi(getenv("SMG_WGS_KB2_MAX_PIECES")) : 1600;
+    static const int kb_small = getenv("SMG_WGS_KB_SMALL") ? atoi(getenv("SMG_WGS_KB_SMALL")) : 1, kb_big = getenv("SMG_WGS_KB_BIG") ? atoi(getenv("SMG_WGS_KB_BIG")) : 4;
+    const int kbp = P.n_pieces <= small_pieces ? kb_small : kb_big;
     for (int c0 = 0; c0 < k;) {
-        int kb = k - c0;
-        if (kb > 4) kb = (kb + 1) / 2;         // 5 -> 3 + 2, 6 -> 3 + 3, 7 -> 4 + 3, 8 -> 4 + 4
-#define SMG_WGS_LAUNCH(NB, KB, RI) hipLaunchKernelGGL((k_wgs<NB, KB, RI>), dim3((unsigned)n_wg), dim3(64), 0, st, P.hdr, P.grow, P.meta, P.diag, P.rim, P.eoff, P.eval, q_begin, n_wg, P.rim_pitch, b + c0, u + c0, k, done, dbg)
+        int kb = k - c0, groups = 1;
+        if (kb >= kbp) { groups = kb / kbp; kb = kbp; }
+#define SMG_WGS_LAUNCH(NB, KB, RI) hipLaunchKernelGGL((k_wgs<NB, KB, RI>), dim3((unsigned)n_wg, (unsigned)groups), dim3(64), 0, st, P.hdr, P.grow, P.meta, P.diag, P.rim, P.eoff, P.eval, q_begin, n_wg, P.rim_pitch, b + c0, u + c0, k, done, dbg)
 #define SMG_WGS_RI(NB, KB) do { if (P.rim_pitch == 2 * WGS_ROWS) SMG_WGS_LAUNCH(NB, KB, 2); else if (P.rim_pitch == 4 * WGS_ROWS) SMG_WGS_LAUNCH(NB, KB, 4); else SMG_WGS_LAUNCH(NB, KB, 7); } while (0)
 #define SMG_WGS_NB(KB) do { if (P.nb_max <= 3) SMG_WGS_RI(3, KB); else if (P.nb_max <= 5) SMG_WGS_RI(5, KB); else SMG_WGS_RI(8, KB); } while (0)
         if (kb == 1) SMG_WGS_NB(1);
@@ -144,7 +154,7 @@ hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, 
 #undef SMG_WGS_NB
 #undef SMG_WGS_RI
 #undef SMG_WGS_LAUNCH
-        c0 += kb;
+        c0 += kb * groups;
     }
     return hipGetLastError();
 }
