@@ -1213,6 +1213,9 @@ def main():
             # memory budget: everything libsmg holds in HBM for this workload (operators in SELL incl. the fixed panel pitch, A^T images of the
             # Galerkin levels, dense coarse inverse, work vectors, graphs' buffers) against the algorithmic size of the hierarchy
             "device_bytes": {"libsmg_live": int(smg._lib.load().smg_device_bytes_live()), "hierarchy_algorithmic": int(sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels))),
+                             "by_purpose": {k_: v for k_, v in sorted(mg.device_bytes().items(), key=lambda kv: -kv[1]) if v >= (1 << 20)},
+                             "note": "by_purpose: what the C3 handle holds, entries >= 1 MiB (smg_debug_device_bytes): level0.A_sell carries the fixed panel pitch (12 columns of room for 7 used: "
+                                     "addressing without a table, DESIGN.md section 2), the coarse inverse is kept whole for the k > 1 kernels, Galerkin levels keep an A^T image (the reference's sweep walks columns)",
                              "hbm_capacity": 288 * 10 ** 9},
         }
         if not args.no_cpu and world == 1:

@@ -90,6 +90,8 @@ const char *smg_last_error(void);
 int smg_device_count(void);
 /* device memory currently held by all libsmg handles / assemblers of this process, in bytes (memory budget reporting) */
 long long smg_device_bytes_live(void);
+/* what ONE handle holds in HBM, by purpose: lines "name bytes" (and "total bytes") written into buf (memory budget reporting) */
+int smg_debug_device_bytes(const smg_hierarchy *h, char *buf, int cap);
 
 /* ---- std::vector<mg_data> (src/mg_data.h:11-27) ---------------------------------------------------------------- */
 /* mg.reserve(nLvs) */

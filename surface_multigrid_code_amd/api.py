@@ -386,6 +386,12 @@ class Hierarchy:
         _chk(self.L.smg_level_get_block_image(self.h, lv, None, None, _ip(sr), _ip(so), _ip(sw), _ip(col), _dp(val)), "smg_level_get_block_image")
         return {"slice_row": sr, "slice_off": so, "slice_w": sw, "col": col.reshape(-1, 64), "val": val.reshape(-1, 9, 64)}
 
+    def device_bytes(self):
+        """what this handle holds in HBM, by purpose: dict name -> bytes (incl. "total")"""
+        buf = C.create_string_buffer(1 << 16)
+        _chk(self.L.smg_debug_device_bytes(self.h, buf, len(buf)), "smg_debug_device_bytes")
+        return {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if ln.strip()}
+
     def spmv_bytes(self, lv=0, k=1):
         return self.L.smg_level_spmv_bytes(self.h, lv, k)
 

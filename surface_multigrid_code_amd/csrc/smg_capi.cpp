@@ -40,6 +40,44 @@ int smg::fail(int code, const char* fmt, ...)
 extern "C" const char* smg_last_error(void) { return g_err.c_str(); }
 extern "C" int smg_version(void) { return SMG_VERSION; }
 extern "C" long long smg_device_bytes_live(void) { return (long long)smg::devbuf_live_bytes().load(); }
+// What one handle holds in HBM, by purpose (memory budget reporting; bench.py's device_bytes, tools/mem_probe.py): text into buf, one "name bytes" line each.
+extern "C" int smg_debug_device_bytes(const smg_hierarchy* h, char* buf, int cap)
+{
+    if (!h || !buf || cap < 1) return SMG_ERR_INVALID;
+    std::string out;
+    auto B = [](const auto& d) { return (long long)(d.n * sizeof(*d.p)); };
+    auto sell = [&](const smg::SellBuf& S) { return B(S.slice_row) + B(S.slice_off) + B(S.slice_w) + B(S.col) + B(S.order) + B(S.val) + B(S.diag_slot) + B(S.long_row) + B(S.long_ptr) + B(S.long_col) + B(S.long_val) + B(S.long_valf); };
+    long long tot = 0;
+    auto line = [&](const std::string& nm, long long v) { if (v) { out += nm + " " + std::to_string(v) + "\n"; tot += v; } };
+    for (int lv = 0; lv < h->n_levels; lv++) {
+        const smg::Level& L = h->lv[lv];
+        const std::string p = "level" + std::to_string(lv) + ".";
+        line(p + "A_sell", sell(L.dA)); line(p + "AT_sell", sell(L.dAT)); line(p + "P_sell", sell(L.dP)); line(p + "PT_sell", sell(L.dPT));
+        line(p + "A_block3", B(L.bA.slice_row) + B(L.bA.slice_off) + B(L.bA.slice_w) + B(L.bA.col) + B(L.bA.order) + B(L.bA.val) + B(L.bA.valf) + B(L.bAT.slice_row) + B(L.bAT.slice_off) + B(L.bAT.slice_w) + B(L.bAT.col) + B(L.bAT.order) + B(L.bAT.val) + B(L.bAT.valf) + B(L.mapB) + B(L.mapBT));
+        line(p + "values_caller_order", B(L.d_Aval) + B(L.d_Tval));
+        line(p + "refresh_maps", B(L.mapA) + B(L.mapAT));
+        line(p + "galerkin_recipes", B(L.r1_ptr) + B(L.r1_idx) + B(L.r2_ptr) + B(L.r2_idx) + B(L.r1_coef) + B(L.r2_coef));
+        long long t = 0;
+        for (const auto& T : L.tiled) t += B(T.hdr) + B(T.ext_rows) + B(T.pcol) + B(T.prow) + B(T.map) + B(T.pval);
+        line(p + "tiled_plans", t);
+        line(p + "bgs_plan", B(L.bgs.hdr) + B(L.bgs.xrow) + B(L.bgs.ugrow) + B(L.bgs.ulrow) + B(L.bgs.eidx) + B(L.bgs.map) + B(L.bgs.mapd) + B(L.bgs.eval) + B(L.bgs.udiag));
+        line(p + "wgs_plan", B(L.wgs.hdr) + B(L.wgs.grow) + B(L.wgs.meta) + B(L.wgs.rim) + B(L.wgs.map) + B(L.wgs.mapd) + B(L.wgs.eoff) + B(L.wgs.eval) + B(L.wgs.diag));
+        line(p + "fp32_images", B(L.a32) + B(L.at32) + B(L.p32) + B(L.pt32) + B(L.b32) + B(L.u32) + B(L.r32) + B(L.t32) + B(L.d32));
+        line(p + "vectors", B(L.b) + B(L.u) + B(L.r) + B(L.t) + B(L.d));
+    }
+    line("coarse.dense_inverse", B(h->d_Ainv) + B(h->d_Ainv32));
+    line("coarse.sym_partials", B(h->d_sympart));
+    line("coarse.sparse_factor", B(h->c_perm) + B(h->c_rptr) + B(h->c_rcol) + B(h->c_cptr) + B(h->c_crow) + B(h->c_err) + B(h->c_rval) + B(h->c_cval) + B(h->c_diag) + B(h->c_work));
+    line("coarse.schur", B(h->sch.irow) + B(h->sch.bsize) + B(h->sch.srow) + B(h->sch.sptr) + B(h->sch.sidx) + B(h->sch.aptr) + B(h->sch.ablk) + B(h->sch.acol) + B(h->sch.rptr) + B(h->sch.coff) + B(h->sch.pos) +
+                         B(h->sch.pos2) + B(h->sch.ones) + B(h->sch.rdst) + B(h->sch.rdst2) + B(h->sch.rsrc) + B(h->sch.arena) + B(h->sch.g) + B(h->sch.xs) + B(h->sch.sym) + B(h->sch.gj) + B(h->sch.arena32) + B(h->sch.g32) + B(h->sch.xs32));
+    line("maps_level0", B(h->d_map0) + B(h->d_perm0) + B(h->d_unknown) + B(h->d_known) + B(h->d_auk_ptr) + B(h->d_auk_col) + B(h->d_auk_val));
+    line("reprecompute_bookkeeping", B(h->d_lhs_src) + B(h->d_auk_src) + B(h->d_diag_idx) + B(h->d_dense_pos) + B(h->d_Afull));
+    line("early_upload", B(h->early0.ptr) + B(h->early0.col) + B(h->early0.val));
+    line("solve_state", B(h->d_ctrl) + B(h->d_rhis) + B(h->d_partials) + B(h->d_lam) + B(h->d_stage_rhs) + B(h->d_stage_z) + B(h->d_stage_kv) + B(h->d_tmp_cm) + B(h->d_zsave));
+    out += "total " + std::to_string(tot) + "\n";
+    std::snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return SMG_OK;
+}
 extern "C" int smg_device_count(void)
 {
     int n = 0;

@@ -29,6 +29,13 @@ using namespace smg;
 // Which levels: scalar fp64 hierarchies, up to 7 columns (groups of 3 per launch; 8 and more take the wide colour kernels), Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
 // 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 12 entries per row.
 // SMG_TILED=0 switches it off (A/B knob; the results are bit-identical either way).
+// The plans of the one-launch / piece-wise / block-wise sweeps hold copies of the level's values; the maps that refresh them (value slot -> index into
+// Level::d_Aval) are only needed by a value-only re-precompute: they stay on the host until the first one (a quarter of a plan's bytes).
+static hipError_t ensure_map(DevBuf<int>& d, const std::vector<int>& host)
+{
+    if (d.n == host.size() && (d.p || host.empty())) return hipSuccess;
+    return d.upload(host);
+}
 static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
 {
     static const int on = env_int("SMG_TILED", 1);
@@ -78,7 +85,7 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
         map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
     }
     HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.ext_rows.upload(P.ext_rows)); HIPCHK(B.pcol.upload(P.pcol)); HIPCHK(B.pval.upload(P.pval));
-    HIPCHK(B.prow.upload(P.prow)); HIPCHK(B.map.upload(map));
+    HIPCHK(B.prow.upload(P.prow)); B.host_map = std::move(map);      // (uploaded when a value-only re-precompute first needs it: ensure_map)
     HIPCHK(tiled_gs_prepare(P.max_ext));
     int wmax = 0;
     for (int t = 0; t < P.n_tiles; t++) wmax = std::max(wmax, P.hdr[(size_t)t * TILED_HDR + 2]);
@@ -87,7 +94,7 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
     B.view.hdr = B.hdr.p; B.view.ext_rows = B.ext_rows.p; B.view.pcol = B.pcol.p; B.view.pval = B.pval.p; B.view.prow = B.prow.p;
     B.updates = P.updates;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
-    if (h->host_stale && Lv.d_Aval.p) HIPCHK(launch_gather_vals(B.pval.p, Lv.d_Aval.p, B.map.p, B.pval.n, h->stream));
+    if (h->host_stale && Lv.d_Aval.p) { HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(launch_gather_vals(B.pval.p, Lv.d_Aval.p, B.map.p, B.pval.n, h->stream)); }
     if (env_int("SMG_DEBUG_TILED", 0))
         std::fprintf(stderr, "tiled relax(%d) level %d: %d rows, %d tiles x %d threads, %d phases, extended tile <= %d rows, %.2fx row updates, entries per row <= %d\n", sweeps, lv, Lv.n,
                      P.n_tiles, threads, P.P, P.max_ext, (double)P.updates / ((double)sweeps * Lv.n), wmax);
@@ -98,15 +105,17 @@ int smg::refresh_tiled_values(smg_hierarchy* h)
     for (int lv = 0; lv < h->n_levels - 1; lv++) {
         for (int s = 1; s <= 3; s++) {
             TiledBuf& B = h->lv[lv].tiled[s];
-            if (B.view.n_tiles > 0) HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
+            if (B.view.n_tiles > 0) { HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream)); }
         }
         WgsBuf& W = h->lv[lv].wgs;
         if (W.view.n_pieces > 0) {
+            HIPCHK(ensure_map(W.map, W.host_map)); HIPCHK(ensure_map(W.mapd, W.host_mapd));
             HIPCHK(launch_gather_vals(W.eval.p, h->lv[lv].d_Aval.p, W.map.p, W.eval.n, h->stream));
             HIPCHK(launch_gather_vals(W.diag.p, h->lv[lv].d_Aval.p, W.mapd.p, W.diag.n, h->stream));
         }
         BgsBuf& Q = h->lv[lv].bgs;
         if (Q.view.n_blocks > 0) {
+            HIPCHK(ensure_map(Q.map, Q.host_map)); HIPCHK(ensure_map(Q.mapd, Q.host_mapd));
             HIPCHK(launch_gather_vals(Q.eval.p, h->lv[lv].d_Aval.p, Q.map.p, Q.eval.n, h->stream));
             HIPCHK(launch_gather_vals(Q.udiag.p, h->lv[lv].d_Aval.p, Q.mapd.p, Q.udiag.n, h->stream));
         }
@@ -160,12 +169,13 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
     };
     const std::vector<int> map = to_level_value(P.eentry), mapd = to_level_value(P.dentry);
     HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.xrow.upload(P.xrow)); HIPCHK(B.ugrow.upload(P.ugrow)); HIPCHK(B.ulrow.upload(P.ulrow)); HIPCHK(B.udiag.upload(P.udiag));
-    HIPCHK(B.eidx.upload(P.eidx)); HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map)); HIPCHK(B.mapd.upload(mapd));
+    HIPCHK(B.eidx.upload(P.eidx)); HIPCHK(B.eval.upload(P.eval)); B.host_map = map; B.host_mapd = mapd;
     B.view.n_blocks = P.n_blocks; B.view.n_colors = P.n_colors; B.view.xrows = P.xrows;
     B.view.hdr = B.hdr.p; B.view.xrow = B.xrow.p; B.view.ugrow = B.ugrow.p; B.view.ulrow = B.ulrow.p; B.view.udiag = B.udiag.p; B.view.eidx = B.eidx.p; B.view.eval = B.eval.p;
     B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_blk_ptr = P.blk_ptr; B.rim = P.rim; B.fill = P.fill;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
     if (h->host_stale && Lv.d_Aval.p) {
+        HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(ensure_map(B.mapd, B.host_mapd));
         HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
         HIPCHK(launch_gather_vals(B.udiag.p, Lv.d_Aval.p, B.mapd.p, B.udiag.n, h->stream));
     }
@@ -224,12 +234,13 @@ static int ensure_wgs(smg_hierarchy* h, int lv)
     };
     const std::vector<int> map = to_level_value(P.eentry), mapd = to_level_value(P.dentry);
     HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.grow.upload(P.grow)); HIPCHK(B.meta.upload(P.meta)); HIPCHK(B.diag.upload(P.diag)); HIPCHK(B.rim.upload(P.rim));
-    HIPCHK(B.eoff.upload(P.eoff)); HIPCHK(B.eval.upload(P.eval)); HIPCHK(B.map.upload(map)); HIPCHK(B.mapd.upload(mapd));
+    HIPCHK(B.eoff.upload(P.eoff)); HIPCHK(B.eval.upload(P.eval)); B.host_map = map; B.host_mapd = mapd;
     B.view.n_pieces = P.n_pieces; B.view.n_colors = P.n_colors; B.view.rim_pitch = P.rim_pitch; B.view.nb_max = P.nb_max;
     B.view.hdr = B.hdr.p; B.view.grow = B.grow.p; B.view.meta = B.meta.p; B.view.diag = B.diag.p; B.view.rim = B.rim.p; B.view.eoff = B.eoff.p; B.view.eval = B.eval.p;
     B.color_ptr = P.color_ptr; B.host_rows = P.rows; B.host_piece_ptr = P.piece_ptr; B.rim_ratio = P.rim_ratio; B.phases_mean = P.phases_mean; B.phases_max = P.phases_max;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy (padding slots keep their +0.0, lanes without a row their 1.0)
     if (h->host_stale && Lv.d_Aval.p) {
+        HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(ensure_map(B.mapd, B.host_mapd));
         HIPCHK(launch_gather_vals(B.eval.p, Lv.d_Aval.p, B.map.p, B.eval.n, h->stream));
         HIPCHK(launch_gather_vals(B.diag.p, Lv.d_Aval.p, B.mapd.p, B.diag.n, h->stream));
     }

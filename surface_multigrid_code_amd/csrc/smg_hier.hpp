@@ -95,6 +95,7 @@ struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
     DevBuf<double> pval;
     TiledDev view;
     long updates = 0;
+    std::vector<int> host_map;   // the map before its first use (uploaded by the first value-only re-precompute)
     bool tried = false;      // a plan was attempted for this (level, sweeps): empty view = the level does not qualify
 };
 
@@ -103,6 +104,7 @@ struct BgsBuf {  // device image of the block-sequential Gauss-Seidel plan of a 
     DevBuf<double> eval, udiag;
     BgsDev view;
     std::vector<int> color_ptr;      // blocks of colour c
+    std::vector<int> host_map, host_mapd;          // the maps before their first use (uploaded by the first value-only re-precompute)
     std::vector<int> host_rows, host_blk_ptr;      // the bgs order (position -> internal row), positions per block: introspection, tests
     double rim = 0.0, fill = 0.0;
     bool tried = false;
@@ -114,6 +116,7 @@ struct WgsBuf {  // device image of the wave Gauss-Seidel plan of a level (smg_w
     DevBuf<double> eval, diag;
     WgsDev view;
     std::vector<int> color_ptr;      // pieces of colour c
+    std::vector<int> host_map, host_mapd;          // the maps before their first use (uploaded by the first value-only re-precompute)
     std::vector<int> host_rows, host_piece_ptr;    // the wgs order (position -> internal row), positions per piece: introspection, tests
     double rim_ratio = 0.0, phases_mean = 0.0;
     int phases_max = 0;

@@ -17,10 +17,34 @@ h.precompute(A)
 b1 = L.smg_device_bytes_live()
 n = A.shape[0]
 rhs = Mb @ np.random.default_rng(1).uniform(-1, 1, n)
+def table(h, title):
+    d = h.device_bytes()
+    print(title, "total %.1f MB" % (d["total"] / 1e6))
+    for k_, v in sorted(d.items(), key=lambda kv: -kv[1]):
+        if k_ != "total" and v > 0.01 * d["total"]:
+            print("   %-34s %8.2f MB" % (k_, v / 1e6))
+table(h, "ogre.obj after precompute:")
 h.solve(rhs, np.zeros(n), None, smg.SolveOpts(tol=1e-10, max_iter=30))
 b2 = L.smg_device_bytes_live()
+table(h, "ogre.obj after a solve (host vectors):")
 h.precompute(A)     # value-only
 b3 = L.smg_device_bytes_live()
 print("rows", [h.rows(l) for l in range(h.n_levels)])
 print("after precompute %.1f MB, after a solve %.1f MB, after a value-only re-precompute %.1f MB" % ((b1 - b0) / 1e6, (b2 - b0) / 1e6, (b3 - b0) / 1e6))
 if os.environ.get("SMG_DEBUG_MEM"): pass
+def table(h, title):
+    d = h.device_bytes()
+    print(title, "total %.1f MB" % (d["total"] / 1e6))
+    for k_, v in sorted(d.items(), key=lambda kv: -kv[1]):
+        if k_ != "total" and v > 0.01 * d["total"]:
+            print("   %-34s %8.2f MB" % (k_, v / 1e6))
+table(h, "ogre.obj handle:")
+if len(sys.argv) > 1:
+    import bench as B
+    mg, A3, Mb3, Vf, Ff, label, _ = B.build_workload(sys.argv[1], smg, mesh)
+    mg.precompute(A3)
+    n3 = A3.shape[0]
+    mg.solve(Mb3 @ np.random.default_rng(1).uniform(-1, 1, n3), np.zeros(n3), None, smg.SolveOpts(tol=1e-10, max_iter=30))
+    table(mg, label)
+    mg.precompute(A3)
+    table(mg, "after a value-only re-precompute:")
