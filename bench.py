@@ -727,29 +727,27 @@ def multi_mesh_leg(smg, mesh, torch, dev, counts=(1, 2, 4, 8), steps=300, repeat
     except Exception as e:     # noqa: BLE001
         cpu = {"error": repr(e)}
     del handles, vecs
-    # ---- the same M meshes as ONE block-diagonal system in ONE handle (disjoint union: P_l = diag(P_l^i), A = diag(A^i)): every launch
-    # serves all M meshes, so the launch latency is shared instead of multiplied.  Hierarchy with nVCoarsest = 100 (the coarsest level of the
-    # union is inverted densely as a whole: small coarsest levels keep that cheap); M = 1 on the same hierarchy is the baseline.
+    # ---- the same M meshes in ONE handle through the ABI: smg_hierarchy_create_union (include/smg.h) -- block-diagonal levels, the members' OWN coarse
+    # inverses, every member its own residual history and break test.  Every launch serves all M meshes: the launch latency is shared, not multiplied.
+    # The hierarchy is the members' own (mg_precompute defaults, the same as by_handles): M = 1 through the union API is the baseline.
     union = {}
     try:
         import scipy.sparse as sp
-        mgu0 = smg.mg_precompute(V, F, 0.25, 100, 1)
-        Pu = [mgu0.matrix(l, "P_full") for l in range(1, mgu0.n_levels)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = torch.cuda.current_stream(dev)
         for m in counts:
-            Psm = [sp.block_diag([P] * m, format="csr") for P in Pu] if m > 1 else Pu
+            hu = smg.Hierarchy.union([mg0] * m)
             Am = sp.block_diag([A] * m, format="csr") if m > 1 else A
-            for X in Psm:
-                X.sort_indices()
             Am.sort_indices()
-            hu = smg.Hierarchy.from_prolongs(Psm)
             hu.precompute(Am)
             hu.set_stream(st.cuda_stream)
             nn = Am.shape[0]
             rhs = torch.from_numpy(np.concatenate([Mb @ np.random.default_rng(300 + i).uniform(-1.0, 1.0, n) for i in range(m)])).to(dev)
             z0 = torch.zeros(nn, dtype=torch.float64, device=dev)
             zz = torch.empty_like(z0)
+            # every member to its own tolerance: cycles per member (they differ: each has its own right-hand side)
+            cv, rh_u = hu.solve_device(rhs.data_ptr(), z0.data_ptr(), zz.data_ptr(), nn, 1, opts=smg.SolveOpts(tol=1e-10, max_iter=100, smoother="gs"))
+            member_cycles = [len(hu.union_history(i)[1]) - 1 for i in range(m)]
             hu.solve_begin(rhs.data_ptr(), nn, z0.data_ptr(), nn, 1, opts=smg.SolveOpts(tol=0.0, max_iter=HIS, smoother="gs"))
             hu.outer_iterations(20)
             ts = []
@@ -763,9 +761,12 @@ def multi_mesh_leg(smg, mesh, torch, dev, counts=(1, 2, 4, 8), steps=300, repeat
             hu.solve_end(zz.data_ptr(), nn, max_iter=HIS)
             ms = float(np.median(ts))
             union[str(m)] = {"meshes": m, "ms_per_iteration": ms, "v_cycles_per_s_aggregate": m * 1e3 / ms, "levels": hu.n_levels,
-                             "colors": [len(hu.colors(l)) - 1 for l in range(hu.n_levels - 1)], "coarsest_rows": hu.rows(hu.n_levels - 1)}
+                             "coarsest_rows_per_member": int(hu.rows(hu.n_levels - 1) // m), "converged_all": bool(cv), "cycles_to_1e-10_per_member": member_cycles,
+                             "device_bytes": int(hu.device_bytes()["total"])}
             del hu, rhs, z0, zz
         union["speedup_at_%d" % max(counts)] = union[str(max(counts))]["v_cycles_per_s_aggregate"] / union[str(counts[0])]["v_cycles_per_s_aggregate"]
+        union["vs_one_stand_alone_handle_at_%d" % max(counts)] = union[str(max(counts))]["v_cycles_per_s_aggregate"] / base
+        union["what"] = "smg_hierarchy_create_union over M copies of the hierarchy above: block-diagonal levels, per-member coarse inverses, per-member residual history / break test (tol = 0 in the timed loop: every iteration is a full one for every member)"
     except Exception as e:     # noqa: BLE001
         union = {"error": repr(e)}
     out = {"workload": "ogre.obj (19 985 verts, %d levels from smg_mg_precompute), M_bary + 0.01(-L), one RHS column per mesh, Gauss-Seidel V(2,2)" % mg0.n_levels,

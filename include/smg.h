@@ -227,6 +227,23 @@ int smg_hierarchy_set_wave_gs(smg_hierarchy *h, int mode);
  * smg_level_get_perm), stats[3] = {rows gathered per row beyond the iterate itself, mean phases per piece, most phases of a piece}.  Any pointer may be
  * NULL.  Returns 1 when level lv sweeps piece-wise for this k, 0 when it does not (nothing is written then), < 0 on error. */
 int smg_level_get_wave_gs_order(smg_hierarchy *h, int lv, int k, int *n_pieces, int *n_colors, int *color_ptr, int *piece_ptr, int *rows, double *stats);
+/* ---- independent meshes in ONE handle (BASELINE north_star: "independent RHS columns / independent meshes shard") ----------------------------------
+ * Across GPUs: one handle per device.  On ONE GPU separate handles do not overlap (a hipGraphLaunch of ~50 kernel nodes is enqueued under a process-wide
+ * lock), so many small meshes go into one block-diagonal handle whose every launch serves all of them.
+ * smg_hierarchy_create_union: members = m hierarchies with their prolongations set (smg_mg_precompute, smg_level_set_prolong, ...; same number of levels,
+ * scalar); *out gets P_full_l = diag(P_full_l of the members), rows and columns in member order.  The members are only read and may be destroyed afterwards.
+ * smg_precompute(out, A, ...) then takes the block-diagonal system (member i's rows are [first, first + count) of smg_union_member_rows; constraints in
+ * that numbering).  What the reference does PER MESH stays per mesh: every member is its own min_quad_with_fixed_mg_solve loop
+ * (src/min_quad_with_fixed_mg.cpp:105-134) -- its own residual norm, history and break test; a member whose test has passed keeps the iterate it had then
+ * while the others go on (smg_union_get_history after smg_solve / smg_solve_end: its residual history, and the reference's return value for it) -- and
+ * coarseSolve() uses the members' OWN dense inverses (sum n_i^2 entries, not (sum n_i)^2; every member's coarsest level must lie in the dense range).
+ * The handle's own r_his is the norm over all members, `converged` = every member's loop ended below the tolerance.  fp64 cycles; no split-phase /
+ * sharded iteration on a union.  Numberings and sweep orders are those of the union's matrices: a member's iterates agree with a stand-alone solve of the
+ * same mesh to the tolerance, not bit for bit. */
+int smg_hierarchy_create_union(const smg_hierarchy *const *members, int m, smg_hierarchy **out);
+int smg_union_members(const smg_hierarchy *h);                                           /* 0: not a union */
+int smg_union_member_rows(const smg_hierarchy *h, int member, int *first, int *count);   /* member's rows in the caller's numbering of level 0 */
+int smg_union_get_history(smg_hierarchy *h, int member, double *r_his, int cap, int *n_his, int *converged);
 /* The coarsest level's solver (coarseSolve(), src/mg_VCycle.cpp:181-201; solver.compute(Ac), src/min_quad_with_fixed_mg.cpp:47-48, :253-254).  Three of them,
  * chosen by size and by what the caller does (all: <= 1e-11 from LDL^T, deterministic):
  *  - DENSE INVERSE, up to n_max unknowns (smg_hierarchy_set_coarse_dense_max, default 16384, or SMG_COARSE_DENSE_MAX): the matrix is inverted on the device

@@ -101,6 +101,10 @@ def load():
         "smg_debug_schur_solve_host": (i, [i, ip, ip, dp, dp, dp, ip, ip]),
         "smg_hierarchy_set_block_gs": (i, [vp, i]),
         "smg_hierarchy_set_wave_gs": (i, [vp, i]),
+        "smg_hierarchy_create_union": (i, [C.POINTER(vp), i, C.POINTER(vp)]),
+        "smg_union_members": (i, [vp]),
+        "smg_union_member_rows": (i, [vp, i, ip, ip]),
+        "smg_union_get_history": (i, [vp, i, dp, i, ip, ip]),
         "smg_debug_device_bytes": (i, [vp, C.c_char_p, i]),
         "smg_level_get_wave_gs_order": (i, [vp, i, i, ip, ip, ip, ip, ip, dp]),
         "smg_debug_check_wave_gs_plan": (i, [vp, i, i, i, ip, ip, dp, dp]),

@@ -347,6 +347,30 @@ class Hierarchy:
             return b["rows"]
         return np.arange(self.rows(lv), dtype=np.int32)
 
+    # ---- independent meshes in one handle (csrc/smg_union.cpp)
+    @classmethod
+    def union(cls, members):
+        """one block-diagonal hierarchy over the members' prolongations (smg_hierarchy_create_union); precompute() then takes the block-diagonal system"""
+        L = _lib.load()
+        arr = (C.c_void_p * len(members))(*[m.h for m in members])
+        out = C.c_void_p()
+        _chk(L.smg_hierarchy_create_union(arr, len(members), C.byref(out)), "smg_hierarchy_create_union")
+        return cls(handle=out.value)
+
+    def union_members(self):
+        return self.L.smg_union_members(self.h)
+
+    def union_member_rows(self, member):
+        a, b = C.c_int(), C.c_int()
+        _chk(self.L.smg_union_member_rows(self.h, member, C.byref(a), C.byref(b)), "smg_union_member_rows")
+        return a.value, b.value
+
+    def union_history(self, member, cap=4096):
+        """(converged, r_his) of one member's own loop in the last solve"""
+        rh, n, cv = np.zeros(cap), C.c_int(), C.c_int()
+        _chk(self.L.smg_union_get_history(self.h, member, _dp(rh), cap, C.byref(n), C.byref(cv)), "smg_union_get_history")
+        return bool(cv.value), rh[:min(n.value, cap)].copy()
+
     # ---- coarsest-level solver
     def set_coarse_dense_max(self, n_max):
         """coarsest levels of more than n_max unknowns get a sparse Cholesky factorisation instead of a dense inverse"""

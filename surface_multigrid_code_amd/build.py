@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmg.so")
-SOURCES = ["smg_device.hip", "smg_bsr3_device.hip", "smg_tiled_device.hip", "smg_coarse_device.hip", "smg_bgs_device.hip", "smg_wgs_device.hip", "smg_schur_device.hip", "smg_bgs.cpp", "smg_wgs.cpp", "smg_schur.cpp", "smg_bsr3.cpp", "smg_tiled.cpp", "smg_coarse.cpp", "smg_capi.cpp", "smg_precompute.cpp", "smg_cycle.cpp", "smg_hierarchy_io.cpp", "smg_sparse.cpp", "smg_mesh.cpp",
+SOURCES = ["smg_device.hip", "smg_bsr3_device.hip", "smg_tiled_device.hip", "smg_coarse_device.hip", "smg_bgs_device.hip", "smg_wgs_device.hip", "smg_union_device.hip", "smg_schur_device.hip", "smg_bgs.cpp", "smg_wgs.cpp", "smg_union.cpp", "smg_schur.cpp", "smg_bsr3.cpp", "smg_tiled.cpp", "smg_coarse.cpp", "smg_capi.cpp", "smg_precompute.cpp", "smg_cycle.cpp", "smg_hierarchy_io.cpp", "smg_sparse.cpp", "smg_mesh.cpp",
            "smg_order.cpp", "smg_decimate.cpp"]
 HEADERS = ["smg_device.hpp", "smg_hier.hpp", "smg_internal.hpp", "smg_device_inl.hpp", "smg_gj_inl.hpp", "smg_schur.hpp", "smg_bsr3.hpp", "smg_tiled.hpp", "smg_coarse.hpp", "smg_bgs.hpp", "smg_wgs.hpp", "smg_sparse.hpp", "smg_mesh.hpp", "smg_order.hpp",
            os.path.join("..", "..", "include", "smg.h")]

@@ -478,6 +478,7 @@ template <> struct Prec<double> {
     { return launch_sell(m, V, s0, s1, x, bb, y, k, ctrl, nullptr, nullptr, st, zero_rows, first, omega); }
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
     {
+        if (h->union_m > 0) return launch_blockdiag_gemv_add(h->un.view, h->d_Ainv.p, h->nc, L.b.p, L.u.p, k, ctrl, h->stream);   // the members' own inverses (smg_union.cpp)
         if (h->coarse_sparse) return launch_sparse_coarse_solve(h->c_view, L.b.p, L.u.p, k, ctrl, h->stream);
         if (h->coarse_schur) return launch_schur_solve(h->sch.view, L.b.p, L.u.p, k, ctrl, h->stream);
         return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p);
@@ -754,7 +755,7 @@ static int enqueue_relax(smg_hierarchy* h, int lv, const double* b, double* u, i
 static bool head_fusable(smg_hierarchy* h, int k)
 {
     static const int on = env_int("SMG_FUSE_HEAD", 1);
-    if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on || h->bs != 1) return false;
+    if (!on || h->precision != 0 || h->n_levels < 2 || h->prof_on || h->bs != 1 || h->union_m > 0) return false;      // (a union needs the residual VECTOR: per-member norms)
     Level& L0 = h->lv[0];
     if (L0.gs_on_transpose) return false;
     if (bgs_plan(h, 0, k) || wgs_plan(h, 0, k)) return false;   // block- / piece-sequential sweeps run in place; their head is the residual launch
@@ -795,6 +796,13 @@ static int enqueue_residual_ss(smg_hierarchy* h, int k, bool fuse_decide = false
         return SMG_OK;
     }
     ProfGuard pg(h, "MG: outer residual");
+    if (h->union_m > 0) {
+        // independent meshes in one handle: r = RHS - A z as a vector, then every member's own norm, history and break test (smg_union_device.hip)
+        if (!fuse_decide) return fail(SMG_ERR_INVALID, "a union handle runs through smg_solve / smg_solve_begin + smg_raw_outer_iteration (no split-phase iteration: its members stop one by one)");
+        HIPCHK(launch_sell(SELL_RESID, L0.dA.view, 0, L0.dA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, nullptr, nullptr, h->stream));
+        HIPCHK(launch_union_sumsq_decide(h->un.view, L0.r.p, L0.u.p, k, h->d_ctrl.p, h->stream));
+        return SMG_OK;
+    }
     if (h->precision == 1 && h->bs == 3)
         HIPCHK(launch_bsr3(SELL_RESID_BOTH, L0.bA.view, 0, L0.bA.view.n_slices, L0.u.p, L0.b.p, L0.r.p, k, h->d_ctrl.p, h->d_partials.p, &nb, h->stream));
     else if (h->precision == 1)   // mixed: the residual itself is the right-hand side of the fp32 correction cycle
@@ -825,6 +833,7 @@ static int enqueue_cycle_part(smg_hierarchy* h, int k, const double* d_sumsq)
         } else {
             int rc = enqueue_vcycle(h, 0, k, h->pre, h->post, h->d_ctrl.p, h->head_fuse ? FIRST_SWEEP : FIRST_NONE);
             if (rc) return rc;
+            if (h->union_m > 0) HIPCHK(launch_union_restore(h->un.view, h->lv[0].u.p, k, h->d_ctrl.p, h->stream));   // members whose loop has ended keep their iterate
         }
     }
     return SMG_OK;
@@ -881,8 +890,10 @@ static int ensure_graphs(smg_hierarchy* h)
         return enqueue_cycle_part(h, k, nullptr);
     });
     if (rc) return rc;
-    rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
-    if (rc) return rc;
+    if (!h->union_m) {      // (a union has no split-phase iteration: its members stop one by one)
+        rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
+        if (rc) return rc;
+    }
     h->g_key = key;
     return SMG_OK;
 }
@@ -1002,6 +1013,10 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     zero.his_cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(h->max_iter, 1));
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     if (memspace == SMG_HOST) HIPCHK(hipStreamSynchronize(h->stream));  // the caller's host blocks may change after this call
+    if (h->union_m > 0) {
+        if (h->precision != 0) return fail(SMG_ERR_INVALID, "a union handle solves in fp64 (no mixed-precision cycle)");
+        if ((rc = union_begin_solve(h, k))) return rc;
+    }
     h->head_fuse = head_fusable(h, k);   // latched: both halves of every iteration of this solve follow it
     h->iters_enqueued = 0;
     h->in_solve = true;
@@ -1132,6 +1147,11 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     if (n_his) *n_his = cnt;
     const double last = cnt > 0 ? his[cnt - 1] : HUGE_VAL;
     if (converged) *converged = (last > h->tol) ? 0 : 1;  // :131-134 / :357-360
+    if (h->union_m > 0 && converged) {      // every member's own loop ended below the tolerance (the handle's history holds the norm over all members)
+        std::vector<int> md((size_t)h->union_m, 0);
+        HIPCHK(hipMemcpy(md.data(), h->un.done.p, md.size() * sizeof(int), hipMemcpyDeviceToHost));
+        *converged = (hc.status == 0 && std::all_of(md.begin(), md.end(), [](int d) { return d != 0; })) ? 1 : 0;
+    }
     if (h->verbosity > 0) {
         for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, his[i]);  // :111
         if (cnt) std::printf("residual norm: %g\n", his[cnt - 1]);                                    // :127

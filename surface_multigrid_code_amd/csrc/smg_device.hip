@@ -2000,6 +2000,16 @@ hipError_t launch_dense_from_csr(double* dense, int np, int n, const double* src
     if (nnz > 0) hipLaunchKernelGGL(k_scatter_dense, dim3(grid1d(nnz, 256)), dim3(256), 0, st, dense, src, pos, nnz);
     return hipGetLastError();
 }
+hipError_t launch_scatter_dense(double* dense, const double* src, const long long* pos, int nnz, hipStream_t st)
+{
+    if (nnz > 0) hipLaunchKernelGGL(k_scatter_dense, dim3(grid1d(nnz, 256)), dim3(256), 0, st, dense, src, pos, nnz);
+    return hipGetLastError();
+}
+hipError_t launch_dense_identity(double* dense, int np, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dense_identity, dim3(grid1d((size_t)np * np, 256)), dim3(256), 0, st, dense, np, n);
+    return hipGetLastError();
+}
 hipError_t launch_add_at(double* v, const int* where, int n, double c, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;

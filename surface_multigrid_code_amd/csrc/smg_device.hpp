@@ -165,6 +165,30 @@ struct WgsDev {
 // the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k, 1 <= k <= 8)
 hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 
+// ---- independent meshes in one handle (smg_hierarchy_create_union; kernels: smg_union_device.hip) ----
+struct UnionDev {
+    int m = 0, his_cap = 0, max_rows = 0;      // members; entries per member history; rows of the largest member on level 0
+    const int* rows = nullptr;                 // level 0: internal row numbers grouped by member ...
+    const int* rptr = nullptr;                 // ... m + 1 offsets
+    const int* crow_member = nullptr;          // coarsest level: row -> member
+    const long long* moff = nullptr;           // per member: offset of its inverse in the handle's d_Ainv
+    const int* mlda = nullptr;                 // ... its leading dimension (rows padded to 64)
+    const int* mrow0 = nullptr;                // ... its first row on the coarsest level
+    double* ss = nullptr;                      // m: sum of squares of the member's residual
+    double* his = nullptr;                     // m x his_cap: the members' residual histories
+    int* nhis = nullptr;                       // m: entries written
+    int* done = nullptr;                       // m: the member's loop has ended
+    double* zsave = nullptr;                   // n_0 x k: the iterate before the cycle
+};
+// u[:, c] += blockdiag(Ainv_i) b[:, c] on the coarsest level (n rows in all)
+hipError_t launch_blockdiag_gemv_add(const UnionDev& U, const double* Ainv, int n, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+// per member: ss = |r|^2 over its rows, zsave = u there; then every member's break test and the handle's (ctrl): done when all members are
+hipError_t launch_union_sumsq_decide(const UnionDev& U, const double* r, const double* u, int k, Ctrl* ctrl, hipStream_t st);
+// after a cycle: members whose loop has ended get their rows of zsave back
+hipError_t launch_union_restore(const UnionDev& U, double* u, int k, const Ctrl* ctrl, hipStream_t st);
+hipError_t launch_scatter_dense(double* dense, const double* src, const long long* pos, int nnz, hipStream_t st);
+hipError_t launch_dense_identity(double* dense, int np, int n, hipStream_t st);
+
 // ---- relax(iters) of a latency-bound level in one launch: overlapped tiling (smg_tiled.hpp plan, smg_tiled_device.hip kernel) ------
 struct TiledDev {
     int n_tiles = 0, nc = 0, P = 0, sweeps = 0, max_ext = 0, w_max = 0, threads = 512;

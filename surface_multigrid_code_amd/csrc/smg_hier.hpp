@@ -262,6 +262,18 @@ struct smg_hierarchy {
     int block_mode = -1;           // smg_hierarchy_set_block_mode: -1 decide at precompute (P = Pv (x) I_3 on every level, no constraints,
                                    // blocks at least half full), 0 never, 3 required (precompute fails if the structure is not there)
     int bs = 1;                    // what the last precompute decided
+    // ---- independent meshes in one handle (smg_hierarchy_create_union, csrc/smg_union.cpp) ----
+    int union_m = 0;                       // members (0: an ordinary handle)
+    std::vector<int> union_off0;           // m + 1: the members' row ranges in the caller's FULL numbering of level 0
+    std::vector<int> union_offc;           // m + 1: their row ranges on the coarsest level (that level's caller numbering); set by the precompute
+    std::vector<long long> union_moff;     // m: offset of member i's inverse in d_Ainv
+    std::vector<int> union_mlda;           // m: its leading dimension
+    struct UnionBuf {
+        smg::DevBuf<int> rows, rptr, crow_member, mlda, mrow0, nhis, done;
+        smg::DevBuf<long long> moff;
+        smg::DevBuf<double> ss, his, zsave;
+        smg::UnionDev view;
+    } un;
     // ---- execution ----
     int device = -1;
     hipStream_t stream = nullptr;

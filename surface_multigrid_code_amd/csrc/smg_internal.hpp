@@ -119,6 +119,10 @@ int refresh_host_values(smg_hierarchy* h);      // host copies of mg[l].A after 
 int ensure_P_int(smg_hierarchy* h, int lv);     // ... and P / PT of the level
 int ensure_A_int(smg_hierarchy* h, int lv);     // the level matrix in the internal numbering on the host (built on demand where the device filled the panels)
 
+// ---- independent meshes in one handle (smg_union.cpp) ---------------------------------------------------------------------------------
+int union_coarse_factor(smg_hierarchy* h, const double* d_vals, bool first);   // the members' dense inverses, side by side (first: + the bookkeeping)
+int union_begin_solve(smg_hierarchy* h, int k);                                // per-member solve state
+
 // ---- cycle (smg_cycle.cpp) -----------------------------------------------------------------------------------------------------------
 enum { LV_GS = 0, LV_JACOBI = 1, LV_CHEBY = 2 };
 int level_kind(const smg_hierarchy* h, int lv);   // the smoother of a level under the handle's selection

@@ -738,6 +738,13 @@ static int coarse_images(smg_hierarchy* h)
     const int np = ((nc + 63) / 64) * 64;
     h->coarse_schur = false;
     h->schur_declined = false;
+    if (h->union_m > 0) {      // independent meshes in one handle: the members' own dense inverses (smg_union.cpp)
+        if (h->bs != 1) return fail(SMG_ERR_INVALID, "a union handle needs scalar hierarchies (no 3-DOF block structure)");
+        h->sch.release(); h->schur = SchurPlan();
+        DevBuf<double> d_val;
+        HIPCHK(d_val.upload(Lc.A.val));
+        return union_coarse_factor(h, d_val.p, true);
+    }
     if (schur_wanted(h, nc, 1)) {
         bool planned = false;
         const int rc = coarse_plan_schur(h, Lc.A, &planned);
@@ -1128,7 +1135,7 @@ static int build_recipes(smg_hierarchy* h)
                 pos[p] = (long long)i * h->nc_pad + Lc.A.col[p];
                 if (Lc.A.col[p] == i) dg.push_back(p);
             }
-        if (!h->coarse_sparse && !h->coarse_schur) HIPCHK(h->d_dense_pos.upload(pos));
+        if (!h->coarse_sparse && !h->coarse_schur && !h->union_m) HIPCHK(h->d_dense_pos.upload(pos));      // (a union keeps its members' block positions)
         HIPCHK(h->d_diag_idx.upload(dg));
     }
     if (!h->has_known && h->lhs_src.size() != (size_t)h->lv[0].A.nnz()) {
@@ -1171,7 +1178,7 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
     }
     // coarsest: solver.compute(Ac) (:47-48 / :253-254) -- the sparse factorisation on the host from the new values, or on the device the
     // Schur-complement factorisation resp. the dense inverse
-    if (!h->coarse_sparse && !h->coarse_schur && schur_wanted(h, h->nc, 2)) {
+    if (!h->coarse_sparse && !h->coarse_schur && !h->union_m && schur_wanted(h, h->nc, 2)) {
         // New values for an old pattern: this caller is a time stepper (05: a new matrix every flow step, 06: ten per step), and from here on the
         // coarse factorisation is what each of its steps pays -- the Schur-complement solver factors in a third of the dense inverse's time and
         // solves within a few us of it (csrc/smg_schur.hpp).  The plan is built once, now.
@@ -1188,7 +1195,10 @@ static int precompute_values_device(smg_hierarchy* h, const double* d_val)
             h->sch.release(); h->schur = SchurPlan();
         }
     }
-    if (h->coarse_sparse) {
+    if (h->union_m > 0) {
+        int rc = union_coarse_factor(h, h->lv[L - 1].d_Aval.p, false);
+        if (rc) return rc;
+    } else if (h->coarse_sparse) {
         Level& Lc = h->lv[L - 1];
         HIPCHK(hipMemcpyAsync(Lc.A.val.data(), Lc.d_Aval.p, Lc.A.val.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

@@ -613,6 +613,44 @@ def test_wave_gauss_seidel_plan_is_the_lexicographic_sweep_in_its_order(smg_mod)
                 assert diff.value == 0.0, "level %d, pieces of %d rows (mode %d): the piece sweep differs by %g" % (lv, piece_rows, mode, diff.value)
 
 
+def test_union_of_hierarchies_is_block_diagonal(smg_mod):
+    """smg_hierarchy_create_union (independent meshes in one handle, csrc/smg_union.cpp): P_full of every level is diag(P_full of the members), member row
+    ranges are reported, the Galerkin operators of the union are the members' (bit for bit: block-diagonal products add nothing), members of unequal depth
+    are refused."""
+    import scipy.sparse as sp
+    smg = smg_mod
+    ms, As = [], []
+    for name, nvc in (("ogre_sim.smgm", 100), ("bunny.smgm", 200), ("ogre_sim.smgm", 100)):
+        V, F = M.read_smgm(name)
+        V = M.normalize_unit_area(V, F)
+        ms.append(smg.mg_precompute(V, F, 0.25, nvc, 1))
+        A = (M.massmatrix(V, F, "barycentric") - 0.01 * M.cotmatrix(V, F)).tocsr(); A.sort_indices()
+        As.append(A)
+    assert all(m.n_levels == 3 for m in ms)
+    u = smg.Hierarchy.union(ms)
+    assert u.union_members() == 3 and ms[0].union_members() == 0
+    off = 0
+    for i, m in enumerate(ms):
+        first, cnt = u.union_member_rows(i)
+        assert first == off and cnt == As[i].shape[0]
+        off += cnt
+    for lv in (1, 2):
+        ref = sp.block_diag([m.matrix(lv, "P_full") for m in ms], format="csr")
+        got = u.matrix(lv, "P_full")
+        assert got.shape == ref.shape and abs(got - ref).max() == 0 and got.nnz == ref.nnz
+    Au = sp.block_diag(As, format="csr"); Au.sort_indices()
+    _host_precompute(smg, u, Au)
+    for m, A in zip(ms, As):
+        _host_precompute(smg, m, A)
+    for lv in (1, 2):
+        ref = sp.block_diag([m.matrix(lv, "A") for m in ms], format="csr")
+        got = u.matrix(lv, "A")
+        assert abs(got - ref).max() == 0
+    with pytest.raises(smg.SmgError):
+        V, F = M.read_smgm("bunny.smgm")
+        smg.Hierarchy.union([ms[0], smg.mg_precompute(M.normalize_unit_area(V, F), F, 0.25, 1000, 1)])      # 2 levels against 3
+
+
 def test_sparse_cholesky_of_the_coarse_solver(smg_mod):
     """csrc/smg_coarse.cpp (coarsest levels beyond the dense range; the reference: Eigen::SimplicialLDLT, src/min_quad_with_fixed_mg.cpp:47-48):
     nested dissection + up-looking Cholesky on mesh operators -- residual of a host solve with the factor at rounding level, fill O(n log n),
