@@ -225,7 +225,7 @@ struct Decimator {
     bool filling = true;
     void seal_initial()
     {
-        std::sort(initial.begin(), initial.end(), [](const QEntry& x, const QEntry& y) { return y < x; });   // best first
+        parallel_sort(initial, [](const QEntry& x, const QEntry& y) { return y < x; });   // best first (3 #V entries: on the host threads -- a fifth of the level's time as one std::sort)
         filling = false;
     }
     bool queue_empty() const { return pq.empty() && ihead == initial.size(); }
@@ -641,7 +641,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
                 int a = D.faces[f][c], b = D.faces[f][(c + 1) % 3];
                 ek.push_back({((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), ((uint64_t)(uint32_t)a << 32) | (uint32_t)b});
             }
-        std::sort(ek.begin(), ek.end());
+        parallel_sort(ek, [](const std::array<uint64_t, 2>& x, const std::array<uint64_t, 2>& y) { return x < y; });
         for (size_t i = 0; i < ek.size();) {
             size_t j = i;
             while (j < ek.size() && ek[j][0] == ek[i][0]) j++;

@@ -4,6 +4,7 @@
 // (column-major, int32) that mg_data carries (reference src/mg_data.h:13-19).  For the symmetric system
 // matrices CSR == CSC; P and PT are both kept explicitly, as the reference does.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <functional>
@@ -79,6 +80,31 @@ int host_threads();   // SMG_HOST_THREADS, default min(hardware threads, 32)
 void parallel_for(long n, long grain, const std::function<void(long, long)>& fn);
 // run independent tasks concurrently (each may itself call parallel_for: nested calls run inline)
 void parallel_tasks(const std::vector<std::function<void()>>& tasks);
+
+// std::sort of a big array on the host threads: chunks sorted side by side, then merged pairwise (log2(chunks) passes of std::inplace_merge, the pairs of a pass
+// side by side).  cmp must be a strict total order for the result to be unique (it is for every caller: ties are broken by ids) -- then the outcome is
+// std::sort's, whatever the number of threads.
+template <class T, class Cmp>
+void parallel_sort(std::vector<T>& v, Cmp cmp)
+{
+    const size_t n = v.size();
+    int chunks = 1;
+    while (chunks * 2 <= host_threads() && chunks < 64 && n / (size_t)(chunks * 2) >= (size_t)1 << 15) chunks *= 2;
+    if (chunks == 1) { std::sort(v.begin(), v.end(), cmp); return; }
+    std::vector<size_t> cut((size_t)chunks + 1);
+    for (int c = 0; c <= chunks; c++) cut[(size_t)c] = n * (size_t)c / (size_t)chunks;
+    {
+        std::vector<std::function<void()>> tasks;
+        for (int c = 0; c < chunks; c++) tasks.push_back([&, c] { std::sort(v.begin() + (long)cut[(size_t)c], v.begin() + (long)cut[(size_t)c + 1], cmp); });
+        parallel_tasks(tasks);
+    }
+    for (int w = 1; w < chunks; w *= 2) {
+        std::vector<std::function<void()>> tasks;
+        for (int c = 0; c + w < chunks; c += 2 * w)
+            tasks.push_back([&, c, w] { std::inplace_merge(v.begin() + (long)cut[(size_t)c], v.begin() + (long)cut[(size_t)c + w], v.begin() + (long)cut[(size_t)std::min(c + 2 * w, chunks)], cmp); });
+        parallel_tasks(tasks);
+    }
+}
 
 // y = A x for dense column-major blocks (host; used only by precompute-time checks and tools)
 void spmv_host(const Csr& A, const double* x, double* y);

@@ -13,6 +13,7 @@ for wl in (sys.argv[1:] or ["C3pdec"]):
     mg, A, Mb, Vf, Ff, label, t_host = B.build_workload(wl, smg, mesh)
     torch.zeros(1, device="cuda"); torch.cuda.synchronize()
     t0 = time.time(); mg.precompute(A); t_pre = time.time() - t0
+    stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); mg.set_stream(stream.cuda_stream)      # events and libsmg's launches on ONE stream
     print(label)
     print("host mesh + hierarchy %.2f s (mg_precompute %.2f s), smg_precompute %.3f s" % (t_host, getattr(B.build_workload, "mg_precompute_s", float("nan")), t_pre))
     for lv in range(mg.n_levels):
@@ -38,7 +39,7 @@ for wl in (sys.argv[1:] or ["C3pdec"]):
         mg.solve_begin(rhs.data_ptr(), n, z0.data_ptr(), n, 1, opts=smg.SolveOpts(tol=0.0, max_iter=1024))
         mg.outer_iterations(50)
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); ea.record(); mg.outer_iterations(300); eb.record(); torch.cuda.synchronize()
+        torch.cuda.synchronize(); ea.record(stream); mg.outer_iterations(300); eb.record(stream); torch.cuda.synchronize()
         mg.solve_end(z.data_ptr(), n, max_iter=1024)
         ms = ea.elapsed_time(eb) / 300
         print("outer iteration %.4f ms = %.1f V-cycles/s; bytes %d -> %.3f TB/s = %.3f of peak; cycles to 1e-10: %d (converged %s)"

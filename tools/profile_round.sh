@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun).  Outputs under gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -19,8 +19,14 @@ python tools/rocpd_timeline.py $OUT/tlg/t_results.db > $OUT/${TAG}_vcycle_timeli
 rocprofv3 --kernel-trace --stats -d $OUT/c4 -o t -- python tools/prof_kernels.py --workload C4k64 --reps 5 --cycles 30 --smoother hybrid_chebyshev > $OUT/c4.log 2>&1
 python tools/rocpd_stats.py $OUT/c4/t_results.db $OUT/${TAG}_c4_k64_kernel_stats.csv > /dev/null
 python tools/rocpd_timeline.py $OUT/c4/t_results.db > $OUT/${TAG}_c4_k64_timeline.txt
+# 2b. the reference's own kind of hierarchy (mg_precompute) on the C3 mesh and on ogre.obj: kernel table + one outer iteration kernel by kernel
+rocprofv3 --kernel-trace --stats -d $OUT/dec -o t -- python tools/prof_kernels.py --workload C3dec --reps 5 --cycles 12 --smoother gs > $OUT/dec.log 2>&1
+python tools/rocpd_stats.py $OUT/dec/t_results.db $OUT/${TAG}_c3dec_kernel_stats.csv > /dev/null
+python tools/rocpd_timeline.py $OUT/dec/t_results.db > $OUT/${TAG}_c3dec_timeline_gs.txt
+rocprofv3 --kernel-trace -d $OUT/ogre -o t -- python tools/prof_kernels.py --workload ogre --reps 5 --cycles 12 --smoother gs > $OUT/ogre.log 2>&1
+python tools/rocpd_timeline.py $OUT/ogre/t_results.db > $OUT/${TAG}_ogre_timeline_gs.txt
 # 3. PMC passes (counters only, each in its own run), fine-level kernels isolated by grid size: C3 (in cache) and C5 (beyond it)
-for wl in C3 C5; do
+for wl in C3 C5 C3dec; do
   mkdir -p $OUT/$wl
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     n=$(echo $c | tr " " "_")
@@ -48,11 +54,16 @@ python tools/make_traffic.py $OUT/${TAG}_pmc_summary_C3.json $OUT/${TAG}_pmc_sum
 #    relax() of the small levels, and the Chebyshev hybrid
 { echo "== Gauss-Seidel everywhere (reference cycle)"; python tools/level_times.py 2>/dev/null; echo "== the same with SMG_TILED=0 (one launch per colour on every level)"; SMG_TILED=0 python tools/level_times.py 2>/dev/null;
   echo "== hybrid Chebyshev (GS above 300 k rows)"; SMG_TOOL_SMOOTHER=hybrid_chebyshev:300000 python tools/level_times.py 2>/dev/null; } > $OUT/${TAG}_level_times.txt
+{ echo "== decimated hierarchies (mg_precompute): level table, per-level times, outer iteration"; python tools/dec_probe.py ogre C3pdec C3dec 2>/dev/null;
+  echo "== the same with one launch per colour (SMG_WGS=0: round 4's path)"; SMG_WGS=0 python tools/dec_probe.py ogre C3dec 2>/dev/null | grep -v "^level [0-9] rows";
+  echo "== relax(2) per level, graph-replayed"; python tools/wgs_probe.py C3dec 2 2>/dev/null | grep level; python tools/wgs_probe.py ogre 2 2>/dev/null | grep level;
+  echo "== ogre.obj by column count"; python tools/c4_time.py 2>/dev/null | grep "k = "; } > $OUT/${TAG}_decimated.txt
+python tools/mem_probe.py C3 > $OUT/${TAG}_device_bytes.txt 2>/dev/null
 python tools/block3_time.py C3 > $OUT/${TAG}_block3_c3.txt 2>/dev/null
 python tools/multi_mesh.py > $OUT/${TAG}_multi_mesh.txt 2>/dev/null
 python tools/reprecompute_time.py > $OUT/${TAG}_reprecompute.txt 2>/dev/null
 # 5. the coarse solver chosen by cost: dense inverse against the Schur-complement solver -- re-precompute, V-cycle and coarse solve per column count,
 #    the flow step, the block system; the kernels of three re-precomputes and of the coarse solves under rocprofv3
 bash tools/schur_legs.sh > /dev/null 2>&1
-rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5 $OUT/B3 $OUT/sch  # keep the summaries only (the dbs are large)
+rm -rf $OUT/trace $OUT/tl $OUT/tlg $OUT/c4 $OUT/c5t $OUT/C3 $OUT/C5 $OUT/C3dec $OUT/B3 $OUT/sch $OUT/dec $OUT/ogre  # keep the summaries only (the dbs are large)
 ls -la $OUT
