@@ -149,7 +149,7 @@ TiledGs build_tiled_gs(const Csr& G, const std::vector<int>& cp, int sweeps, int
                     }
                     for (int d = P + 1; d <= TILED_PMAX; d++) D.cnt[(size_t)c][(size_t)d] = run;
                     D.n_loc[(size_t)c] = run;
-                    D.m[(size_t)c] = D.cnt[(size_t)c][(size_t)P - 1];
+                    D.m[(size_t)c] = D.cnt[(size_t)c][(size_t)(P - c - 1)];      // the colour's first phase is phase c + 1: rows within P - (c + 1) rings; later phases fewer
                 }
                 for (int c = 0; c < nc; c++) if (D.m[(size_t)c] > max_panel_rows) D.ok = false;
             }

@@ -23,7 +23,8 @@ constexpr int TILED_PMAX = 15;     // phases = sweeps x colours
 constexpr int TILED_WMAX = 12;     // stored entries per row
 constexpr int TILED_THREADS = 512; // threads of a tile's workgroup = most rows a colour may have in a tile's panel (one row per thread)
 // per tile: [0] ext_off  [1] n_ext  [2] W  [3] reserved, then per colour c (stride 4 + TILED_PMAX + 1):
-//   [0] panel offset (entries)  [1] rows in the panel m_c  [2] row offset (prow)  [3] first local index of the colour's rows
+//   [0] panel offset (entries)  [1] rows in the panel m_c (those within P - c - 1 rings: what the colour's first phase updates)  [2] row offset (prow)
+//   [3] first local index of the colour's rows
 //   [4 + d] rows of the colour within d rings of the tile, d = 0 .. TILED_PMAX
 constexpr int TILED_CSTRIDE = 4 + TILED_PMAX + 1;
 constexpr int TILED_HDR = 4 + TILED_NCMAX * TILED_CSTRIDE;
