@@ -124,10 +124,11 @@ int smg::ensure_device(smg_hierarchy* h)
 void smg::drop_graphs(smg_hierarchy* h)
 {
     if (h->g_iter) (void)hipGraphExecDestroy(h->g_iter);
+    if (h->g_iter_n) (void)hipGraphExecDestroy(h->g_iter_n);
     if (h->g_resid) (void)hipGraphExecDestroy(h->g_resid);
     if (h->g_cycle) (void)hipGraphExecDestroy(h->g_cycle);
     if (h->g_spec) (void)hipGraphExecDestroy(h->g_spec);
-    h->g_iter = h->g_resid = h->g_cycle = h->g_spec = nullptr;
+    h->g_iter = h->g_iter_n = h->g_resid = h->g_cycle = h->g_spec = nullptr;
     h->g_key = smg::GraphKey();
 }
 

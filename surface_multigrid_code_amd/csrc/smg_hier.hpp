@@ -304,6 +304,7 @@ struct smg_hierarchy {
     int cur_ld_kv = 0;
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
+    hipGraphExec_t g_iter_n = nullptr;    // graph_iters() outer iterations in one graph (smg_cycle.cpp: enqueue_outer_iterations)
     double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
     smg::GraphKey g_key;             // what the cached graphs were captured with (k == 0: nothing cached)
     bool head_fuse = false;          // this solve takes the outer residual out of the first sweep (latched at smg_solve_begin)
