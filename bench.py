@@ -574,6 +574,25 @@ def c3_decimated_leg(smg, mesh, torch, dev, stream, ms_subdiv, bytes_subdiv):
         out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["ms_per_cycle"] / ms
     except Exception as e:     # noqa: BLE001
         out["cpu_baseline"] = {"error": repr(e)}
+    # The caller's knob, not the library's: mg_precompute's nVCoarsest (src/mg_precompute.cpp:15, 03_mg_solver/main.cpp:37).  The same hierarchy stopped one
+    # level earlier -- coarsest level 15 804 unknowns, solved by the Schur-complement solver -- is ANOTHER cycle (an exact solve where the 5-level cycle
+    # smooths and recurses): reported beside the leg, never in place of it.
+    try:
+        Ps = [mg.matrix(l, "P_full") for l in range(1, mg.n_levels - 1)]
+        m4 = smg.Hierarchy.from_prolongs(Ps)
+        t0 = time.time()
+        m4.precompute(A)
+        t4 = time.time() - t0
+        m4.set_stream(stream.cuda_stream)
+        m4.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+        cv4, rh4 = m4.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+        ms4 = steady_ms(torch, stream, m4, rhs, z0, z, n, 1, dict(smoother="gs"), iters=60)
+        out["stopped_one_level_earlier_option"] = {"levels": [m4.rows(l) for l in range(m4.n_levels)], "coarse_solver": m4.coarse_solver(), "smg_precompute_s": t4, "ms_per_step": ms4,
+                                                   "cycles_to_1e-10": len(rh4) - 1, "converged": bool(cv4), "time_to_tol_ms": ms4 * (len(rh4) - 1),
+                                                   "note": "mg_precompute with a larger nVCoarsest: the caller's choice; a different cycle"}
+        del m4
+    except Exception as e:     # noqa: BLE001
+        out["stopped_one_level_earlier_option"] = {"error": repr(e)}
     return out
 
 
