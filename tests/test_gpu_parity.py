@@ -708,7 +708,7 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
     """The launch-count / latency shortcuts of the cycle -- the restriction launch producing the first colour of the coarse level's
     first sweep (SMG_FUSE_FIRST), small colour sweeps confined to one XCD (SMG_ONE_XCD_MAX), the whole panel pitch requested
     ahead on tiny launches (SMG_PITCH_SPEC_MAX), relax() of the latency-bound levels as ONE launch by overlapped tiling (SMG_TILED,
-    csrc/smg_tiled.hpp: levels 1 and 2 of this hierarchy) -- are re-orderings of WHERE and WHEN the same arithmetic runs: a full-depth
+    csrc/smg_tiled.hpp: levels 1 and 2 of this hierarchy), four outer iterations in one graph (SMG_GRAPH_ITERS) -- are re-orderings of WHERE and WHEN the same arithmetic runs: a full-depth
     V-cycle and a solve on a 4-level hierarchy give identical bits with all of them off.  (The knobs are read once per process,
     hence the two child processes.)"""
     import subprocess, sys
@@ -718,7 +718,7 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
         env = dict(os.environ)
         env["SMG_DEVICE_FILL_MIN"] = "1000"     # the panels of every big enough A filled on the device from the caller's arrays + the permutation ...
         if off:
-            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0", SMG_DEVICE_FILL="0")   # ... or built on the host
+            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0", SMG_DEVICE_FILL="0", SMG_GRAPH_ITERS="1")   # ... or built on the host; one outer iteration per graph instead of four
         r = subprocess.run([sys.executable, "-c", _SHORTCUT_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("mcf", "poisson"))]
