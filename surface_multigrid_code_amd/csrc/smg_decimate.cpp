@@ -69,9 +69,12 @@ struct Patch {
 };
 struct Pin { int idx; double val; };            // idx in [0, 2n): u block first, then v
 
-static void add_conformal_energy(int n, const std::vector<V3>& X, const std::vector<std::array<int, 3>>& F, std::vector<double>& Q)
+// The energy's matrix Q (2n x 2n, u block first) is never formed: the constrained system only needs its free x free part -- of which
+// the Cholesky factorisation reads the lower triangle -- and, for the right-hand side, the columns of the pins with a non-zero value.
+// `sym(I, J, w)` stands for the pair Q[I][J] += w, Q[J][I] += w; every entry receives its terms in the order the full matrix would.
+template <class Sym, class Diag>
+static inline void add_conformal_energy(int n, const std::vector<V3>& X, const std::vector<std::array<int, 3>>& F, Sym&& sym, Diag&& diag)
 {
-    const int N = 2 * n;
     for (const auto& f : F) {
         for (int c = 0; c < 3; c++) {
             const int i = f[c], j = f[(c + 1) % 3], k = f[(c + 2) % 3];   // edge (i,j), opposite corner k
@@ -80,12 +83,12 @@ static void add_conformal_energy(int n, const std::vector<V3>& X, const std::vec
             const double w = cr > 0 ? 0.5 * dot(e1, e2) / cr : 0.0;       // 1/2 cot(angle at k)
             for (int d = 0; d < 2; d++) {                                   // K (+)= w (x_i - x_j)^2 for u and v
                 const int I = i + d * n, J = j + d * n;
-                Q[(size_t)I * N + I] += w; Q[(size_t)J * N + J] += w;
-                Q[(size_t)I * N + J] -= w; Q[(size_t)J * N + I] -= w;
+                diag(I, w); diag(J, w);
+                sym(I, J, -w);
             }
             // - 2 S:  Area = 1/2 sum over directed face edges (u_i v_j - u_j v_i)
-            Q[(size_t)i * N + (j + n)] -= 0.5; Q[(size_t)(j + n) * N + i] -= 0.5;
-            Q[(size_t)j * N + (i + n)] += 0.5; Q[(size_t)(i + n) * N + j] += 0.5;
+            sym(i, j + n, -0.5);
+            sym(j, i + n, 0.5);
         }
     }
 }
@@ -116,23 +119,40 @@ static bool solve_joint_flattening(Patch& pt, const std::vector<Pin>& pins)
 {
     const int n = pt.n, N = 2 * n;
     // (scratch vectors live across calls: a collapse is a few microseconds of arithmetic, allocation would be a good part of it)
-    static thread_local std::vector<double> Q, M, rhs, x;
-    static thread_local std::vector<int> freei;
-    static thread_local std::vector<char> pinned;
-    Q.assign((size_t)N * N, 0.0);
-    add_conformal_energy(n, pt.P, pt.pre, Q);
-    add_conformal_energy(n, pt.Ppost, pt.post, Q);
-    pinned.assign(N, 0);
+    static thread_local std::vector<double> M, rhs, x, qpin;
+    static thread_local std::vector<int> freei, fpos, pslot;
+    fpos.assign(N, 0);                         // >= 0: position among the free unknowns; -1: pinned
+    pslot.assign(N, -1);                       // pinned with a non-zero value: its column of Q is kept (qpin)
     x.assign(N, 0.0);
-    for (const Pin& p : pins) { pinned[p.idx] = 1; x[p.idx] = p.val; }
+    int n_slots = 0;
+    for (const Pin& p : pins) {
+        if (fpos[p.idx] < 0) { x[p.idx] = p.val; continue; }
+        fpos[p.idx] = -1; x[p.idx] = p.val;
+    }
+    for (const Pin& p : pins) if (p.val != 0.0 && pslot[p.idx] < 0) pslot[p.idx] = n_slots++;
     freei.clear();
-    for (int i = 0; i < N; i++) if (!pinned[i]) freei.push_back(i);
+    for (int i = 0; i < N; i++) if (fpos[i] >= 0) { fpos[i] = (int)freei.size(); freei.push_back(i); }
     const int m = (int)freei.size();
-    M.resize((size_t)m * m); rhs.resize(m);
+    M.assign((size_t)m * m, 0.0); rhs.resize(m);
+    qpin.assign((size_t)n_slots * m, 0.0);
+    {
+        double* Mp = M.data();
+        double* qp = qpin.data();
+        const int* fp = fpos.data();
+        const int* ps = pslot.data();
+        auto sym = [&](int I, int J, double w) {
+            const int a = fp[I], b = fp[J];
+            if (a >= 0 && b >= 0) { if (a >= b) Mp[(size_t)a * m + b] += w; else Mp[(size_t)b * m + a] += w; }
+            else if (a >= 0) { if (ps[J] >= 0) qp[(size_t)ps[J] * m + a] += w; }
+            else if (b >= 0) { if (ps[I] >= 0) qp[(size_t)ps[I] * m + b] += w; }
+        };
+        auto diag = [&](int I, double w) { const int a = fp[I]; if (a >= 0) Mp[(size_t)a * m + a] += w; };
+        add_conformal_energy(n, pt.P, pt.pre, sym, diag);
+        add_conformal_energy(n, pt.Ppost, pt.post, sym, diag);
+    }
     for (int r = 0; r < m; r++) {
-        for (int c = 0; c < m; c++) M[(size_t)r * m + c] = Q[(size_t)freei[r] * N + freei[c]];
         double s = 0.0;
-        for (const Pin& p : pins) if (p.val != 0.0) s += Q[(size_t)freei[r] * N + p.idx] * p.val;
+        for (const Pin& p : pins) if (p.val != 0.0) s += qpin[(size_t)pslot[p.idx] * m + r] * p.val;
         rhs[r] = -s;
     }
     // dense Cholesky (the pinned conformal energy is positive definite on a valid patch)
@@ -142,9 +162,19 @@ static bool solve_joint_flattening(Patch& pt, const std::vector<Pin>& pins)
         if (!(d > 1e-14)) return false;
         d = std::sqrt(d);
         M[(size_t)j * m + j] = d;
-        for (int i = j + 1; i < m; i++) {
+        // (four rows side by side: each entry's sum keeps its order, the four chains of dependent subtractions overlap)
+        const double* Mj = &M[(size_t)j * m];
+        int i = j + 1;
+        for (; i + 3 < m; i += 4) {
+            double* r0 = &M[(size_t)i * m];
+            double *r1 = r0 + m, *r2 = r1 + m, *r3 = r2 + m;
+            double s0 = r0[j], s1 = r1[j], s2 = r2[j], s3 = r3[j];
+            for (int k = 0; k < j; k++) { const double t = Mj[k]; s0 -= r0[k] * t; s1 -= r1[k] * t; s2 -= r2[k] * t; s3 -= r3[k] * t; }
+            r0[j] = s0 / d; r1[j] = s1 / d; r2[j] = s2 / d; r3[j] = s3 / d;
+        }
+        for (; i < m; i++) {
             double sx = M[(size_t)i * m + j];
-            for (int k = 0; k < j; k++) sx -= M[(size_t)i * m + k] * M[(size_t)j * m + k];
+            for (int k = 0; k < j; k++) sx -= M[(size_t)i * m + k] * Mj[k];
             M[(size_t)i * m + j] = sx / d;
         }
     }
@@ -231,7 +261,29 @@ struct Decimator {
     bool queue_empty() const { return pq.empty() && ihead == initial.size(); }
     QEntry pop_next()
     {
-        if (pq.empty() || (ihead < initial.size() && !(initial[ihead] < pq.top()))) return initial[ihead++];
+        if (pq.empty() || (ihead < initial.size() && !(initial[ihead] < pq.top()))) {
+            // the sorted front is consumed in order: what the collapses a few places down will touch is requested now (the loop is a
+            // chain of cache misses otherwise) -- list headers first, a few pops later the lists, then the faces and their point lists
+            const size_t n = initial.size();
+            if (ihead + 64 < n) {
+                const QEntry& e = initial[ihead + 64];
+                __builtin_prefetch(&vfaces[e.a]); __builtin_prefetch(&vfaces[e.b]);
+                __builtin_prefetch(&pos[e.a]); __builtin_prefetch(&pos[e.b]);
+                __builtin_prefetch(&version[e.a]); __builtin_prefetch(&version[e.b]);
+                __builtin_prefetch(&valive[e.a]); __builtin_prefetch(&valive[e.b]);
+            }
+            if (ihead + 48 < n) {
+                const QEntry& e = initial[ihead + 48];
+                __builtin_prefetch(vfaces[e.a].data()); __builtin_prefetch(vfaces[e.b].data());
+            }
+            if (ihead + 32 < n) {
+                const QEntry& e = initial[ihead + 32];
+                if (valive[e.a] && valive[e.b] && version[e.a] == e.va && version[e.b] == e.vb)
+                    for (int v : {e.a, e.b})
+                        for (int f : vfaces[v]) { __builtin_prefetch(&faces[f]); __builtin_prefetch(&fpoints[f]); __builtin_prefetch(&falive[f]); }
+            }
+            return initial[ihead++];
+        }
         QEntry e = pq.top();
         pq.pop();
         return e;
@@ -241,6 +293,15 @@ struct Decimator {
     int nF_real = 0;                         // faces [nF_real, ...) are phantom: (b, a, inf) for every boundary edge a -> b
     int vinf = -1;                           // the vertex at infinity (-1: closed mesh)
     std::unordered_set<uint64_t> refused;    // edges whose collapse was refused (cost infinity in the reference's queue)
+    std::vector<int> n_refused;              // per vertex: refused edges at it (the set is only consulted when both ends have some)
+    void refuse(int a, int b) { if (refused.insert(edge_key(a, b)).second) { n_refused[a]++; n_refused[b]++; } }
+    bool unrefuse(int a, int b)
+    {
+        if (n_refused[a] == 0 || n_refused[b] == 0) return false;
+        if (!refused.erase(edge_key(a, b))) return false;
+        n_refused[a]--; n_refused[b]--;
+        return true;
+    }
     bool phantom(int f) const { return f >= nF_real; }
     static uint64_t edge_key(int a, int b) { if (a > b) std::swap(a, b); return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; }
     // dec_type 0 (the reference's "qslim", src/SSP_qslim.cpp): quadric error metric -- every vertex carries the area-weighted
@@ -335,7 +396,7 @@ struct Decimator {
     {
         if (a == vinf || b == vinf) return;   // infinite cost: never collapsed (SSP_midpoint.cpp:196-200)
         if (a > b) std::swap(a, b);
-        if (!refused.empty()) refused.erase(edge_key(a, b));
+        unrefuse(a, b);
         const QEntry e{dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]};
         if (filling) initial.push_back(e); else pq.push(e);
     }
@@ -590,7 +651,7 @@ struct Decimator {
             for (int c = 0; c < 3; c++) {
                 const int x = faces[f][c], y = faces[f][(c + 1) % 3];
                 if (x == a || y == a || x == vinf || y == vinf) continue;
-                if (refused.erase(edge_key(x, y))) push_edge(x, y);
+                if (unrefuse(x, y)) push_edge(x, y);
             }
         }
         return true;
@@ -620,10 +681,18 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
     for (int i = 0; i < nV; i++) D.pos[i] = {fine.V[3 * i], fine.V[3 * i + 1], fine.V[3 * i + 2]};
     D.faces.resize(nF);
     D.vfaces.assign(nV, {});
+    {
+        std::vector<int> deg(nV, 0);
+        for (size_t t = 0; t < (size_t)nF * 3; t++) {
+            const int v = fine.F[t];
+            if (v < 0 || v >= nV) { err = "face index out of range"; return -1; }
+            deg[v]++;
+        }
+        for (int v = 0; v < nV; v++) D.vfaces[v].reserve((size_t)deg[v] + 3);   // one allocation per list (+ room for a phantom face / a first merge)
+    }
     for (int f = 0; f < nF; f++) {
         for (int c = 0; c < 3; c++) {
             int v = fine.F[3 * f + c];
-            if (v < 0 || v >= nV) { err = "face index out of range"; return -1; }
             D.faces[f][c] = v;
             D.vfaces[v].push_back(f);
         }
@@ -633,24 +702,47 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
     std::vector<std::array<int, 2>> bedges;   // directed as in their face
     std::vector<uint64_t> ekeys;
     {
-        // sorted edge keys: equal keys are adjacent (a hash map over 3 #F edges cost a tenth of the whole decimation)
-        std::vector<std::array<uint64_t, 2>> ek;   // (key, directed code)
-        ek.reserve((size_t)nF * 3);
-        for (int f = 0; f < nF; f++)
-            for (int c = 0; c < 3; c++) {
-                int a = D.faces[f][c], b = D.faces[f][(c + 1) % 3];
-                ek.push_back({((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), ((uint64_t)(uint32_t)a << 32) | (uint32_t)b});
+        // The undirected edges in ascending (min, max) order, enumerated at their smaller end point from that vertex's face list -- blocks of
+        // vertices side by side on the host threads, outputs concatenated in block order (a global sort of the 3 #F directed edges cost a
+        // tenth of the level's time).  An edge met more than twice, or twice in the same direction, is an error; once = boundary.
+        const int n_blocks = (int)std::min<long>(256, std::max<long>(1, nV / 4096));
+        struct Blk { std::vector<uint64_t> keys; std::vector<std::array<int, 2>> bedges; int bad = 0; };
+        std::vector<Blk> blk((size_t)n_blocks);
+        parallel_for(n_blocks, 1, [&](long b0, long b1) {
+            std::vector<std::array<int, 2>> nb;   // (other end point, 0: the face runs a -> b, 1: b -> a)
+            for (long bi = b0; bi < b1; bi++) {
+                Blk& B = blk[(size_t)bi];
+                const int v0 = (int)((long)nV * bi / n_blocks), v1 = (int)((long)nV * (bi + 1) / n_blocks);
+                B.keys.reserve((size_t)(v1 - v0) * 3 + 16);
+                for (int a = v0; a < v1; a++) {
+                    nb.clear();
+                    for (int f : D.vfaces[a]) {
+                        const auto& fc = D.faces[f];
+                        const int c = fc[0] == a ? 0 : (fc[1] == a ? 1 : 2);
+                        const int nx = fc[(c + 1) % 3], pv = fc[(c + 2) % 3];
+                        if (nx > a) nb.push_back({nx, 0});
+                        if (pv > a) nb.push_back({pv, 1});
+                    }
+                    std::sort(nb.begin(), nb.end());
+                    for (size_t i = 0; i < nb.size();) {
+                        size_t j = i;
+                        while (j < nb.size() && nb[j][0] == nb[i][0]) j++;
+                        if (j - i > 2) { if (!B.bad) B.bad = 1; }
+                        else if (j - i == 2 && nb[i][1] == nb[i + 1][1]) { if (!B.bad) B.bad = 2; }
+                        if (j - i == 1) B.bedges.push_back(nb[i][1] == 0 ? std::array<int, 2>{a, nb[i][0]} : std::array<int, 2>{nb[i][0], a});
+                        B.keys.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)nb[i][0]);
+                        i = j;
+                    }
+                }
             }
-        parallel_sort(ek, [](const std::array<uint64_t, 2>& x, const std::array<uint64_t, 2>& y) { return x < y; });
-        for (size_t i = 0; i < ek.size();) {
-            size_t j = i;
-            while (j < ek.size() && ek[j][0] == ek[i][0]) j++;
-            if (j - i > 2) { err = "input mesh is not edge-manifold"; return -1; }
-            if (j - i == 2 && ek[i][1] == ek[i + 1][1]) { err = "input mesh is not consistently oriented"; return -1; }
-            if (j - i == 1) bedges.push_back({(int)(ek[i][1] >> 32), (int)(ek[i][1] & 0xffffffffu)});
-            ekeys.push_back(ek[i][0]);
-            i = j;
+        });
+        size_t nk = 0;
+        for (const Blk& B : blk) {
+            if (B.bad) { err = B.bad == 1 ? "input mesh is not edge-manifold" : "input mesh is not consistently oriented"; return -1; }
+            nk += B.keys.size();
         }
+        ekeys.reserve(nk);
+        for (const Blk& B : blk) { ekeys.insert(ekeys.end(), B.keys.begin(), B.keys.end()); bedges.insert(bedges.end(), B.bedges.begin(), B.bedges.end()); }
     }
     // close the boundary with a vertex at infinity (igl::connect_boundary_to_infinity, SSP_midpoint.cpp:31): boundary edge (a -> b) of
     // a face gets the phantom face (b, a, inf)
@@ -670,6 +762,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
     const int nVall = (int)D.pos.size(), nFall = (int)D.faces.size();
     D.valive.assign(nVall, 1);
     D.version.assign(nVall, 0);
+    D.n_refused.assign(nVall, 0);
     D.falive.assign(nFall, 1);
     D.fpoints.assign(nFall, {});
     D.n_alive_faces = nF;
@@ -704,7 +797,7 @@ int decimate_level(const Mesh& fine, int tarF, int dec_type, int absorption_cap_
         if (!D.valive[e.a] || !D.valive[e.b] || D.version[e.a] != e.va || D.version[e.b] != e.vb) continue;
         if (capped && weight[e.a] + weight[e.b] > cap) { waiting.push_back(e); continue; }
         if (D.collapse(e.a, e.b)) { if (capped) weight[e.a] += weight[e.b]; }   // b merges into a
-        else D.refused.insert(Decimator::edge_key(e.a, e.b));                     // cost infinity until re-costed (SSP_collapse_edge.cpp:522-531)
+        else D.refuse(e.a, e.b);                     // cost infinity until re-costed (SSP_collapse_edge.cpp:522-531)
     }
     if (std::getenv("SMG_DEC_STATS")) {
         std::fprintf(stderr, "[smg decimate] faces %d -> %d; refusals by site:", nF, D.n_alive_faces);
