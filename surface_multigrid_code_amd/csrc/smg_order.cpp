@@ -264,6 +264,48 @@ struct Recolor {
         for (int w : B) mark[w] = 0;
         return ok;
     }
+    // The stragglers' last resort: a random walk of Kempe interchanges (the heuristic of Morgenstern & Shapiro for planar graphs).  The vertex
+    // stays uncoloured while a two-colour component hanging off one of its neighbours is swapped -- the rest stays properly coloured whatever the
+    // component -- until one of the K colours is missing around it.  kempe() above only takes the swaps that free a colour at once; the walk takes
+    // those that do not, and gets there a few dozen swaps later.  Sequential, fixed-seed generator: the colouring depends on the matrix alone.
+    uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+    uint32_t rnd(uint32_t m) { rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)((rng_state >> 33) % m); }
+    long walk_budget = 0;
+    bool walk(int v, int max_swaps, int cap)
+    {
+        std::vector<int> comp, stack, cand;
+        for (int it = 0; it < max_swaps && walk_budget > 0; it++) {
+            const int d = free_color(v, -1);
+            if (d >= 0) { color[v] = d; return true; }
+            const int a = (int)rnd((uint32_t)K);
+            int b = (int)rnd((uint32_t)(K - 1));
+            if (b >= a) b++;
+            cand.clear();
+            for (int p = A.ptr[v]; p < A.ptr[v + 1]; p++) { const int w = A.col[p]; if (w != v && color[w] == a) cand.push_back(w); }
+            walk_budget -= A.ptr[v + 1] - A.ptr[v];
+            if (cand.empty()) continue;
+            const int w0 = cand[rnd((uint32_t)cand.size())];
+            comp.clear(); stack.clear();
+            mark[w0] = 1; comp.push_back(w0); stack.push_back(w0);
+            bool too_big = false;
+            while (!stack.empty()) {
+                const int u = stack.back();
+                stack.pop_back();
+                for (int p = A.ptr[u]; p < A.ptr[u + 1]; p++) {
+                    const int w = A.col[p];
+                    if (w == u || w == v || mark[w] || (color[w] != a && color[w] != b)) continue;
+                    mark[w] = 1; comp.push_back(w); stack.push_back(w);
+                }
+                if ((int)comp.size() > cap) { too_big = true; break; }
+            }
+            walk_budget -= 8L * (long)comp.size();
+            if (!too_big) for (int u : comp) color[u] = (color[u] == a) ? b : a;
+            for (int u : comp) mark[u] = 0;
+        }
+        const int d = free_color(v, -1);
+        if (d >= 0) { color[v] = d; return true; }
+        return false;
+    }
     bool run()
     {
         std::vector<int> todo, left;
@@ -318,6 +360,28 @@ struct Recolor {
                 bool ok = false;
                 for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
             }
+        // what is still there takes the random walk, within a budget of elementary steps proportional to the graph
+        {
+            // (only the 5 -> 4 step: where a colour is a launch per sweep; the wide Galerkin levels of decimated hierarchies are swept piece-wise.)
+            // Passes with growing component caps, like the Kempe passes above: small components are cheap to swap and settle nearly everybody
+            // (252 834-row mesh level: 5 542 stragglers -> 17 at cap 128), the few survivors get the big ones.
+            walk_budget = 2000L * A.nr + 4000000L;
+            std::vector<int> pending;
+            for (int v = 0; v < A.nr; v++) if (color[v] == K) pending.push_back(v);
+            if (K <= 4 || pending.size() <= 64) {      // (or a class of a handful: a launch per sweep for next to nothing, where the level is swept colour by colour)
+                const int caps_walk[] = {128, 512, 2048, 8192, 32768, 1 << 30};
+                for (int ci = 0; ci < 6 && !pending.empty() && walk_budget > 0; ci++) {
+                    if (caps_walk[ci] > 32768 && A.nr > 70000) break;
+                    std::vector<int> still;
+                    for (int v : pending) {
+                        if (color[v] != K) continue;
+                        if (walk_budget <= 0 || !walk(v, 64, caps_walk[ci])) still.push_back(v);
+                    }
+                    pending.swap(still);
+                }
+            }
+            if (std::getenv("SMG_TIMING_COLOR")) { long left = 0; for (int v = 0; v < A.nr; v++) left += color[v] == K; std::fprintf(stderr, "[colour]   walk: K %d, %ld left, budget left %ld\n", K, left, walk_budget); }
+        }
         for (int v = 0; v < A.nr; v++) if (color[v] == K) return false;
         return true;
     }
@@ -396,7 +460,10 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     // (7 per row) and the small, wide Galerkin levels of decimated hierarchies, where a colour less is a launch less per sweep, keep
     // the full treatment.
     const bool heavy = A.nr > 100000 && A.nnz() > 12L * A.nr;
-    if (!heavy) {
+    // (DSATUR is a sequential search with a priority queue: a second on a million rows, where it found nothing first-fit + iterated greedy + the
+    //  class-dissolving passes below do not -- 6 colours, then 5, then 4 either way on the 1 011 330-row mesh level; below that size it is cheap and
+    //  lowers the count the later passes start from on the wide Galerkin levels.)
+    if (!heavy && A.nr <= 400000) {
         if (dsatur_color(A, cur) <= nbest) best = cur;
         compact_colors(best);
         nbest = count_colors(best);

@@ -152,6 +152,35 @@ def test_colour_ordering_is_a_valid_colouring(smg_mod):
             assert abs(mg.matrix(lv, "PT", internal=True) - Pi.T).max() == 0
 
 
+def test_mesh_level_of_a_decimated_hierarchy_gets_a_clean_four_colouring(smg_mod):
+    """No colours to inherit on a mesh the library does not know to be subdivided (ogre.obj under mg_precompute): DSATUR + the class-dissolving
+    passes used to leave ONE vertex in a fifth class (a launch per sweep, two more phases per one-launch relax); the random walk of Kempe
+    interchanges settles it.  The colouring is valid, has four classes, and depends on the matrix alone (two builds, same numbering)."""
+    smg = smg_mod
+    mesh = smg.mesh
+    V, F = mesh.read_triangle_mesh("ogre.smgm")
+    V = mesh.normalize_unit_area(V, F)
+    A = (mesh.massmatrix(V, F, "barycentric") - 0.01 * mesh.cotmatrix(V, F)).tocsr()
+    A.sort_indices()
+    perms = []
+    for rep in range(2):
+        mg = _host_precompute(smg, smg.mg_precompute(V, F, 0.25, 500, 1), A)
+        cp = np.asarray(mg.colors(0))
+        assert len(cp) - 1 == 4, "level 0 of ogre.obj: %d colour classes %s" % (len(cp) - 1, np.diff(cp).tolist())
+        Ai = mg.matrix(0, "A", internal=True).tocoo()
+        col_of = np.searchsorted(cp, np.arange(mg.rows(0)), side="right") - 1
+        off = Ai.row != Ai.col
+        assert (col_of[Ai.row[off]] != col_of[Ai.col[off]]).all()
+        for lv in range(1, mg.n_levels - 1):      # Galerkin levels: valid, and no class of a handful of rows
+            cl = np.asarray(mg.colors(lv)); Al = mg.matrix(lv, "A", internal=True).tocoo()
+            c_of = np.searchsorted(cl, np.arange(mg.rows(lv)), side="right") - 1
+            o = Al.row != Al.col
+            assert (c_of[Al.row[o]] != c_of[Al.col[o]]).all()
+            assert np.diff(cl).min() > 8, np.diff(cl).tolist()
+        perms.append(np.asarray(mg.perm(0)).copy())
+    assert np.array_equal(perms[0], perms[1])
+
+
 def test_mg_precompute_invariants(smg_mod):
     smg, mesh = smg_mod, smg_mod.mesh
     V, F = mesh.read_triangle_mesh("bunny.smgm")
@@ -302,6 +331,45 @@ def test_malformed_inputs_are_rejected(smg_mod):
     rc = L.smg_precompute(mgA.h, A.shape[0], ip(ptr2), ip(cols[order].astype(np.int32)), dp(vals[order].copy()), None, 0)
     assert rc in (0, -2)                                                    # -2: host half done, no GPU here
     assert abs(mgA.matrix(0, "A") - A).max() == 0
+
+
+def test_mg_precompute_rejects_meshes_the_reference_bails_out_on(smg_mod):
+    """src/SSP_decimate.cpp:20-23 (the reference stops on non-manifold input): an edge with three faces, two faces running along an edge in
+    the same direction, an out-of-range index and a degenerate face each fail smg_mg_precompute with a message saying which; a valid
+    mesh with a boundary (open fan) goes through."""
+    import ctypes as C
+    smg = smg_mod
+    L = smg._lib.load()
+    V, F = smg.mesh.torus(12, 10)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+
+    def run(Fx, Vx=V):
+        Fx = np.ascontiguousarray(Fx, dtype=np.int32)
+        out = C.c_void_p()
+        rc = L.smg_mg_precompute(Vx.ctypes.data_as(C.POINTER(C.c_double)), Vx.shape[0], Fx.ctypes.data_as(C.POINTER(C.c_int)), Fx.shape[0],
+                                 C.c_float(0.25), 10, 1, C.byref(out))
+        msg = L.smg_last_error()
+        if rc == 0: L.smg_hierarchy_destroy(out)
+        return rc, msg
+
+    assert run(F)[0] == 0
+    a, b, c = (int(x) for x in F[0])
+    far = [v for v in range(V.shape[0]) if v not in set(F[np.any(np.isin(F, [a, b]), axis=1)].ravel())][0]
+    rc, msg = run(np.vstack([F, [[a, b, far]]]))                 # a third face on the edge (a, b)
+    assert rc == -1 and b"edge-manifold" in msg
+    Fo = F.copy(); Fo[0] = [a, c, b]                             # face 0 flipped: its three edges now run the way the neighbours' do
+    rc, msg = run(Fo)
+    assert rc == -1 and b"consistently oriented" in msg
+    Fb = F.copy(); Fb[5, 1] = V.shape[0]
+    rc, msg = run(Fb)
+    assert rc == -1 and b"out of range" in msg
+    Fd = F.copy(); Fd[7, 2] = Fd[7, 1]
+    rc, msg = run(Fd)
+    assert rc == -1 and b"degenerate" in msg
+    keep = ~np.any(np.isin(F, [a]), axis=1)                     # the torus with the star of one vertex removed: a boundary loop
+    Vh = np.delete(V, a, axis=0)
+    Fh = F[keep].copy(); Fh[Fh > a] -= 1
+    assert run(Fh, np.ascontiguousarray(Vh))[0] == 0
 
 
 def test_kat_bunny_500_faces(smg_mod):
