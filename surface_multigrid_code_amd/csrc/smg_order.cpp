@@ -527,13 +527,15 @@ bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, cons
     return bad.load() == 0;
 }
 
-Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors, const std::vector<int>* rcm_in)
+std::vector<int> colours_for_ordering(const Csr& A, const std::vector<int>& rcm) { return color_graph(A, rcm); }
+
+Ordering make_ordering(const Csr& A, int sigma, const std::vector<int>* preset_colors, const std::vector<int>* rcm_in, bool preset_final)
 {
     int n = A.nr;
     Ordering o;
     std::vector<int> rcm = rcm_in ? *rcm_in : rcm_order(A);  // new -> old
     std::vector<int> color = preset_colors ? *preset_colors : color_graph(A, rcm);
-    if (preset_colors) compact_colors(color);
+    if (preset_colors && !preset_final) compact_colors(color);
     int ncol = count_colors(color);
     o.color_of = color;
     // colour-major, RCM rank inside a colour (counting sort keeps the RCM order stable)

@@ -30,7 +30,11 @@ std::vector<int> rcm_order_arrays(int n, const int* ptr, const int* col);   // t
 // together.  O(nnz(P)), against a sequential breadth-first search over the fine matrix for RCM.
 std::vector<int> induced_order(const Csr& P, const std::vector<int>& coarse_rank);
 // A: square, structurally symmetric.  rcm: a precomputed rcm_order(A) (lets callers run the per-level RCMs concurrently).
-Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* preset_colors = nullptr, const std::vector<int>* rcm = nullptr);
+// preset_final: the preset IS colours_for_ordering(A, rcm), computed ahead on another thread -- used as it stands, so that the numbering is the one
+// make_ordering(A, sigma, nullptr, rcm) builds.
+Ordering make_ordering(const Csr& A, int sigma = 512, const std::vector<int>* preset_colors = nullptr, const std::vector<int>* rcm = nullptr, bool preset_final = false);
+// the from-scratch colouring make_ordering computes when no colours are handed in (rcm: rcm_order(A))
+std::vector<int> colours_for_ordering(const Csr& A, const std::vector<int>& rcm);
 // 4-colouring of a mid-point-subdivided level from a 4-colouring of its parent; false if P / A do not fit
 bool subdivision_colors(const Csr& P, const std::vector<int>& coarse_color, const Csr& A, std::vector<int>& out);
 Ordering identity_ordering(int n);                           // single "colour" (debug / non-smoothed levels)

@@ -91,7 +91,14 @@ struct Early0 {
     bool rcm_started = false;
     std::vector<int> rcm;      // empty after the join: the level's pattern is the one its present numbering was built on
     double rcm_ms = 0.0;
-    ~Early0() { if (rcm_t.joinable()) rcm_t.join(); }
+    // Level 0's colours, when it has none to inherit (its prolongation is no subdivision operator: known from the start): the from-scratch
+    // colouring of a million rows is the longest sequential piece of such a precompute (0.8 s) and needs nothing but level 0's pattern and its
+    // locality order -- colour_t joins rcm_t, then colours, beside everything else the host half does.  wait() is the ONLY way to join either.
+    std::thread colour_t;
+    std::vector<int> colours;
+    double colour_ms = 0.0;
+    void wait() { if (colour_t.joinable()) colour_t.join(); if (rcm_t.joinable()) rcm_t.join(); }
+    ~Early0() { wait(); }
 };
 // The panels of a big level's A can be filled on the device straight from the caller's arrays and the permutation (launch_sell_fill):
 // the host then skips the permuted copy and the transposition test of 7 M entries, and ships 85 MB instead of 145 MB of padded
@@ -314,11 +321,11 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
         return pattern_key_arrays(M.nr, lv < L - 1, h->bs, M.ptr.data(), M.col.data());
     };
     const bool use_rcm = use_rcm_order();
-    struct E0Join { Early0& e; ~E0Join() { if (e.rcm_t.joinable()) e.rcm_t.join(); } } e0_join{e0};   // (it may read this frame)
+    struct E0Join { Early0& e; ~E0Join() { e.wait(); } } e0_join{e0};   // (they may read this frame)
     // Level 0's locality order (Early0) runs on a thread of its own, beside the Galerkin products: started by smg_precompute on the
     // caller's arrays where it could, else here.
     if (e0.rcm_started && (blk || h->has_known)) {       // (cannot happen: the caller starts them only for scalar, unconstrained systems)
-        if (e0.rcm_t.joinable()) e0.rcm_t.join();
+        e0.wait();
         e0.rcm_started = false; e0.rcm.clear();
     }
     uint64_t key0 = 0;
@@ -334,6 +341,24 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 e0.rcm_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             });
         }
+    }
+    // A level can inherit colours only through a prolongation whose rows have one or two entries (subdivision_colors, preset_from_coarsest): where
+    // the next level's P has a wider row -- the reference's own mg_precompute: three per row -- the level is coloured from scratch whatever the
+    // coarser levels' colours turn out to be, so its colouring need not wait for them.
+    auto may_inherit = [&](int lv) {
+        if (lv + 1 >= L) return false;
+        const Csr& Pn = blk ? h->lv[lv + 1].Pv : h->lv[lv + 1].P;
+        for (int i = 0; i < Pn.nr; i++) if (Pn.ptr[i + 1] - Pn.ptr[i] > 2) return false;
+        return true;
+    };
+    if (e0.rcm_started && use_rcm && L >= 3 && host_threads() > 1 && !may_inherit(0)) {
+        e0.colour_t = std::thread([&] {
+            if (e0.rcm_t.joinable()) e0.rcm_t.join();
+            if ((int)e0.rcm.size() != graph(0).nr) return;      // (pattern unchanged since the last precompute: nothing to number)
+            const auto t0 = std::chrono::steady_clock::now();
+            e0.colours = colours_for_ordering(graph(0), e0.rcm);
+            e0.colour_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
     }
     {
         std::vector<std::function<void()>> tasks;
@@ -466,7 +491,7 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
     // 0.1 s less setup, sweeps 1-3 % slower.
     tm.lap("host:   pattern hashes");
     if (cl_started) { keys[(size_t)L - 2] = 0; need[(size_t)L - 2] = 0; }      // (numbered on its own thread: joined below, after the other levels' searches)
-    std::vector<std::vector<int>> rcm(L);
+    std::vector<std::vector<int>> rcm(L), pre_colours(L);      // pre_colours: from-scratch colours of levels with nothing to inherit, found beside the searches
     const bool any_need = std::any_of(need.begin(), need.end(), [](char c) { return c != 0; });
     if (any_need) {
         if (use_rcm) {
@@ -486,7 +511,10 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
                 need[L - 2] = 0; fresh_early[(size_t)L - 2] = 1;
             });
             const bool early0 = e0.rcm_started;
-            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] { rcm[lv] = rcm_order(graph(lv)); });
+            for (int lv = 0; lv < L - 2; lv++) if (need[lv] && !(lv == 0 && early0)) tasks.push_back([&, lv] {
+                rcm[lv] = rcm_order(graph(lv));
+                if (!may_inherit(lv)) pre_colours[lv] = colours_for_ordering(graph(lv), rcm[lv]);
+            });
             parallel_tasks(tasks);      // (level 0's search, on its own thread since the start, is waited for when level 0's turn comes)
         } else {
             std::vector<int> rank;
@@ -512,19 +540,22 @@ static int precompute_host(smg_hierarchy* h, Csr&& A, const int* known, int n_kn
             if (lv == L - 1) { Lv.ord = identity_ordering(Lv.n); if (blk) Lv.vord = identity_ordering(Lv.n / 3); }
             else {
                 if (lv == 0 && use_rcm && e0.rcm_started) {
-                    if (e0.rcm_t.joinable()) e0.rcm_t.join();
-                    if (tm.on) { std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms)\n", e0.rcm_ms); tm.lap("host:   waiting for level 0's locality order"); }
-                    if ((int)e0.rcm.size() != graph(0).nr) e0.rcm = rcm_order(graph(0));     // (the early thread found the pattern unchanged, the key says otherwise: cannot happen)
+                    e0.wait();
+                    if (tm.on) { std::fprintf(stderr, "[smg timing] host:   (level 0 locality order, own thread: %.1f ms; colours from scratch beside it: %.1f ms)\n", e0.rcm_ms, e0.colour_ms); tm.lap("host:   waiting for level 0's locality order / colours"); }
+                    if ((int)e0.rcm.size() != graph(0).nr) { e0.rcm = rcm_order(graph(0)); e0.colours.clear(); }     // (the early thread found the pattern unchanged, the key says otherwise: cannot happen)
                     rcm[0] = std::move(e0.rcm);
+                    if ((int)e0.colours.size() == graph(0).nr) pre_colours[0] = std::move(e0.colours);
                 }
                 std::vector<int> inherited;
                 const Level& Lc = h->lv[lv + 1];
                 const Ordering& Oc = order_of(lv + 1);
-                const bool ok = ((lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
-                                 subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited)) ||
-                                (looks_subdivided(lv) && preset_from_coarsest(lv, inherited));      // (SMG_ORDER=induced: the coarsest smoothed level is numbered here)
+                const bool have_pre = (int)pre_colours[lv].size() == graph(lv).nr && graph(lv).nr > 0;      // (only ever set where nothing can be inherited)
+                const bool ok = !have_pre &&
+                                (((lv + 1 < L - 1) && Oc.n_colors() <= 4 && (int)Oc.color_of.size() == graph(lv + 1).nr &&
+                                  subdivision_colors(blk ? Lc.Pv : Lc.P, Oc.color_of, graph(lv), inherited)) ||
+                                 (looks_subdivided(lv) && preset_from_coarsest(lv, inherited)));      // (SMG_ORDER=induced: the coarsest smoothed level is numbered here)
                 if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d colours inherited=%d", lv, (int)ok); tm.lap(nm); }
-                order_of(lv) = make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
+                order_of(lv) = have_pre ? make_ordering(graph(lv), 512, &pre_colours[lv], &rcm[lv], true) : make_ordering(graph(lv), 512, ok ? &inherited : nullptr, &rcm[lv]);
                 if (tm.on) { char nm[64]; std::snprintf(nm, sizeof nm, "host:   level %d make_ordering", lv); tm.lap(nm); }
             }
             Lv.ord_key = keys[lv];
