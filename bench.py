@@ -26,6 +26,12 @@ import os
 import sys
 import time
 
+# The CPU legs' OpenMP runtime (the oracle's libgomp, loaded with oracle/_build/libsmg_oracle.so) reads these when it starts: threads pinned to
+# cores, spread over the sockets -- with the first-touch placement of orc_enable_parallel that is what makes `cpu_allcore` a fair all-core figure
+# on a multi-socket host.  (A caller's own settings win.)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -218,7 +224,7 @@ def cpu_allcore(mg, A, rhs, budget_s=6.0):
     ncpu = os.cpu_count() or 1
     best = None
     sweep = {}
-    for th in (8, 16, 32, 64):      # more threads than that only add fork/join and NUMA traffic to this memory-bound loop
+    for th in (8, 16, 32, 64, 128):      # (threads pinned and the matrices placed by first touch -- orc_enable_parallel -- since round 5: the sweep used to turn at 16)
         if th > ncpu:
             break
         orc.set_parallel(colors, th)

@@ -779,6 +779,24 @@ static int solve_loop(orc_mg *mg, const double *RHS, double *z, int k, double to
     return (residual > tol) ? 0 : 1;                    /* :131-134 */
 }
 
+/* a level-0 vector copied into a fresh buffer; all-core mode: by the threads that sweep it, block by block (first touch, see csc_place) */
+static void copy_level0(const orc_mg *mg, double *dst, const double *src, int n)
+{
+#ifdef _OPENMP
+    if (mg->par && n > ORC_PAR_MIN_ROWS) {
+        const int one[2] = {0, n};
+        const int *cp = (mg->color_ptr && mg->color_ptr[0]) ? mg->color_ptr[0] : one;
+        const int nc = (mg->color_ptr && mg->color_ptr[0]) ? mg->n_colors[0] : 1;
+        for (int c = 0; c < nc; c++) {
+#pragma omp parallel for schedule(static)
+            for (int i = cp[c]; i < cp[c + 1]; i++) dst[i] = src[i];
+        }
+        return;
+    }
+#endif
+    memcpy(dst, src, (size_t)n * sizeof(double));
+}
+
 /* min_quad_with_fixed_mg.cpp:80-135 */
 int orc_solve(orc_mg *mg, const double *RHS, int ld_rhs, const double *z0, int ld_z0, int k,
               double tol, int max_iter, double *z, int ld_z, double *r_his, int *n_his)
@@ -787,8 +805,8 @@ int orc_solve(orc_mg *mg, const double *RHS, int ld_rhs, const double *z0, int l
     double *rhs = (double *)xmalloc((size_t)n * (size_t)k * sizeof(double));
     double *zz = (double *)xmalloc((size_t)n * (size_t)k * sizeof(double));
     for (int c = 0; c < k; c++) {
-        memcpy(rhs + (size_t)c * n, RHS + (size_t)c * ld_rhs, (size_t)n * sizeof(double));
-        memcpy(zz + (size_t)c * n, z0 + (size_t)c * ld_z0, (size_t)n * sizeof(double)); /* z = z0, :97 */
+        copy_level0(mg, rhs + (size_t)c * n, RHS + (size_t)c * ld_rhs, n);
+        copy_level0(mg, zz + (size_t)c * n, z0 + (size_t)c * ld_z0, n); /* z = z0, :97 */
     }
     int conv = solve_loop(mg, rhs, zz, k, tol, max_iter, r_his, n_his);
     for (int c = 0; c < k; c++) memcpy(z + (size_t)c * ld_z, zz + (size_t)c * n, (size_t)n * sizeof(double));
@@ -865,6 +883,36 @@ int orc_set_parallel(orc_mg *mg, int lv, int n_colors, const int *color_ptr)
     csc_transpose(&mg->AT[lv], A);
     return 0;
 }
+/* all-core mode only: the arrays of a matrix re-allocated and copied by the threads that will stream them -- the same loop
+ * structure and static schedule as the sweeps / products (cp: the nc + 1 offsets of the blocks the columns are visited by; one
+ * block = all columns) -- so that on a multi-socket host every thread's share of the matrix lives in its own socket's memory
+ * (first touch).  Built by one thread the whole hierarchy sits on one NUMA node and every other socket reads it over the fabric:
+ * the thread sweep of bench.py's cpu_allcore leg got SLOWER beyond 16 threads on a 2 x 64-core host.  Values are untouched. */
+static void csc_place(orc_csc *M, const int *cp, int nc)
+{
+#ifdef _OPENMP
+    if (!M->colptr || M->n_cols <= ORC_PAR_MIN_ROWS) return;
+    const int one[2] = {0, M->n_cols};
+    if (!cp) { cp = one; nc = 1; }
+    const long nnz = M->colptr[M->n_cols];
+    int *ri = (int *)xmalloc((size_t)nnz * sizeof(int));
+    double *va = (double *)xmalloc((size_t)nnz * sizeof(double));
+    int *cptr = (int *)xmalloc((size_t)(M->n_cols + 1) * sizeof(int));
+    for (int c = 0; c < nc; c++) {
+#pragma omp parallel for schedule(static)
+        for (int j = cp[c]; j < cp[c + 1]; j++) {
+            cptr[j] = M->colptr[j];
+            for (int p = M->colptr[j]; p < M->colptr[j + 1]; p++) { ri[p] = M->rowidx[p]; va[p] = M->val[p]; }
+        }
+    }
+    cptr[M->n_cols] = M->colptr[M->n_cols];
+    free(M->colptr); free(M->rowidx); free(M->val);
+    M->colptr = cptr; M->rowidx = ri; M->val = va;
+#else
+    (void)M; (void)cp; (void)nc;
+#endif
+}
+
 int orc_enable_parallel(orc_mg *mg, int on, int threads)
 {
     mg->par = on ? 1 : 0;
@@ -874,6 +922,27 @@ int orc_enable_parallel(orc_mg *mg, int on, int threads)
     }
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
+    if (on) for (int lv = 0; lv < mg->n_levels; lv++) {
+        /* (again at every call: the static schedule's shares depend on the thread count) */
+        const int *cp = (mg->color_ptr && mg->color_ptr[lv]) ? mg->color_ptr[lv] : NULL;
+        csc_place(&mg->lv[lv].A, cp, cp ? mg->n_colors[lv] : 0);   /* swept block by block (orc_relax) */
+        csc_place(&mg->AT[lv], NULL, 0);                            /* row-wise products (orc_A) */
+        csc_place(&mg->lv[lv].P, NULL, 0);
+        csc_place(&mg->lv[lv].PT, NULL, 0);
+        if (mg->lv[lv].A_diag && mg->lv[lv].A.n_cols > ORC_PAR_MIN_ROWS) {
+            const int n = mg->lv[lv].A.n_cols;
+            double *d = (double *)xmalloc((size_t)n * sizeof(double));
+            const int one[2] = {0, n};
+            const int *bp = cp ? cp : one;
+            const int nb = cp ? mg->n_colors[lv] : 1;
+            for (int c = 0; c < nb; c++) {
+#pragma omp parallel for schedule(static)
+                for (int j = bp[c]; j < bp[c + 1]; j++) d[j] = mg->lv[lv].A_diag[j];
+            }
+            free(mg->lv[lv].A_diag);
+            mg->lv[lv].A_diag = d;
+        }
+    }
     return on ? omp_get_max_threads() : 1;
 #else
     (void)threads;

@@ -36,6 +36,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <queue>
 #include <string>
@@ -246,7 +247,46 @@ struct Decimator {
     std::vector<std::vector<int>> fpoints;  // fine points living on each face
     std::vector<int> pface;
     std::vector<std::array<double, 3>> pbary;
+    // Edges created or re-offered during the loop.  One heap over all of them grows to millions of entries at a million vertices (lazy
+    // deletion: ten fresh entries per collapse, the stale ones leave only when they surface), and every pop walks twenty levels of cache
+    // misses.  Costs rise as the mesh coarsens, so entries are kept by cost CLASS (the bit pattern of the non-negative double, 8 classes per
+    // octave): classes up to `cur_class` live in the heap `pq`, the rest wait in unsorted buckets and enter the heap when the front of the
+    // queue reaches their class.  The heap then holds the entries within a tenth of the current cost; the pop sequence is the one heap's.
     std::priority_queue<QEntry> pq;
+    std::vector<std::pair<uint32_t, std::vector<QEntry>>> far;   // (class, entries), classes ascending
+    uint32_t cur_class = 0;
+    size_t n_far = 0;
+    static uint32_t cost_class(double c)
+    {
+        if (!(c > 0.0)) return 0;                 // zero, negative (rounding of a quadric cost) or NaN: always in the heap
+        uint64_t b; std::memcpy(&b, &c, 8);
+        return (uint32_t)(b >> 49) + 1;            // sign 0: monotone in c
+    }
+    void offer(const QEntry& e)
+    {
+        const uint32_t k = cost_class(e.cost);
+        if (k <= cur_class) { pq.push(e); return; }
+        auto it = std::lower_bound(far.begin(), far.end(), k, [](const std::pair<uint32_t, std::vector<QEntry>>& x, uint32_t key) { return x.first < key; });
+        if (it == far.end() || it->first != k) it = far.insert(it, {k, {}});
+        it->second.push_back(e);
+        n_far++;
+    }
+    // makes sure the smallest live entry is at one of the two fronts: while the heap is empty, or its top lies beyond the current class,
+    // -- and the sorted front does not come first anyway -- the next class moves in
+    void settle()
+    {
+        while (!far.empty()) {
+            const bool init_left = ihead < initial.size();
+            const uint32_t next = far.front().first;
+            const bool heap_ok = !pq.empty() && cost_class(pq.top().cost) < next;
+            const bool init_ok = init_left && cost_class(initial[ihead].cost) < next;
+            if (heap_ok || init_ok) return;        // an entry of a class below every waiting one exists: it is the minimum's class
+            cur_class = next;
+            for (const QEntry& e : far.front().second) pq.push(e);
+            n_far -= far.front().second.size();
+            far.erase(far.begin());
+        }
+    }
     // The edges of the input mesh -- most of what the queue ever holds -- are sorted once and consumed front to back; the heap only
     // takes the edges created or re-offered later.  pop_next() returns the better of the two fronts: the same sequence one heap
     // holding everything would produce (the order of QEntry is total), at a fraction of the cache misses.
@@ -258,9 +298,10 @@ struct Decimator {
         parallel_sort(initial, [](const QEntry& x, const QEntry& y) { return y < x; });   // best first (3 #V entries: on the host threads -- a fifth of the level's time as one std::sort)
         filling = false;
     }
-    bool queue_empty() const { return pq.empty() && ihead == initial.size(); }
+    bool queue_empty() const { return pq.empty() && ihead == initial.size() && n_far == 0; }
     QEntry pop_next()
     {
+        settle();
         if (pq.empty() || (ihead < initial.size() && !(initial[ihead] < pq.top()))) {
             // the sorted front is consumed in order: what the collapses a few places down will touch is requested now (the loop is a
             // chain of cache misses otherwise) -- list headers first, a few pops later the lists, then the faces and their point lists
@@ -398,7 +439,7 @@ struct Decimator {
         if (a > b) std::swap(a, b);
         unrefuse(a, b);
         const QEntry e{dec_type == 0 ? qem(a, b, nullptr) : norm(pos[a] - pos[b]), a, b, version[a], version[b]};
-        if (filling) initial.push_back(e); else pq.push(e);
+        if (filling) initial.push_back(e); else offer(e);
     }
     void push_star(int v)
     {
