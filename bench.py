@@ -26,12 +26,6 @@ import os
 import sys
 import time
 
-# The CPU legs' OpenMP runtime (the oracle's libgomp, loaded with oracle/_build/libsmg_oracle.so) reads these when it starts: threads pinned to
-# cores, spread over the sockets -- with the first-touch placement of orc_enable_parallel that is what makes `cpu_allcore` a fair all-core figure
-# on a multi-socket host.  (A caller's own settings win.)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
-
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -222,10 +216,11 @@ def cpu_allcore(mg, A, rhs, budget_s=6.0):
     z0 = np.zeros_like(b)
     colors = [mg.colors(l) for l in range(L - 1)]
     ncpu = os.cpu_count() or 1
+    quota = host_info().get("cpu_quota")
     best = None
     sweep = {}
-    for th in (8, 16, 32, 64, 128):      # (threads pinned and the matrices placed by first touch -- orc_enable_parallel -- since round 5: the sweep used to turn at 16)
-        if th > ncpu:
+    for th in (8, 16, 32, 64, 128):      # (matrices and level-0 vectors placed by first touch since round 5, orc_enable_parallel; the box's CPU quota, not NUMA, is what turns the sweep)
+        if th > ncpu or (quota and th > 2 * quota):      # beyond the container's CPU quota the threads are throttled, not faster
             break
         orc.set_parallel(colors, th)
         orc.solve(b, z0, tol=0.0, max_iter=2)
@@ -486,7 +481,13 @@ def host_info():
                 break
     except Exception:
         pass
-    return {"cpu_model": model, "nproc": os.cpu_count()}
+    quota = None
+    try:      # the container's CPU quota (cgroup v2): "max 100000" = none; "1600000 100000" = 16 CPUs' worth of time -- what bounds every all-core CPU figure here
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cpu_quota": quota}
 
 
 def oracle_cycle_ms(mg, A, rhs, budget_s=6.0, known=None, known_val=None):

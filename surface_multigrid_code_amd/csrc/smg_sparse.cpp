@@ -11,17 +11,46 @@
 #include <cstdint>
 #include <cstdlib>
 #include <numeric>
+#include <cmath>
+#include <cstdio>
+#include <string>
 #include <thread>
 #include <utility>
 
 namespace smg {
 
 // ---------------------------------------------------------------------------------------------- host parallelism
+// CPUs this process may actually use: the hardware threads, cut down to the cgroup's CPU quota where there is one (a container on a
+// 256-thread host with cpu.max = "1600000 100000" gets 16 CPUs' worth of time per period: 32 runnable threads spend their budget in half
+// a period and are then ALL stalled for the other half).
+static int usable_cpus()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    auto read_pair = [](const char* path, double& a, double& b) {
+        std::FILE* f = std::fopen(path, "r");
+        if (!f) return false;
+        char s1[64] = {0}, s2[64] = {0};
+        const int got = std::fscanf(f, "%63s %63s", s1, s2);
+        std::fclose(f);
+        if (got < 1 || std::string(s1) == "max") return false;
+        a = std::atof(s1); b = got >= 2 ? std::atof(s2) : 0.0;
+        return a > 0.0;
+    };
+    double quota = 0.0, period = 0.0;
+    if (read_pair("/sys/fs/cgroup/cpu.max", quota, period) && period > 0.0) n = std::min(n, std::max(1, (int)std::ceil(quota / period)));      // cgroup v2
+    else {
+        double q = 0.0, p = 0.0, dummy = 0.0;
+        if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, dummy) && read_pair("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p, dummy) && p > 0.0)
+            n = std::min(n, std::max(1, (int)std::ceil(q / p)));                                                                             // cgroup v1
+    }
+    return n;
+}
+
 int host_threads()
 {
     static const int n = [] {
         const char* v = std::getenv("SMG_HOST_THREADS");
-        int t = v && *v ? std::atoi(v) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        int t = v && *v ? std::atoi(v) : std::min(32, usable_cpus());
         return std::max(1, t);
     }();
     return n;
