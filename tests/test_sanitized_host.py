@@ -42,7 +42,8 @@ def test_host_fuzz_under_asan_ubsan():
 
 def test_threaded_host_half_of_the_precompute_under_tsan():
     """ThreadSanitizer over the host half of a first smg_precompute (its own thread beside the caller's, the early locality-order and colouring
-    threads, the persistent pool, the hand-over object): tests/tsan_precompute_driver.cpp, three rounds on a 77 k-row, 4-level system.
+    threads, the persistent pool, the hand-over object): tests/tsan_precompute_driver.cpp, three rounds on a 77 k-row, 4-level system, two of them also under the
+    decimated hierarchy smg_mg_precompute builds for the same mesh (level 0 coloured from scratch on its own thread).
     Without a device the call ends with SMG_ERR_NO_DEVICE after the host half has run -- which is what this lane is about."""
     from surface_multigrid_code_amd import build as smg_build
     exe = smg_build.build_tsan()
@@ -60,4 +61,4 @@ def test_threaded_host_half_of_the_precompute_under_tsan():
         if "unexpected memory mapping" in out:
             pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
     assert "ThreadSanitizer" not in out, out[-6000:]
-    assert out.count("precompute rc = ") == 3 and r.returncode == 0, out[-3000:]
+    assert out.count("levels, precompute rc = ") == 3 and out.count("decimated precompute rc = ") == 2 and r.returncode == 0, out[-3000:]

@@ -1,6 +1,6 @@
 // ThreadSanitizer driver (tests/test_sanitized_host.py, surface_multigrid_code_amd/build.py: build_tsan): the host half of a first
 // smg_precompute -- its own thread, the locality-order and colouring threads, the persistent pool, the hand-over to the device half -- on a
-// subdivided torus through the C ABI.  No device needed: without one the call ends with SMG_ERR_NO_DEVICE after the host half has run.
+// subdivided torus through the C ABI, under its subdivision hierarchy and under smg_mg_precompute's (decimated) one.  No device needed: without one the call ends with SMG_ERR_NO_DEVICE after the host half has run.
 #include <cstdio>
 #include <cmath>
 #include <vector>
@@ -28,6 +28,17 @@ int main()
         rc = smg_precompute(h, nVf, ptr.data(), col.data(), val.data(), nullptr, 0);
         printf("round %d: %d rows, %d levels, precompute rc = %d (%s)\n", round, nVf, smg_hierarchy_levels(h), rc, smg_last_error());
         smg_hierarchy_destroy(h);
+        // the same fine mesh under the reference's own kind of hierarchy (smg_mg_precompute: edges enumerated on the host threads, the queue's
+        // sorts) -- no level can inherit colours there, so level 0 is coloured on its own thread beside the host half and the other levels inside
+        // the locality-order tasks
+        if (round < 2) {
+            smg_hierarchy* hd = nullptr;
+            rc = smg_mg_precompute(Vf.data(), nVf, Ff.data(), nFf, 0.25f, 500, 1, &hd);
+            if (rc) { printf("mg_precompute: %d %s\n", rc, smg_last_error()); return 1; }
+            rc = smg_precompute(hd, nVf, ptr.data(), col.data(), val.data(), nullptr, 0);
+            printf("round %d (decimated): %d levels, decimated precompute rc = %d (%s)\n", round, smg_hierarchy_levels(hd), rc, smg_last_error());
+            smg_hierarchy_destroy(hd);
+        }
     }
     return 0;
 }
