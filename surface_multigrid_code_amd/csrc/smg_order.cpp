@@ -308,6 +308,9 @@ struct Recolor {
     }
     bool run()
     {
+        const bool tm_on = std::getenv("SMG_TIMING_COLOR") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what, size_t left_now) { if (!tm_on) return; auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[colour]     K %d: %-34s %7.1f ms  (%zu left)\n", K, what, 1e3 * std::chrono::duration<double>(t - t_last).count(), left_now); t_last = t; };
         std::vector<int> todo, left;
         for (int v = 0; v < A.nr; v++) if (color[v] == K) todo.push_back(v);
         for (int v : todo) {
@@ -316,6 +319,7 @@ struct Recolor {
             if (exchange(v)) continue;
             left.push_back(v);
         }
+        lap("free colour / exchange", left.size());
         // Kempe passes with growing component caps: the expensive caps only ever see the few survivors
         // small graphs (coarse levels) get an all-out search: a clean 4-colouring there is inherited by every finer
         // subdivision level for free (subdivision_colors), and costs little in absolute terms
@@ -324,6 +328,18 @@ struct Recolor {
         const int caps_big[] = {256, 2048, 16384};
         const int* caps = small ? caps_small : caps_big;
         const int ncaps = small ? 4 : 3;
+        auto balls = [&]() {
+            todo.swap(left); left.clear();
+            for (int v : todo) {
+                if (color[v] != K) continue;
+                const int d = free_color(v, -1);
+                if (d >= 0) { color[v] = d; continue; }
+                bool ok = false;
+                for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
+                if (!ok) left.push_back(v);
+            }
+            lap("ball searches", left.size());
+        };
         for (int ci = 0; ci < ncaps; ci++) {
             const int cap = caps[ci];
             if (left.empty()) break;
@@ -337,51 +353,32 @@ struct Recolor {
                 if (budget > 0 && kempe(v, cap)) continue;
                 left.push_back(v);
             }
+            if (tm_on) { char nm[64]; std::snprintf(nm, sizeof nm, "Kempe pass, cap %d", cap); lap(nm, left.size()); }
+            if (ci > 0) continue;
             // after the cheapest Kempe pass the survivors first get the small exhaustive ball searches: on meshes those settle
             // nearly all of them in about a millisecond, where the passes with large component caps walk half the graph per
             // attempt (C3's 15.8 k-vertex level: 18 stragglers, 137 ms of large-cap passes without a single success)
-            if (ci == 0 && left.size() <= 256) {
-                todo.swap(left); left.clear();
-                for (int v : todo) {
-                    if (color[v] != K) continue;
-                    const int d = free_color(v, -1);
-                    if (d >= 0) { color[v] = d; continue; }
-                    bool ok = false;
-                    for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
-                    if (!ok) left.push_back(v);
-                }
-            }
-        }
-        if (left.size() <= 256)
-            for (int v : left) {
-                if (color[v] != K) continue;
-                const int d = free_color(v, -1);
-                if (d >= 0) { color[v] = d; continue; }
-                bool ok = false;
-                for (int rad = 2; rad <= (small ? 5 : 3) && !ok; rad++) ok = ball(v, rad, 8000L * rad);
-            }
-        // what is still there takes the random walk, within a budget of elementary steps proportional to the graph
-        {
-            // (only the 5 -> 4 step: where a colour is a launch per sweep; the wide Galerkin levels of decimated hierarchies are swept piece-wise.)
-            // Passes with growing component caps, like the Kempe passes above: small components are cheap to swap and settle nearly everybody
-            // (252 834-row mesh level: 5 542 stragglers -> 17 at cap 128), the few survivors get the big ones.
+            if (left.size() <= 256) balls();
+            // ... and then the random walk, BEFORE the passes with large caps (1 011 330-row mesh level: 1 990 stragglers after the pass with cap 256;
+            // caps 2 048 and 16 384 settled 197 and 4 of them in 0.38 + 0.45 s, the walk all 1 789 that were left in 0.17 s).
+            // Only the 5 -> 4 step (where a colour is a launch per sweep; the wide Galerkin levels of decimated hierarchies are swept piece-wise), or a
+            // class of a handful of rows.  Component caps grow like those of the Kempe passes: small components are cheap to swap and settle nearly
+            // everybody (252 834-row mesh level: 5 542 stragglers -> 17 at cap 128), the few survivors get the big ones.
             walk_budget = 2000L * A.nr + 4000000L;
-            std::vector<int> pending;
-            for (int v = 0; v < A.nr; v++) if (color[v] == K) pending.push_back(v);
-            if (K <= 4 || pending.size() <= 64) {      // (or a class of a handful: a launch per sweep for next to nothing, where the level is swept colour by colour)
+            if (!left.empty() && (K <= 4 || left.size() <= 64)) {
                 const int caps_walk[] = {128, 512, 2048, 8192, 32768, 1 << 30};
-                for (int ci = 0; ci < 6 && !pending.empty() && walk_budget > 0; ci++) {
-                    if (caps_walk[ci] > 32768 && A.nr > 70000) break;
-                    std::vector<int> still;
-                    for (int v : pending) {
+                for (int wi = 0; wi < 6 && !left.empty() && walk_budget > 0; wi++) {
+                    if (caps_walk[wi] > 32768 && A.nr > 70000) break;
+                    todo.swap(left); left.clear();
+                    for (int v : todo) {
                         if (color[v] != K) continue;
-                        if (walk_budget <= 0 || !walk(v, 64, caps_walk[ci])) still.push_back(v);
+                        if (walk_budget <= 0 || !walk(v, 64, caps_walk[wi])) left.push_back(v);
                     }
-                    pending.swap(still);
                 }
+                lap("random walk of Kempe interchanges", left.size());
             }
-            if (std::getenv("SMG_TIMING_COLOR")) { long left = 0; for (int v = 0; v < A.nr; v++) left += color[v] == K; std::fprintf(stderr, "[colour]   walk: K %d, %ld left, budget left %ld\n", K, left, walk_budget); }
         }
+        if (!left.empty() && left.size() <= 256) balls();
         for (int v = 0; v < A.nr; v++) if (color[v] == K) return false;
         return true;
     }
