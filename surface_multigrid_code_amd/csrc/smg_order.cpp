@@ -328,6 +328,9 @@ struct Recolor {
         const int caps_big[] = {256, 2048, 16384};
         const int* caps = small ? caps_small : caps_big;
         const int ncaps = small ? 4 : 3;
+        // (on a big mesh level the walk below does the cheap Kempe pass's work at a third of its price: 1 011 330 rows, 5 054 stragglers: pass with cap 256
+        //  0.36 s for 3 064 of them + walk 0.17 s for the rest, against the walk alone 0.40 s)
+        const bool walk_first = K <= 4 && A.nr > 100000;
         auto balls = [&]() {
             todo.swap(left); left.clear();
             for (int v : todo) {
@@ -350,7 +353,7 @@ struct Recolor {
                 const int d = free_color(v, -1);   // earlier swaps may have freed a colour
                 if (d >= 0) { color[v] = d; continue; }
                 if (exchange(v)) continue;
-                if (budget > 0 && kempe(v, cap)) continue;
+                if (budget > 0 && !(ci == 0 && walk_first) && kempe(v, cap)) continue;
                 left.push_back(v);
             }
             if (tm_on) { char nm[64]; std::snprintf(nm, sizeof nm, "Kempe pass, cap %d", cap); lap(nm, left.size()); }
