@@ -461,6 +461,11 @@ static void cheby_coefs(double lam, double frac, int degree, std::vector<ChebyCo
 
 // one accessor set per arithmetic: fp64 (the reference's) and the fp32 images of the mixed-precision V-cycle
 template <typename T> struct Prec;
+// The dense coarse product of a padded solve (internal_cols below) is formed for the caller's columns only: which of its kernels serves a column
+// (1 / 2 - 7 / 8 and more columns) then follows the CALLER's column count, as it would without padding -- a column-sharded solve stays bit-identical
+// to the fused one (tests/test_gpu_dist.py), and the padding columns' coarse iterate stays the zero the restriction wrote.
+static inline int coarse_cols(const smg_hierarchy* h, int k) { return (h->coarse_cols > 0 && h->coarse_cols < k) ? h->coarse_cols : k; }
+
 template <> struct Prec<double> {
     static double* b(Level& L) { return L.b.p; }
     static double* u(Level& L) { return L.u.p; }
@@ -481,7 +486,7 @@ template <> struct Prec<double> {
         if (h->union_m > 0) return launch_blockdiag_gemv_add(h->un.view, h->d_Ainv.p, h->nc, L.b.p, L.u.p, k, ctrl, h->stream);   // the members' own inverses (smg_union.cpp)
         if (h->coarse_sparse) return launch_sparse_coarse_solve(h->c_view, L.b.p, L.u.p, k, ctrl, h->stream);
         if (h->coarse_schur) return launch_schur_solve(h->sch.view, L.b.p, L.u.p, k, ctrl, h->stream);
-        return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, k, ctrl, h->stream, h->d_sympart.p);
+        return launch_dense_gemv_add(h->d_Ainv.p, h->nc, h->nc_pad, L.b.p, L.u.p, coarse_cols(h, k), k, ctrl, h->stream, h->d_sympart.p);
     }
     // an operation with the level's matrix in whatever format it lives in: SELL panels, or 3 x 3 blocks on block hierarchies.
     // smoother_image: the matrix the smoother streams (A^T where A is not bit-symmetric), else A.  s1 < 0: all slices.
@@ -514,7 +519,7 @@ template <> struct Prec<float> {
     static hipError_t coarse(smg_hierarchy* h, Level& L, int k, const Ctrl* ctrl)
     {
         if (h->coarse_schur) return launch_schur_solve_f32(h->sch.view, L.b32.p, L.u32.p, k, ctrl, h->stream);
-        return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, k, ctrl, h->stream, (float*)h->d_sympart.p);
+        return launch_dense_gemv_add_f32(h->d_Ainv32.p, h->nc, h->nc_pad, L.b32.p, L.u32.p, coarse_cols(h, k), k, ctrl, h->stream, (float*)h->d_sympart.p);
     }
     static hipError_t opA(smg_hierarchy* h, Level& L, bool smoother_image, SellMode m, int s0, int s1, const float* x, const float* bb, float* y, int k,
                           const Ctrl* ctrl, const FirstColour* fc = nullptr, double omega = 1.0)
@@ -873,7 +878,7 @@ static int capture_split_graphs(smg_hierarchy* h, double* buf)
 static GraphKey current_graph_key(const smg_hierarchy* h)
 {
     GraphKey key;
-    key.k = h->k; key.pre = h->pre; key.post = h->post; key.precision = h->precision; key.smoother = h->smoother;
+    key.k = h->k; key.k_user = h->k_user; key.pre = h->pre; key.post = h->post; key.precision = h->precision; key.smoother = h->smoother;
     key.jacobi_max_rows = h->jacobi_max_rows; key.omega = h->omega; key.cheby_fraction = h->cheby_fraction; key.head_fuse = h->head_fuse;
     return key;
 }
@@ -967,6 +972,26 @@ int smg::check_ready(const smg_hierarchy* h, const char* who)
     return SMG_OK;
 }
 
+// Columns of the solve's internal (row-major n x kin) blocks.  The kernels for 8 and more columns read a row's columns as 64- to 512-byte
+// segments; a row length that is no multiple of such a segment puts every row across cache-line boundaries and splits the columns over a
+// wide and one or two narrow launches per operation.  C3, ms per outer iteration (tools/k_solve_time.py, same box, SMG_PAD_COLS=0 / 1):
+//   k = 5: 1.068 / 1.044   6: 1.180 / 1.045   7: 1.393 / 1.066   (8: 0.97)   12: 1.981 / 1.602   13: 2.857 / 1.602   (16: 1.60)
+//   24: 2.91 / 2.87   48: 4.59 / 4.34   (64: 4.33);  33 columns as 64: 4.10 -> 4.37 -- not padded.
+// So 5 - 32 columns run as the next power of two and 41 - 63 as 64, with zero columns as padding: a zero right-hand side and iterate stay
+// exactly zero through every kernel of the cycle and add exact zeros to the residual's sum of squares.  The sparse kernels compute every
+// column independently of how many others there are, and the dense coarse product is formed for the caller's columns only (coarse_cols
+// above), so the caller's columns come out bit for bit as without padding (the tool prints a checksum of z; SMG_PAD_COLS=0: A/B knob).
+// (Schur / sparse coarse solvers take the padded block as it is.)  Union handles keep their own per-member bookkeeping and are not padded.
+static int internal_cols(const smg_hierarchy* h, int k)
+{
+    static const int on = env_int("SMG_PAD_COLS", 1);
+    if (!on || k <= 4 || k > 64 || h->union_m > 0) return k;
+    if (k > 32) return k > 40 ? 64 : k;
+    int p = 8;
+    while (p < k) p *= 2;
+    return p;
+}
+
 static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
                                const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts)
 {
@@ -992,10 +1017,12 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     if ((rc = smg_hierarchy_set_smoother(h, o.smoother, o.omega, o.jacobi_max_rows))) return rc;
     if ((rc = smg_hierarchy_set_chebyshev(h, o.cheby_fraction))) return rc;
     DeviceScope dsc(h->device);
-    rc = ensure_work(h, k);
+    const int kin = internal_cols(h, k);
+    rc = ensure_work(h, kin);
     if (rc) return rc;
-    if (h->precision == 1 && (rc = ensure_fp32(h, k))) return rc;
-    h->k = k;
+    if (h->precision == 1 && (rc = ensure_fp32(h, kin))) return rc;
+    h->k = kin; h->k_user = k;
+    h->coarse_cols = kin > k ? k : 0;
     const int nk = (int)h->known.size();
     // stage host inputs
     const double *dR = RHS, *dZ = z0, *dK = known_val;
@@ -1020,16 +1047,16 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     h->cur_kv = dK; h->cur_ld_kv = ldK;
     Level& L0 = h->lv[0];
     // z_u = z0(unknown)  (:310-311)  /  z = z0 (:97)
-    HIPCHK(launch_gather_in(L0.u.p, dZ, h->d_map0.p, L0.n, k, ldZ, h->stream));
+    HIPCHK(launch_gather_in(L0.u.p, dZ, h->d_map0.p, L0.n, k, kin, ldZ, h->stream));
     if (h->has_known) {
         // RHS_u = RHS(unknown) - Auk * known_val  (:316-318)
         const int nu = L0.n;
         HIPCHK(h->d_tmp_cm.ensure((size_t)nu * k));
         HIPCHK(launch_gather_cm(h->d_tmp_cm.p, dR, h->d_unknown.p, nu, k, ldR, nu, h->stream));
         HIPCHK(launch_csr_sub(nu, h->d_auk_ptr.p, h->d_auk_col.p, h->d_auk_val.p, dK, ldK, h->d_tmp_cm.p, nu, k, h->stream));
-        HIPCHK(launch_gather_in(L0.b.p, h->d_tmp_cm.p, h->d_perm0.p, nu, k, nu, h->stream));
+        HIPCHK(launch_gather_in(L0.b.p, h->d_tmp_cm.p, h->d_perm0.p, nu, k, kin, nu, h->stream));
     } else {
-        HIPCHK(launch_gather_in(L0.b.p, dR, h->d_map0.p, L0.n, k, ldR, h->stream));
+        HIPCHK(launch_gather_in(L0.b.p, dR, h->d_map0.p, L0.n, k, kin, ldR, h->stream));
     }
     // the residual history lives in HBM, sized from max_iter (the reference's r_his grows with the loop, .cpp:112)
     HIPCHK(h->d_rhis.ensure((size_t)std::max(h->max_iter, 1)));
@@ -1044,7 +1071,7 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
         if (h->precision != 0) return fail(SMG_ERR_INVALID, "a union handle solves in fp64 (no mixed-precision cycle)");
         if ((rc = union_begin_solve(h, k))) return rc;
     }
-    h->head_fuse = head_fusable(h, k);   // latched: both halves of every iteration of this solve follow it
+    h->head_fuse = head_fusable(h, kin);   // latched: both halves of every iteration of this solve follow it
     h->iters_enqueued = 0;
     h->in_solve = true;
     return SMG_OK;
@@ -1144,7 +1171,7 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
 {
     if (!h || !h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_end: no solve in progress");
     DeviceScope dsc(h->device);
-    const int n = h->n_full, k = h->k;
+    const int n = h->n_full, k = h->k_user;
     if (!z || ld_z < n) return fail(SMG_ERR_INVALID, "smg_solve_end: bad z / ld_z");
     Level& L0 = h->lv[0];
     double* dz = z;
@@ -1154,7 +1181,7 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
         dz = h->d_stage_z.p; ldz = n;
     }
     // z(unknown) = z_u ; z(known) = known_val  (:353-355)
-    HIPCHK(launch_scatter_out(dz, L0.u.p, h->d_map0.p, L0.n, k, ldz, h->stream));
+    HIPCHK(launch_scatter_out(dz, L0.u.p, h->d_map0.p, L0.n, k, h->k, ldz, h->stream));
     if (h->has_known)
         HIPCHK(launch_scatter_cm(dz, h->cur_kv, h->d_known.p, (int)h->known.size(), k, h->cur_ld_kv, ldz, h->stream));
     if (memspace == SMG_HOST)
@@ -1168,7 +1195,7 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     HIPCHK(hipMemcpyAsync(his.data(), h->d_rhis.p, (size_t)cap * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int cnt = std::max(0, std::min(std::min(hc.n_his, hc.his_cap), cap));
-    h->in_solve = false;
+    h->in_solve = false; h->coarse_cols = 0;
     prof_collect(h);
     if (r_his) for (int i = 0; i < cnt; i++) r_his[i] = his[i];
     if (n_his) *n_his = cnt;
@@ -1227,7 +1254,7 @@ extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const 
     int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
     if (rc) return rc;
     rc = run_outer_loop(h, [&](int n) { return enqueue_outer_iterations(h, n); });
-    if (rc) { h->in_solve = false; return rc; }
+    if (rc) { h->in_solve = false; h->coarse_cols = 0; return rc; }
     return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
 }
 
@@ -1299,7 +1326,7 @@ extern "C" int smg_solve_sharded(smg_hierarchy* h, const double* RHS, int ld_rhs
             }
             return SMG_OK;
         });
-        if (rc) { h->in_solve = false; return rc; }
+        if (rc) { h->in_solve = false; h->coarse_cols = 0; return rc; }
         return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
     });
 }

@@ -1245,12 +1245,13 @@ __global__ __launch_bounds__(256) void k_sym_gemv_sum(const T* __restrict__ part
 }
 
 template <typename T>
-static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, const Ctrl* ctrl, hipStream_t st, void* sym_work)
+// k columns of the row-major n x ld blocks b, u (ld >= k: the solve pads its blocks to kernel-friendly row lengths, the product is formed for the caller's columns only)
+static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u, int k, int ld, const Ctrl* ctrl, hipStream_t st, void* sym_work)
 {
     const int* done = ctrl ? &ctrl->done : never_done();
     const int nb = (n + 3) / 4;
     if (n <= 0) return hipSuccess;
-    if (k == 1 && sym_work && lda % 64 == 0 && lda >= 512) {
+    if (k == 1 && ld == 1 && sym_work && lda % 64 == 0 && lda >= 512) {
         const int nt = lda / 64;
         hipLaunchKernelGGL((k_sym_gemv_tiles<T>), dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Ainv, lda, b, (T*)sym_work, nt);
         hipLaunchKernelGGL((k_sym_gemv_sum<T>), dim3(nt), dim3(256), 0, st, (const T*)sym_work, nt, n, u, done);
@@ -1270,30 +1271,30 @@ static hipError_t launch_dense_T(const T* Ainv, int n, int lda, const T* b, T* u
                 // 64 columns: two column tiles per workgroup (92 -> 75 us at 3 952 unknowns, same bits; four: too few workgroups, 91 us; two tiles at 32
                 // columns: 54 -> 63 us).  SMG_COARSE_CPW=1 is the A/B knob.
                 static const int cpw = getenv("SMG_COARSE_CPW") ? atoi(getenv("SMG_COARSE_CPW")) : 2;
-                if (kc == 64 && cpw == 2) { hipLaunchKernelGGL((k_dense_gemm_mfma_multi<64, 2>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); c0 += kv; continue; }
+                if (kc == 64 && cpw == 2) { hipLaunchKernelGGL((k_dense_gemm_mfma_multi<64, 2>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done, kv); c0 += kv; continue; }
                 switch (kc) {
-                    case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
-                    case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
-                    default: hipLaunchKernelGGL((k_dense_gemm_mfma<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done, kv); break;
+                    case 64: hipLaunchKernelGGL((k_dense_gemm_mfma<64>), dim3(tb * 4), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done, kv); break;
+                    case 32: hipLaunchKernelGGL((k_dense_gemm_mfma<32>), dim3(tb * 2), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done, kv); break;
+                    default: hipLaunchKernelGGL((k_dense_gemm_mfma<16>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done, kv); break;
                 }
                 c0 += kv;
                 continue;
             }
         }
         switch (kc) {
-            case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            default: hipLaunchKernelGGL((k_dense_gemm_tile<16, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 64: hipLaunchKernelGGL((k_dense_gemm_tile<64, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
+            case 32: hipLaunchKernelGGL((k_dense_gemm_tile<32, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemm_tile<16, T>), dim3(tb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
         }
         c0 += kc;
     }
     for (; c0 < k; c0 += 4) {
         const int kb = (k - c0) < 4 ? (k - c0) : 4;
         switch (kb) {
-            case 1: hipLaunchKernelGGL((k_dense_gemv_add<1, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 2: hipLaunchKernelGGL((k_dense_gemv_add<2, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            case 3: hipLaunchKernelGGL((k_dense_gemv_add<3, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
-            default: hipLaunchKernelGGL((k_dense_gemv_add<4, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, k, done); break;
+            case 1: hipLaunchKernelGGL((k_dense_gemv_add<1, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
+            case 2: hipLaunchKernelGGL((k_dense_gemv_add<2, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
+            case 3: hipLaunchKernelGGL((k_dense_gemv_add<3, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
+            default: hipLaunchKernelGGL((k_dense_gemv_add<4, T>), dim3(nb), dim3(256), 0, st, Ainv, n, lda, b + c0, u + c0, ld, done); break;
         }
     }
     return hipGetLastError();
@@ -1312,15 +1313,15 @@ hipError_t launch_sym_gemv_tiles_f32(const float* Ainv, int lda, const float* b,
     hipLaunchKernelGGL((k_sym_gemv_tiles<float>), dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Ainv, lda, b, part, nt);
     return hipGetLastError();
 }
-hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
+hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k, int ld,
                                  const Ctrl* ctrl, hipStream_t st, double* sym_work)
 {
-    return launch_dense_T<double>(Ainv, n, lda, b, u, k, ctrl, st, sym_work);
+    return launch_dense_T<double>(Ainv, n, lda, b, u, k, ld, ctrl, st, sym_work);
 }
-hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
+hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k, int ld,
                                      const Ctrl* ctrl, hipStream_t st, float* sym_work)
 {
-    return launch_dense_T<float>(Ainv, n, lda, b, u, k, ctrl, st, sym_work);
+    return launch_dense_T<float>(Ainv, n, lda, b, u, k, ld, ctrl, st, sym_work);
 }
 
 // ---- mixed precision glue: fp64 outer iterate / residual  <->  fp32 V-cycle ----------------------------------------
@@ -1713,19 +1714,20 @@ hipError_t launch_spd_inverse(double* M, int n, double* work, hipStream_t st)
 
 // ---------------------------------------------------------------------------------------------- layout helpers
 
-__global__ void k_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src)
+// kin >= k: the internal block's row length (columns k .. kin - 1 are padding: zero on the way in, skipped on the way out)
+__global__ void k_gather_in(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_src)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)n * k) return;
-    const int i = (int)(t / k), c = (int)(t % k);
-    dst[t] = src[(size_t)map[i] + (size_t)c * ld_src];
+    if (t >= (size_t)n * kin) return;
+    const int i = (int)(t / kin), c = (int)(t % kin);
+    dst[t] = c < k ? src[(size_t)map[i] + (size_t)c * ld_src] : 0.0;
 }
-__global__ void k_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst)
+__global__ void k_scatter_out(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_dst)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)n * k) return;
     const int i = (int)(t / k), c = (int)(t % k);
-    dst[(size_t)map[i] + (size_t)c * ld_dst] = src[t];
+    dst[(size_t)map[i] + (size_t)c * ld_dst] = src[(size_t)i * kin + c];
 }
 __global__ void k_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst)
 {
@@ -2017,16 +2019,16 @@ hipError_t launch_add_at(double* v, const int* where, int n, double c, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src, hipStream_t st)
+hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_src, hipStream_t st)
 {
     if ((size_t)n * k == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_in, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, map, n, k, ld_src);
+    hipLaunchKernelGGL(k_gather_in, dim3(grid1d((size_t)n * kin, 256)), dim3(256), 0, st, dst, src, map, n, k, kin, ld_src);
     return hipGetLastError();
 }
-hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst, hipStream_t st)
+hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_dst, hipStream_t st)
 {
     if ((size_t)n * k == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scatter_out, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, map, n, k, ld_dst);
+    hipLaunchKernelGGL(k_scatter_out, dim3(grid1d((size_t)n * k, 256)), dim3(256), 0, st, dst, src, map, n, k, kin, ld_dst);
     return hipGetLastError();
 }
 hipError_t launch_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,

@@ -260,9 +260,10 @@ hipError_t launch_ss_finalize_decide(const double* partials, int n, Ctrl* ctrl, 
 // u[i,:] += sum_j Ainv[i,j] * b[j,:]   (mg_VCycle.cpp:199-200 with the factorisation pre-inverted)
 // sym_work (optional, (lda/64)^2 * 64 elements): with it, a single column (k = 1) is multiplied through the lower triangle of
 // tiles only (the inverse is symmetric): half the bytes, two launches, deterministic per-row summation in block order.
-hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k,
+// b, u: row-major n x ld blocks of which the first k columns take part (ld >= k)
+hipError_t launch_dense_gemv_add(const double* Ainv, int n, int lda, const double* b, double* u, int k, int ld,
                                  const Ctrl* ctrl, hipStream_t st, double* sym_work = nullptr);
-hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k,
+hipError_t launch_dense_gemv_add_f32(const float* Ainv, int n, int lda, const float* b, float* u, int k, int ld,
                                      const Ctrl* ctrl, hipStream_t st, float* sym_work = nullptr);
 // first half of the symmetric k = 1 product alone: part[(I * (lda / 64) + J) * 64 + r] = the share of tile (I, J) in row 64 I + r of Ainv b; lda % 64 == 0
 hipError_t launch_sym_gemv_tiles(const double* Ainv, int lda, const double* b, double* part, hipStream_t st);
@@ -306,11 +307,11 @@ hipError_t launch_assemble(int nV, int nF, int nnz, const double* V, const int* 
                            double* Md, double mass_coef, double lap_coef, double* val, double* Lval, hipStream_t st);
 
 // layout helpers ------------------------------------------------------------------------------------------
-// dst[i*k + c] = src[map[i] + c*ld_src]      (column-major caller block -> internal block)
-hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int ld_src,
+// dst[i*kin + c] = c < k ? src[map[i] + c*ld_src] : 0      (column-major caller block -> internal block of kin >= k columns per row)
+hipError_t launch_gather_in(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_src,
                             hipStream_t st);
-// dst[map[i] + c*ld_dst] = src[i*k + c]
-hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int ld_dst,
+// dst[map[i] + c*ld_dst] = src[i*kin + c], c < k
+hipError_t launch_scatter_out(double* dst, const double* src, const int* map, int n, int k, int kin, int ld_dst,
                               hipStream_t st);
 // dst[idx[i] + c*ld_dst] = src[i + c*ld_src]  (column-major -> column-major scatter, known values)
 hipError_t launch_scatter_cm(double* dst, const double* src, const int* idx, int n, int k, int ld_src, int ld_dst,

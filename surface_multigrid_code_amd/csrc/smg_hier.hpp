@@ -180,12 +180,12 @@ struct Level {
 // selection compares equal to the key it was captured with.  A new mode that changes the launch sequence or a kernel argument of the
 // cycle gets a field HERE (one place), not a hand-written comparison.
 struct GraphKey {
-    int k = 0, pre = 0, post = 0, precision = 0, smoother = 0, jacobi_max_rows = 0;
+    int k = 0, k_user = 0, pre = 0, post = 0, precision = 0, smoother = 0, jacobi_max_rows = 0;
     double omega = 0.0, cheby_fraction = 0.0;
     bool head_fuse = false;
     bool operator==(const GraphKey& o) const
     {
-        return k == o.k && pre == o.pre && post == o.post && precision == o.precision && smoother == o.smoother &&
+        return k == o.k && k_user == o.k_user && pre == o.pre && post == o.post && precision == o.precision && smoother == o.smoother &&
                jacobi_max_rows == o.jacobi_max_rows && omega == o.omega && cheby_fraction == o.cheby_fraction && head_fuse == o.head_fuse;
     }
     bool operator!=(const GraphKey& o) const { return !(*this == o); }
@@ -286,7 +286,9 @@ struct smg_hierarchy {
     int kcap = 0;
     // ---- solve state ----
     bool in_solve = false;
-    int k = 0;
+    int k = 0;                      // columns of the internal blocks of the solve in progress (internal_cols(k_user): smg_cycle.cpp)
+    int k_user = 0;                 // the caller's column count
+    int coarse_cols = 0;            // > 0 during a padded solve: the dense coarse product takes these (the caller's) columns only
     double tol = 1e-3;
     int max_iter = 20, pre = 2, post = 2, verbosity = 0, check_every = 1, use_graph = 1, precision = 0;
     // ---- smoother selection (smg_hierarchy_set_smoother / smg_solve_opts): 0 GS everywhere (reference), 1 Jacobi, 2 hybrid ----

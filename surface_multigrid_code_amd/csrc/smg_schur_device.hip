@@ -391,7 +391,7 @@ template <> struct SchurPtrs<double> {
     static double* g(const SchurDev& F) { return F.g; }
     static double* xs(const SchurDev& F) { return F.xs; }
     static hipError_t dense(const SchurDev& F, int k, const Ctrl* ctrl, hipStream_t st)
-    { return launch_dense_gemv_add(F.arena + F.off_S, F.ns, F.ns_pad, F.g, F.xs, k, ctrl, st, nullptr); }
+    { return launch_dense_gemv_add(F.arena + F.off_S, F.ns, F.ns_pad, F.g, F.xs, k, k, ctrl, st, nullptr); }
     static hipError_t tiles(const SchurDev& F, hipStream_t st) { return launch_sym_gemv_tiles(F.arena + F.off_S, F.ns_pad, F.g, F.sym_work, st); }
 };
 template <> struct SchurPtrs<float> {
@@ -399,7 +399,7 @@ template <> struct SchurPtrs<float> {
     static float* g(const SchurDev& F) { return F.g32; }
     static float* xs(const SchurDev& F) { return F.xs32; }
     static hipError_t dense(const SchurDev& F, int k, const Ctrl* ctrl, hipStream_t st)
-    { return launch_dense_gemv_add_f32(F.arena32 + F.off_S, F.ns, F.ns_pad, F.g32, F.xs32, k, ctrl, st, nullptr); }
+    { return launch_dense_gemv_add_f32(F.arena32 + F.off_S, F.ns, F.ns_pad, F.g32, F.xs32, k, k, ctrl, st, nullptr); }
     static hipError_t tiles(const SchurDev& F, hipStream_t st) { return launch_sym_gemv_tiles_f32(F.arena32 + F.off_S, F.ns_pad, F.g32, (float*)F.sym_work, st); }
 };
 

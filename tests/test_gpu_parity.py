@@ -689,7 +689,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import numpy as np
 import surface_multigrid_code_amd as smg
 from problems import subdiv_problem
-for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2), ("poisson", 5)):     # the tiles take columns in groups of up to 3: 1, 3, 2, 3 + 2
+for kind, k in (("mcf", 1), ("mcf", 3), ("poisson", 2), ("poisson", 5), ("mcf", 7), ("poisson", 13)):     # the tiles take columns in groups of up to 3: 1, 3, 2, 3 + 2; 5, 7, 13: padded solves
     p = subdiv_problem(kind=kind, k=k, n_sub=3)
     mg = smg.Hierarchy.from_prolongs(p["Ps"])
     mg.precompute(p["A"], p["known"])
@@ -708,7 +708,8 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
     """The launch-count / latency shortcuts of the cycle -- the restriction launch producing the first colour of the coarse level's
     first sweep (SMG_FUSE_FIRST), small colour sweeps confined to one XCD (SMG_ONE_XCD_MAX), the whole panel pitch requested
     ahead on tiny launches (SMG_PITCH_SPEC_MAX), relax() of the latency-bound levels as ONE launch by overlapped tiling (SMG_TILED,
-    csrc/smg_tiled.hpp: levels 1 and 2 of this hierarchy), four outer iterations in one graph (SMG_GRAPH_ITERS) -- are re-orderings of WHERE and WHEN the same arithmetic runs: a full-depth
+    csrc/smg_tiled.hpp: levels 1 and 2 of this hierarchy), four outer iterations in one graph (SMG_GRAPH_ITERS), the solve's internal blocks padded to
+    kernel-friendly column counts (SMG_PAD_COLS: 5 -> 8, 7 -> 8, 13 -> 16 columns) -- are re-orderings of WHERE and WHEN the same arithmetic runs: a full-depth
     V-cycle and a solve on a 4-level hierarchy give identical bits with all of them off.  (The knobs are read once per process,
     hence the two child processes.)"""
     import subprocess, sys
@@ -718,11 +719,11 @@ def test_launch_shortcuts_do_not_change_a_bit(smg):
         env = dict(os.environ)
         env["SMG_DEVICE_FILL_MIN"] = "1000"     # the panels of every big enough A filled on the device from the caller's arrays + the permutation ...
         if off:
-            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0", SMG_DEVICE_FILL="0", SMG_GRAPH_ITERS="1")   # ... or built on the host; one outer iteration per graph instead of four
+            env.update(SMG_FUSE_FIRST="0", SMG_ONE_XCD_MAX="0", SMG_PITCH_SPEC_MAX="0", SMG_TILED="0", SMG_DEVICE_FILL="0", SMG_GRAPH_ITERS="1", SMG_PAD_COLS="0")   # ... or built on the host; one outer iteration per graph instead of four; no column padding
         r = subprocess.run([sys.executable, "-c", _SHORTCUT_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("mcf", "poisson"))]
-        assert len(lines) == 4, r.stdout
+        assert len(lines) == 6, r.stdout
         outs.append(lines)
     assert all(int(ln.split()[2]) >= 4 for ln in outs[0])   # deep enough for the fused restriction to be in play
     # ... and it IS in play on every coarse smoothed level, whether the host or the device filled its image (the device works the diagonal

@@ -9,6 +9,6 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 mg, A, Mb, Vf, Ff, label, _ = B.build_workload(wl, smg, mesh)
 mg.precompute(A)
 print(label)
-for k in (1, 2, 3, 4, 8, 16, 32, 64):
+for k in [int(x) for x in os.environ.get("SMG_TOOL_KS", "1,2,3,4,5,6,7,8,12,16,32,64").split(",")]:
     us = mg.bench_vcycle(0, k, 2, 2, 50 if k <= 8 else 20)
     print("k = %2d: %8.1f us per V(2,2) cycle, %7.1f us per column" % (k, us, us / k), flush=True)
