@@ -26,8 +26,9 @@ using namespace smg;
 // ------------------------------------------------------------------------------------------------ V-cycle
 
 // ---- overlapped tiling of the Gauss-Seidel sweeps of the latency-bound levels (smg_tiled.hpp): relax(sweeps) as ONE launch ----------
-// Which levels: scalar fp64 hierarchies, up to 7 columns (groups of 3 per launch; 8 and more take the wide colour kernels), Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 2048 ..
-// 100000: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows), at most 5 colours and 12 entries per row.
+// Which levels: scalar fp64 hierarchies, up to 7 columns (groups of 3 per launch; 8 and more take the wide colour kernels), Gauss-Seidel, SMG_TILED_MIN_ROWS <= rows <= SMG_TILED_MAX_ROWS (default 512 ..
+// 122880 = one round of 240 parts of 512 rows: above, the redundant halo work of the tiles costs more than the launches it saves -- measured at C3 level 1, 253 k rows, and again on a 160 k-row
+// union level; below 2 048 rows it pays as well: a 768-row level 37.5 -> 18.0 us per visit, tools/size_sweep.py), at most 5 colours and 12 entries per row.
 // SMG_TILED=0 switches it off (A/B knob; the results are bit-identical either way).
 // The plans of the one-launch / piece-wise / block-wise sweeps hold copies of the level's values; the maps that refresh them (value slot -> index into
 // Level::d_Aval) are only needed by a value-only re-precompute: they stay on the host until the first one (a quarter of a plan's bytes).
@@ -39,7 +40,7 @@ static hipError_t ensure_map(DevBuf<int>& d, const std::vector<int>& host)
 static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
 {
     static const int on = env_int("SMG_TILED", 1);
-    static const int max_rows = env_int("SMG_TILED_MAX_ROWS", 100000), min_rows = env_int("SMG_TILED_MIN_ROWS", 2048);
+    static const int max_rows = env_int("SMG_TILED_MAX_ROWS", 122880), min_rows = env_int("SMG_TILED_MIN_ROWS", 512);
     if (!on || h->bs != 1 || k < 1 || k > 7 || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || sweeps > 3) return false;
     if (level_kind(h, lv) != LV_GS) return false;
     const int n = h->lv[lv].n;
@@ -62,8 +63,11 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
     // Tile size (measured at C3, tools/tiled_sweep.sh): parts of 128 .. 256 rows, 512 threads (one row of every colour per thread).
     // Smaller tiles put more CUs to work but the halo of P rings then dominates (6x redundant row updates at 64 rows: slower);
     // larger ones run too few workgroups.
+    // Beyond 65 536 rows parts of 256 rows are more workgroups than the part has compute units (a second round of them: tools/size_sweep.py, a
+    // 69 120-row level 45.8 us per visit against 28 us at 56 320 rows): the parts grow to 512 rows so that the level stays one round up to 122 880
+    // rows (69 120 rows: 34.2 us, 77 824: 43.4 -> 32.2, 101 376: 47.5 (colour launches) -> 36.7; at 30 720 rows parts of 512 rows lose: 25.1 -> 28.0).
     static const int rows_env = env_int("SMG_TILED_ROWS", 0), nt_env = env_int("SMG_TILED_NT", 0);
-    const int tile_rows0 = rows_env > 0 ? rows_env : 256;
+    const int tile_rows0 = rows_env > 0 ? rows_env : std::min(512, std::max(256, (Lv.n + 239) / 240));
     constexpr int max_ext = (64 * 1024 - TILED_LDS_STATIC) / 8;    // 64 KB of LDS, the kernel's static header included
     // the matrix the smoother streams, in the internal numbering; entry -> index into the level's values in the caller's CSR order
     std::vector<int> tsrc;
