@@ -482,6 +482,10 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     nbest = count_colors(best);
     lap("iterated greedy", nbest);
     if (heavy) return coloring_is_valid(A, best) ? best : fallback;
+    // Wide graphs of any size (the Galerkin levels of the reference's own hierarchies: 18 - 30 entries per row, 10 - 15 colours) stop here too: such a
+    // level is swept piece-wise (csrc/smg_wgs.hpp), where a colour is not a launch, and the class-dissolving searches below cost more than everything
+    // else in the first precompute of a small mesh (ogre.obj: 47 of 96 ms for taking the 5 038-row level from 11 colours to 10).
+    if (A.nnz() > 12L * A.nr) return coloring_is_valid(A, best) ? best : fallback;
     // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle, 4 with an odd wheel)
     const int floor_colors = (nbest > 3 && has_odd_wheel(A)) ? 4 : 3;
     for (int guard = 0; guard < 6 && nbest > floor_colors; guard++) {
