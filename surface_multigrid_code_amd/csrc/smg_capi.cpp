@@ -128,7 +128,9 @@ void smg::drop_graphs(smg_hierarchy* h)
     if (h->g_resid) (void)hipGraphExecDestroy(h->g_resid);
     if (h->g_cycle) (void)hipGraphExecDestroy(h->g_cycle);
     if (h->g_spec) (void)hipGraphExecDestroy(h->g_spec);
-    h->g_iter = h->g_iter_n = h->g_resid = h->g_cycle = h->g_spec = nullptr;
+    if (h->g_rd) (void)hipGraphExecDestroy(h->g_rd);
+    if (h->g_cyc) (void)hipGraphExecDestroy(h->g_cyc);
+    h->g_iter = h->g_iter_n = h->g_resid = h->g_cycle = h->g_spec = h->g_rd = h->g_cyc = nullptr;
     h->g_key = smg::GraphKey();
 }
 

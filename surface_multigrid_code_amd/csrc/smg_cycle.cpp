@@ -917,6 +917,11 @@ static int ensure_graphs(smg_hierarchy* h)
     if (!h->union_m) {      // (a union has no split-phase iteration: its members stop one by one)
         rc = capture_split_graphs(h, h->g_sumsq_ptr ? h->g_sumsq_ptr : &h->d_ctrl.p->sumsq);
         if (rc) return rc;
+        // the two halves of an iteration the host looks into (enqueue_checked_iteration)
+        rc = capture_graph(h, &h->g_rd, [&]() { return enqueue_residual_ss(h, k, true); });
+        if (rc) return rc;
+        rc = capture_graph(h, &h->g_cyc, [&]() { return enqueue_cycle_part(h, k, nullptr); });
+        if (rc) return rc;
     }
     h->g_key = key;
     return SMG_OK;
@@ -951,6 +956,31 @@ static int enqueue_outer_iteration(smg_hierarchy* h)
         if (rc) return rc;
     }
     h->iters_enqueued++;
+    return SMG_OK;
+}
+
+// One outer iteration the host looks INTO: residual + break test, a look at the flag, and the V-cycle only if the loop goes on.  An iteration
+// enqueued whole runs its cycle even when its own break test has just fired (every launch after the break stores nothing, but does its work):
+// the last iteration of every solve -- 0.31 ms at C3, of a 3.6 ms solve; a whole cycle more than the one a tol = 1e-3 solve of a small mesh
+// needs.  The host looks at the flag after every chunk of iterations anyway; where the chunk is a single iteration (the end of every solve
+// under the adaptive schedule), the look moves in front of the cycle.  Same launches in the same order as the whole iteration.
+static int enqueue_checked_iteration(smg_hierarchy* h, Ctrl* seen)
+{
+    const bool graphs = graphs_usable(h);
+    if (graphs) {
+        int rc = ensure_graphs(h);
+        if (rc) return rc;
+        HIPCHK(hipGraphLaunch(h->g_rd, h->stream));
+    } else {
+        int rc = enqueue_residual_ss(h, h->k, true);
+        if (rc) return rc;
+    }
+    h->iters_enqueued++;      // (its residual is recorded whether or not the cycle follows)
+    HIPCHK(hipMemcpyAsync(seen, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));      // (the flag and what the adaptive schedule reads)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (seen->done) return SMG_OK;
+    if (graphs) HIPCHK(hipGraphLaunch(h->g_cyc, h->stream));
+    else { int rc = enqueue_cycle_part(h, h->k, nullptr); if (rc) return rc; }
     return SMG_OK;
 }
 
@@ -1226,26 +1256,35 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
 // on this: an iteration enqueued after the break stores nothing).  The schedule is a function of the residual history alone, so the
 // ranks of a column-sharded solve -- who all see the same reduced residuals -- enqueue (and reduce) the same number of times.
 template <typename Iter>
-static int run_outer_loop(smg_hierarchy* h, Iter&& iterations)
+static int run_outer_loop(smg_hierarchy* h, Iter&& iterations, bool look_into_single_iterations = false)
 {
     int it = 0;
     int chunk_next = 1;
+    static const int look_env = env_int("SMG_LOOK_INTO", 1);      // A/B knob
+    const bool look = look_into_single_iterations && look_env != 0;
     while (it < h->max_iter) {
         const int want = h->check_every > 0 ? h->check_every : chunk_next;
         const int chunk = std::min(want, h->max_iter - it);
-        { int rc = iterations(chunk); if (rc) return rc; }
-        it += chunk;
-        if (it < h->max_iter) {
-            Ctrl hc;
+        Ctrl hc;
+        if (look && chunk == 1) {
+            // the look happens between the iteration's break test and its cycle; the cycle is enqueued behind it and the loop goes straight on
+            int rc = enqueue_checked_iteration(h, &hc);
+            if (rc) return rc;
+            if (hc.done) break;
+            it += 1;
+        } else {
+            { int rc = iterations(chunk); if (rc) return rc; }
+            it += chunk;
+            if (it >= h->max_iter) break;
             hipError_t e = hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return fail(SMG_ERR_HIP, "smg_solve: %s", hipGetErrorString(e));
             if (hc.done) break;
-            chunk_next = 1;
-            if (h->check_every == 0 && hc.n_his >= 2 && hc.r_last > 0.0 && hc.r_last < hc.r_prev && h->tol > 0.0 && hc.r_last > h->tol) {
-                const double need = std::ceil(std::log(h->tol / hc.r_last) / std::log(hc.r_last / hc.r_prev));   // more residuals until < tol
-                if (need > 2.0) chunk_next = (int)std::min(need - 1.0, 64.0);
-            }
+        }
+        chunk_next = 1;
+        if (h->check_every == 0 && hc.n_his >= 2 && hc.r_last > 0.0 && hc.r_last < hc.r_prev && h->tol > 0.0 && hc.r_last > h->tol) {
+            const double need = std::ceil(std::log(h->tol / hc.r_last) / std::log(hc.r_last / hc.r_prev));   // more residuals until < tol
+            if (need > 2.0) chunk_next = (int)std::min(need - 1.0, 64.0);
         }
     }
     return SMG_OK;
@@ -1257,7 +1296,7 @@ extern "C" int smg_solve(smg_hierarchy* h, const double* RHS, int ld_rhs, const 
 {
     int rc = smg_solve_begin(h, RHS, ld_rhs, known_val, ld_kv, z0, ld_z0, k, memspace, opts);
     if (rc) return rc;
-    rc = run_outer_loop(h, [&](int n) { return enqueue_outer_iterations(h, n); });
+    rc = run_outer_loop(h, [&](int n) { return enqueue_outer_iterations(h, n); }, h->union_m == 0);
     if (rc) { h->in_solve = false; h->coarse_cols = 0; return rc; }
     return smg_solve_end(h, z, ld_z, memspace, r_his, n_his, converged);
 }

@@ -307,6 +307,7 @@ struct smg_hierarchy {
     // ---- hipGraph cache (one outer iteration; and its two halves for the split-phase API) ----
     hipGraphExec_t g_iter = nullptr, g_resid = nullptr, g_cycle = nullptr;
     hipGraphExec_t g_iter_n = nullptr;    // graph_iters() outer iterations in one graph (smg_cycle.cpp: enqueue_outer_iterations)
+    hipGraphExec_t g_rd = nullptr, g_cyc = nullptr;   // residual + break test | the cycle that follows it: an iteration the host looks into (enqueue_checked_iteration)
     double* g_sumsq_ptr = nullptr;   // the buffer g_resid writes / g_cycle reads (the caller's all-reduce buffer, or ctrl->sumsq)
     smg::GraphKey g_key;             // what the cached graphs were captured with (k == 0: nothing cached)
     bool head_fuse = false;          // this solve takes the outer residual out of the first sweep (latched at smg_solve_begin)
