@@ -959,6 +959,16 @@ static int enqueue_outer_iteration(smg_hierarchy* h)
     return SMG_OK;
 }
 
+// the control block as the stream has it now (one synchronisation); through page-locked memory
+static int read_ctrl(smg_hierarchy* h, Ctrl* out)
+{
+    HIPCHK(h->pin_ctrl.ensure(1));
+    HIPCHK(hipMemcpyAsync(h->pin_ctrl.p, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = *h->pin_ctrl.p;
+    return SMG_OK;
+}
+
 // One outer iteration the host looks INTO: residual + break test, a look at the flag, and the V-cycle only if the loop goes on.  An iteration
 // enqueued whole runs its cycle even when its own break test has just fired (every launch after the break stores nothing, but does its work):
 // the last iteration of every solve -- 0.31 ms at C3, of a 3.6 ms solve; a whole cycle more than the one a tol = 1e-3 solve of a small mesh
@@ -976,8 +986,7 @@ static int enqueue_checked_iteration(smg_hierarchy* h, Ctrl* seen)
         if (rc) return rc;
     }
     h->iters_enqueued++;      // (its residual is recorded whether or not the cycle follows)
-    HIPCHK(hipMemcpyAsync(seen, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));      // (the flag and what the adaptive schedule reads)
-    HIPCHK(hipStreamSynchronize(h->stream));
+    { int rc = read_ctrl(h, seen); if (rc) return rc; }      // (the flag and what the adaptive schedule reads)
     if (seen->done) return SMG_OK;
     if (graphs) HIPCHK(hipGraphLaunch(h->g_cyc, h->stream));
     else { int rc = enqueue_cycle_part(h, h->k, nullptr); if (rc) return rc; }
@@ -1026,6 +1035,9 @@ static int internal_cols(const smg_hierarchy* h, int k)
     return p;
 }
 
+// host blocks of up to 1 MiB travel through page-locked staging (pin_vec): packed by the host, one DMA each way
+static bool small_host_block(int n, int k) { return (size_t)n * k * 8 <= ((size_t)1 << 20); }
+
 static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs, const double* known_val, int ld_kv,
                                const double* z0, int ld_z0, int k, int memspace, const smg_solve_opts* opts)
 {
@@ -1064,8 +1076,19 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     if (memspace == SMG_HOST) {
         HIPCHK(h->d_stage_rhs.ensure((size_t)n * k));
         HIPCHK(h->d_stage_z.ensure((size_t)n * k));
-        HIPCHK(hipMemcpy2DAsync(h->d_stage_rhs.p, (size_t)n * 8, RHS, (size_t)ld_rhs * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpy2DAsync(h->d_stage_z.p, (size_t)n * 8, z0, (size_t)ld_z0 * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
+        if (small_host_block(n, k)) {
+            // small blocks: packed into page-locked memory by the host, then ONE copy each
+            HIPCHK(h->pin_vec.ensure((size_t)2 * n * k));
+            for (int c = 0; c < k; c++) {
+                std::memcpy(h->pin_vec.p + (size_t)c * n, RHS + (size_t)c * ld_rhs, (size_t)n * 8);
+                std::memcpy(h->pin_vec.p + (size_t)(k + c) * n, z0 + (size_t)c * ld_z0, (size_t)n * 8);
+            }
+            HIPCHK(hipMemcpyAsync(h->d_stage_rhs.p, h->pin_vec.p, (size_t)n * k * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_stage_z.p, h->pin_vec.p + (size_t)n * k, (size_t)n * k * 8, hipMemcpyHostToDevice, h->stream));
+        } else {
+            HIPCHK(hipMemcpy2DAsync(h->d_stage_rhs.p, (size_t)n * 8, RHS, (size_t)ld_rhs * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpy2DAsync(h->d_stage_z.p, (size_t)n * 8, z0, (size_t)ld_z0 * 8, (size_t)n * 8, k, hipMemcpyHostToDevice, h->stream));
+        }
         dR = h->d_stage_rhs.p; dZ = h->d_stage_z.p; ldR = n; ldZ = n;
         if (h->has_known) {
             HIPCHK(h->d_stage_kv.ensure((size_t)nk * k));
@@ -1218,16 +1241,23 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     HIPCHK(launch_scatter_out(dz, L0.u.p, h->d_map0.p, L0.n, k, h->k, ldz, h->stream));
     if (h->has_known)
         HIPCHK(launch_scatter_cm(dz, h->cur_kv, h->d_known.p, (int)h->known.size(), k, h->cur_ld_kv, ldz, h->stream));
-    if (memspace == SMG_HOST)
+    const bool z_pinned = memspace == SMG_HOST && small_host_block(n, k);
+    if (z_pinned) {
+        HIPCHK(h->pin_vec.ensure((size_t)2 * n * k));
+        HIPCHK(hipMemcpyAsync(h->pin_vec.p, dz, (size_t)n * k * 8, hipMemcpyDeviceToHost, h->stream));
+    } else if (memspace == SMG_HOST)
         HIPCHK(hipMemcpy2DAsync(z, (size_t)ld_z * 8, dz, (size_t)n * 8, (size_t)n * 8, k, hipMemcpyDeviceToHost, h->stream));
-    static thread_local Ctrl hc;
-    static thread_local std::vector<double> his;
+    Ctrl hc;
     // the history can hold at most one entry per enqueued iteration: fetched together with the control block, one synchronisation
     const int cap = (int)std::min<size_t>(h->d_rhis.n, (size_t)std::max(std::min(h->iters_enqueued, std::max(h->max_iter, 1)), 1));
-    his.resize((size_t)cap);
-    HIPCHK(hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(his.data(), h->d_rhis.p, (size_t)cap * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h->pin_his.ensure((size_t)cap));
+    HIPCHK(h->pin_ctrl.ensure(1));
+    const double* his = h->pin_his.p;
+    HIPCHK(hipMemcpyAsync(h->pin_ctrl.p, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pin_his.p, h->d_rhis.p, (size_t)cap * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    hc = *h->pin_ctrl.p;
+    if (z_pinned) for (int c = 0; c < k; c++) std::memcpy(z + (size_t)c * ld_z, h->pin_vec.p + (size_t)c * n, (size_t)n * 8);
     const int cnt = std::max(0, std::min(std::min(hc.n_his, hc.his_cap), cap));
     h->in_solve = false; h->coarse_cols = 0;
     prof_collect(h);
@@ -1276,9 +1306,7 @@ static int run_outer_loop(smg_hierarchy* h, Iter&& iterations, bool look_into_si
             { int rc = iterations(chunk); if (rc) return rc; }
             it += chunk;
             if (it >= h->max_iter) break;
-            hipError_t e = hipMemcpyAsync(&hc, h->d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) return fail(SMG_ERR_HIP, "smg_solve: %s", hipGetErrorString(e));
+            { int rc = read_ctrl(h, &hc); if (rc) return rc; }
             if (hc.done) break;
         }
         chunk_next = 1;

@@ -25,6 +25,27 @@ namespace smg {
 // bytes of device memory currently held by all DevBufs of the process (smg_device_bytes_live(): memory budget reporting)
 inline std::atomic<long long>& devbuf_live_bytes() { static std::atomic<long long> v{0}; return v; }
 
+// page-locked host memory (the small transfers of a solve: control block, residual history, the vectors of a small mesh -- a copy to or from
+// pageable memory goes through the runtime's own staging and costs tens of microseconds per call, a good part of a 0.4 ms solve)
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() { release(); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -282,6 +303,9 @@ struct smg_hierarchy {
     smg::DevBuf<smg::Ctrl> d_ctrl;
     smg::Ctrl host_ctrl;            // staging of the control block smg_solve_begin uploads (must outlive the asynchronous copy)
     smg::DevBuf<double> d_rhis;     // residual history (Ctrl::r_his points here), at least max_iter entries
+    smg::PinBuf<smg::Ctrl> pin_ctrl;   // where the host reads the control block to (read_ctrl)
+    smg::PinBuf<double> pin_his;       // ... and the residual history at the end of a solve
+    smg::PinBuf<double> pin_vec;       // host-buffer solves of small systems: RHS and z0 on their way in, z on its way out
     smg::DevBuf<double> d_partials;
     int kcap = 0;
     // ---- solve state ----

@@ -16,8 +16,8 @@ n = A.shape[0]
 rhs = np.asfortranarray((Mb @ np.random.default_rng(3).uniform(-1, 1, n))[:, None]); z0 = np.zeros_like(rhs)
 cyc = mg.bench_vcycle(0, 1, 2, 2, 200)
 print("%s: %d rows, V(2,2) cycle %.1f us graph-replayed" % (name, n, cyc))
-for tol in (1e-1, 1e-3, 1e-6, 1e-10):
-    for ce in (0, 1):
+for tol in [float(x) for x in os.environ.get("SMG_TOOL_TOLS", "1e-1,1e-3,1e-6,1e-10").split(",")]:
+    for ce in ((0,) if os.environ.get("SMG_TOOL_TOLS") else (0, 1)):
         o = smg.SolveOpts(tol=tol, max_iter=60, check_every=ce)
         mg.solve(rhs, z0, None, o)
         ts = []
