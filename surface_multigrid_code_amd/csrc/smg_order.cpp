@@ -323,14 +323,14 @@ struct Recolor {
         // Kempe passes with growing component caps: the expensive caps only ever see the few survivors
         // small graphs (coarse levels) get an all-out search: a clean 4-colouring there is inherited by every finer
         // subdivision level for free (subdivision_colors), and costs little in absolute terms
-        const bool small = A.nr <= 70000 && K <= 4;   // only the 5 -> 4 step is worth an all-out search
+        const bool small = A.nr <= 70000 && K == 4;   // only the 5 -> 4 step is worth an all-out search (the 4 -> 3 step of a regular mesh gets the cheap passes: 0.39 s on a 51 200-row torus otherwise)
         const int caps_small[] = {256, 2048, 16384, 1 << 30};
         const int caps_big[] = {256, 2048, 16384};
         const int* caps = small ? caps_small : caps_big;
         const int ncaps = small ? 4 : 3;
         // (on a big mesh level the walk below does the cheap Kempe pass's work at a third of its price: 1 011 330 rows, 5 054 stragglers: pass with cap 256
         //  0.36 s for 3 064 of them + walk 0.17 s for the rest, against the walk alone 0.40 s)
-        const bool walk_first = K <= 4 && A.nr > 100000;
+        const bool walk_first = K == 4 && A.nr > 100000;
         auto balls = [&]() {
             todo.swap(left); left.clear();
             for (int v : todo) {
@@ -368,7 +368,7 @@ struct Recolor {
             // class of a handful of rows.  Component caps grow like those of the Kempe passes: small components are cheap to swap and settle nearly
             // everybody (252 834-row mesh level: 5 542 stragglers -> 17 at cap 128), the few survivors get the big ones.
             walk_budget = 2000L * A.nr + 4000000L;
-            if (!left.empty() && (K <= 4 || left.size() <= 64)) {
+            if (!left.empty() && (K == 4 || left.size() <= 64)) {
                 const int caps_walk[] = {128, 512, 2048, 8192, 32768, 1 << 30};
                 for (int wi = 0; wi < 6 && !left.empty() && walk_budget > 0; wi++) {
                     if (caps_walk[wi] > 32768 && A.nr > 70000) break;
@@ -489,6 +489,9 @@ static std::vector<int> color_graph(const Csr& A, const std::vector<int>& rcm)
     // dissolve the smallest class while that succeeds (3 colours is the floor for any mesh with a triangle, 4 with an odd wheel)
     const int floor_colors = (nbest > 3 && has_odd_wheel(A)) ? 4 : 3;
     for (int guard = 0; guard < 6 && nbest > floor_colors; guard++) {
+        // below four colours only small graphs are searched: a mesh without an odd wheel (a regular torus) may be 3-colourable, but two of three colours
+        // are two thirds of the vertices -- every Kempe component is the whole graph -- and the attempt cost 1.5 s on a 901 120-row torus, mostly in vain
+        if (nbest <= 4 && A.nr > 70000) break;
         cur = best;
         const bool emptied = dissolve_top_class(A, cur, nbest - 1);
         best = cur;  // partial progress is kept: the colouring stays valid
