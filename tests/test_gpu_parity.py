@@ -682,6 +682,37 @@ def test_block_hierarchy_solves_a_3dof_system(smg, oracle_mod):
     assert np.linalg.norm(rhs - A @ a[1]) < 1.5e-10
 
 
+def test_relax_bit_exact_at_the_ends_of_the_one_launch_range(smg, oracle_mod):
+    """relax() as one launch (overlapped tiling, csrc/smg_tiled.hpp) now also serves levels of 512 - 2 047 rows and, with parts of up to 512 rows, levels
+    of 65 537 - 122 880 rows (tools/size_sweep.py: a 768-row level 37.5 -> 18.1 us per visit, a 69 120-row level 45.8 -> 33.9): Gauss-Seidel stays the
+    oracle's lexicographic sweep on the level's numbering, bit for bit, on a 768-row and a 69 120-row level, one and three columns, 1 - 3 sweeps."""
+    mesh = smg.mesh
+    for (nu, nv), levels in (((16, 12), (0, 2)), ((36, 30), (0,))):
+        V, F = mesh.torus(nu, nv)
+        mg, Vf, Ff = smg.mg_precompute_subdiv(V, F, 3, n_extra_levels=0)
+        Vf = mesh.normalize_unit_area(Vf, Ff)
+        A = (mesh.massmatrix(Vf, Ff, "barycentric") - 0.01 * mesh.cotmatrix(Vf, Ff)).tocsr()
+        A.sort_indices()
+        mg.precompute(A)
+        rng = np.random.default_rng(11)
+        for lv in levels:
+            n = mg.rows(lv)
+            assert n in (12288, 768, 69120)
+            for k in (1, 3):
+                b, x = rng.uniform(-1, 1, (n, k)), rng.uniform(-1, 1, (n, k))
+                for iters in (1, 2, 3):
+                    assert gs_bit_exact(oracle_mod, mg, lv, b, x, iters), "relax(%d) not bit-exact on the %d-row level, %d columns" % (iters, n, k)
+        # ... and a solve on the hierarchy agrees with the oracle's
+        rhs = np.asfortranarray((mesh.massmatrix(Vf, Ff, "barycentric") @ rng.uniform(-1, 1, A.shape[0]))[:, None])
+        z0 = np.zeros_like(rhs)
+        a = mg.solve(rhs, z0, None, smg.SolveOpts(tol=1e-10, max_iter=40))
+        o = oracle_mod.OracleMG([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
+        o.precompute(A)
+        bref = o.solve(rhs, z0, tol=1e-10, max_iter=40)
+        assert a[0] and bref[0] and abs(len(a[2]) - len(bref[2])) <= 2
+        assert np.linalg.norm(a[1] - bref[1]) <= 1e-8 * np.linalg.norm(bref[1])
+
+
 # ----------------------------------------------------------------------------------------------- launch shortcuts
 _SHORTCUT_CHILD = r"""
 import hashlib, os, sys
