@@ -254,6 +254,21 @@ static int ensure_wgs(smg_hierarchy* h, int lv)
     return SMG_OK;
 }
 
+// Called by the first precompute for a level whose images exist, while its device half would otherwise wait for the host half (smg_precompute.cpp):
+// the plans prepare_tiled() below would build at the first solve with the handle's present selection (smoother, pre / post sweeps), one column.
+// Small levels only (a plan of tens of milliseconds at most: the 63 210-row Galerkin level of decimated C3 64 ms, its 252 834-row level 220 ms -- building
+// that one here kept level 0's images waiting and cost the precompute more than it saved the first solve).  First smg_solve on a fresh handle:
+// bunny.obj 8.4 -> 4.2 ms, ogre.obj 17 -> 11 ms (tools/first_solve.py).
+int smg::prepare_level_plans(smg_hierarchy* h, int lv)
+{
+    static const int on = env_int("SMG_EARLY_PLANS", 1), max_rows = env_int("SMG_EARLY_PLANS_MAX_ROWS", 70000);      // A/B knobs
+    if (!on || lv <= 0 || lv >= h->n_levels - 1 || h->precision != 0 || h->lv[lv].n > max_rows) return SMG_OK;
+    const int sa = h->pre, sb = h->post;
+    for (int sw : {sa, sb}) if (sw > 0 && tiled_wanted(h, lv, 1, sw)) { int rc = ensure_tiled(h, lv, sw); if (rc) return rc; }
+    if (wgs_wanted(h, lv, 1) && !h->lv[lv].wgs.tried && !tiled_plan(h, lv, 1, sa) && !tiled_plan(h, lv, 1, sb)) { int rc = ensure_wgs(h, lv); if (rc) return rc; }
+    return SMG_OK;
+}
+
 // plans + second iterate for relax(sa) / relax(sb) wherever they are wanted (host work and uploads: never inside a graph capture)
 static int prepare_tiled(smg_hierarchy* h, int k, int sa, int sb)
 {

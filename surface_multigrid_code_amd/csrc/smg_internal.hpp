@@ -87,6 +87,8 @@ struct StageTimer {
 
 int ensure_device(smg_hierarchy* h);            // first use of the device by a handle: stream, control block
 void drop_graphs(smg_hierarchy* h);             // the cached hipGraphs no longer describe the handle
+// the sweep plans a small level would want for a default solve (one column, the handle's pre / post sweeps), built ahead of the first solve (smg_cycle.cpp)
+int prepare_level_plans(smg_hierarchy* h, int lv);
 int check_ready(const smg_hierarchy* h, const char* who);
 
 // ---- profc mirror (PROFC_NODE, reference src/profc.h:9-13), timed on the GPU timeline -----------------------------------------

@@ -230,6 +230,7 @@ struct Handoff {
     // false: the host half ended without getting there
     bool wait_coarse() { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return coarse_ready || host_over; }); return coarse_ready; }
     bool wait_level(int lv) { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return level_ready[(size_t)lv] || host_over; }); return level_ready[(size_t)lv] != 0; }
+    bool level_posted(int lv) { std::lock_guard<std::mutex> g(m); return level_ready[(size_t)lv] != 0 || host_over; }      // (would wait_level return at once?)
 };
 
 // Host half: the reference's sparse algebra, in the caller's numbering, bit-compatible accumulation order.
@@ -1448,10 +1449,16 @@ static int smg_precompute_impl(smg_hierarchy* h, int n, const int* rowptr, const
         if (rc == SMG_OK && hand.wait_coarse()) {
             rc = coarse_images(h);
             tmv.lap("precompute: coarse factorisation (beside the host half)");
+            // While this thread would only wait for the next finer level's numbering, it builds the sweep plans (overlapped tiles, wave Gauss-Seidel
+            // pieces: host work + uploads, csrc/smg_cycle.cpp: prepare_level_plans) of the small levels whose images exist -- otherwise the first solve
+            // pays for them.  A level that is ready is never kept waiting for more than the plan in hand.
+            std::vector<int> plans_due;
             for (int lv = L - 2; lv >= 0 && rc == SMG_OK; lv--) {
                 if (lv == L - 2 && !hand.wait_level(L - 1)) break;
-                if (!hand.wait_level(lv)) break;
+                while (rc == SMG_OK && !plans_due.empty() && !hand.level_posted(lv)) { rc = prepare_level_plans(h, plans_due.front()); plans_due.erase(plans_due.begin()); }
+                if (rc != SMG_OK || !hand.wait_level(lv)) break;
                 rc = level_images(h, lv, lv == 0 ? sym0 : -1);
+                if (lv > 0) plans_due.push_back(lv);
             }
         }
     }
