@@ -23,7 +23,7 @@ for wl in (sys.argv[1:] or ["bunny", "ogre"]):
         if m0 is not None: m0.precompute(A); m0.solve(rhs, z0, None, smg.SolveOpts(tol=1e-3, max_iter=20)); del m0
         first = False
     t = time.perf_counter(); mg.precompute(A); tp = time.perf_counter() - t
-    o = smg.SolveOpts(tol=1e-3, max_iter=20)
+    o = smg.SolveOpts(tol=1e-3, max_iter=20, use_graph=int(os.environ.get("SMG_TOOL_USE_GRAPH", "1")))
     t = time.perf_counter(); r1 = mg.solve(rhs, z0, None, o); t1 = time.perf_counter() - t
     t = time.perf_counter(); r2 = mg.solve(rhs, z0, None, o); t2 = time.perf_counter() - t
     more = []
