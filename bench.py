@@ -17,7 +17,8 @@ sides and measured with HIP events on the solve's stream (max over ranks per rep
 The timed cycle is the REFERENCE's: V(2,2) with Gauss-Seidel on every level (`--smoother gs`, the library default); libsmg's
 Chebyshev-Jacobi hybrid is reported next to it in `smoothers` as an extension, with its own byte count.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line (< 8 000 characters: `compact_line`) on rank 0 as the LAST line of stdout; the full record of every leg goes to
+bench_extra.json.
 """
 import hashlib
 import argparse
@@ -944,6 +945,127 @@ def c4_k64_sharded(smg, mesh, torch, dist, rank, world, dev, stream, stream_ar, 
             "hierarchy_build_s": t_hier}
 
 
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The line the driver parses.  Everything the legs measure goes to bench_extra.json (beside this file, and under gpurun_out/ when that
+# exists); stdout's LAST line is the compact record below: the contract's keys, `roofline`, `cpu_baseline`, and a handful of scalars.
+# Hard cap 8 000 characters (tests/test_host_logic.py::test_bench_line_is_compact): round 5's 23.7 KB line could not be parsed.
+LINE_HARD_CAP = 8000
+
+
+def _num(v, nd=6):
+    """a JSON-safe number: finite floats rounded to `nd` significant digits, NaN / Inf -> None (strict JSON has neither)"""
+    if isinstance(v, (bool, np.bool_)):
+        return bool(v)
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (nd, v))
+    if isinstance(v, str) and len(v) > 240:      # prose belongs in bench_extra.json
+        return v[:237] + "..."
+    return v
+
+
+def _dig(d, *path):
+    for p in path:
+        if not isinstance(d, dict) or p not in d:
+            return None
+        d = d[p]
+    return d
+
+
+def compact_line(out):
+    """`out` = everything bench.py measured (the dict that goes to bench_extra.json) -> the dict printed as the last stdout line."""
+    cfg = out.get("config") or {}
+    line = {k: _num(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                          "dtype", "data")}
+    line["config"] = {k: _num(cfg.get(k)) for k in ("workload", "n_verts", "nnz", "levels", "level_rows", "cycle", "smoother", "rhs_columns_per_gpu", "parallelism")
+                      if cfg.get(k) is not None}
+    rf = out.get("roofline") or {}
+    line["roofline"] = {k: _num(rf.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "us_per_launch", "traffic",
+                                                      "traffic_source", "infinity_cache_resident")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _num(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "ms_per_cycle")}
+        line["cpu_baseline"]["host"] = _dig(out, "host", "cpu_model")
+        line["speedup_vs_cpu_baseline"] = _num(out.get("speedup_vs_cpu_baseline"), 4)
+    pf = out.get("multi_gpu_preflight")
+    line["multi_gpu_preflight"] = None if not pf else {k: pf.get(k) for k in ("rccl_comm_ranks", "distinct_devices", "backend", "visible_devices_per_rank", "sharing_detectable")}
+    t = out.get("timing") or {}
+    extras = {
+        "ms_per_step_min": _dig(t, "ms_per_step_min"), "ms_per_step_max": _dig(t, "ms_per_step_max"),
+        "cycles_to_tol": out.get("cycles_to_tol"), "time_to_tol_ms": out.get("time_to_tol_ms"),
+        "roofline_vcycle_frac": _dig(out, "roofline_vcycle", "frac"), "vcycle_bytes_per_step": _dig(out, "roofline_vcycle", "bytes_per_step"),
+        "roofline_gs_sweep_frac": _dig(out, "roofline_gs_sweep", "frac"), "gs_sweep_us": _dig(out, "roofline_gs_sweep", "us_per_sweep"),
+        "roofline_c5_frac": _dig(out, "roofline_c5", "frac"), "roofline_c5_f32_frac": _dig(out, "roofline_c5", "f32", "spmv_f32", "frac"),
+        "c3_decimated_ms_per_step": _dig(out, "c3_decimated", "ms_per_step"), "c3_decimated_frac": _dig(out, "c3_decimated", "frac_of_hbm_peak"),
+        "c3_decimated_cycles_to_tol": _dig(out, "c3_decimated", "cycles_to_1e-10"),
+        "c3_k3_ms_per_step": _dig(out, "c3_k3", "ms_per_step"), "c3_k3_frac": _dig(out, "c3_k3", "frac"),
+        "c3_k3_speedup_vs_cpu": _dig(out, "c3_k3", "speedup_vs_cpu_baseline"),
+        "c3_k64_ms_per_step": _dig(out, "c3_k64_sharded", "ms_per_step"), "c4_k64_ms_per_step": _dig(out, "c4_k64_sharded", "ms_per_step"),
+        "c4_k64_allreduce_us": _dig(out, "c4_k64_sharded", "allreduce_us"),
+        "c1_bunny_ms_per_cycle": _dig(out, "c1_03_mg_solver", "bunny.obj", "ms_per_step"), "c1_ogre_ms_per_cycle": _dig(out, "c1_03_mg_solver", "ogre.obj", "ms_per_step"),
+        "cpu_allcore_v_cycles_per_s": _dig(out, "cpu_allcore", "value"), "cpu_allcore_cores": _dig(out, "cpu_allcore", "cores"),
+        "reprecompute_ms": _dig(out, "reprecompute", "schur_complement", "reprecompute_ms"),
+        "block3_ms_per_step": _dig(out, "block3_c3", "block", "ms_per_step"),
+        "multi_mesh_union_speedup_at_8": _dig(out, "multi_mesh", "union_in_one_handle", "speedup_at_8"),
+        "device_bytes_live": _dig(out, "device_bytes", "libsmg_live"), "device_bytes_algorithmic": _dig(out, "device_bytes", "hierarchy_algorithmic"),
+        "c3_decimated_device_bytes_live": _dig(out, "c3_decimated", "device_bytes_live"),
+        "c3_decimated_device_bytes_algorithmic": _dig(out, "c3_decimated", "hierarchy_algorithmic_bytes"),
+        "setup_precompute_s": _dig(out, "setup_s", "precompute"),
+    }
+    line["extra"] = {k: _num(v, 5) for k, v in extras.items() if v is not None}
+    errs = [k for k, v in out.items() if isinstance(v, dict) and "error" in v]
+    if errs:
+        line["leg_errors"] = {k: str(out[k]["error"])[:120] for k in errs}
+    line["extra_file"] = "bench_extra.json (every leg in full: same directory as bench.py, and gpurun_out/ when present)"
+    s = json.dumps(line, allow_nan=False)
+    if len(s) > LINE_HARD_CAP:       # never lose the line to verbosity again: drop the optional parts, keep the contract
+        for k in ("extra_file", "leg_errors", "extra"):
+            line.pop(k, None)
+            if len(json.dumps(line, allow_nan=False)) <= LINE_HARD_CAP:
+                break
+    return line
+
+
+def _json_safe(o):
+    """the full record, strict-JSON safe (NaN / Inf -> null), numpy scalars / arrays -> Python"""
+    if isinstance(o, dict):
+        return {str(k): _json_safe(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_json_safe(v) for v in o]
+    if isinstance(o, np.ndarray):
+        return _json_safe(o.tolist())
+    if isinstance(o, (np.bool_,)):
+        return bool(o)
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, (float, np.floating)):
+        o = float(o)
+        return o if (o == o and o not in (float("inf"), float("-inf"))) else None
+    return o
+
+
+def write_extra(out):
+    """everything measured, for people: bench_extra.json beside bench.py and under gpurun_out/ (the directory gpurun merges back)"""
+    full = json.dumps(_json_safe(out), allow_nan=False, indent=1)
+    written = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if d.endswith("gpurun_out"):
+                os.makedirs(d, exist_ok=True)
+            p = os.path.join(d, "bench_extra.json")
+            with open(p, "w") as f:
+                f.write(full)
+            written.append(p)
+        except OSError:
+            pass
+    return written
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1342,7 +1464,9 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        paths = write_extra(out)
+        print("bench: full record (%d legs) -> %s" % (len(out), ", ".join(paths) or "nowhere (not writable)"), file=sys.stderr)
+        print(json.dumps(compact_line(out), allow_nan=False), flush=True)
 
 
 if __name__ == "__main__":
