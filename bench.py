@@ -994,6 +994,8 @@ def compact_line(out):
         line["speedup_vs_cpu_baseline"] = _num(out.get("speedup_vs_cpu_baseline"), 4)
     pf = out.get("multi_gpu_preflight")
     line["multi_gpu_preflight"] = None if not pf else {k: pf.get(k) for k in ("rccl_comm_ranks", "distinct_devices", "backend", "visible_devices_per_rank", "sharing_detectable")}
+    if cfg.get("allreduce") is not None:
+        line["config"]["allreduce"] = _num(cfg["allreduce"])
     t = out.get("timing") or {}
     extras = {
         "ms_per_step_min": _dig(t, "ms_per_step_min"), "ms_per_step_max": _dig(t, "ms_per_step_max"),
@@ -1053,7 +1055,10 @@ def write_extra(out):
     """everything measured, for people: bench_extra.json beside bench.py and under gpurun_out/ (the directory gpurun merges back)"""
     full = json.dumps(_json_safe(out), allow_nan=False, indent=1)
     written = []
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    dirs = (ROOT, os.path.join(ROOT, "gpurun_out"))
+    if os.environ.get("SMG_BENCH_EXTRA_DIR"):      # tests: keep the working tree clean
+        dirs = (os.environ["SMG_BENCH_EXTRA_DIR"],)
+    for d in dirs:
         try:
             if d.endswith("gpurun_out"):
                 os.makedirs(d, exist_ok=True)

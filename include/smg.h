@@ -237,7 +237,10 @@ int smg_level_get_wave_gs_order(smg_hierarchy *h, int lv, int k, int *n_pieces, 
  * (src/min_quad_with_fixed_mg.cpp:105-134) -- its own residual norm, history and break test; a member whose test has passed keeps the iterate it had then
  * while the others go on (smg_union_get_history after smg_solve / smg_solve_end: its residual history, and the reference's return value for it) -- and
  * coarseSolve() uses the members' OWN dense inverses (sum n_i^2 entries, not (sum n_i)^2; every member's coarsest level must lie in the dense range).
- * The handle's own r_his is the norm over all members, `converged` = every member's loop ended below the tolerance.  fp64 cycles; no split-phase /
+ * The handle's own r_his is the norm over all members, `converged` = every member's loop ended below the tolerance.  Members are numerically isolated:
+ * one whose residual stops being finite ends ITS loop as failed (its history ends with that value, its `converged` is 0, the handle's too) while the
+ * others iterate on to their own tolerance, unaffected bit for bit; it no longer enters the handle's norm.  fp64 cycles only (precision = 1 is refused
+ * before anything of the handle changes); no split-phase /
  * sharded iteration on a union.  Numberings and sweep orders are those of the union's matrices: a member's iterates agree with a stand-alone solve of the
  * same mesh to the tolerance, not bit for bit. */
 int smg_hierarchy_create_union(const smg_hierarchy *const *members, int m, smg_hierarchy **out);

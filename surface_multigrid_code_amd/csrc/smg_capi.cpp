@@ -363,7 +363,11 @@ extern "C" int smg_hierarchy_set_coarse_dense_max(smg_hierarchy* h, int n_max)
 extern "C" int smg_hierarchy_coarse_solver(const smg_hierarchy* h, long* factor_entries)
 {
     if (!h) return SMG_ERR_INVALID;
-    if (factor_entries) *factor_entries = h->coarse_sparse ? h->chol.nnzL() : h->coarse_schur ? (long)h->schur.off_C : (long)h->nc_pad * h->nc_pad;
+    if (factor_entries && h->union_m > 0) {      // a union keeps one dense inverse per member: sum of pad_i^2 entries
+        long tot = 0;
+        for (int l : h->union_mlda) tot += (long)l * l;
+        *factor_entries = tot;
+    } else if (factor_entries) *factor_entries = h->coarse_sparse ? h->chol.nnzL() : h->coarse_schur ? (long)h->schur.off_C : (long)h->nc_pad * h->nc_pad;
     return h->coarse_sparse ? 1 : h->coarse_schur ? 2 : 0;
 }
 extern "C" int smg_hierarchy_set_coarse_schur(smg_hierarchy* h, int when, int n_min)

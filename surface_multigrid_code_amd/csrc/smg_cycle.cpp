@@ -354,6 +354,7 @@ static int ensure_work(smg_hierarchy* h, int k)
 static int ensure_fp32(smg_hierarchy* h, int k)
 {
     const int L = h->n_levels;
+    if (h->union_m > 0) return fail(SMG_ERR_INVALID, "a union handle solves in fp64 (its coarse inverses are per-member blocks: no fp32 image)");
     if (h->coarse_sparse) return fail(SMG_ERR_INVALID, "the mixed-precision cycle is not available with a sparse coarse factorisation (coarsest level of %d unknowns)", h->nc);
     if (!h->f32_valid) {
         drop_graphs(h);
@@ -1072,6 +1073,7 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     if (o.omega > 2.0 || o.omega != o.omega) return fail(SMG_ERR_INVALID, "omega must be in (0, 2]");
     if (o.cheby_fraction >= 1.0 || o.cheby_fraction != o.cheby_fraction) return fail(SMG_ERR_INVALID, "cheby_fraction must be in (0, 1)");
     if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_solve_begin: a split-phase solve is already in progress (smg_solve_end)");
+    if (h->union_m > 0 && o.precision != 0) return fail(SMG_ERR_INVALID, "a union handle solves in fp64 (no mixed-precision cycle)");
     h->tol = o.tol; h->max_iter = o.max_iter; h->pre = o.pre; h->post = o.post; h->verbosity = o.verbosity;
     h->check_every = std::max(0, o.check_every); h->use_graph = o.use_graph;
     h->precision = o.precision;
@@ -1140,7 +1142,6 @@ static int smg_solve_begin_impl(smg_hierarchy* h, const double* RHS, int ld_rhs,
     HIPCHK(hipMemcpyAsync(h->d_ctrl.p, &zero, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     if (memspace == SMG_HOST) HIPCHK(hipStreamSynchronize(h->stream));  // the caller's host blocks may change after this call
     if (h->union_m > 0) {
-        if (h->precision != 0) return fail(SMG_ERR_INVALID, "a union handle solves in fp64 (no mixed-precision cycle)");
         if ((rc = union_begin_solve(h, k))) return rc;
     }
     h->head_fuse = head_fusable(h, kin);   // latched: both halves of every iteration of this solve follow it
@@ -1283,7 +1284,7 @@ extern "C" int smg_solve_end(smg_hierarchy* h, double* z, int ld_z, int memspace
     if (h->union_m > 0 && converged) {      // every member's own loop ended below the tolerance (the handle's history holds the norm over all members)
         std::vector<int> md((size_t)h->union_m, 0);
         HIPCHK(hipMemcpy(md.data(), h->un.done.p, md.size() * sizeof(int), hipMemcpyDeviceToHost));
-        *converged = (hc.status == 0 && std::all_of(md.begin(), md.end(), [](int d) { return d != 0; })) ? 1 : 0;
+        *converged = (hc.status == 0 && std::all_of(md.begin(), md.end(), [](int d) { return d == 1; })) ? 1 : 0;      // 2 = that member's residual went non-finite
     }
     if (h->verbosity > 0) {
         for (int i = 0; i < cnt; i++) std::printf("MG iteration: %d, residual: %g\n", i, his[i]);  // :111

@@ -138,8 +138,7 @@ int smg::union_coarse_factor(smg_hierarchy* h, const double* d_vals, bool first)
         HIPCHK(h->d_dense_pos.upload(pos));
         HIPCHK(h->d_Ainv.ensure((size_t)tot));
         HIPCHK(B.crow_member.upload(mc)); HIPCHK(B.moff.upload(h->union_moff)); HIPCHK(B.mlda.upload(h->union_mlda));
-        std::vector<int> row0(h->union_offc.begin(), h->union_offc.end() - 1);
-        HIPCHK(B.mrow0.upload(row0));
+        HIPCHK(B.mrow0.upload(h->union_offc));      // m + 1 entries: member i owns rows [mrow0[i], mrow0[i + 1]) of the coarsest level
         HIPCHK(B.ss.alloc((size_t)m)); HIPCHK(B.nhis.alloc((size_t)m)); HIPCHK(B.done.alloc((size_t)m));
         UnionDev& V = B.view;
         V = UnionDev();      // (rows / rptr: union_begin_solve -- level 0's numbering does not exist yet when the coarsest level's images are built)
@@ -218,7 +217,7 @@ extern "C" int smg_union_get_history(smg_hierarchy* h, int member, double* r_his
     if (n > 0) HIPCHK(hipMemcpy(tmp.data(), h->un.his.p + (size_t)member * h->un.view.his_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (r_his) for (int i = 0; i < std::min(n, cap); i++) r_his[i] = tmp[(size_t)i];
     // the reference's return value per member (src/min_quad_with_fixed_mg.cpp:131-134): the last recorded residual against the tolerance
-    if (converged) *converged = (n > 0 && !(tmp[(size_t)n - 1] > h->tol)) ? 1 : 0;
-    (void)dn;
+    // (a member whose residual stopped being finite ended its own loop as failed: done == 2)
+    if (converged) *converged = (n > 0 && dn != 2 && !(tmp[(size_t)n - 1] > h->tol)) ? 1 : 0;
     return SMG_OK;
 }

@@ -14,7 +14,8 @@
 namespace smg {
 
 // u[row, 0..KB) += Ainv_i[row - row0_i, :] * b[row0_i .., 0..KB): one wavefront per row, the arithmetic of k_dense_gemv_add (16 B per lane per load,
-// shuffle-tree reduction) on the member's own inverse.  The padding columns of an inverse are zero: what they multiply (the next member's rows) does not count.
+// shuffle-tree reduction) on the member's own inverse.  The padding columns of an inverse are zero, and what they would multiply -- the next member's rows -- is
+// not read (0 x NaN of a diverging neighbour would be NaN): members are numerically isolated.  mrow0 has m + 1 entries.
 template <int KB>
 __global__ __launch_bounds__(256) void k_blockdiag_gemv_add(const double* __restrict__ Ainv, const int* __restrict__ row_member, const long long* __restrict__ moff,
                                                             const int* __restrict__ mlda, const int* __restrict__ mrow0, int n, const double* __restrict__ b, double* u, int ld,
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void k_blockdiag_gemv_add(const double* __rest
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const int i = row_member[row];
-    const int lda = mlda[i], r0 = mrow0[i];
+    const int lda = mlda[i], r0 = mrow0[i], ni = mrow0[i + 1] - r0;
     typedef double V2 __attribute__((ext_vector_type(2)));
     const V2* a2 = reinterpret_cast<const V2*>(Ainv + moff[i] + (size_t)(row - r0) * lda);
     const double* bb = b + (size_t)r0 * ld;
@@ -38,8 +39,8 @@ __global__ __launch_bounds__(256) void k_blockdiag_gemv_add(const double* __rest
         const V2 a = a2[jj];
 #pragma unroll
         for (int q = 0; q < KB; q++) {
-            acc[q] += a.x * bb[(size_t)(2 * jj) * ld + q];
-            acc[q] += a.y * bb[(size_t)(2 * jj + 1) * ld + q];
+            acc[q] += a.x * (2 * jj < ni ? bb[(size_t)(2 * jj) * ld + q] : 0.0);
+            acc[q] += a.y * (2 * jj + 1 < ni ? bb[(size_t)(2 * jj + 1) * ld + q] : 0.0);
         }
     }
 #pragma unroll
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(1024) void k_union_sumsq(const double* __restrict__
 
 // The break test of every member's own loop (src/min_quad_with_fixed_mg.cpp:108-116): residual recorded, `res < tol` ends THAT member's loop; the handle's
 // loop ends when every member's has.  The handle's own history keeps the Frobenius norm over all members (what a caller of the plain API reads).
+// A member whose residual is not finite ends ITS loop (mdone = 2: failed; smg_union_get_history reports it, the handle's `converged` is 0); the others
+// go on, and the failed member's sum no longer enters the handle's norm.
 __global__ void k_union_decide(Ctrl* ctrl, const double* ss, int m, double* his, int* nhis, int* mdone, int cap)
 {
     if (threadIdx.x != 0 || ctrl->done) return;
@@ -99,15 +102,15 @@ __global__ void k_union_decide(Ctrl* ctrl, const double* ss, int m, double* his,
     double tot = 0.0;
     int all = 1;
     for (int i = 0; i < m; i++) {
-        tot += ss[i];
         if (!mdone[i]) {
             const double r = sqrt(ss[i]);
             const int j = nhis[i];
             if (j < cap) his[(size_t)i * cap + j] = r;
             nhis[i] = j + 1;
-            if (!(r == r) || r > 1.7e308) { ctrl->status = -1; mdone[i] = 1; }
+            if (!(r == r) || r > 1.7e308) mdone[i] = 2;
             else if (r < tol) mdone[i] = 1;
         }
+        if (mdone[i] != 2) tot += ss[i];
         if (!mdone[i]) all = 0;
     }
     const double r = sqrt(tot);

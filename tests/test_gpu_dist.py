@@ -164,27 +164,47 @@ def test_handle_lives_on_the_device_that_was_current_at_precompute(smg_mod):
     assert torch.cuda.mem_get_info(0)[0] <= free0 + (64 << 20)   # nothing of mg1 had been living on device 0
 
 
+def _bench_n_ranks_on_one_gpu(tmp_path, n, port):
+    import json
+    import subprocess
+    env = dict(os.environ, SMG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SMG_BENCH_EXTRA_DIR=str(tmp_path))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2", "--no-c5", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE JSON line ...
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8000          # ... the last one, compact (the driver parses it)
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["allreduce"] == "torch.distributed"
+    pf = d["multi_gpu_preflight"]
+    assert pf["rccl_comm_ranks"] == n and pf["backend"] == "gloo" and pf["distinct_devices"] == 1      # n ranks in the communicator, ONE device: gloo only
+    assert d["extra"]["c4_k64_ms_per_step"] > 0 and d["extra"]["c3_k64_ms_per_step"] > 0 and "leg_errors" not in d
+    full = json.load(open(os.path.join(str(tmp_path), "bench_extra.json")))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5)
+    return d, full
+
+
 def test_bench_runs_its_multi_rank_path_with_two_ranks(tmp_path):
     """bench.py --gpus 2 launched the way the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on GPU 0
     over gloo (SMG_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): the split-phase iteration with the all-reduce between
     its halves, the weak-scaling `value` (one C3 column per rank) and the C4 leg (64 columns split by column_range) -- every rank records
     the same residual history and the job converges in the cycles the unsharded solve needs."""
-    import json
-    import subprocess
-    env = dict(os.environ, SMG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-c5", "--no-cpu"],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE JSON line
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["allreduce"] == "torch.distributed"
-    c4 = d["c4_k64_sharded"]
+    d, full = _bench_n_ranks_on_one_gpu(tmp_path, 2, 29533)
+    c4 = full["c4_k64_sharded"]
     assert c4["scaling"] == "strong" and c4["solve"]["converged"] and c4["solve"]["same_history_on_all_ranks"]
     assert c4["smoother"] == "gs" and c4["solve"]["cycles"] == 15 and c4["solve"]["final_residual"] < 5e-7     # the reference's cycle (16 with the Chebyshev hybrid)
     # the leg that shards usefully (C3 mesh x 64 columns) runs through the library's own loop, smg_solve_sharded, with a host closure here
-    c3 = d["c3_k64_sharded"]
+    c3 = full["c3_k64_sharded"]
     assert c3["scaling"] == "strong" and c3["columns_per_gpu"] == 32 and c3["solve"]["converged"] and c3["solve"]["same_history_on_all_ranks"]
     assert "smg_solve_sharded" in c3["loop"] and c3["ms_per_step"] > 0
+
+
+def test_bench_dry_run_of_the_eight_rank_launch(tmp_path):
+    """The driver's 8-GPU launch line, dry: 8 ranks over gloo sharing GPU 0 (no 8-GPU box has ever been reachable, so the first real run must not
+    fail on plumbing).  BASELINE config C4's shape: 64 columns, 8 per rank; C3 x 64 columns likewise; one C3 column per rank for `value`."""
+    d, full = _bench_n_ranks_on_one_gpu(tmp_path, 8, 29541)
+    c4, c3 = full["c4_k64_sharded"], full["c3_k64_sharded"]
+    assert c4["columns_per_gpu"] == 8 and c4["solve"]["converged"] and c4["solve"]["same_history_on_all_ranks"] and c4["solve"]["cycles"] == 15
+    assert c3["columns_per_gpu"] == 8 and c3["solve"]["converged"] and c3["solve"]["same_history_on_all_ranks"]

@@ -96,3 +96,43 @@ def test_union_with_constraints_and_value_only_reprecompute(smg):
     u.precompute(A2, known)
     conv2, z2, rh2 = u.solve(Bu, np.zeros_like(Bu), kv, o)
     assert conv2 and np.linalg.norm((Bu[:, 0] - A2 @ z2[:, 0])[unk]) < 4e-9
+
+
+def test_a_failing_member_does_not_touch_its_neighbours_and_mixed_precision_is_refused_cleanly(smg):
+    """Members of a union are numerically isolated: a NaN in one member's right-hand side ends THAT member's loop as failed while the others run the very
+    iterations they run without it (same histories, same iterates, bit for bit) -- the block-diagonal coarse product does not read across members
+    (0 x NaN = NaN) and the break test is per member.  And a mixed-precision solve on a union is refused before the handle changes."""
+    ms, As, Bs = members(smg, 1)
+    u = smg.Hierarchy.union(ms)
+    Au = sp.block_diag(As, format="csr"); Au.sort_indices()
+    u.precompute(Au)
+    fe = u.coarse_solver()["factor_entries"]
+    for m_, A_ in zip(ms, As):
+        m_.precompute(A_)
+    pads = [(m_.rows(m_.n_levels - 1) + 63) // 64 * 64 for m_ in ms]
+    assert fe == sum(p * p for p in pads), (fe, pads)                       # sum of the members' padded inverses, not (sum n_i)^2
+    o = smg.SolveOpts(tol=1e-9, max_iter=60)
+    Bu = np.asfortranarray(np.concatenate(Bs, axis=0))
+    conv, z, rh = u.solve(Bu, np.zeros_like(Bu), None, o)
+    clean = [u.union_history(i) for i in range(len(ms))]
+    assert conv and all(c for c, _ in clean)
+    with pytest.raises(smg.SmgError) as ei:
+        u.solve(Bu, np.zeros_like(Bu), None, smg.SolveOpts(tol=1e-9, max_iter=60, precision="mixed"))
+    assert ei.value.code == -1 and "fp64" in str(ei.value)
+    conv1, z1, rh1 = u.solve(Bu, np.zeros_like(Bu), None, o)               # the refused call left the handle as it was
+    assert conv1 and np.array_equal(z1, z) and np.array_equal(rh1, rh)
+    bad = 1
+    first, cnt = u.union_member_rows(bad)
+    Bn = Bu.copy()
+    Bn[first + cnt // 2] = np.nan
+    conv2, z2, rh2 = u.solve(Bn, np.zeros_like(Bn), None, o)
+    assert not conv2
+    for i in range(len(ms)):
+        f, c = u.union_member_rows(i)
+        cvi, rhi = u.union_history(i)
+        if i == bad:
+            assert not cvi and len(rhi) == 1 and not np.isfinite(rhi[-1])
+        else:
+            assert cvi and np.array_equal(rhi, clean[i][1]), i
+            assert np.array_equal(z2[f:f + c], z[f:f + c]), i
+    assert np.isfinite(rh2).all()                                            # the handle's norm: over the members still in the running
