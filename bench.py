@@ -472,6 +472,34 @@ def c3_k64_sharded(smg, mg, Mb, n, torch, dist, rank, world, dev, stream, stream
                       "final_residual": float(rh[-1]) if len(rh) else None}}
 
 
+def c3_k3_leg(smg, mg, A, Mb, Vf, n, torch, dev, stream, with_cpu=True):
+    """The reference's real multi-right-hand-side shape: THREE columns -- one mean-curvature-flow step solves (M - dt L) U' = M U for the x / y / z coordinates at once
+    (05_example_mean_curvature_flow/main.cpp:74-76, tol 5e-7 at :60).  C3 mesh and hierarchy, RHS = M V, z0 = V (the step's own start), the reference's Gauss-Seidel cycle.
+    ms per outer iteration graph-replayed; bytes: the cycle's model with k = 3 (per operator 12 nnz + 16 n k: smg_vcycle_bytes); the oracle on the same three columns beside it."""
+    U = np.ascontiguousarray(Vf[:, :3].T)                                   # (3, n): column-major n x 3
+    rhs_h = np.ascontiguousarray(np.stack([Mb @ U[c] for c in range(3)], axis=0))
+    rhs = torch.from_numpy(rhs_h).to(dev)
+    z0 = torch.from_numpy(U).to(dev)
+    z = torch.empty_like(z0)
+    ms = steady_ms(torch, stream, mg, rhs, z0, z, n, 3, dict(smoother="gs"), warm=20, iters=100)
+    byt = int(mg.vcycle_bytes(3, 2, 2))
+    o = smg.SolveOpts(tol=5e-7, max_iter=60, smoother="gs")
+    mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 3, opts=o)
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    cv, rh = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 3, opts=o)
+    wall = 1e3 * (time.perf_counter() - tw)
+    out = {"workload": "C3 mesh and hierarchy, k = 3: (M + 0.01(-L)) U' = M V for the three coordinate columns, z0 = V (05_example_mean_curvature_flow/main.cpp:74-76)",
+           "k": 3, "smoother": "gs", "ms_per_step": ms, "v_cycles_per_s": 1e3 / ms, "column_cycles_per_s": 3e3 / ms, "bytes_per_step": byt,
+           "gbs": byt / (ms * 1e-3) / 1e9, "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "solve": {"tol": 5e-7, "converged": bool(cv), "cycles": len(rh) - 1, "wall_ms": wall, "final_residual": float(rh[-1]) if len(rh) else None}}
+    if with_cpu:
+        cb = oracle_cycle_ms(mg, A, np.asfortranarray(rhs_h.T), budget_s=6.0)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = cb["ms_per_cycle"] / ms
+    return out
+
+
 def host_info():
     """CPU model + logical cores of this box, printed once per line (the CPU comparators beside the legs ran here)"""
     model = None
@@ -508,6 +536,29 @@ def oracle_cycle_ms(mg, A, rhs, budget_s=6.0, known=None, known_val=None):
     dt = time.time() - t0
     return {"ms_per_cycle": 1e3 * dt / m, "v_cycles_per_s": m / dt, "cores": 1, "kind": "port", "precompute_s": t_pre,
             "sample": "%d outer iterations, oracle/smg_oracle.c, gcc -O3, 1 thread" % m}
+
+
+def algorithmic_bytes(mg):
+    """the hierarchy as the reference holds it (mg_data: A, P, PT per level in CSC: 12 bytes per stored entry)"""
+    return int(sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels)))
+
+
+def memory_lean_leg(smg, mg, A, rhs, z0, z, n, torch, stream):
+    """smg_hierarchy_set_memory_lean: the same hierarchy with compact SELL panels -- bytes of the handle after a solve, ms per outer iteration, same bits"""
+    m2 = smg.Hierarchy.from_prolongs([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
+    m2.set_memory_lean(True)
+    m2.precompute(A)
+    m2.set_stream(stream.cuda_stream)
+    o = smg.SolveOpts(tol=1e-10, max_iter=100)
+    cv, rh = m2.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    z_lean = z.clone()
+    ms = steady_ms(torch, stream, m2, rhs, z0, z, n, 1, dict(smoother="gs"), iters=100)
+    live = int(m2.device_bytes()["total"])
+    cv0, rh0 = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    same = bool(torch.equal(z, z_lean)) and list(rh) == list(rh0)
+    alg = algorithmic_bytes(m2)
+    del m2
+    return {"handle_bytes": live, "ratio_to_algorithmic": live / max(alg, 1), "ms_per_step": ms, "cycles_to_1e-10": len(rh) - 1, "converged": bool(cv), "bit_identical_to_default": same}
 
 
 def steady_ms(torch, stream, mg, rhs, z0, z, n, k, opts_kw, warm=30, iters=200, repeats=3, his=1024):
@@ -580,7 +631,10 @@ def c3_decimated_leg(smg, mesh, torch, dev, stream, ms_subdiv, bytes_subdiv):
            "one_launch_per_colour": {"ms_per_step": ms_colour, "cycles_to_1e-10": len(rhc) - 1, "converged": bool(cvc), "note": "the same handle with smg_hierarchy_set_wave_gs(h, 0): multi-colour order on every level"},
            "cost_per_byte_vs_subdivision": (ms / byt) / (ms_subdiv / bytes_subdiv) if ms_subdiv and bytes_subdiv else None,
            "subdivision_cycle": {"ms_per_step": ms_subdiv, "bytes_per_step": int(bytes_subdiv) if bytes_subdiv else None},
-           "device_bytes_live": int(smg._lib.load().smg_device_bytes_live())}
+           # THIS handle's HBM (round 5 printed the process-wide figure here, the headline's handle and the other legs' included: 2.31 GB)
+           "device_bytes_live": int(mg.device_bytes()["total"]), "hierarchy_algorithmic_bytes": algorithmic_bytes(mg),
+           "device_bytes_process_wide": int(smg._lib.load().smg_device_bytes_live())}
+    out["device_bytes_ratio"] = out["device_bytes_live"] / max(out["hierarchy_algorithmic_bytes"], 1)
     try:
         out["cpu_baseline"] = oracle_cycle_ms(mg, A, rhs_h, budget_s=8.0)
         out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["ms_per_cycle"] / ms
@@ -1015,6 +1069,7 @@ def compact_line(out):
         "block3_ms_per_step": _dig(out, "block3_c3", "block", "ms_per_step"),
         "multi_mesh_union_speedup_at_8": _dig(out, "multi_mesh", "union_in_one_handle", "speedup_at_8"),
         "device_bytes_live": _dig(out, "device_bytes", "libsmg_live"), "device_bytes_algorithmic": _dig(out, "device_bytes", "hierarchy_algorithmic"),
+        "memory_lean_bytes": _dig(out, "device_bytes", "memory_lean_option", "handle_bytes"), "memory_lean_ms_per_step": _dig(out, "device_bytes", "memory_lean_option", "ms_per_step"),
         "c3_decimated_device_bytes_live": _dig(out, "c3_decimated", "device_bytes_live"),
         "c3_decimated_device_bytes_algorithmic": _dig(out, "c3_decimated", "hierarchy_algorithmic_bytes"),
         "setup_precompute_s": _dig(out, "setup_s", "precompute"),
@@ -1086,6 +1141,7 @@ def main():
     ap.add_argument("--no-block3-scalar", action="store_true", help="block leg without the scalar-kernel comparison (its host precompute takes ~17 s)")
     ap.add_argument("--no-c3dec", action="store_true", help="skip the leg with the reference's own (mg_precompute, SSP-decimated) hierarchy on the C3 mesh")
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 leg (03_mg_solver on bunny.obj / ogre.obj, GPU and oracle)")
+    ap.add_argument("--no-c3k3", action="store_true", help="skip the C3 x 3 columns leg (the reference's own multi-RHS shape: 05_example_mean_curvature_flow)")
     ap.add_argument("--no-c3k64", action="store_true", help="skip the C3 x 64 columns column-sharded (strong scaling) leg")
     ap.add_argument("--repeats", type=int, default=9, help="the --steps iterations are timed this many times; the line reports the median repeat")
     ap.add_argument("--spmv-reps", type=int, default=500)
@@ -1373,12 +1429,18 @@ def main():
                         "precompute_note": "first (pattern-changing) smg_precompute of the process, HIP runtime already initialised; libsmg's own code object is loaded inside it"},
             # memory budget: everything libsmg holds in HBM for this workload (operators in SELL incl. the fixed panel pitch, A^T images of the
             # Galerkin levels, dense coarse inverse, work vectors, graphs' buffers) against the algorithmic size of the hierarchy
-            "device_bytes": {"libsmg_live": int(smg._lib.load().smg_device_bytes_live()), "hierarchy_algorithmic": int(sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels))),
+            "device_bytes": {"libsmg_live": int(smg._lib.load().smg_device_bytes_live()), "hierarchy_algorithmic": algorithmic_bytes(mg),
                              "by_purpose": {k_: v for k_, v in sorted(mg.device_bytes().items(), key=lambda kv: -kv[1]) if v >= (1 << 20)},
                              "note": "by_purpose: what the C3 handle holds, entries >= 1 MiB (smg_debug_device_bytes): level0.A_sell carries the fixed panel pitch (12 columns of room for 7 used: "
                                      "addressing without a table, DESIGN.md section 2), the coarse inverse is kept whole for the k > 1 kernels, Galerkin levels keep an A^T image (the reference's sweep walks columns)",
                              "hbm_capacity": 288 * 10 ** 9},
         }
+        out["device_bytes"]["ratio_to_algorithmic"] = out["device_bytes"]["libsmg_live"] / max(out["device_bytes"]["hierarchy_algorithmic"], 1)
+        if world == 1 and not force_split and args.workload == "C3":
+            try:
+                out["device_bytes"]["memory_lean_option"] = memory_lean_leg(smg, mg, A, rhs, z0, z, n, torch, stream)
+            except Exception as e:
+                out["device_bytes"]["memory_lean_option"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(mg, A, rhs_h)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
@@ -1396,6 +1458,12 @@ def main():
             out["roofline_c5"] = roofline_c5(smg, mesh, torch, dev, stream)
         except Exception as e:
             out["roofline_c5"] = {"error": repr(e)}
+    # ---- the reference's own multi-RHS shape: three coordinate columns (05_example_mean_curvature_flow), rank 0 at N = 1 only
+    if rank == 0 and world == 1 and not args.no_c3k3 and args.workload == "C3":
+        try:
+            out["c3_k3"] = c3_k3_leg(smg, mg, A, Mb, Vf, n, torch, dev, stream, with_cpu=not args.no_cpu)
+        except Exception as e:
+            out["c3_k3"] = {"error": repr(e)}
     # ---- a column-sharded job that shards usefully: the C3 mesh x 64 columns (strong scaling), through smg_solve_sharded
     if not args.no_c3k64 and args.workload == "C3":
         try:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMG_VERSION 500
+#define SMG_VERSION 501
 
 enum {
     SMG_OK = 0,
@@ -222,6 +222,12 @@ int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks,
  * like the fused one), fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range.
  * SMG_WGS=0 / 1 / 2 overrides (off / automatic / every level).  Takes effect at the next solve. */
 int smg_hierarchy_set_wave_gs(smg_hierarchy *h, int mode);
+/* Memory against speed (the reference has no counterpart: mg_data holds Eigen's compact CSC, src/mg_data.h:11-27).  By default every operator's SELL panels get a
+ * FIXED pitch -- room for the level's widest slice (A_0 of a triangle mesh: 12 columns for 7 used) -- so that a wave addresses its panel from its slice number alone
+ * and no launch waits for a table: 545 MB for the 171 MB of CSR operators of the 1 M-vertex benchmark hierarchy.  on = 1: compact panels + a slice-offset table
+ * (what matrices with a few very wide slices get anyway): 421 MB there, the V(2,2) cycle 14 - 16 % slower (0.313 -> 0.362 ms: one more dependent load in front of
+ * every launch), results bit-identical.  For many resident meshes per GPU.  Takes effect at the next smg_precompute, which is then a full one. */
+int smg_hierarchy_set_memory_lean(smg_hierarchy *h, int on);
 /* The piece-sequential order of level lv as a solve with k columns would use it (after smg_precompute; builds the plan): *n_pieces, *n_colors,
  * color_ptr[n_colors + 1] (pieces per piece colour), piece_ptr[n_pieces + 1] (positions per piece), rows[n] (position -> row in the INTERNAL numbering,
  * smg_level_get_perm), stats[3] = {rows gathered per row beyond the iterate itself, mean phases per piece, most phases of a piece}.  Any pointer may be

@@ -101,6 +101,7 @@ def load():
         "smg_debug_schur_solve_host": (i, [i, ip, ip, dp, dp, dp, ip, ip]),
         "smg_hierarchy_set_block_gs": (i, [vp, i]),
         "smg_hierarchy_set_wave_gs": (i, [vp, i]),
+        "smg_hierarchy_set_memory_lean": (i, [vp, i]),
         "smg_hierarchy_create_union": (i, [C.POINTER(vp), i, C.POINTER(vp)]),
         "smg_union_members": (i, [vp]),
         "smg_union_member_rows": (i, [vp, i, ip, ip]),

@@ -382,6 +382,10 @@ class Hierarchy:
         unknowns from the first value-only re-precompute on -- what a time-stepping caller does --, from 6 144 on and above the dense range at once)."""
         _chk(self.L.smg_hierarchy_set_coarse_schur(self.h, {"never": 0, "always": 1, "refactor": 2}[when], int(n_min)), "smg_hierarchy_set_coarse_schur")
 
+    def set_memory_lean(self, on=True):
+        """compact SELL panels instead of the fixed panel pitch: ~0.77 x the device memory, the cycle ~15 % slower, same bits; the next precompute is a full one"""
+        _chk(self.L.smg_hierarchy_set_memory_lean(self.h, 1 if on else 0), "smg_hierarchy_set_memory_lean")
+
     def coarse_solver(self):
         ne = C.c_long()
         kind = self.L.smg_hierarchy_coarse_solver(self.h, C.byref(ne))

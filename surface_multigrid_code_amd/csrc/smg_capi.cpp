@@ -360,6 +360,13 @@ extern "C" int smg_hierarchy_set_coarse_dense_max(smg_hierarchy* h, int n_max)
     if (n_max != h->coarse_dense_max || !h->coarse_dense_max_user) { h->coarse_dense_max = n_max; h->coarse_dense_max_user = true; h->precomputed = false; }   // the next smg_precompute is a full one
     return SMG_OK;
 }
+extern "C" int smg_hierarchy_set_memory_lean(smg_hierarchy* h, int on)
+{
+    if (!h || (on != 0 && on != 1)) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_memory_lean: bad arguments (on: 0 fixed panel pitch, 1 compact panels)");
+    if (h->in_solve) return fail(SMG_ERR_INVALID, "smg_hierarchy_set_memory_lean called during a split-phase solve");
+    if ((on != 0) != h->mem_lean) { h->mem_lean = on != 0; h->precomputed = false; }   // the next smg_precompute is a full one
+    return SMG_OK;
+}
 extern "C" int smg_hierarchy_coarse_solver(const smg_hierarchy* h, long* factor_entries)
 {
     if (!h) return SMG_ERR_INVALID;

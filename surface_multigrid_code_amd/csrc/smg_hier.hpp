@@ -252,6 +252,7 @@ struct smg_hierarchy {
     bool coarse_sparse = false;
     int coarse_dense_max = 16384;   // smg_hierarchy_set_coarse_dense_max
     bool coarse_dense_max_user = false;   // ... was called: above it the caller gets the sparse factorisation, not the Schur stand-in (schur_wanted)
+    bool mem_lean = false;          // smg_hierarchy_set_memory_lean: compact SELL panels (slice_off table) instead of the fixed panel pitch
     int wgs_mode = -1;              // smg_hierarchy_set_wave_gs: -1 automatic (levels the colour launches serve badly: > 5 colours or rows of > 12 entries), 0 never, 1 every Gauss-Seidel level in range
     int bgs_min_rows = -1;          // smg_hierarchy_set_block_gs: levels of at least this many rows sweep block-sequentially when k % 16 == 0, k >= 16 (< 0: never, the default)
     smg::SparseChol chol;

@@ -611,7 +611,7 @@ std::vector<int> induced_order(const Csr& P, const std::vector<int>& coarse_rank
     return order;
 }
 
-Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const std::vector<int>* row_breaks, int C, bool region_order)
+Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const std::vector<int>* row_breaks, int C, bool region_order, int pitch_policy)
 {
     Sell S;
     S.C = C;
@@ -637,7 +637,7 @@ Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const st
     }
     S.n_slices = (int)S.slice_row.size() - 1;
     // fixed stride unless a few very wide slices would blow the storage up (then: compact panels, table-driven addressing)
-    const int allow_stride = std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob, and the tests' way to the compact layout
+    const int allow_stride = pitch_policy >= 0 ? pitch_policy : std::getenv("SMG_SELL_STRIDE") ? std::atoi(std::getenv("SMG_SELL_STRIDE")) : 1;   // A/B knob, and the tests' way to the compact layout
     if (allow_stride && S.n_slices > 0 && wmax > 0 && (long)wmax * S.n_slices <= (5 * sum_w) / 2 + 64) {
         // columns requested before a slice's width is known: the smallest W that covers 90% of the slices (narrower slices read
         // padding there, which the stride guarantees to exist; wider ones continue table-driven)
@@ -665,11 +665,11 @@ Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const st
     return S;
 }
 
-Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order)
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C, bool region_order, int pitch_policy)
 {
     std::vector<int> row_len((size_t)A.nr);
     for (int r = 0; r < A.nr; r++) row_len[(size_t)r] = A.ptr[(size_t)r + 1] - A.ptr[(size_t)r];
-    Sell S = sell_layout(row_len, A.nc, A.nnz(), row_breaks, C, region_order);
+    Sell S = sell_layout(row_len, A.nc, A.nnz(), row_breaks, C, region_order, pitch_policy);
     size_t tot = (size_t)C * (size_t)S.slice_off.back();
     S.col.assign(tot, -1);
     S.val.assign(tot, 0.0);

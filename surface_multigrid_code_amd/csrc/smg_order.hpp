@@ -70,9 +70,10 @@ struct Sell {
 };
 
 // row_breaks: optional ascending row offsets (e.g. Ordering::color_ptr) at which a new slice must start.
-Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C = SELL_C, bool region_order = false);
+Sell build_sell(const Csr& A, const std::vector<int>* row_breaks, int C = SELL_C, bool region_order = false, int pitch_policy = -1);
 // the same container from the row lengths alone: slice tables, pitch, launch order -- col / val / entry stay empty (the panels are then
 // filled on the device, smg_device.hpp: launch_sell_fill)
-Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const std::vector<int>* row_breaks, int C = SELL_C, bool region_order = false);
+// pitch_policy: 1 fixed panel pitch where it costs <= 2.5 x (the default), 0 compact panels + slice_off table (smg_hierarchy_set_memory_lean), -1: SMG_SELL_STRIDE or 1
+Sell sell_layout(const std::vector<int>& row_len, int n_cols, long nnz, const std::vector<int>* row_breaks, int C = SELL_C, bool region_order = false, int pitch_policy = -1);
 
 }  // namespace smg

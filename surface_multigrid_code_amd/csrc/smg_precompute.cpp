@@ -135,7 +135,7 @@ struct DeviceCsr {
 // symmetric, rperm == cperm) -- built on the device from M's arrays: layout from the row lengths on the host, panels by launch_sell_fill.
 // Called from the precompute's worker threads (own stream).
 static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const DeviceCsr& D, const std::vector<int>& rperm, const std::vector<int>& ciperm,
-                                   const std::vector<int>* breaks, bool region, hipStream_t st2, bool transposed = false)
+                                   const std::vector<int>* breaks, bool region, hipStream_t st2, bool transposed = false, int pitch_policy = -1)
 {
     static const bool tm_on = env_int("SMG_TIMING", 0) >= 2;
     auto t_last = std::chrono::steady_clock::now();
@@ -151,7 +151,7 @@ static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const DeviceCsr& 
         for (long r = r0; r < r1; r++) { const int o = rperm[(size_t)r]; row_len[(size_t)r] = M.ptr[(size_t)o + 1] - M.ptr[(size_t)o]; }
     });
     lap("row_len");
-    Sell S = sell_layout(row_len, M.nc, M.nnz(), breaks, SELL_C, region);
+    Sell S = sell_layout(row_len, M.nc, M.nnz(), breaks, SELL_C, region, pitch_policy);
     lap("layout");
     hipError_t e = dst.upload(S);
     lap("panels");
@@ -188,11 +188,11 @@ static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const DeviceCsr& 
     return e;
 }
 static hipError_t device_fill_sell(SellBuf& dst, const Csr& M, const std::vector<int>& rperm, const std::vector<int>& ciperm, const std::vector<int>* breaks, bool region,
-                                   hipStream_t st2)
+                                   hipStream_t st2, int pitch_policy)
 {
     DeviceCsr D;
     hipError_t e = D.put(M, nullptr);
-    return e == hipSuccess ? device_fill_sell(dst, M, D, rperm, ciperm, breaks, region, st2) : e;
+    return e == hipSuccess ? device_fill_sell(dst, M, D, rperm, ciperm, breaks, region, st2, false, pitch_policy) : e;
 }
 int smg::ensure_P_int(smg_hierarchy* h, int lv)
 {
@@ -763,7 +763,7 @@ static int coarse_images(smg_hierarchy* h)
     std::iota(Lc.A_int_src.begin(), Lc.A_int_src.end(), 0);
     if (L == 1) {
         // a single level goes straight to coarseSolve (src/mg_VCycle.cpp:28-33); the outer loop still needs A_0 for its residual
-        Sell S = build_sell(Lc.A_int, nullptr, SELL_C, false);
+        Sell S = build_sell(Lc.A_int, nullptr, SELL_C, false, h->mem_lean ? 0 : -1);
         HIPCHK(Lc.dA.upload(S));
     }
     const int nc = Lc.n;
@@ -927,11 +927,11 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
             Lw.A_bit_symmetric = differs == 0;
             Lw.gs_on_transpose = differs != 0;
             Lw.dAT = SellBuf(); Lw.bAT = Bsr3Buf();
-            eA = device_fill_sell(Lw.dA, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region, h->aux[0]);
-            if (eA == hipSuccess && Lw.gs_on_transpose) eT = device_fill_sell(Lw.dAT, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, false, h->aux[0], true);
+            eA = device_fill_sell(Lw.dA, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, region, h->aux[0], false, h->mem_lean ? 0 : -1);
+            if (eA == hipSuccess && Lw.gs_on_transpose) eT = device_fill_sell(Lw.dAT, Lw.A, D, Lw.ord.perm, Lw.ord.iperm, &Lw.ord.color_ptr, false, h->aux[0], true, h->mem_lean ? 0 : -1);
             return;
         }
-        Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region);
+        Sell S = build_sell(Lw.A_int, &Lw.ord.color_ptr, sellC, region, h->mem_lean ? 0 : -1);
         eA = Lw.dA.upload(S);
     });
     // relax() iterates InnerIterator(A, colIdx): the entries A(j, i) of COLUMN i (src/mg_VCycle.cpp:149-155,
@@ -949,7 +949,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         if (Lw.gs_on_transpose) {
             if (!(AT.ptr == Lw.A_int.ptr && AT.col == Lw.A_int.col)) { bad = 1; return; }
             if (blk) { Bsr3Sell S = build_bsr3(AT, &Lw.vord.color_ptr, false, false); eT = Lw.bAT.upload(S); }
-            else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false); eT = Lw.dAT.upload(S); }
+            else { Sell S = build_sell(AT, &Lw.ord.color_ptr, sellC, false, h->mem_lean ? 0 : -1); eT = Lw.dAT.upload(S); }
         }
     });
     // P and PT are launched whole: with their rows cut at the colour boundaries of the level they belong to, the slices get
@@ -963,12 +963,12 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         const Ordering& Of = blk ? Lw.vord : Lw.ord;
         const bool cut = tr_region && region && Of.color_ptr.size() > 2;
         if (!blk && Lp.P_device_filled) {
-            eP = device_fill_sell(Lp.dP, Lp.P, Of.perm, Lp.ord.iperm, cut ? &Of.color_ptr : nullptr, cut, h->aux[1]);
+            eP = device_fill_sell(Lp.dP, Lp.P, Of.perm, Lp.ord.iperm, cut ? &Of.color_ptr : nullptr, cut, h->aux[1], h->mem_lean ? 0 : -1);
             return;
         }
         Csr Pvi;
         if (blk) Pvi = permute(Lp.Pv, Of.perm, Lp.vord.perm);
-        Sell S = build_sell(blk ? Pvi : Lp.P_int, cut ? &Of.color_ptr : nullptr, sellC, cut);
+        Sell S = build_sell(blk ? Pvi : Lp.P_int, cut ? &Of.color_ptr : nullptr, sellC, cut, h->mem_lean ? 0 : -1);
         eP = Lp.dP.upload(S);
     });
     tasks.push_back([&] {
@@ -980,7 +980,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
         // (ogre.obj level 0 -> 1: a row of 177 entries, 32 us of a 260 us cycle); see SellDev::long_* / k_long_ax
         static const int long_min = env_int("SMG_LONG_ROW_MIN", 65);
         if (!blk && Lp.PT_device_filled) {
-            eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut, h->aux[2]);
+            eQ = device_fill_sell(Lp.dPT, Lp.PT, Oc.perm, Lw.ord.iperm, cut ? &Oc.color_ptr : nullptr, cut, h->aux[2], h->mem_lean ? 0 : -1);
             if (eQ == hipSuccess) eQ = Lp.dPT.upload_long({}, {0}, {}, {});
             return;
         }
@@ -998,7 +998,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
                     lptr.push_back((int)lcol.size());
                 }
         if (lrow.empty()) {
-            Sell S = build_sell(M, cut ? &Oc.color_ptr : nullptr, sellC, cut);
+            Sell S = build_sell(M, cut ? &Oc.color_ptr : nullptr, sellC, cut, h->mem_lean ? 0 : -1);
             eQ = Lp.dPT.upload(S);
             if (eQ == hipSuccess) eQ = Lp.dPT.upload_long(lrow, lptr, lcol, lval);
             return;
@@ -1014,7 +1014,7 @@ static int level_images(smg_hierarchy* h, int lv, int sym0)
                 Ms.ptr[(size_t)r + 1] = (int)Ms.col.size();
             }
         }
-        Sell S = build_sell(Ms, cut ? &Oc.color_ptr : nullptr, sellC, cut);
+        Sell S = build_sell(Ms, cut ? &Oc.color_ptr : nullptr, sellC, cut, h->mem_lean ? 0 : -1);
         eQ = Lp.dPT.upload(S);
         if (eQ == hipSuccess) eQ = Lp.dPT.upload_long(lrow, lptr, lcol, lval);
     });
@@ -1097,7 +1097,7 @@ static int build_recipes(smg_hierarchy* h)
                     if (!Lv.gs_on_transpose && er == hipSuccess) {      // (values: whatever A holds now -- refreshed through the map right after)
                         DeviceCsr D;
                         D.ptr = d_ptr.p; D.col = d_col.p; D.val = Lv.d_Aval.p;
-                        up(er, device_fill_sell(Lv.dAT, Lv.A, D, Lv.ord.perm, Lv.ord.iperm, &Lv.ord.color_ptr, false, st2, true));
+                        up(er, device_fill_sell(Lv.dAT, Lv.A, D, Lv.ord.perm, Lv.ord.iperm, &Lv.ord.color_ptr, false, st2, true, h->mem_lean ? 0 : -1));
                         Lv.gs_on_transpose = true;
                     }
                     up(er, Lv.mapAT.alloc((size_t)Lv.dAT.padded));
@@ -1124,12 +1124,12 @@ static int build_recipes(smg_hierarchy* h)
                     return;
                 }
                 {
-                    Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false);
+                    Sell S = build_sell(Lv.A_int, &Lv.ord.color_ptr, sellC, false, h->mem_lean ? 0 : -1);
                     m.resize(S.entry.size());
                     for (size_t i = 0; i < S.entry.size(); i++) m[i] = S.entry[i] >= 0 ? Lv.A_int_src[S.entry[i]] : -1;
                 }
                 up(er, Lv.mapA.upload(m));
-                Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false);
+                Sell ST = build_sell(AT, &Lv.ord.color_ptr, sellC, false, h->mem_lean ? 0 : -1);
                 m.resize(ST.entry.size());
                 for (size_t i = 0; i < ST.entry.size(); i++) m[i] = ST.entry[i] >= 0 ? Lv.A_int_src[tsrc[ST.entry[i]]] : -1;
                 up(er, Lv.mapAT.upload(m));

@@ -67,6 +67,33 @@ def test_solve_full_size_against_oracle(c3, oracle_mod):
         assert np.array_equal(mg.matrix(l, "A").data, Ao.data)
 
 
+def test_memory_budget_at_full_size_default_and_lean(c3):
+    """What one handle holds in HBM against the hierarchy as the reference holds it (mg_data: A, P, PT per level in CSC, 12 bytes per stored entry): the default
+    layout (fixed panel pitch: no launch waits for a table) stays below 3.3 x after a solve, smg_hierarchy_set_memory_lean (compact panels) below 2.5 x --
+    with bit-identical iterates: the layout of the panels is not the order of the sums."""
+    import torch
+    smg, mg, A, Mb, Vf = c3
+    n = A.shape[0]
+    dev = torch.device("cuda", 0)
+    rhs = torch.from_numpy(Mb @ np.random.default_rng(100).uniform(-1.0, 1.0, n)).to(dev)      # vectors resident in HBM, as in bench.py (host blocks add 16 MB of staging)
+    z0, z, z2 = torch.zeros(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+    o = smg.SolveOpts(tol=1e-10, max_iter=30)
+    conv, rh = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    alg = sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels))
+    fat = mg.device_bytes()["total"]
+    assert conv and fat <= 3.3 * alg, (fat, alg)
+    m2 = smg.Hierarchy.from_prolongs([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
+    m2.set_memory_lean(True)
+    m2.precompute(A)
+    conv2, rh2 = m2.solve_device(rhs.data_ptr(), z0.data_ptr(), z2.data_ptr(), n, 1, opts=o)
+    lean, lean_a0 = m2.device_bytes()["total"], m2.device_bytes()["level0.A_sell"]
+    assert conv2 and torch.equal(z, z2) and np.array_equal(rh, rh2)
+    assert lean <= 2.5 * alg and lean < 0.8 * fat, (lean, fat, alg)
+    m2.set_memory_lean(False)                                    # back: the next precompute is a full one, the pitch returns
+    m2.precompute(A)
+    assert m2.device_bytes()["level0.A_sell"] > 1.5 * lean_a0
+
+
 def test_c5_four_million_vertices_fp64_and_mixed(smg_mod):
     """BASELINE config C5 (synthetic 4 M-vertex closed surface: torus 64 x 64, five mid-point subdivisions re-projected onto the
     torus, 6 levels): beyond the oracle's reach in test time, so size-independent properties only -- SpMV against an independent
