@@ -219,7 +219,8 @@ int smg_level_get_block_gs_order(smg_hierarchy *h, int lv, int k, int *n_blocks,
  * multi-colour one: iterates differ, converged solutions agree to the tolerance, cycle counts are the same (measured).
  * mode: -1 (default) automatic = Gauss-Seidel levels of 512 - 600 000 rows with more than 5 colours or rows of more than 12 entries that have no
  * one-launch relax() (overlapped tiling), any number of columns (the order of a level's sweep never depends on k: a column-sharded solve iterates bit for bit
- * like the fused one), fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range.
+ * like the fused one), fp64 cycles; 0 never (one launch per colour); 1 every Gauss-Seidel level in that size range, for every k (such a level then takes no
+ * one-launch relax() either: that exists for k <= 7 only, and the order must not depend on k).
  * SMG_WGS=0 / 1 / 2 overrides (off / automatic / every level).  Takes effect at the next solve. */
 int smg_hierarchy_set_wave_gs(smg_hierarchy *h, int mode);
 /* Memory against speed (the reference has no counterpart: mg_data holds Eigen's compact CSC, src/mg_data.h:11-27).  By default every operator's SELL panels get a

@@ -37,9 +37,12 @@ static hipError_t ensure_map(DevBuf<int>& d, const std::vector<int>& host)
     if (d.n == host.size() && (d.p || host.empty())) return hipSuccess;
     return d.upload(host);
 }
+static bool wgs_forced(const smg_hierarchy* h, int lv);
 static bool tiled_wanted(const smg_hierarchy* h, int lv, int k, int sweeps)
 {
     static const int on = env_int("SMG_TILED", 1);
+    if (wgs_forced(h, lv)) return false;      // smg_hierarchy_set_wave_gs(h, 1): the level sweeps piece-wise for EVERY k (the one-launch relax exists for k <= 7 only,
+                                              // and the order of a level's sweep must not depend on the number of columns: column-sharded == fused)
     static const int max_rows = env_int("SMG_TILED_MAX_ROWS", 122880), min_rows = env_int("SMG_TILED_MIN_ROWS", 512);
     if (!on || h->bs != 1 || k < 1 || k > 7 || lv < 0 || lv >= h->n_levels - 1 || sweeps < 1 || sweeps > 3) return false;
     if (level_kind(h, lv) != LV_GS) return false;
@@ -193,11 +196,22 @@ static int ensure_bgs(smg_hierarchy* h, int lv)
 // Which levels: scalar fp64 hierarchies, Gauss-Seidel, any number of columns, SMG_WGS_MIN_ROWS <= rows <= SMG_WGS_MAX_ROWS, no one-launch relax()
 // (overlapped tiling) available; automatic mode: only levels the colour launches serve badly -- more than TILED_NCMAX colours or rows of more
 // than TILED_WMAX entries, i.e. the Galerkin levels of the reference's own hierarchies (mg_precompute).  smg_hierarchy_set_wave_gs / SMG_WGS=0|1|2.
-static bool wgs_wanted(const smg_hierarchy* h, int lv, int k)
+static int wgs_mode_now(const smg_hierarchy* h)
 {
     static const int env = env_int("SMG_WGS", -1);
+    return env >= 0 ? (env == 0 ? 0 : env == 1 ? -1 : 1) : h->wgs_mode;      // SMG_WGS: 0 off, 1 automatic, 2 every level in range
+}
+// mode 1 (every Gauss-Seidel level in range): what the level needs to sweep piece-wise, whatever k -- such a level takes no one-launch relax (tiled_wanted)
+static bool wgs_forced(const smg_hierarchy* h, int lv)
+{
     static const int max_rows = env_int("SMG_WGS_MAX_ROWS", 600000), min_rows = env_int("SMG_WGS_MIN_ROWS", 512);
-    const int mode = env >= 0 ? (env == 0 ? 0 : env == 1 ? -1 : 1) : h->wgs_mode;      // SMG_WGS: 0 off, 1 automatic, 2 every level in range
+    if (wgs_mode_now(h) != 1 || h->bs != 1 || h->precision != 0 || lv < 0 || lv >= h->n_levels - 1 || level_kind(h, lv) != LV_GS) return false;
+    return h->lv[lv].n >= min_rows && h->lv[lv].n <= max_rows;
+}
+static bool wgs_wanted(const smg_hierarchy* h, int lv, int k)
+{
+    static const int max_rows = env_int("SMG_WGS_MAX_ROWS", 600000), min_rows = env_int("SMG_WGS_MIN_ROWS", 512);
+    const int mode = wgs_mode_now(h);
     if (mode == 0 || h->bs != 1 || h->precision != 0 || k < 1 || lv < 0 || lv >= h->n_levels - 1) return false;      // (every k: the order of a level's sweep must not depend on how the columns are sharded)
     if (level_kind(h, lv) != LV_GS) return false;
     const Level& Lv = h->lv[lv];

@@ -1774,7 +1774,7 @@ __global__ void k_gather_vals(double* dst, const double* src, const int* map, si
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int m = map[i];
-    dst[i] = m >= 0 ? src[m] : 0.0;
+    if (m >= 0) dst[i] = src[m];      // padding slots keep what the image was built with (+0.0; 1.0 on the diagonal of lanes without a row)
 }
 __global__ void k_scatter_dense(double* dense, const double* src, const long long* pos, int n)
 {

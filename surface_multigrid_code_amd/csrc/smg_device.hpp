@@ -162,7 +162,7 @@ struct WgsDev {
     const unsigned* eoff = nullptr;   // per piece 64 x 4 NB: byte offsets of two entry slots' columns in the one-column image, 16 + 16 bits
     const double* eval = nullptr;     // per piece 64 x 8 NB: the values
 };
-// the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k, 1 <= k <= 8)
+// the pieces [q_begin, q_end) -- one piece colour -- of one sweep, in place on u (row-major n x k, any k >= 1: column groups ride in the grid's second dimension)
 hipError_t launch_wgs(const WgsDev& P, int q_begin, int q_end, const double* b, double* u, int k, const Ctrl* ctrl, hipStream_t st);
 
 // ---- independent meshes in one handle (smg_hierarchy_create_union; kernels: smg_union_device.hip) ----

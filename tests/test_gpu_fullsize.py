@@ -78,9 +78,12 @@ def test_memory_budget_at_full_size_default_and_lean(c3):
     rhs = torch.from_numpy(Mb @ np.random.default_rng(100).uniform(-1.0, 1.0, n)).to(dev)      # vectors resident in HBM, as in bench.py (host blocks add 16 MB of staging)
     z0, z, z2 = torch.zeros(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
     o = smg.SolveOpts(tol=1e-10, max_iter=30)
-    conv, rh = mg.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
+    m1 = smg.Hierarchy.from_prolongs([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])      # a fresh handle: one column, nothing staged (the fixture's has served other tests)
+    m1.precompute(A)
+    conv, rh = m1.solve_device(rhs.data_ptr(), z0.data_ptr(), z.data_ptr(), n, 1, opts=o)
     alg = sum(12 * mg.matrix(l, "A").nnz for l in range(mg.n_levels)) + sum(24 * mg.matrix(l, "P").nnz for l in range(1, mg.n_levels))
-    fat = mg.device_bytes()["total"]
+    fat = m1.device_bytes()["total"]
+    del m1
     assert conv and fat <= 3.3 * alg, (fat, alg)
     m2 = smg.Hierarchy.from_prolongs([mg.matrix(l, "P_full") for l in range(1, mg.n_levels)])
     m2.set_memory_lean(True)
