@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun).  Outputs under gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_round
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. kernel trace + stats of the very command the driver runs (C3 main loop = the reference's Gauss-Seidel cycle, smoother comparison, C5, C3 x 64 columns,
 #    C4 legs; the block leg's scalar comparison is left out: host precompute that adds nothing to the kernel table; the multi-mesh leg too:
 #    its 8 host threads launching at once crash rocprofv3's tool thread)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 200 --warmup 20 --no-cpu --no-block3-scalar --no-multi-mesh > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err
+SMG_BENCH_EXTRA_DIR=$OUT rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 200 --warmup 20 --no-cpu --no-block3-scalar --no-multi-mesh > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err
+mv $OUT/bench_extra.json $OUT/${TAG}_bench_extra_under_rocprof.json 2>/dev/null
 python tools/rocpd_stats.py $OUT/trace/bench_results.db $OUT/${TAG}_bench_kernel_stats.csv > /dev/null
 # 2. one outer iteration of the timed configuration (GS above 300 k rows, Chebyshev-Jacobi below), kernel by kernel -- and of the
 #    reference's Gauss-Seidel everywhere; and of the wide (k = 64) kernels of C4
