@@ -1074,6 +1074,7 @@ def compact_line(out):
         "c3_decimated_device_bytes_algorithmic": _dig(out, "c3_decimated", "hierarchy_algorithmic_bytes"),
         "setup_precompute_s": _dig(out, "setup_s", "precompute"),
     }
+    line["env_overrides"] = list(out.get("env_overrides") or [])[:20]
     line["extra"] = {k: _num(v, 5) for k, v in extras.items() if v is not None}
     errs = [k for k, v in out.items() if isinstance(v, dict) and "error" in v]
     if errs:
@@ -1384,6 +1385,8 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "scaling_note": "top-level value: one right-hand-side column per GPU, hierarchy replicated (fixed work per GPU as N grows); the c3_k64_sharded / c4_k64_sharded legs split a FIXED 64-column job over the ranks and say 'strong' themselves",
             "vs_baseline": None, "host": host_info(),
+            # every SMG_* variable set in this run's environment (A/B knobs: DESIGN.md section 11): [] = the documented defaults
+            "env_overrides": sorted(k_ for k_ in os.environ if k_.startswith("SMG_") and k_ not in ("SMG_BENCH_EXTRA_DIR",)),
             "dtype": "f64" if args.precision == "f64" else "f64 outer loop + f32 V-cycle (mixed)", "data": "synthetic",
             "config": {"workload": label, "n_verts": n, "nnz": int(nnz0), "levels": mg.n_levels,
                        "level_rows": [mg.rows(l) for l in range(mg.n_levels)],

@@ -808,3 +808,23 @@ def test_coarsest_smoothed_level_inherits_its_colouring_from_the_coarsest_level(
         col_of = np.searchsorted(cp, np.arange(mg.rows(lv)), side="right") - 1
         off = Ai.row != Ai.col
         assert (col_of[Ai.row[off]] != col_of[Ai.col[off]]).all()
+
+
+def test_every_environment_knob_is_documented():
+    """DESIGN.md section 11 lists every SMG_* variable the sources read (65 of them; round 5 documented 20), with its default -- and bench.py says which ones were
+    set when it ran (`env_overrides` in its line), so that a number can be told from a number measured under a knob."""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "surface_multigrid_code_amd", "csrc", "*")):
+        names |= set(re.findall(r'(?:env_int|getenv)\(\s*"(SMG_[A-Z0-9_]+)"', open(f).read()))
+    for f in glob.glob(os.path.join(ROOT, "surface_multigrid_code_amd", "*.py")) + [os.path.join(ROOT, "bench.py")]:
+        names |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(SMG_[A-Z0-9_]+)"', open(f).read()))
+    assert len(names) > 60
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sec = design[design.index("## 11. Environment knobs"):design.index("## 12.")]
+    missing = sorted(n for n in names if "`%s`" % n not in sec)
+    assert not missing, "knobs read by the sources but absent from DESIGN.md section 11: %s" % missing
+    listed = set(re.findall(r"`(SMG_[A-Z0-9_]+)`", sec))
+    stale = sorted(n for n in listed if n not in names)
+    assert not stale, "knobs DESIGN.md section 11 lists that nothing reads any more: %s" % stale
