@@ -12,11 +12,12 @@ mg.precompute(A)
 sm = os.environ.get("SMG_TOOL_SMOOTHER", "gs")      # gs | jacobi | hybrid[:max_rows[:omega]]
 parts = sm.split(":")
 mg.set_smoother(parts[0], float(parts[2]) if len(parts) > 2 else 0.8, int(parts[1]) if len(parts) > 1 else 100000)   # gs | jacobi | hybrid | chebyshev | hybrid_chebyshev
-print(label, "k =", k, "smoother", sm)
+SW = int(os.environ.get("SMG_TOOL_SWEEPS", "2"))      # pre = post sweeps of the cycle
+print(label, "k =", k, "smoother", sm, "V(%d,%d)" % (SW, SW))
 prev = None
 ts = []
 for lv in range(mg.n_levels):
-    t = mg.bench_vcycle(lv, k, 2, 2, 100)
+    t = mg.bench_vcycle(lv, k, SW, SW, 100)
     ts.append(t)
 for lv in range(mg.n_levels):
     own = ts[lv] - (ts[lv + 1] if lv + 1 < mg.n_levels else 0.0)
