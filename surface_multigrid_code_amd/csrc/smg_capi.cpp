@@ -58,7 +58,7 @@ extern "C" int smg_debug_device_bytes(const smg_hierarchy* h, char* buf, int cap
         line(p + "refresh_maps", B(L.mapA) + B(L.mapAT));
         line(p + "galerkin_recipes", B(L.r1_ptr) + B(L.r1_idx) + B(L.r2_ptr) + B(L.r2_idx) + B(L.r1_coef) + B(L.r2_coef));
         long long t = 0;
-        for (const auto& T : L.tiled) t += B(T.hdr) + B(T.ext_rows) + B(T.pcol) + B(T.prow) + B(T.map) + B(T.pval);
+        for (const auto& T : L.tiled) t += B(T.hdr) + B(T.ext_rows) + B(T.pcol) + B(T.prow) + B(T.map) + B(T.mapd) + B(T.pval) + B(T.pdiag);
         line(p + "tiled_plans", t);
         line(p + "bgs_plan", B(L.bgs.hdr) + B(L.bgs.xrow) + B(L.bgs.ugrow) + B(L.bgs.ulrow) + B(L.bgs.eidx) + B(L.bgs.map) + B(L.bgs.mapd) + B(L.bgs.eval) + B(L.bgs.udiag));
         line(p + "wgs_plan", B(L.wgs.hdr) + B(L.wgs.grow) + B(L.wgs.meta) + B(L.wgs.rim) + B(L.wgs.map) + B(L.wgs.mapd) + B(L.wgs.eoff) + B(L.wgs.eval) + B(L.wgs.diag));
@@ -626,14 +626,13 @@ extern "C" int smg_debug_check_tiling_plan(smg_hierarchy* h, int lv, int sweeps,
                 const int* C = H + 4 + ((p - 1) % nc) * TILED_CSTRIDE;
                 const int pan = C[0], m = C[1], ro = C[2], lbase = C[3], cnt = C[4 + (PP - p)];
                 for (int i = 0; i < cnt; i++) {
-                    double acc = 0.0, diag = 1.0;
+                    double acc = 0.0;      // exactly the kernel's loop: every slot, the diagonal's and the padding's hold +0.0 at the row's own index
                     for (int j = 0; j < w; j++) {
                         const int cl = P.pcol[(size_t)pan + (size_t)j * m + i];
-                        const double v = P.pval[(size_t)pan + (size_t)j * m + i];
-                        if (cl < 0) continue;
-                        if (cl == lbase + i) diag = v; else acc += v * xs[(size_t)cl];
+                        if (cl < 0 || cl >= n_ext) return fail(SMG_ERR_INVALID, "tiling plan: tile %d holds a column outside its image", t);
+                        acc += P.pval[(size_t)pan + (size_t)j * m + i] * xs[(size_t)cl];
                     }
-                    xs[(size_t)lbase + i] = (b[(size_t)P.prow[(size_t)ro + i]] - acc) / diag;
+                    xs[(size_t)lbase + i] = (b[(size_t)P.prow[(size_t)ro + i]] - acc) / P.pdiag[(size_t)ro + i];
                 }
             }
             for (int c = 0; c < nc; c++) {

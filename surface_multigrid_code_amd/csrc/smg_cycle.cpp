@@ -86,22 +86,31 @@ static int ensure_tiled(smg_hierarchy* h, int lv, int sweeps)
         P = build_tiled_gs(G, Lv.ord.color_ptr, sweeps, tile_rows, max_ext, threads);
     }
     if (P.empty()) return SMG_OK;
-    std::vector<int> map(P.pentry.size());
-    for (size_t i = 0; i < map.size(); i++) {
-        const int e = P.pentry[i];
-        map[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
-    }
+    auto to_level_value = [&](const std::vector<int>& entries) {
+        std::vector<int> m(entries.size());
+        for (size_t i = 0; i < m.size(); i++) {
+            const int e = entries[i];
+            m[i] = e < 0 ? -1 : Lv.A_int_src[(size_t)(Lv.gs_on_transpose ? tsrc[(size_t)e] : e)];
+        }
+        return m;
+    };
+    std::vector<int> map = to_level_value(P.pentry), mapd = to_level_value(P.pdentry);
     HIPCHK(B.hdr.upload(P.hdr)); HIPCHK(B.ext_rows.upload(P.ext_rows)); HIPCHK(B.pcol.upload(P.pcol)); HIPCHK(B.pval.upload(P.pval));
-    HIPCHK(B.prow.upload(P.prow)); B.host_map = std::move(map);      // (uploaded when a value-only re-precompute first needs it: ensure_map)
+    HIPCHK(B.prow.upload(P.prow)); HIPCHK(B.pdiag.upload(P.pdiag));
+    B.host_map = std::move(map); B.host_mapd = std::move(mapd);      // (uploaded when a value-only re-precompute first needs them: ensure_map)
     HIPCHK(tiled_gs_prepare(P.max_ext));
     int wmax = 0;
     for (int t = 0; t < P.n_tiles; t++) wmax = std::max(wmax, P.hdr[(size_t)t * TILED_HDR + 2]);
     B.view.threads = threads;
     B.view.n_tiles = P.n_tiles; B.view.nc = P.nc; B.view.P = P.P; B.view.sweeps = sweeps; B.view.max_ext = P.max_ext; B.view.w_max = wmax;
-    B.view.hdr = B.hdr.p; B.view.ext_rows = B.ext_rows.p; B.view.pcol = B.pcol.p; B.view.pval = B.pval.p; B.view.prow = B.prow.p;
+    B.view.hdr = B.hdr.p; B.view.ext_rows = B.ext_rows.p; B.view.pcol = B.pcol.p; B.view.pval = B.pval.p; B.view.prow = B.prow.p; B.view.pdiag = B.pdiag.p;
     B.updates = P.updates;
     // after a value-only re-precompute the host copy of the values is stale: take them from the device copy
-    if (h->host_stale && Lv.d_Aval.p) { HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(launch_gather_vals(B.pval.p, Lv.d_Aval.p, B.map.p, B.pval.n, h->stream)); }
+    if (h->host_stale && Lv.d_Aval.p) {
+        HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(ensure_map(B.mapd, B.host_mapd));
+        HIPCHK(launch_gather_vals(B.pval.p, Lv.d_Aval.p, B.map.p, B.pval.n, h->stream));
+        HIPCHK(launch_gather_vals(B.pdiag.p, Lv.d_Aval.p, B.mapd.p, B.pdiag.n, h->stream));
+    }
     if (env_int("SMG_DEBUG_TILED", 0))
         std::fprintf(stderr, "tiled relax(%d) level %d: %d rows, %d tiles x %d threads, %d phases, extended tile <= %d rows, %.2fx row updates, entries per row <= %d\n", sweeps, lv, Lv.n,
                      P.n_tiles, threads, P.P, P.max_ext, (double)P.updates / ((double)sweeps * Lv.n), wmax);
@@ -112,7 +121,11 @@ int smg::refresh_tiled_values(smg_hierarchy* h)
     for (int lv = 0; lv < h->n_levels - 1; lv++) {
         for (int s = 1; s <= 3; s++) {
             TiledBuf& B = h->lv[lv].tiled[s];
-            if (B.view.n_tiles > 0) { HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream)); }
+            if (B.view.n_tiles > 0) {
+                HIPCHK(ensure_map(B.map, B.host_map)); HIPCHK(ensure_map(B.mapd, B.host_mapd));
+                HIPCHK(launch_gather_vals(B.pval.p, h->lv[lv].d_Aval.p, B.map.p, B.pval.n, h->stream));
+                HIPCHK(launch_gather_vals(B.pdiag.p, h->lv[lv].d_Aval.p, B.mapd.p, B.pdiag.n, h->stream));
+            }
         }
         WgsBuf& W = h->lv[lv].wgs;
         if (W.view.n_pieces > 0) {

@@ -197,6 +197,7 @@ struct TiledDev {
     const int* pcol = nullptr;
     const double* pval = nullptr;
     const int* prow = nullptr;
+    const double* pdiag = nullptr;     // like prow: the diagonal entry of every panel row (its slot in the panel holds +0.0)
 };
 // y = relax(sweeps) of x with right-hand side b, x != y, row-major n x k blocks
 hipError_t launch_tiled_gs(const TiledDev& T, const double* x, const double* b, double* y, int k, const Ctrl* ctrl, hipStream_t st);

@@ -112,11 +112,11 @@ struct Bsr3Buf {  // device image of one block (3 x 3) SELL matrix, smg_bsr3.hpp
 };
 
 struct TiledBuf {  // device image of one overlapped-tiling plan (smg_tiled.hpp)
-    DevBuf<int> hdr, ext_rows, pcol, prow, map;   // map: value slot -> index into Level::d_Aval (value-only re-precompute)
-    DevBuf<double> pval;
+    DevBuf<int> hdr, ext_rows, pcol, prow, map, mapd;   // map / mapd: value slot / diagonal of a panel row -> index into Level::d_Aval (value-only re-precompute), -1: leave
+    DevBuf<double> pval, pdiag;
     TiledDev view;
     long updates = 0;
-    std::vector<int> host_map;   // the map before its first use (uploaded by the first value-only re-precompute)
+    std::vector<int> host_map, host_mapd;   // the maps before their first use (uploaded by the first value-only re-precompute)
     bool tried = false;      // a plan was attempted for this (level, sweeps): empty view = the level does not qualify
 };
 

@@ -13,8 +13,8 @@ struct TileData {
     std::array<int, TILED_NCMAX> n_loc{}, m{};            // rows of the colour in the extended tile / in the panel
     std::array<std::array<int, TILED_PMAX + 1>, TILED_NCMAX> cnt{};
     int W = 0;
-    std::array<std::vector<int>, TILED_NCMAX> pcol, pentry, prow;
-    std::array<std::vector<double>, TILED_NCMAX> pval;
+    std::array<std::vector<int>, TILED_NCMAX> pcol, pentry, prow, pdentry;
+    std::array<std::vector<double>, TILED_NCMAX> pval, pdiag;
     long updates = 0;
     bool ok = true;
 };
@@ -163,15 +163,19 @@ TiledGs build_tiled_gs(const Csr& G, const std::vector<int>& cp, int sweeps, int
                 base = 0;
                 for (int c = 0; c < nc; c++) {
                     const int m = D.m[(size_t)c];
-                    D.pcol[(size_t)c].assign((size_t)W * m, -1);
+                    D.pcol[(size_t)c].assign((size_t)W * m, 0);
                     D.pentry[(size_t)c].assign((size_t)W * m, -1);
                     D.pval[(size_t)c].assign((size_t)W * m, 0.0);
                     D.prow[(size_t)c].resize((size_t)m);
+                    D.pdiag[(size_t)c].assign((size_t)m, 1.0);
+                    D.pdentry[(size_t)c].assign((size_t)m, -1);
                     for (int i = 0; i < m; i++) {
                         const int r = D.ext[(size_t)base + i];
                         D.prow[(size_t)c][(size_t)i] = r;
+                        for (int j = 0; j < W; j++) D.pcol[(size_t)c][(size_t)j * m + i] = base + i;      // padding: the row's own local index, value +0.0
                         int j = 0;
                         for (int p = G.ptr[(size_t)r]; p < G.ptr[(size_t)r + 1]; p++, j++) {   // ascending column of the internal numbering: the order of the sums
+                            if (G.col[(size_t)p] == r) { D.pdiag[(size_t)c][(size_t)i] = G.val[(size_t)p]; D.pdentry[(size_t)c][(size_t)i] = p; continue; }      // (its slot stays padding)
                             D.pcol[(size_t)c][(size_t)j * m + i] = loc[(size_t)G.col[(size_t)p]];
                             D.pval[(size_t)c][(size_t)j * m + i] = G.val[(size_t)p];
                             D.pentry[(size_t)c][(size_t)j * m + i] = p;
@@ -203,6 +207,8 @@ TiledGs build_tiled_gs(const Csr& G, const std::vector<int>& cp, int sweeps, int
             R.pval.insert(R.pval.end(), D.pval[(size_t)c].begin(), D.pval[(size_t)c].end());
             R.pentry.insert(R.pentry.end(), D.pentry[(size_t)c].begin(), D.pentry[(size_t)c].end());
             R.prow.insert(R.prow.end(), D.prow[(size_t)c].begin(), D.prow[(size_t)c].end());
+            R.pdiag.insert(R.pdiag.end(), D.pdiag[(size_t)c].begin(), D.pdiag[(size_t)c].end());
+            R.pdentry.insert(R.pdentry.end(), D.pdentry[(size_t)c].begin(), D.pdentry[(size_t)c].end());
             lbase += D.n_loc[(size_t)c];
         }
     }

@@ -35,10 +35,15 @@ struct TiledGs {
     long updates = 0;                // row updates per relax() over all tiles and phases (redundancy = updates / (sweeps * n))
     std::vector<int> hdr;            // n_tiles * TILED_HDR
     std::vector<int> ext_rows;       // global row of every local index, tile after tile
-    std::vector<int> pcol;           // panels, column-major per (tile, colour): local column, -1 = padding
+    // panels, column-major per (tile, colour): local column + value.  The DIAGONAL has left the row: its slot holds +0.0 at the row's own local index, like every
+    // padding slot (a sum that starts at +0 is not changed by adding +-0: the bits are those of the sum that skips these slots), and a_ii sits in pdiag --
+    // the kernel's phases are W straight-line LDS reads and multiply-adds, and nothing is sorted out per launch (round 6: that cost 2 us of every launch).
+    std::vector<int> pcol;
     std::vector<double> pval;
-    std::vector<int> pentry;         // like pval: index of the entry of G the slot holds (-1 padding): value refresh
+    std::vector<int> pentry;         // like pval: index of the entry of G the slot holds (-1: padding / the diagonal's slot): value refresh
     std::vector<int> prow;           // global row of every panel row
+    std::vector<double> pdiag;       // like prow: a_ii (1.0 for a row without a stored diagonal)
+    std::vector<int> pdentry;        // like prow: index of the diagonal entry of G (-1: none): value refresh
     bool empty() const { return n_tiles == 0; }
 };
 

@@ -19,7 +19,7 @@ constexpr int TILED_NT = TILED_THREADS;   // most threads of a tile's workgroup 
 // in flight together, and stay in registers for all sweeps -- after the prologue the phases touch nothing but LDS.
 template <int NC, int W, int KB>
 __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ hdr, const int* __restrict__ ext_rows, const int* __restrict__ pcol,
-                                                       const double* __restrict__ pval, const int* __restrict__ prow, const double* __restrict__ b,
+                                                       const double* __restrict__ pval, const int* __restrict__ prow, const double* __restrict__ pdiag, const double* __restrict__ b,
                                                        const double* __restrict__ x, double* __restrict__ y, int ld, int nc, int sweeps, const int* done, int dbg_phases)
 {
     extern __shared__ double xs[];      // the extended tile's iterate: n_ext x KB, row-major like the global blocks
@@ -30,45 +30,59 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
     __syncthreads();
     const int ext_off = Hs[0], n_ext = Hs[1], w = Hs[2];
     const int P = sweeps * nc;
-    for (int i = tid; i < n_ext; i += (int)blockDim.x) {
-        double g[KB];
-        gather_kb<KB, double>(x + (size_t)ext_rows[ext_off + i] * ld, true, g);
+    // The prologue is two round trips behind the header, whatever the size of the tile: (A) every index the workgroup needs -- the rows of the image (U per
+    // thread at a time), the panels' rows, columns and values -- requested together; (B) the gathers they address: the image's x, the right-hand sides.
+    // (Until round 6 this was a loop of "index, then gather" per 512 rows of the image, then the panel loads, then the right-hand sides: 2 x (n_ext / 512) + 3
+    // dependent round trips in front of the first phase.)
+    constexpr int U = 4;
+    const int nt = (int)blockDim.x;
+    int er[U];
+    auto image_indices = [&](const int i0) {
 #pragma unroll
-        for (int q = 0; q < KB; q++) xs[i * KB + q] = g[q];
-    }
+        for (int t = 0; t < U; t++) { const int i = i0 + t * nt; er[t] = i < n_ext ? ext_rows[ext_off + i] : -1; }
+    };
+    auto image_gather = [&](const int i0) {
+        double g[U][KB];
+#pragma unroll
+        for (int t = 0; t < U; t++) gather_kb<KB, double>(x + (size_t)(er[t] >= 0 ? er[t] : 0) * ld, er[t] >= 0, g[t]);
+#pragma unroll
+        for (int t = 0; t < U; t++) {
+            const int i = i0 + t * nt;
+            if (i < n_ext) {
+#pragma unroll
+                for (int q = 0; q < KB; q++) xs[i * KB + q] = g[t][q];
+            }
+        }
+    };
+    // (A)
+    image_indices(tid);
     int cR[NC][W], gR[NC];
     double vR[NC][W], bR[NC][KB], dR[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        gR[c] = -1;
+        gR[c] = -1; dR[c] = 1.0;
 #pragma unroll
-        for (int j = 0; j < W; j++) { cR[c][j] = -1; vR[c][j] = 0.0; }
+        for (int j = 0; j < W; j++) { cR[c][j] = 0; vR[c][j] = 0.0; }      // slots beyond the tile's width, lanes without a row: +0.0 times the image's first (finite) value
         if (c < nc) {
             const int* C = Hs + 4 + c * TILED_CSTRIDE;
             const int pan = C[0], m = C[1];
             if (tid < m) {
                 gR[c] = prow[C[2] + tid];
+                dR[c] = pdiag[C[2] + tid];
 #pragma unroll
                 for (int j = 0; j < W; j++)
                     if (j < w) { cR[c][j] = pcol[(size_t)pan + (size_t)j * m + tid]; vR[c][j] = pval[(size_t)pan + (size_t)j * m + tid]; }
             }
         }
     }
+    // (B)
+    image_gather(tid);
 #pragma unroll
     for (int c = 0; c < NC; c++) gather_kb<KB, double>(b + (size_t)(gR[c] >= 0 ? gR[c] : 0) * ld, gR[c] >= 0, bR[c]);
-    // Branch-free phases: the diagonal leaves the row (its slot keeps a zero that multiplies the row's own, finite, value) and padding
-    // slots point at the row itself with a zero -- a sum that starts at +0 is not changed by adding +-0 (it never holds -0), so the bits
-    // are those of the sum that skips these slots, and the phase loop is W straight-line LDS reads and multiply-adds per column.
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int lrow = (c < nc ? Hs[4 + c * TILED_CSTRIDE + 3] : 0) + tid;
-        dR[c] = 1.0;
-#pragma unroll
-        for (int j = 0; j < W; j++) {
-            if (cR[c][j] == lrow) { dR[c] = vR[c][j]; vR[c][j] = 0.0; }
-            else if (cR[c][j] < 0) { cR[c][j] = gR[c] >= 0 ? lrow : 0; vR[c][j] = 0.0; }
-        }
-    }
+    for (int i0 = tid + U * nt; i0 < n_ext; i0 += U * nt) { image_indices(i0); image_gather(i0); }      // extended tiles of more than U x threads rows: two more round trips per chunk
+    // Branch-free phases: the diagonal has left the row at plan time (its slot, like every padding slot, holds +0.0 at the row's own local index: a sum that
+    // starts at +0 is not changed by adding +-0 -- it never holds -0 --, so the bits are those of the sum that skips these slots), and the phase loop is
+    // W straight-line LDS reads and multiply-adds per column.
     __syncthreads();
     for (int s = 0; s < sweeps; s++) {
 #pragma unroll
@@ -113,7 +127,7 @@ static void launch_tiled_one(const TiledDev& Tl, const double* x, const double* 
 {
     const size_t lds = (size_t)Tl.max_ext * kb * sizeof(double);
     static const int dbg = getenv("SMG_DEBUG_TILED_PHASES") ? atoi(getenv("SMG_DEBUG_TILED_PHASES")) : 1 << 20;   // timing probe (wrong results)
-#define SMG_TILED_LAUNCH(KB) hipLaunchKernelGGL((k_tiled_gs<NC, W, KB>), dim3(Tl.n_tiles), dim3(Tl.threads), lds, st, Tl.hdr, Tl.ext_rows, Tl.pcol, Tl.pval, Tl.prow, b, x, y, ld, Tl.nc, Tl.sweeps, done, dbg)
+#define SMG_TILED_LAUNCH(KB) hipLaunchKernelGGL((k_tiled_gs<NC, W, KB>), dim3(Tl.n_tiles), dim3(Tl.threads), lds, st, Tl.hdr, Tl.ext_rows, Tl.pcol, Tl.pval, Tl.prow, Tl.pdiag, b, x, y, ld, Tl.nc, Tl.sweeps, done, dbg)
     if (kb == 1) SMG_TILED_LAUNCH(1);
     else if (kb == 2) SMG_TILED_LAUNCH(2);
     else SMG_TILED_LAUNCH(3);
