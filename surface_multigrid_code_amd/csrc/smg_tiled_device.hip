@@ -37,14 +37,15 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
     constexpr int U = 4;
     const int nt = (int)blockDim.x;
     int er[U];
+    // (unconditional loads at clamped -- valid -- indices: a predicated vector load becomes a branch, and a branch between two requests a wait)
     auto image_indices = [&](const int i0) {
 #pragma unroll
-        for (int t = 0; t < U; t++) { const int i = i0 + t * nt; er[t] = i < n_ext ? ext_rows[ext_off + i] : -1; }
+        for (int t = 0; t < U; t++) { const int i = i0 + t * nt; er[t] = ext_rows[ext_off + (i < n_ext ? i : n_ext - 1)]; }
     };
     auto image_gather = [&](const int i0) {
         double g[U][KB];
 #pragma unroll
-        for (int t = 0; t < U; t++) gather_kb<KB, double>(x + (size_t)(er[t] >= 0 ? er[t] : 0) * ld, er[t] >= 0, g[t]);
+        for (int t = 0; t < U; t++) gather_kb<KB, double>(x + (size_t)er[t] * ld, true, g[t]);
 #pragma unroll
         for (int t = 0; t < U; t++) {
             const int i = i0 + t * nt;
@@ -80,6 +81,15 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
 #pragma unroll
     for (int c = 0; c < NC; c++) gather_kb<KB, double>(b + (size_t)(gR[c] >= 0 ? gR[c] : 0) * ld, gR[c] >= 0, bR[c]);
     for (int i0 = tid + U * nt; i0 < n_ext; i0 += U * nt) { image_indices(i0); image_gather(i0); }      // extended tiles of more than U x threads rows: two more round trips per chunk
+    // The slots' positions in the image, scaled to KB columns HERE, behind every request of the prologue: left to itself the compiler scales each column index
+    // where it is loaded -- under the per-column `j < w` branch, i.e. one wait per panel column (12 x 4 dependent round trips: k = 3 went from 52 to 69 us per
+    // level visit when the loop that used to sort the diagonals out, and with it this anchor, was removed).
+    if constexpr (KB > 1) {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int j = 0; j < W; j++) { int v = cR[c][j]; asm volatile("" : "+v"(v)); cR[c][j] = v * KB; }
+    }
     // Branch-free phases: the diagonal has left the row at plan time (its slot, like every padding slot, holds +0.0 at the row's own local index: a sum that
     // starts at +0 is not changed by adding +-0 -- it never holds -0 --, so the bits are those of the sum that skips these slots), and the phase loop is
     // W straight-line LDS reads and multiply-adds per column.
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(TILED_NT) void k_tiled_gs(const int* __restrict__ h
 #pragma unroll
                     for (int j = 0; j < W; j++) {
                         const double v = vR[c][j];
-                        const int at = cR[c][j] * KB;
+                        const int at = cR[c][j];      // (already scaled by KB)
 #pragma unroll
                         for (int q = 0; q < KB; q++) acc[q] += v * xs[at + q];
                     }
