@@ -1040,7 +1040,7 @@ def compact_line(out):
                       if cfg.get(k) is not None}
     rf = out.get("roofline") or {}
     line["roofline"] = {k: _num(rf.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "bytes_per_launch", "us_per_launch", "traffic",
-                                                      "traffic_source", "infinity_cache_resident")}
+                                                      "traffic_kind", "traffic_source", "infinity_cache_resident")}
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: _num(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "ms_per_cycle")}
@@ -1405,7 +1405,8 @@ def main():
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          # the committed PMC figure of this kernel at this grid (rocprofv3 cannot run inside the benchmark): fabric-side
                          # requests, which do not tell Infinity-Cache hits from HBM reads
-                         "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic": traffic, "traffic_kind": "committed rocprofv3 PMC figure for these kernel sources (hash-checked), not a measurement of this run" if traffic is not None else None,
+                         "traffic_source": traffic_note,
                          "bytes_per_launch": int(spmv_bytes), "us_per_launch": spmv_us, "us_per_launch_repeats": spmv_all,
                          "timing": "median of 5 HIP-event-timed loops on the launch stream",
                          "sell_padding": st["padded"] / max(st["stored"], 1) - 1.0,
